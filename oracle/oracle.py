@@ -1,0 +1,195 @@
+"""ctypes/numpy front end of the CPU oracle (oracle/spx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+
+Every function takes/returns numpy float64 arrays and mirrors one reference prox! body
+(file:line citations are in spx_oracle.c).  `mask` is a uint8 array (1 = index selected) or None.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libspx_oracle.so")
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int64_p = ctypes.POINTER(ctypes.c_int64)
+_c_uint8_p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force=False):
+    """Compile oracle/spx_oracle.c with gcc (no FMA contraction, no fast-math)."""
+    src = os.path.join(_HERE, "spx_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"] if force else ["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = ctypes.CDLL(_SO)
+        d, i64, dp, ip, up = ctypes.c_double, ctypes.c_int64, _c_double_p, _c_int64_p, _c_uint8_p
+        base = [dp, dp, dp, dp, i64]
+        L.orc_prox_l1.argtypes = base + [d, d]
+        L.orc_prox_l0.argtypes = base + [d, d]
+        L.orc_prox_lhalf.argtypes = base + [d, d]
+        box = base + [d, d, dp, dp, d, d, up]
+        L.orc_prox_l1_box.argtypes = box
+        L.orc_prox_l0_box.argtypes = box
+        L.orc_prox_lhalf_box.argtypes = box
+        L.orc_prox_indball_l0.argtypes = base + [i64]
+        L.orc_prox_indball_l0_binf.argtypes = base + [i64, d]
+        L.orc_prox_group_l2.argtypes = base + [ip, i64, i64, dp, d]
+        L.orc_prox_group_l2_binf.argtypes = base + [ip, i64, i64, dp, d, d]
+        L.orc_rootnormlhalf_prox.argtypes = [dp, dp, i64, d, d]
+        L.orc_rootnormlhalf_prox.restype = d
+        for name in ("orc_prox_l1", "orc_prox_l0", "orc_prox_lhalf", "orc_prox_l1_box", "orc_prox_l0_box",
+                     "orc_prox_lhalf_box", "orc_prox_indball_l0", "orc_prox_indball_l0_binf",
+                     "orc_prox_group_l2", "orc_prox_group_l2_binf"):
+            getattr(L, name).restype = None
+        _lib = L
+    return _lib
+
+
+def _f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a
+
+
+def _dp(a):
+    return a.ctypes.data_as(_c_double_p) if a is not None else None
+
+
+def _prep(q, xk, sj):
+    q, xk, sj = _f64(q), _f64(xk), _f64(sj)
+    n = q.shape[0]
+    assert xk.shape[0] == n and sj.shape[0] == n
+    return q, xk, sj, n, np.empty(n, dtype=np.float64)
+
+
+def _bounds(l, u, n):
+    lv = uv = None
+    ls = us = 0.0
+    if np.ndim(l) == 0:
+        ls = float(l)
+    else:
+        lv = _f64(l)
+        assert lv.shape[0] == n
+    if np.ndim(u) == 0:
+        us = float(u)
+    else:
+        uv = _f64(u)
+        assert uv.shape[0] == n
+    return lv, uv, ls, us
+
+
+def _mask(mask, n):
+    if mask is None:
+        return None, None
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    assert m.shape[0] == n
+    return m, m.ctypes.data_as(_c_uint8_p)
+
+
+def mask_from_selected(selected, n):
+    """`selected` = iterable of 1-based indices (any order, duplicates allowed); membership only."""
+    m = np.zeros(n, dtype=np.uint8)
+    idx = np.asarray(list(selected), dtype=np.int64) - 1
+    idx = idx[(idx >= 0) & (idx < n)]
+    m[idx] = 1
+    return m
+
+
+def prox_l1(q, xk, sj, lam, sigma):
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    lib().orc_prox_l1(_dp(y), _dp(q), _dp(xk), _dp(sj), n, lam, sigma)
+    return y
+
+
+def prox_l0(q, xk, sj, lam, sigma):
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    lib().orc_prox_l0(_dp(y), _dp(q), _dp(xk), _dp(sj), n, lam, sigma)
+    return y
+
+
+def prox_lhalf(q, xk, sj, lam, sigma):
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    lib().orc_prox_lhalf(_dp(y), _dp(q), _dp(xk), _dp(sj), n, lam, sigma)
+    return y
+
+
+def _box(fn, q, xk, sj, lam, sigma, l, u, mask):
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    lv, uv, ls, us = _bounds(l, u, n)
+    m, mp = _mask(mask, n)
+    fn(_dp(y), _dp(q), _dp(xk), _dp(sj), n, lam, sigma, _dp(lv), _dp(uv), ls, us, mp)
+    return y
+
+
+def prox_l1_box(q, xk, sj, lam, sigma, l, u, mask=None):
+    return _box(lib().orc_prox_l1_box, q, xk, sj, lam, sigma, l, u, mask)
+
+
+def prox_l0_box(q, xk, sj, lam, sigma, l, u, mask=None):
+    return _box(lib().orc_prox_l0_box, q, xk, sj, lam, sigma, l, u, mask)
+
+
+def prox_lhalf_box(q, xk, sj, lam, sigma, l, u, mask=None):
+    return _box(lib().orc_prox_lhalf_box, q, xk, sj, lam, sigma, l, u, mask)
+
+
+def prox_indball_l0(q, xk, sj, r):
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    lib().orc_prox_indball_l0(_dp(y), _dp(q), _dp(xk), _dp(sj), n, int(r))
+    return y
+
+
+def prox_indball_l0_binf(q, xk, sj, r, delta):
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    lib().orc_prox_indball_l0_binf(_dp(y), _dp(q), _dp(xk), _dp(sj), n, int(r), delta)
+    return y
+
+
+def _groups(n, offsets, gsize):
+    if offsets is not None:
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        return off, off.ctypes.data_as(_c_int64_p), 0, off.shape[0] - 1
+    assert gsize > 0 and n % gsize == 0
+    return None, None, int(gsize), n // gsize
+
+
+def prox_group_l2(q, xk, sj, lam, sigma, offsets=None, gsize=0):
+    """Groups = contiguous ranges: 0-based CSR `offsets` (len ngroups+1) or uniform `gsize`."""
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    y[:] = 0.0
+    off, offp, gs, ng = _groups(n, offsets, gsize)
+    lam = _f64(lam)
+    assert lam.shape[0] == ng
+    lib().orc_prox_group_l2(_dp(y), _dp(q), _dp(xk), _dp(sj), n, offp, gs, ng, _dp(lam), sigma)
+    return y
+
+
+def prox_group_l2_binf(q, xk, sj, lam, sigma, delta, offsets=None, gsize=0):
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    y[:] = 0.0
+    off, offp, gs, ng = _groups(n, offsets, gsize)
+    lam = _f64(lam)
+    assert lam.shape[0] == ng
+    lib().orc_prox_group_l2_binf(_dp(y), _dp(q), _dp(xk), _dp(sj), n, offp, gs, ng, _dp(lam), sigma, delta)
+    return y
+
+
+def rootnormlhalf_prox(x, lam, gamma):
+    x = _f64(x).ravel()
+    y = np.empty_like(x)
+    val = lib().orc_rootnormlhalf_prox(_dp(y), _dp(x), x.shape[0], lam, gamma)
+    return y, val

@@ -1,0 +1,212 @@
+"""Pins the CPU oracle against every known-answer vector the reference's tests hold for the
+prox! hot path (tests/golden/reference_kats.json, transcribed from /root/reference/test), plus an
+independent brute-force objective minimiser.  CPU only."""
+import numpy as np
+import pytest
+
+BOX_FN = {"ShiftedNormL0Box": "prox_l0_box", "ShiftedNormL1Box": "prox_l1_box",
+          "ShiftedRootNormLhalfBox": "prox_lhalf_box"}
+
+
+@pytest.mark.parametrize("op", list(BOX_FN))
+def test_box_golden_runtests(orc, kats, op):
+    # test/runtests.jl:449-494
+    k = kats["box_golden"]
+    y = getattr(orc, BOX_FN[op])(k["q"], k["x"], k["s"], k["lambda"], k["sigma"], -k["delta"], k["delta"])
+    np.testing.assert_allclose(y, k["expected"][op], rtol=k["rtol"], atol=0)
+
+
+@pytest.mark.parametrize("op", list(BOX_FN))
+def test_testsbox_enumerated_cases(orc, kats, op):
+    # test/testsbox.jl:13-97: psi = shifted(h, x, l, u); omega = shifted(psi, s); prox(omega, q, sigma)
+    t = kats["testsbox"]
+    c = t[op]
+    for qi, xi, lam, sol in zip(c["q"], c["x"], c["lambda"], c["sol"]):
+        y = getattr(orc, BOX_FN[op])([qi], [xi], [t["s"]], lam, t["sigma"], t["l"], t["u"])
+        assert abs(y[0] - sol) <= t["atol"], (op, qi, xi, lam, y[0], sol)
+        # vector-bounds form gives the same answer
+        y2 = getattr(orc, BOX_FN[op])([qi], [xi], [t["s"]], lam, t["sigma"], [t["l"]], [t["u"]])
+        assert y2[0] == y[0]
+
+
+def test_testsbox_lhalf_exact_values(orc, kats):
+    # exact values behind the rounded 1.6054 / 2.702 of testsbox.jl:77
+    t = kats["testsbox"]
+    c = t["ShiftedRootNormLhalfBox"]
+    y4 = orc.prox_lhalf_box([c["q"][3]], [c["x"][3]], [t["s"]], c["lambda"][3], 1.0, 0.0, 3.0)[0]
+    y8 = orc.prox_lhalf_box([c["q"][7]], [c["x"][7]], [t["s"]], c["lambda"][7], 1.0, 0.0, 3.0)[0]
+    assert abs(y4 - 1.6053779404795958) < 1e-13
+    assert abs(y8 - 2.7015158583813426) < 1e-13
+
+
+def test_rootnormlhalf_unshifted_golden(orc, kats):
+    # test/runtests.jl:113-126
+    k = kats["rootnormlhalf_unshifted"]
+    y, val = orc.rootnormlhalf_prox(k["q"], k["lambda"], k["nu"])
+    assert np.sum((y - np.array(k["expected"])) ** 2) <= k["sumsq_tol"]
+    assert abs(val - k["lambda"] * np.sum(np.sqrt(np.abs(y)))) < 1e-14
+
+
+@pytest.mark.parametrize("name", ["group_l2_binf_single", "group_l2_binf_two"])
+def test_group_l2_binf_golden(orc, kats, name):
+    # test/runtests.jl:587-606, 658-705
+    k = kats[name]
+    y = orc.prox_group_l2_binf(k["q"], k["x"], k["s"], k["lambda"], k["sigma"], k["delta"], offsets=k["offsets"])
+    np.testing.assert_allclose(y, k["expected"], rtol=k["rtol"], atol=0)
+    assert np.max(np.abs(y)) <= k["delta"] * (1 + 1e-8)
+
+
+def _norml2_prox(x, lam, gamma):
+    # ProximalOperators.NormL2 prox [ext]: max(1 - gamma*lam/||x||, 0) * x
+    nx = np.linalg.norm(x)
+    return np.zeros_like(x) if nx == 0 else max(1 - gamma * lam / nx, 0.0) * x
+
+
+def test_group_l2_equals_per_group_norml2(orc):
+    # test/runtests.jl:244-251, 318-329
+    rng = np.random.default_rng(7)
+    for trial in range(20):
+        x, q = rng.random(6), rng.random(6)
+        lam, nu = rng.random(2), rng.random()
+        y = orc.prox_group_l2(q, x, np.zeros(6), lam, nu, offsets=[0, 3, 6])
+        yp = np.concatenate([_norml2_prox((q + x)[:3], lam[0], nu), _norml2_prox((q + x)[3:], lam[1], nu)])
+        assert np.linalg.norm(y - (yp - x)) <= 1e-11
+        # NormL2 -> single group [:]
+        y1 = orc.prox_group_l2(q, x, np.zeros(6), [lam[0]], nu, offsets=[0, 6])
+        assert np.linalg.norm(y1 - (_norml2_prox(q + x, lam[0], nu) - x)) <= 1e-11
+
+
+def test_l1box_equals_softthreshold_then_clamp(orc):
+    # test/runtests.jl:814-843
+    rng = np.random.default_rng(11)
+    for trial in range(50):
+        n = 4
+        delta = 2 * rng.random()
+        q = 2 * (rng.random(n) - 0.5)
+        nu = rng.random()
+        xk = rng.random(n) - 0.5
+        st = lambda v: np.sign(v) * np.maximum(np.abs(v) - nu, 0.0)
+        p1 = np.minimum(np.maximum(st(xk + q), xk - delta), xk + delta) - xk
+        p2 = orc.prox_l1_box(q, xk, np.zeros(n), 1.0, nu, -delta, delta)
+        np.testing.assert_allclose(p1, p2, rtol=1.5e-8, atol=1e-15)
+        sj = rng.random(n) - 0.5
+        p1 = np.minimum(np.maximum(st(xk + sj + q), xk - delta), xk + delta) - (xk + sj)
+        p2 = orc.prox_l1_box(q, xk, sj, 1.0, nu, -delta, delta)
+        np.testing.assert_allclose(p1, p2, rtol=1.5e-8, atol=1e-15)
+
+
+@pytest.mark.parametrize("op", list(BOX_FN))
+def test_partial_prox(orc, op):
+    # test/partial_prox.jl:14-39: selected = 1:2:n -> selected entries equal the full prox,
+    # the others equal prox_zero = clamp(q, l - s, u - s)
+    rng = np.random.default_rng(3)
+    n = 5
+    x, s, q = rng.random(n), rng.random(n), rng.random(n) - 0.5
+    if op == "ShiftedRootNormLhalfBox":
+        l, u = -0.5, 0.5
+    else:
+        l, u = np.zeros(n), np.ones(n)
+    fn = getattr(orc, BOX_FN[op])
+    y = fn(q, x, s, 3.14, 1.0, l, u)
+    mask = orc.mask_from_selected(range(1, n + 1, 2), n)
+    z = fn(q, x, s, 3.14, 1.0, l, u, mask=mask)
+    p = np.minimum(np.maximum(q, l - s), u - s)
+    for i in range(n):
+        assert z[i] == (y[i] if mask[i] else p[i])
+
+
+def test_derived_kats(orc, kats):
+    d = kats["derived"]
+    A = d["setA_unboxed"]
+    np.testing.assert_array_equal(orc.prox_l1(A["q"], A["x"], A["s"], A["lambda"], A["sigma"]), A["ShiftedNormL1"])
+    np.testing.assert_array_equal(orc.prox_l0(A["q"], A["x"], A["s"], A["lambda"], A["sigma"]), A["ShiftedNormL0"])
+    np.testing.assert_allclose(orc.prox_lhalf(A["q"], A["x"], A["s"], A["lambda"], A["sigma"]),
+                               A["ShiftedRootNormLhalf"], rtol=1e-12)
+    # consistency link to the reference goldens: clamping the unboxed answers to +-0.01 reproduces
+    # the boxed golden vectors (runtests.jl:460-490)
+    g = kats["box_golden"]
+    for un, bx in (("ShiftedNormL1", "ShiftedNormL1Box"), ("ShiftedNormL0", "ShiftedNormL0Box"),
+                   ("ShiftedRootNormLhalf", "ShiftedRootNormLhalfBox")):
+        np.testing.assert_allclose(np.clip(A[un], -0.01, 0.01), g["expected"][bx], rtol=g["rtol"])
+    B = d["setB"]
+    y = orc.prox_l1(B["q"], B["x"], B["s"], B["lambda"], B["sigma"])
+    np.testing.assert_array_equal(y, B["ShiftedNormL1"])
+    assert np.signbit(y[6])  # -0.0 as in Julia
+    y = orc.prox_l0(B["q"], B["x"], B["s"], B["lambda"], B["sigma"])
+    np.testing.assert_array_equal(y, B["ShiftedNormL0"])
+    np.testing.assert_allclose(orc.prox_lhalf(B["q"], B["x"], B["s"], B["lambda"], B["sigma"]),
+                               B["ShiftedRootNormLhalf"], rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(orc.prox_indball_l0(B["q"], B["x"], B["s"], 3), B["ShiftedIndBallL0_r3"])
+    np.testing.assert_array_equal(orc.prox_indball_l0_binf(B["q"], B["x"], B["s"], 3, 0.6),
+                                  B["ShiftedIndBallL0BInf_r3_delta0.6"])
+    T = d["tiebreak"]
+    for r in (2, 3, 4):
+        np.testing.assert_array_equal(orc.prox_indball_l0(T["q"], T["x"], T["s"], r), T["r%d" % r])
+
+
+# ---- independent second oracle: brute-force minimisation of the prox objective over the box ----
+def _brute(obj, lo, hi, extra):
+    grid = np.linspace(lo, hi, 200001)
+    cand = np.concatenate([grid, [c for c in extra if lo <= c <= hi]])
+    return np.min(obj(cand))
+
+
+@pytest.mark.parametrize("op", list(BOX_FN))
+def test_box_prox_is_objective_minimiser(orc, op):
+    rng = np.random.default_rng(5)
+    h = {"ShiftedNormL0Box": lambda v: (v != 0).astype(float),
+         "ShiftedNormL1Box": np.abs,
+         "ShiftedRootNormLhalfBox": lambda v: np.sqrt(np.abs(v))}[op]
+    for trial in range(300):
+        x, q = rng.normal(), rng.normal()
+        s = rng.uniform(-0.5, 0.5)
+        lam, sigma = rng.uniform(0.1, 2.0), rng.uniform(0.1, 2.0)
+        l, u = -rng.uniform(0.2, 1.5), rng.uniform(0.2, 1.5)
+        if trial % 3 == 0:  # make 0 in v-space often infeasible / box tight
+            l, u = sorted((rng.normal(), rng.normal()))
+            s = rng.uniform(l, u)
+        t = getattr(orc, BOX_FN[op])([q], [x], [s], lam, sigma, l, u)[0]
+        obj = lambda tt: (tt - q) ** 2 / (2 * sigma) + lam * h(x + s + tt)
+        assert l - s - 1e-12 <= t <= u - s + 1e-12
+        best = _brute(obj, l - s, u - s, [-(x + s), q])
+        assert obj(np.array([t]))[0] <= best + 1e-9 * max(1.0, abs(best)), (op, trial, t)
+
+
+def test_unboxed_prox_is_objective_minimiser(orc):
+    rng = np.random.default_rng(6)
+    for name, h in (("prox_l1", np.abs), ("prox_l0", lambda v: (v != 0).astype(float)),
+                    ("prox_lhalf", lambda v: np.sqrt(np.abs(v)))):
+        for trial in range(200):
+            x, q, s = rng.normal(), rng.normal(), rng.uniform(-0.5, 0.5)
+            lam, sigma = rng.uniform(0.1, 2.0), rng.uniform(0.1, 2.0)
+            t = getattr(orc, name)([q], [x], [s], lam, sigma)[0]
+            obj = lambda tt: (tt - q) ** 2 / (2 * sigma) + lam * h(x + s + tt)
+            best = _brute(obj, q - 6, q + 6, [-(x + s), q])
+            assert obj(np.array([t]))[0] <= best + 1e-9 * max(1.0, abs(best)), (name, trial)
+
+
+def test_indball_l0_matches_numpy_stable_sort(orc):
+    rng = np.random.default_rng(9)
+    n = 2000
+    x, s = rng.normal(size=n), rng.uniform(-0.5, 0.5, size=n)
+    q = np.round(rng.normal(size=n) * 8) / 8  # many equal magnitudes after adding quantised x below
+    x = np.round(x * 8) / 8
+    s = np.round(s * 8) / 8
+    for r in (0, 1, 17, 500, n - 1, n, n + 5):
+        v = (x + s) + q
+        order = np.argsort(-np.abs(v), kind="stable")
+        keep = np.zeros(n, bool)
+        keep[order[:r]] = True
+        expect = np.where(keep, v, 0.0) - (x + s)
+        np.testing.assert_array_equal(orc.prox_indball_l0(q, x, s, r), expect)
+        np.testing.assert_array_equal(orc.prox_indball_l0_binf(q, x, s, r, 0.7), np.clip(expect, -0.7, 0.7))
+
+
+def test_l1_aliased_call_matches_reference_two_pass_semantics(orc):
+    # reference shiftedNormL1.jl:47 overwrites y before the loop reads q: with y === q the result is -(xk)-sj
+    import ctypes
+    x = np.array([0.5, -1.0, 2.0]); s = np.array([0.25, 0.5, -0.5]); q = np.array([3.0, -4.0, 0.1])
+    L = orc.lib()
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    L.orc_prox_l1(dp(q), dp(q), dp(x), dp(s), 3, 1.0, 1.0)
+    np.testing.assert_array_equal(q, (-x) - s)
