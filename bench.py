@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- prox! throughput of the MI355X-native shifted proximal operators.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+    ShiftedNormL1Box prox!, n = 10^8 fp64, Delta = 1.0 (scalar bounds l = -1, u = 1, every index selected),
+    twice shifted (xk ~ N(0,1), sj ~ U(-1/2, 1/2)), q ~ N(0,1), lambda = sigma = 1.  Synthetic data.
+A "step" is one prox! call over the whole n-vector.  Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n N_ELEMS] [--no-cpu] [--no-extra]
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): the operators are separable, so every rank
+owns its own contiguous n-element shard and there is NO data-path collective ("replicas / weak scaling",
+SURVEY.md 8e); the only collectives are the barrier and a MAX over ranks of the elapsed time.
+
+One JSON line on rank 0: metric/value/... plus
+  roofline      -- dominant kernel (k_sep_vec<OpL1Box>): algorithmic bytes (32 B/element) / average launch
+                   duration measured with HIP events on the launching stream over the timed region
+  cpu_baseline  -- the CPU oracle (literal single-thread C restatement of the reference's Julia loop; the
+                   reference itself cannot run here: no Julia) timed on rank 0's host core
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+BYTES_PER_ELEM = 32    # read q, xk, sj + write y (scalar bounds, no mask)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=100_000_000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary operators")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; libspx has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    s = ge.build()
+    L = s._lib.load()
+
+    n = args.n
+    gen = torch.Generator(device=dev).manual_seed(20250613 + rank)
+    xk = torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
+    sj = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) - 0.5
+    q = torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
+    y = torch.empty_like(q)
+    psi = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, s.NormLinf(1.0)), sj)
+    ctx = s.context(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        s.prox_bang(y, psi, q, 1.0)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s._lib.check(L.spx_timer_start(ctx))
+    for _ in range(args.steps):
+        s.prox_bang(y, psi, q, 1.0)
+    ms = ctypes.c_float()
+    s._lib.check(L.spx_timer_stop(ctx, ctypes.byref(ms)))  # HIP events on the launching stream
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall, ms.value], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(t[0]), float(t[1])
+    else:
+        ev_ms = float(ms.value)
+
+    total_elems = float(n) * world * args.steps
+    value = total_elems / wall / 1e9
+    launch_ms = ev_ms / args.steps
+    achieved = BYTES_PER_ELEM * n / (launch_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "prox! throughput (ShiftedNormL1Box, n=1e8 fp64 per GPU)",
+        "value": round(value, 3),
+        "unit": "G-elements/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "ShiftedNormL1Box prox!, n=%d fp64 per GPU, Delta=1.0 scalar bounds, all selected, "
+                               "twice shifted, lambda=sigma=1 (BASELINE configs[1])" % n,
+                   "elements_per_gpu": n, "parallelism": "replicas (independent shards, no collective)"},
+        "roofline": {"bound": "hbm", "kernel": "k_sep_vec<OpL1Box,4,false,false>",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "avg_launch_ms": round(launch_ms, 5), "algorithmic_bytes_per_launch": BYTES_PER_ELEM * n,
+                     "traffic": _pmc_traffic()},
+    }
+
+    if rank == 0 and not args.no_extra:
+        out["other_operators"] = _extra(s, L, ctx, dev, n, torch)
+    if rank == 0 and not args.no_cpu:
+        out["cpu_baseline"] = _cpu_baseline(s, psi, q, xk, sj, y, n, torch)
+    barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*traffic*.json), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic_l1box.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def _time_op(s, L, ctx, fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    ms = ctypes.c_float()
+    s._lib.check(L.spx_timer_start(ctx))
+    for _ in range(iters):
+        fn()
+    s._lib.check(L.spx_timer_stop(ctx, ctypes.byref(ms)))
+    return ms.value / iters
+
+
+def _extra(s, L, ctx, dev, n, torch):
+    """Secondary lines: the other BASELINE configs at full size (ms per call, G-elements/s, GB/s on the
+    algorithmic byte count)."""
+    res = {}
+    gen = torch.Generator(device=dev).manual_seed(99)
+    xk = torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
+    sj = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) - 0.5
+    q = torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
+    y = torch.empty_like(q)
+    chi = s.NormLinf(1.0)
+
+    def line(name, psi, bytes_per_elem, nel, yy, qq):
+        ms = _time_op(s, L, ctx, lambda: s.prox_bang(yy, psi, qq, 1.0))
+        res[name] = {"ms": round(ms, 4), "gelem_s": round(nel / ms / 1e6, 2),
+                     "gbs_algorithmic": round(bytes_per_elem * nel / ms / 1e6, 1),
+                     "frac_of_peak": round(bytes_per_elem * nel / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+    line("ShiftedNormL1", s.shifted(s.shifted(s.NormL1(1.0), xk), sj), 32, n, y, q)
+    line("ShiftedNormL0", s.shifted(s.shifted(s.NormL0(1.0), xk), sj), 32, n, y, q)
+    line("ShiftedNormL0Box", s.shifted(s.shifted(s.NormL0(1.0), xk, 1.0, chi), sj), 32, n, y, q)
+    line("ShiftedRootNormLhalf", s.shifted(s.shifted(s.RootNormLhalf(1.0), xk), sj), 32, n, y, q)
+    line("ShiftedRootNormLhalfBox", s.shifted(s.shifted(s.RootNormLhalf(1.0), xk, 1.0, chi), sj), 32, n, y, q)
+    lv = -1.0 - 0.1 * torch.rand(n, dtype=torch.float64, device=dev, generator=gen)
+    uv = 1.0 + 0.1 * torch.rand(n, dtype=torch.float64, device=dev, generator=gen)
+    line("ShiftedNormL1Box_vector_bounds", s.shifted(s.shifted(s.NormL1(1.0), xk, lv, uv), sj), 48, n, y, q)
+    del lv, uv
+    r = max(1, n // 100)
+    line("ShiftedIndBallL0BInf_r=n/100", s.shifted(s.shifted(s.IndBallL0(r), xk, 1.0, chi), sj), 32, n, y, q)
+    # group config: (n // 100) groups of 128  (10^6 x 128 at n = 10^8)
+    ng = max(1, n // 100)
+    m = ng * 128
+    del xk, sj, q, y
+    torch.cuda.empty_cache()
+    xk = torch.randn(m, dtype=torch.float64, device=dev, generator=gen)
+    sj = torch.rand(m, dtype=torch.float64, device=dev, generator=gen) - 0.5
+    q = torch.randn(m, dtype=torch.float64, device=dev, generator=gen)
+    y = torch.empty_like(q)
+    lam = torch.rand(ng, dtype=torch.float64, device=dev, generator=gen) + 0.5
+    h = s.GroupNormL2(lam, [range(i, i + 128) for i in range(0, m, 128)])
+    bpe = 32 + 8 / 128
+    line("ShiftedGroupNormL2_%dx128" % ng, s.shifted(s.shifted(h, xk), sj), bpe, m, y, q)
+    line("ShiftedGroupNormL2Binf_%dx128" % ng, s.shifted(s.shifted(h, xk, 1.0, chi), sj), bpe, m, y, q)
+    return res
+
+
+def _cpu_baseline(s, psi, q, xk, sj, y, n, torch):
+    """The CPU oracle = literal C restatement of src/shiftedNormL1Box.jl:89-125, one thread (the reference
+    is single-threaded Julia), on a bounded sample of the same workload; also used as a parity spot check."""
+    from oracle import oracle
+    import numpy as np
+    m = min(n, 100_000_000)
+    qh, xh, sh = (t[:m].cpu().numpy() for t in (q, xk, sj))
+    best = None
+    reps = 0
+    t_all = time.perf_counter()
+    while reps < 3 and (time.perf_counter() - t_all) < 20.0:
+        t0 = time.perf_counter()
+        ref = oracle.prox_l1_box(qh, xh, sh, 1.0, 1.0, -1.0, 1.0)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    s.prox_bang(y, psi, q, 1.0)
+    same = bool(np.array_equal(y[:m].cpu().numpy().view(np.int64), ref.view(np.int64)))
+    return {"value": round(m / best / 1e9, 4), "unit": "G-elements/s", "cores": 1, "kind": "port",
+            "host_cores_available": os.cpu_count(),
+            "sample": "first %d elements of the same workload, best of %d runs (%.2f s each)" % (m, reps, best),
+            "note": "reference (Julia) cannot run in this image; port = oracle/spx_oracle.c, gcc -O2 -ffp-contract=off",
+            "gpu_bit_exact_on_sample": same}
+
+
+if __name__ == "__main__":
+    main()

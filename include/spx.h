@@ -1,0 +1,135 @@
+/*
+ * spx.h -- C ABI of libspx: MI355X (gfx950) shifted proximal operators, fp64.
+ *
+ * This is the drop-in boundary for the prox!() hot path of ShiftedProximalOperators.jl v0.2.2
+ * (reference paths below are relative to the reference repository).  In the reference the path sits
+ * behind Julia multiple dispatch,
+ *     prox!(y::AbstractVector{R}, psi::<ShiftedType>, q::AbstractVector{R}, sigma::R) -> y
+ * (src/ShiftedProximalOperators.jl:135-152; one method per operator, cited at each entry point).
+ * A Julia maintainer binds these entry points with `ccall` from `prox!` methods specialised on
+ * device-array-backed psi (julia/SPXShim.jl); this repository's own host-side mirror
+ * of the reference API (Python, ctypes) binds exactly the same symbols.
+ *
+ * Conventions
+ *   - Every data pointer is a DEVICE pointer to contiguous float64 (or as typed) memory on the
+ *     context's device.  Nothing is retained past a call; the caller owns all vectors
+ *     (the reference borrows xk/sj/l/u by reference too: src/shiftedNormL1Box.jl:22-47).
+ *   - `y` may alias `q` exactly (test/test_allocs.jl:108-113) and may be the operator's own `sol`
+ *     (prox(), src/ShiftedProximalOperators.jl:189-190).  Partial overlap is undefined.
+ *   - Calls are asynchronous on the context's HIP stream and ordered on it; spx_sync() waits.
+ *     A context is not re-entrant (neither is a reference psi: shared scratch sol/xsy/p).
+ *   - Return value: 0 = SPX_OK, else an spx_status; spx_last_error() gives a thread-local message.
+ *   - Indices handed over in arrays (selected sets, group offsets) are 0-BASED int64.
+ *   - Floating-point semantics: no FMA contraction, reference operation order; min/max follow
+ *     Julia (IEEE-754-2019 minimum/maximum).  L1/L0 families and the IndBallL0 selection are
+ *     bit-exact w.r.t. the reference formulas; Lhalf and group-L2 families agree to <= 1e-12 relative.
+ */
+#ifndef SPX_H
+#define SPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPX_ABI_VERSION 1
+
+typedef enum spx_status {
+  SPX_OK = 0,
+  SPX_ERR_INVALID_ARG = 1, /* NULL pointer, negative length, bad group description ...            */
+  SPX_ERR_BOUNDS = 2,      /* reserved for "at least one lower bound is greater than the upper"   */
+  SPX_ERR_HIP = 3,         /* a HIP runtime call failed (message has the HIP error string)        */
+  SPX_ERR_ALLOC = 4,       /* workspace allocation failed                                         */
+  SPX_ERR_NO_DEVICE = 5    /* no usable gfx950 device                                             */
+} spx_status;
+
+typedef struct spx_ctx spx_ctx; /* opaque: device id, HIP stream, library-owned scratch */
+
+/* ---- library / context ------------------------------------------------------------------- */
+int spx_abi_version(void);
+const char* spx_last_error(void);
+
+/* device: HIP device ordinal.  spx_ctx_create: the context creates and owns a non-blocking stream.
+ * spx_ctx_create_on_stream: enqueue on the caller's hipStream_t (passed as void*; NULL = the legacy
+ * default stream), e.g. the array library's current stream, so that calls are ordered with the
+ * caller's own kernels; the stream is borrowed, never destroyed. */
+int spx_ctx_create(int device, spx_ctx** out);
+int spx_ctx_create_on_stream(int device, void* stream, spx_ctx** out);
+int spx_ctx_destroy(spx_ctx* ctx);
+int spx_sync(spx_ctx* ctx);
+/* HIP-event stopwatch on the context's stream (used by bench.py for per-launch durations). */
+int spx_timer_start(spx_ctx* ctx);
+int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms); /* records stop, waits, returns milliseconds */
+
+/* Kernel-benchmark knob, not part of the reference API: key 0 = workgroups per CU of the separable grid
+ * (1..64), key 1 = non-temporal loads/stores (0/1).  Process-wide. */
+int spx_set_tuning(int key, int value);
+
+/* ---- construction-time helpers (the reference's constructors) ---------------------------- */
+/* any(l .> u) of the Box constructors (src/shiftedNormL1Box.jl:33-35, shiftedNormL0Box.jl:33-35).
+ * Vector bound if the pointer is non-NULL, else the scalar.  Synchronous; *any_l_gt_u = 0/1. */
+int spx_check_bounds(spx_ctx* ctx, const double* l_vec, const double* u_vec, double l_scalar,
+                     double u_scalar, int64_t n, int* any_l_gt_u);
+/* Byte mask of the `selected` index set (src/shiftedNormL1Box.jl:106 `i in psi.selected`): mask[i] = 1
+ * iff i occurs in selected[0..nsel) (0-based, any order, duplicates allowed, out-of-range ignored). */
+int spx_build_mask(spx_ctx* ctx, uint8_t* mask, int64_t n, const int64_t* selected, int64_t nsel);
+
+/* ---- separable operators: y[i] depends on q[i], xk[i], sj[i] only ------------------------- */
+/* ShiftedNormL1.prox!        src/shiftedNormL1.jl:40-54 */
+int spx_prox_l1(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                int64_t n, double lambda, double sigma);
+/* ShiftedNormL0.prox!        src/shiftedNormL0.jl:38-55 */
+int spx_prox_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                int64_t n, double lambda, double sigma);
+/* ShiftedRootNormLhalf.prox! src/shiftedRootNormLhalf.jl:41-63 */
+int spx_prox_lhalf(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                   int64_t n, double lambda, double sigma);
+
+/* Box forms.  Bounds: l_vec/u_vec (length n) if non-NULL, else l_scalar/u_scalar
+ * (`isa(psi.l, Real) ? psi.l : psi.l[i]`).  sel_mask: byte per index (1 = selected), NULL = all
+ * selected; unselected entries get prox_zero = clamp(q, l - s, u - s)
+ * (src/ShiftedProximalOperators.jl:203). */
+/* ShiftedNormL1Box.prox!        src/shiftedNormL1Box.jl:89-125  (BASELINE headline operator) */
+int spx_prox_l1_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                    int64_t n, double lambda, double sigma, const double* l_vec, const double* u_vec,
+                    double l_scalar, double u_scalar, const uint8_t* sel_mask);
+/* ShiftedNormL0Box.prox!        src/shiftedNormL0Box.jl:89-131 */
+int spx_prox_l0_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                    int64_t n, double lambda, double sigma, const double* l_vec, const double* u_vec,
+                    double l_scalar, double u_scalar, const uint8_t* sel_mask);
+/* ShiftedRootNormLhalfBox.prox! src/shiftedRootNormLhalfBox.jl:86-120 */
+int spx_prox_lhalf_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                       int64_t n, double lambda, double sigma, const double* l_vec,
+                       const double* u_vec, double l_scalar, double u_scalar,
+                       const uint8_t* sel_mask);
+
+/* ---- top-r selection ------------------------------------------------------------------- */
+/* ShiftedIndBallL0.prox!     src/shiftedIndBallL0.jl:54-72 : keep the r entries of (xk+sj)+q largest in
+ * magnitude (ties: lowest index first, = stable sortperm), zero the rest, subtract xk+sj. */
+int spx_prox_indball_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                        int64_t n, int64_t r);
+/* ShiftedIndBallL0BInf.prox! src/shiftedIndBallL0BInf.jl:73-95 : as above, then clamp y to [-delta, delta]. */
+int spx_prox_indball_l0_binf(spx_ctx* ctx, double* y, const double* q, const double* xk,
+                             const double* sj, int64_t n, int64_t r, double delta);
+
+/* ---- group operators -------------------------------------------------------------------- */
+/* Groups are contiguous index ranges (the reference's `idx` entries as UnitRanges / [:]):
+ *   group_offsets != NULL : CSR offsets (device, int64, length ngroups+1, 0-based, non-decreasing,
+ *                           offsets[0] >= 0, offsets[ngroups] <= n); group g = [off[g], off[g+1])
+ *   group_offsets == NULL : uniform groups of group_size, ngroups * group_size == n.
+ * lambda_vec: device, length ngroups (GroupNormL2.lambda, src/groupNormL2.jl:15-28). */
+/* ShiftedGroupNormL2.prox!     src/shiftedGroupNormL2.jl:52-79 */
+int spx_prox_group_l2(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                      int64_t n, const int64_t* group_offsets, int64_t group_size, int64_t ngroups,
+                      const double* lambda_vec, double sigma);
+/* ShiftedGroupNormL2Binf.prox! src/shiftedGroupNormL2Binf.jl:67-119 */
+int spx_prox_group_l2_binf(spx_ctx* ctx, double* y, const double* q, const double* xk,
+                           const double* sj, int64_t n, const int64_t* group_offsets,
+                           int64_t group_size, int64_t ngroups, const double* lambda_vec,
+                           double sigma, double delta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPX_H */

@@ -1,0 +1,176 @@
+// spx_ctx.hip -- context, errors, stopwatch and the construction-time helpers of the C ABI.
+#include "spx_common.hpp"
+
+static thread_local char g_err[512] = "";
+
+void spx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+SPX_EXPORT int spx_abi_version(void) { return SPX_ABI_VERSION; }
+SPX_EXPORT const char* spx_last_error(void) { return g_err; }
+
+static int ctx_create_impl(int device, bool borrow, void* stream, spx_ctx** out) {
+  SPX_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    spx_set_error("no HIP device visible; libspx has no CPU path");
+    return SPX_ERR_NO_DEVICE;
+  }
+  SPX_REQUIRE(device >= 0 && device < count, "device ordinal out of range");
+  SPX_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  SPX_HIP(hipGetDeviceProperties(&prop, device));
+  spx_ctx* c = new spx_ctx();
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (borrow) {
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+    c->owns_stream = false;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      spx_set_error("hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+      return SPX_ERR_HIP;
+    }
+    c->owns_stream = true;
+  }
+  if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+    spx_set_error("hipEventCreate failed");
+    delete c;
+    return SPX_ERR_HIP;
+  }
+  *out = c;
+  return SPX_OK;
+}
+
+SPX_EXPORT int spx_ctx_create(int device, spx_ctx** out) { return ctx_create_impl(device, false, nullptr, out); }
+SPX_EXPORT int spx_ctx_create_on_stream(int device, void* stream, spx_ctx** out) {
+  return ctx_create_impl(device, true, stream, out);
+}
+
+SPX_EXPORT int spx_ctx_destroy(spx_ctx* ctx) {
+  if (!ctx) return SPX_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return SPX_OK;
+}
+
+SPX_EXPORT int spx_sync(spx_ctx* ctx) {
+  SPX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  SPX_HIP(hipStreamSynchronize(ctx->stream));
+  return SPX_OK;
+}
+
+SPX_EXPORT int spx_timer_start(spx_ctx* ctx) {
+  SPX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  SPX_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+  return SPX_OK;
+}
+
+SPX_EXPORT int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms) {
+  SPX_REQUIRE(ctx != nullptr && elapsed_ms != nullptr, "ctx or elapsed_ms is NULL");
+  SPX_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
+  SPX_HIP(hipEventSynchronize(ctx->ev_stop));
+  SPX_HIP(hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+  return SPX_OK;
+}
+
+// Grows the context scratch.  Called from entry points BEFORE any launch of that call; growing
+// synchronises the stream (the old block may still be in use by earlier calls).
+int spx_ws_reserve(spx_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return SPX_OK;
+  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->ws) SPX_HIP(hipFree(ctx->ws));
+  ctx->ws = nullptr;
+  ctx->ws_bytes = 0;
+  hipError_t e = hipMalloc(&ctx->ws, bytes);
+  if (e != hipSuccess) {
+    spx_set_error("workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return SPX_ERR_ALLOC;
+  }
+  ctx->ws_bytes = bytes;
+  return SPX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// any(l .> u)      src/shiftedNormL1Box.jl:33-35, src/shiftedNormL0Box.jl:33-35
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_check_bounds(const double* __restrict__ l, const double* __restrict__ u,
+                                                       double ls, double us, int64_t n, int* __restrict__ flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; i < n; i += stride) {
+    double li = l ? l[i] : ls;
+    double ui = u ? u[i] : us;
+    bad |= (li > ui);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+SPX_EXPORT int spx_check_bounds(spx_ctx* ctx, const double* l_vec, const double* u_vec, double l_scalar,
+                                double u_scalar, int64_t n, int* any_l_gt_u) {
+  SPX_REQUIRE(ctx != nullptr && any_l_gt_u != nullptr, "ctx or result pointer is NULL");
+  SPX_REQUIRE(n >= 0, "n < 0");
+  *any_l_gt_u = 0;
+  if (!l_vec && !u_vec) {  // both scalar: `any(l .> u)` on two scalars
+    *any_l_gt_u = (l_scalar > u_scalar) ? 1 : 0;
+    return SPX_OK;
+  }
+  if (n == 0) return SPX_OK;
+  int rc = spx_ws_reserve(ctx, 256);
+  if (rc) return rc;
+  SPX_HIP(hipSetDevice(ctx->device));
+  int* flag = reinterpret_cast<int*>(ctx->ws);
+  SPX_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 8 * (int64_t)ctx->num_cu) blocks = 8 * (int64_t)ctx->num_cu;
+  hipLaunchKernelGGL(k_check_bounds, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, l_vec, u_vec, l_scalar,
+                     u_scalar, n, flag);
+  SPX_LAUNCH_CHECK();
+  SPX_HIP(hipMemcpyAsync(any_l_gt_u, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  SPX_HIP(hipStreamSynchronize(ctx->stream));
+  return SPX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// selected -> byte mask    (`i in psi.selected`, src/shiftedNormL1Box.jl:106)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter_mask(uint8_t* __restrict__ mask, int64_t n,
+                                                       const int64_t* __restrict__ sel, int64_t nsel) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; k < nsel; k += stride) {
+    int64_t i = sel[k];
+    if (i >= 0 && i < n) mask[i] = 1;  // duplicates write the same byte
+  }
+}
+
+SPX_EXPORT int spx_build_mask(spx_ctx* ctx, uint8_t* mask, int64_t n, const int64_t* selected, int64_t nsel) {
+  SPX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  SPX_REQUIRE(n >= 0 && nsel >= 0, "negative length");
+  if (n == 0) return SPX_OK;
+  SPX_REQUIRE(mask != nullptr, "mask is NULL");
+  SPX_REQUIRE(nsel == 0 || selected != nullptr, "selected is NULL");
+  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_HIP(hipMemsetAsync(mask, 0, (size_t)n, ctx->stream));
+  if (nsel > 0) {
+    int64_t blocks = (nsel + 255) / 256;
+    if (blocks > 8 * (int64_t)ctx->num_cu) blocks = 8 * (int64_t)ctx->num_cu;
+    hipLaunchKernelGGL(k_scatter_mask, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, mask, n, selected, nsel);
+    SPX_LAUNCH_CHECK();
+  }
+  return SPX_OK;
+}

@@ -1,0 +1,356 @@
+// spx_separable.hip -- the six separable prox! kernels (ShiftedNormL1/L0/RootNormLhalf and their Box
+// forms).  One streaming skeleton, one functor per operator.
+//
+// HBM layout: q, xk, sj, y (and l, u when they are vectors) are plain contiguous fp64 vectors.
+// Algorithmic traffic: 3 reads + 1 write = 32 B/element (48 B with vector bounds, +1 B with a mask).
+// Roofline: HBM bandwidth (no reuse, no contraction -> MFMA not applicable).
+//
+// Skeleton: a workgroup of 256 lanes walks tiles of 256*UNROLL 16-byte pairs with a block stride.
+// Within a tile every wave instruction touches 1 KiB contiguous (lane i -> base + 16*i), all
+// 3*UNROLL loads of a tile are issued before the first use so each lane keeps 3*UNROLL*16 B in
+// flight, results are written with 16-byte stores.  q[i] is read before y[i] is written by the same
+// lane and no other lane touches index i, so y may alias q.
+#include <cmath>
+
+#include "spx_common.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// per-element operators.  Signature: (q, x, s, l, u, selected) -> y.  Unboxed ones ignore l, u, selected.
+// Every expression keeps the reference's association (cited); the library is built with
+// -ffp-contract=off so a*b+c never becomes an FMA.
+// ---------------------------------------------------------------------------------------------
+struct OpL1 {  // src/shiftedNormL1.jl:46-51
+  double ls;   // lambda * sigma
+  static constexpr bool kBox = false;
+  __device__ __forceinline__ double operator()(double q, double x, double s, double, double, bool) const {
+    double t = (-x) - s;                          // :47  @. y = -xk - sj
+    return jl_min(jl_max(t, q - ls), q + ls);     // :50
+  }
+};
+struct OpL1Aliased {  // y === q in the reference: the broadcast at :47 overwrites q before :50 reads it
+  static constexpr bool kBox = false;
+  __device__ __forceinline__ double operator()(double, double x, double s, double, double, bool) const {
+    return (-x) - s;  // min(max(t, t - ls), t + ls) == t bit for bit whenever ls >= 0
+  }
+};
+struct OpL0 {  // src/shiftedNormL0.jl:45-52
+  double c;    // sqrt(2 * lambda * sigma)
+  static constexpr bool kBox = false;
+  __device__ __forceinline__ double operator()(double q, double x, double s, double, double, bool) const {
+    double xps = x + s;
+    return (fabs(xps + q) <= c) ? -xps : q;
+  }
+};
+struct OpL1Box {  // src/shiftedNormL1Box.jl:96-122
+  double sl;      // sigma * lambda
+  static constexpr bool kBox = true;
+  __device__ __forceinline__ double operator()(double q, double x, double s, double l, double u, bool sel) const {
+    double xs = x + s;
+    double xsq = xs + q;
+    double t = (xsq <= -sl) ? (q + sl) : ((xsq >= sl) ? (q - sl) : -xs);  // :111-117
+    t = sel ? t : q;                                                       // :121 prox_zero(qi, ...)
+    return jl_min(jl_max(t, l - s), u - s);                                // :118
+  }
+};
+struct OpL0Box {  // src/shiftedNormL0Box.jl:96-128
+  double c;       // 2 * lambda * sigma
+  static constexpr bool kBox = true;
+  __device__ __forceinline__ double operator()(double q, double x, double s, double l, double u, bool sel) const {
+    double sq = s + q;
+    double xs = x + s;
+    double xsq = xs + q;
+    double dl = l - sq, du = u - sq;
+    double val_left = dl * dl + ((x == -l) ? 0.0 : c);   // :110
+    double val_right = du * du + ((x == -u) ? 0.0 : c);  // :111
+    double yi = (val_left < val_right) ? (l - s) : (u - s);  // :114
+    double val_min = jl_min(val_left, val_right);
+    double mx = -x;
+    if (l <= mx && mx <= u) {  // :116
+      double val_0 = xsq * xsq;
+      yi = (val_0 < val_min) ? -xs : yi;
+      val_min = jl_min(val_0, val_min);
+    }
+    if (l <= sq && sq <= u) {  // :121
+      double val_xsq = (xsq == 0.0) ? 0.0 : c;
+      yi = (val_xsq < val_min) ? q : yi;
+    }
+    return sel ? yi : prox_zero(q, l - s, u - s);  // :127
+  }
+};
+
+// (2/3) sign(z) |z| (1 + cos(2pi/3 - (2/3) acos(a))),  a = (sl/4) (|z|/3)^(-3/2)
+// src/shiftedRootNormLhalf.jl:48,57 and src/shiftedRootNormLhalfBox.jl:92,106 (real branch, a <= 1)
+__device__ __forceinline__ double lhalf_val(double z, double az, double sl4) {
+  const double twopi3 = 2.0943951023931953;  // 2 * pi / 3 rounded once, as Julia's 2 * pi / 3
+  double a = sl4 * pow(az / 3, -1.5);
+  double phi = acos(a);
+  return 2 * jl_sign(z) / 3 * az * (1 + cos(twopi3 - 2 * phi / 3));
+}
+struct OpLhalf {  // src/shiftedRootNormLhalf.jl:47-60
+  double sl4;     // (sigma * lambda) / 4
+  double p;       // 54^(1/3) * (2 sigma lambda)^(2/3) / 4
+  static constexpr bool kBox = false;
+  __device__ __forceinline__ double operator()(double q, double x, double s, double, double, bool) const {
+    double xs = x + s;
+    double sol = q + xs;  // :50
+    double aq = fabs(sol);
+    double yi = (aq <= p) ? 0.0 : lhalf_val(sol, aq, sl4);
+    return yi - xs;  // :59
+  }
+};
+struct OpLhalfBox {  // src/shiftedRootNormLhalfBox.jl:92-117
+  double sl4;        // sigma * lambda / 4
+  double lambda, sigma;
+  static constexpr bool kBox = true;
+  __device__ __forceinline__ double rnorm(double tt, double q, double xs) const {  // :95
+    double d = tt - q;
+    return d * d / 2 / sigma + lambda * sqrt(fabs(tt + xs));
+  }
+  __device__ __forceinline__ double operator()(double q, double x, double s, double l, double u, bool sel) const {
+    double xs = x + s;  // :94
+    double xsq = xs + q;
+    double axsq = fabs(xsq);
+    double tl = l - s, tu = u - s;
+    // candidates 1..3 (:109-111); findmin keeps the FIRST minimum -> strict < when a later one replaces
+    double best = rnorm(tl, q, xs);
+    double yi = tl;
+    double c2 = rnorm(tu, q, xs);
+    if (c2 < best) { best = c2; yi = tu; }
+    double mx = -x;
+    if (l <= mx && mx <= u) {
+      double c3 = rnorm(-xs, q, xs);
+      if (c3 < best) { best = c3; yi = -xs; }
+    }
+    // candidate 4 (:106,:112): the stationary point.  When the acos argument a exceeds 1 the reference
+    // takes the real part of a complex expression, which is not a stationary point; the objective is
+    // then V-shaped around v = 0 so that candidate can never be strictly smaller than the first three
+    // (DESIGN.md "RootNormLhalfBox, a > 1") and is skipped here.  a is NaN for xsq == 0 -> skipped too,
+    // as in the reference (`li <= NaN <= ui` is false).
+    double a = sl4 * pow(axsq / 3, -1.5);
+    if (a <= 1.0) {
+      const double twopi3 = 2.0943951023931953;
+      double val = 2 * jl_sign(xsq) / 3 * axsq * (1 + cos(twopi3 - 2 * acos(a) / 3));
+      double vx = val - x;
+      if (l <= vx && vx <= u) {
+        double c4 = rnorm(val - xs, q, xs);
+        if (c4 < best) { best = c4; yi = val - xs; }
+      }
+    }
+    return sel ? yi : prox_zero(q, tl, tu);  // :116
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// streaming skeleton
+// ---------------------------------------------------------------------------------------------
+template <bool NT>
+__device__ __forceinline__ f64x2 ld2(const f64x2* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st2(f64x2* p, f64x2 v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+// n2 = number of 16-byte pairs.  VECB: l/u are vectors.  MASK: sel mask present.
+template <class Op, int UNROLL, bool VECB, bool MASK, bool NT>
+__global__ __launch_bounds__(256) void k_sep_vec(double* y_, const double* q_, const double* xk_, const double* sj_,
+                                                  const double* l_, const double* u_, const uint8_t* mask_,
+                                                  double ls, double us, int64_t n2, Op op) {
+  constexpr int64_t TILE = 256 * UNROLL;
+  f64x2* y = reinterpret_cast<f64x2*>(y_);
+  const f64x2* q = reinterpret_cast<const f64x2*>(q_);
+  const f64x2* xk = reinterpret_cast<const f64x2*>(xk_);
+  const f64x2* sj = reinterpret_cast<const f64x2*>(sj_);
+  const f64x2* lv = reinterpret_cast<const f64x2*>(l_);
+  const f64x2* uv = reinterpret_cast<const f64x2*>(u_);
+  const uint16_t* mk = reinterpret_cast<const uint16_t*>(mask_);
+  const int64_t ntiles = (n2 + TILE - 1) / TILE;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t base = tile * TILE + threadIdx.x;
+    f64x2 vq[UNROLL], vx[UNROLL], vs[UNROLL], vl[UNROLL], vu[UNROLL];
+    uint16_t vm[UNROLL];
+    if (base - threadIdx.x + TILE <= n2) {
+#pragma unroll
+      for (int k = 0; k < UNROLL; ++k) {
+        const int64_t i = base + k * 256;
+        vq[k] = ld2<NT>(q + i);
+        vx[k] = ld2<NT>(xk + i);
+        vs[k] = ld2<NT>(sj + i);
+        if constexpr (VECB && Op::kBox) {
+          vl[k] = l_ ? ld2<NT>(lv + i) : f64x2{ls, ls};
+          vu[k] = u_ ? ld2<NT>(uv + i) : f64x2{us, us};
+        }
+        if constexpr (MASK && Op::kBox) vm[k] = mk[i];
+      }
+#pragma unroll
+      for (int k = 0; k < UNROLL; ++k) {
+        const int64_t i = base + k * 256;
+        double l0 = ls, l1 = ls, u0 = us, u1 = us;
+        bool s0 = true, s1 = true;
+        if constexpr (VECB && Op::kBox) { l0 = vl[k].x; l1 = vl[k].y; u0 = vu[k].x; u1 = vu[k].y; }
+        if constexpr (MASK && Op::kBox) { s0 = (vm[k] & 0xff) != 0; s1 = (vm[k] >> 8) != 0; }
+        f64x2 r;
+        r.x = op(vq[k].x, vx[k].x, vs[k].x, l0, u0, s0);
+        r.y = op(vq[k].y, vx[k].y, vs[k].y, l1, u1, s1);
+        st2<NT>(y + i, r);
+      }
+    } else {  // last, partial tile
+#pragma unroll
+      for (int k = 0; k < UNROLL; ++k) {
+        const int64_t i = base + k * 256;
+        if (i < n2) {
+          f64x2 a = q[i], b = xk[i], c = sj[i];
+          double l0 = ls, l1 = ls, u0 = us, u1 = us;
+          bool s0 = true, s1 = true;
+          if constexpr (VECB && Op::kBox) {
+            if (l_) { f64x2 t = lv[i]; l0 = t.x; l1 = t.y; }
+            if (u_) { f64x2 t = uv[i]; u0 = t.x; u1 = t.y; }
+          }
+          if constexpr (MASK && Op::kBox) { uint16_t m = mk[i]; s0 = (m & 0xff) != 0; s1 = (m >> 8) != 0; }
+          f64x2 r;
+          r.x = op(a.x, b.x, c.x, l0, u0, s0);
+          r.y = op(a.y, b.y, c.y, l1, u1, s1);
+          y[i] = r;
+        }
+      }
+    }
+  }
+}
+
+// scalar path: unaligned vectors, and the odd last element of the vector path ([begin, n))
+template <class Op>
+__global__ __launch_bounds__(256) void k_sep_scalar(double* y, const double* q, const double* xk, const double* sj,
+                                                     const double* l_, const double* u_, const uint8_t* mask,
+                                                     double ls, double us, int64_t begin, int64_t n, Op op) {
+  int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    double li = l_ ? l_[i] : ls;
+    double ui = u_ ? u_[i] : us;
+    bool sel = mask ? (mask[i] != 0) : true;
+    y[i] = op(q[i], xk[i], sj[i], li, ui, sel);
+  }
+}
+
+static int g_sep_blocks_per_cu = 8;  // tuning knobs (spx_set_tuning)
+static int g_sep_nt = 0;
+
+template <class Op, bool VECB, bool MASK>
+static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, const double* l,
+                      const double* u, const uint8_t* mask, double ls, double us, int64_t n2, Op op) {
+  constexpr int UNROLL = 4;
+  const int64_t ntiles = (n2 + 256 * UNROLL - 1) / (256 * UNROLL);
+  int64_t blocks = ntiles;
+  const int64_t cap = (int64_t)ctx->num_cu * g_sep_blocks_per_cu;
+  if (blocks > cap) blocks = cap;
+  if (g_sep_nt)
+    hipLaunchKernelGGL((k_sep_vec<Op, UNROLL, VECB, MASK, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y,
+                       q, xk, sj, l, u, mask, ls, us, n2, op);
+  else
+    hipLaunchKernelGGL((k_sep_vec<Op, UNROLL, VECB, MASK, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       y, q, xk, sj, l, u, mask, ls, us, n2, op);
+  SPX_LAUNCH_CHECK();
+  return SPX_OK;
+}
+
+template <class Op>
+static int run_separable(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                         const double* l, const double* u, double ls, double us, const uint8_t* mask, Op op) {
+  if (n == 0) return SPX_OK;
+  SPX_HIP(hipSetDevice(ctx->device));
+  bool vec_ok = spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj) &&
+                (!l || spx_aligned16(l)) && (!u || spx_aligned16(u)) &&
+                (!mask || (reinterpret_cast<uintptr_t>(mask) & 1u) == 0);
+  int64_t done = 0;
+  if (vec_ok && n >= 2) {
+    const int64_t n2 = n / 2;
+    int rc;
+    if constexpr (Op::kBox) {
+      const bool vecb = (l || u);
+      const bool msk = (mask != nullptr);
+      if (vecb && msk) rc = launch_vec<Op, true, true>(ctx, y, q, xk, sj, l, u, mask, ls, us, n2, op);
+      else if (vecb) rc = launch_vec<Op, true, false>(ctx, y, q, xk, sj, l, u, mask, ls, us, n2, op);
+      else if (msk) rc = launch_vec<Op, false, true>(ctx, y, q, xk, sj, l, u, mask, ls, us, n2, op);
+      else rc = launch_vec<Op, false, false>(ctx, y, q, xk, sj, l, u, mask, ls, us, n2, op);
+    } else {
+      rc = launch_vec<Op, false, false>(ctx, y, q, xk, sj, l, u, mask, ls, us, n2, op);
+    }
+    if (rc) return rc;
+    done = 2 * n2;
+  }
+  if (done < n) {
+    int64_t rem = n - done;
+    int64_t blocks = (rem + 255) / 256;
+    const int64_t cap = (int64_t)ctx->num_cu * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((k_sep_scalar<Op>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj, l, u,
+                       mask, ls, us, done, n, op);
+    SPX_LAUNCH_CHECK();
+  }
+  return SPX_OK;
+}
+
+// undocumented-in-reference tuning hook used by the kernel benchmarks: key 0 = workgroups per CU of the
+// separable grid, key 1 = non-temporal loads/stores on/off.
+SPX_EXPORT int spx_set_tuning(int key, int value) {
+  if (key == 0 && value >= 1 && value <= 64) { g_sep_blocks_per_cu = value; return SPX_OK; }
+  if (key == 1) { g_sep_nt = value ? 1 : 0; return SPX_OK; }
+  spx_set_error("invalid argument: unknown tuning key/value");
+  return SPX_ERR_INVALID_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C entry points
+// ---------------------------------------------------------------------------------------------
+SPX_EXPORT int spx_prox_l1(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                           double lambda, double sigma) {
+  int rc = spx_check_common(ctx, y, q, xk, sj, n);
+  if (rc) return rc;
+  if (y == q && lambda * sigma >= 0.0)  // the reference's two-pass body with y === q (see OpL1Aliased)
+    return run_separable(ctx, y, q, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, OpL1Aliased{});
+  return run_separable(ctx, y, q, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, OpL1{lambda * sigma});
+}
+
+SPX_EXPORT int spx_prox_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                           double lambda, double sigma) {
+  int rc = spx_check_common(ctx, y, q, xk, sj, n);
+  if (rc) return rc;
+  return run_separable(ctx, y, q, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, OpL0{std::sqrt(2 * lambda * sigma)});
+}
+
+SPX_EXPORT int spx_prox_lhalf(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                              double lambda, double sigma) {
+  int rc = spx_check_common(ctx, y, q, xk, sj, n);
+  if (rc) return rc;
+  const double nl = sigma * lambda;
+  const double p = std::pow(54.0, 1.0 / 3.0) * std::pow(2 * nl, 2.0 / 3.0) / 4;  // shiftedRootNormLhalf.jl:49
+  return run_separable(ctx, y, q, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, OpLhalf{nl / 4, p});
+}
+
+SPX_EXPORT int spx_prox_l1_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                               double lambda, double sigma, const double* l_vec, const double* u_vec, double l_scalar,
+                               double u_scalar, const uint8_t* sel_mask) {
+  int rc = spx_check_common(ctx, y, q, xk, sj, n);
+  if (rc) return rc;
+  return run_separable(ctx, y, q, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask, OpL1Box{sigma * lambda});
+}
+
+SPX_EXPORT int spx_prox_l0_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                               double lambda, double sigma, const double* l_vec, const double* u_vec, double l_scalar,
+                               double u_scalar, const uint8_t* sel_mask) {
+  int rc = spx_check_common(ctx, y, q, xk, sj, n);
+  if (rc) return rc;
+  return run_separable(ctx, y, q, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask, OpL0Box{2 * lambda * sigma});
+}
+
+SPX_EXPORT int spx_prox_lhalf_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                                  int64_t n, double lambda, double sigma, const double* l_vec, const double* u_vec,
+                                  double l_scalar, double u_scalar, const uint8_t* sel_mask) {
+  int rc = spx_check_common(ctx, y, q, xk, sj, n);
+  if (rc) return rc;
+  return run_separable(ctx, y, q, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask,
+                       OpLhalfBox{sigma * lambda / 4, lambda, sigma});
+}

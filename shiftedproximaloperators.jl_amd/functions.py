@@ -1,0 +1,97 @@
+"""Value types of the proximable functions h that the shifted operators wrap.
+
+NormL0 / NormL1 / NormL2 / IndBallL0 / NormLinf come from ProximalOperators.jl in the reference
+(Project.toml:6-12; only their fields `lambda` / `r` are used on the prox! path); RootNormLhalf and
+GroupNormL2 are defined by the reference itself (src/rootNormLhalf.jl:14-25, src/groupNormL2.jl:15-31).
+Constructor checks and messages follow those files.
+"""
+
+
+class ProximableFunction:
+    pass
+
+
+class NormL0(ProximableFunction):
+    def __init__(self, lam=1.0):
+        if lam < 0:
+            raise ValueError("parameter λ must be nonnegative")
+        self.lam = float(lam)
+
+    lambda_ = property(lambda self: self.lam)
+
+
+class NormL1(ProximableFunction):
+    def __init__(self, lam=1.0):
+        if lam < 0:
+            raise ValueError("parameter λ must be nonnegative")
+        self.lam = float(lam)
+
+    lambda_ = property(lambda self: self.lam)
+
+
+class NormL2(ProximableFunction):
+    def __init__(self, lam=1.0):
+        if lam < 0:
+            raise ValueError("parameter λ must be nonnegative")
+        self.lam = float(lam)
+
+    lambda_ = property(lambda self: self.lam)
+
+
+class NormLinf(ProximableFunction):
+    """Stands for `Conjugate{IndBallL1}` = NormLinf(1.0), the trust-region norm argument χ of
+    shifted(h, x, Δ, χ) (src/shiftedNormL1Box.jl:57-63)."""
+
+    def __init__(self, lam=1.0):
+        self.lam = float(lam)
+
+    def __call__(self, y):
+        return self.lam * float(abs(y).max()) if len(y) else 0.0
+
+
+class RootNormLhalf(ProximableFunction):
+    """h(x) = λ Σ sqrt|x_i|   (src/rootNormLhalf.jl:14-29)"""
+
+    def __init__(self, lam=1.0):
+        if lam < 0:
+            raise ValueError("parameter λ must be nonnegative")  # rootNormLhalf.jl:17-18
+        self.lam = float(lam)
+
+    lambda_ = property(lambda self: self.lam)
+
+
+class IndBallL0(ProximableFunction):
+    """Indicator of {x : ||x||_0 <= r}."""
+
+    def __init__(self, r=1):
+        if int(r) != r or r <= 0:
+            raise ValueError("parameter r must be a positive integer")
+        self.r = int(r)
+
+
+class GroupNormL2(ProximableFunction):
+    """h(x) = Σ_g λ_g ||x[idx_g]||_2   (src/groupNormL2.jl:15-39).
+
+    `lam`: sequence (or device tensor) of group weights.  `idx`: list of groups; each group is a Python
+    `range`/`slice` with step 1 over 0-based indices, or `slice(None)` (= Julia `:`) for "everything".
+    Default `[slice(None)]` as in the reference (`idx = [:]`, groupNormL2.jl:30-31).
+    """
+
+    def __init__(self, lam=(1.0,), idx=None):
+        import torch
+        idx = [slice(None)] if idx is None else list(idx)
+        if isinstance(lam, torch.Tensor):
+            if bool((lam < 0).any()):
+                raise ValueError("weights λ must be nonnegative")  # groupNormL2.jl:20-21
+            nlam = lam.numel()
+        else:
+            lam = [float(v) for v in lam]
+            if any(v < 0 for v in lam):
+                raise ValueError("weights λ must be nonnegative")
+            nlam = len(lam)
+        if nlam != len(idx):
+            raise ValueError("number of weights and groups must be the same")  # groupNormL2.jl:22-23
+        self.lam = lam
+        self.idx = idx
+
+    lambda_ = property(lambda self: self.lam)

@@ -1,0 +1,363 @@
+"""GPU parity: the HIP path (through the C ABI, via the host mirror of the reference API) against the CPU
+oracle on the same seeded inputs, the committed golden fixtures, and the reference's own test shapes.
+
+Bars (BASELINE.json north_star):
+  * ShiftedNormL1(Box), ShiftedNormL0(Box), ShiftedIndBallL0(BInf): BIT-EXACT (np.array_equal incl. signed zeros)
+  * ShiftedRootNormLhalf(Box), ShiftedGroupNormL2(Binf): <= 1e-12 relative (LHALF_TOL / GROUP_TOL below)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LHALF_TOL = 1e-12   # |y_gpu - y_ref| <= LHALF_TOL * max(|y_ref|, |x + s|, |q|)   (y = val - (x+s): scale of the operands)
+GROUP_TOL = 1e-12   # |y_gpu - y_ref| <= GROUP_TOL * max(|y_ref|_i, ||S_group||_2)  (norm-relative inside a group)
+
+
+@pytest.fixture(scope="module")
+def s():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as ge
+    return ge.build()
+
+
+def _data(n, seed, quant=None):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=n)
+    sj = rng.uniform(-0.5, 0.5, size=n)
+    q = rng.normal(size=n)
+    if quant:
+        x, sj, q = (np.round(v * quant) / quant for v in (x, sj, q))
+    return x, sj, q
+
+
+def _dev(*arrs):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0") for a in arrs]
+
+
+def _bits_equal(a, b):
+    return np.array_equal(np.asarray(a).view(np.int64), np.asarray(b).view(np.int64))
+
+
+SIZES = [0, 1, 2, 3, 63, 255, 1024, 2049, 10_000, 1_000_003]
+
+
+# ------------------------------------------------------------------ unboxed separable
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("op", ["l1", "l0", "lhalf"])
+def test_unboxed(s, orc, op, n):
+    x, sj, q = _data(n, 100 + n)
+    lam, sigma = 0.7, 1.3
+    h = {"l1": s.NormL1, "l0": s.NormL0, "lhalf": s.RootNormLhalf}[op](lam)
+    xd, sd, qd = _dev(x, sj, q)
+    psi = s.shifted(s.shifted(h, xd), sd)
+    y = s.prox(psi, qd, sigma).cpu().numpy()
+    ref = getattr(orc, "prox_" + op)(q, x, sj, lam, sigma)
+    if op == "lhalf":
+        scale = np.maximum(np.maximum(np.abs(ref), np.abs(x + sj)), np.abs(q))
+        assert np.all(np.abs(y - ref) <= LHALF_TOL * scale)
+    else:
+        assert _bits_equal(y, ref)
+    # once-shifted (sj = 0) too
+    psi1 = s.shifted(h, xd)
+    y1 = s.prox(psi1, qd, sigma).cpu().numpy()
+    ref1 = getattr(orc, "prox_" + op)(q, x, np.zeros(n), lam, sigma)
+    if op == "lhalf":
+        scale = np.maximum(np.maximum(np.abs(ref1), np.abs(x)), np.abs(q))
+        assert np.all(np.abs(y1 - ref1) <= LHALF_TOL * scale)
+    else:
+        assert _bits_equal(y1, ref1)
+
+
+def test_config1_l1_n1e4_nu1(s, orc):
+    # BASELINE config 1: ShiftedNormL1 prox! on n = 10^4 fp64 random q/x/s, nu = 1.0
+    x, sj, q = _data(10_000, 20250613)
+    xd, sd, qd = _dev(x, sj, q)
+    y = s.prox(s.shifted(s.shifted(s.NormL1(1.0), xd), sd), qd, 1.0).cpu().numpy()
+    assert _bits_equal(y, orc.prox_l1(q, x, sj, 1.0, 1.0))
+
+
+# ------------------------------------------------------------------ boxed separable
+BOX = {"l1_box": "NormL1", "l0_box": "NormL0", "lhalf_box": "RootNormLhalf"}
+
+
+def _check_box(op, y, ref, x, sj, q):
+    if op == "lhalf_box":
+        scale = np.maximum(np.maximum(np.abs(ref), np.abs(x + sj)), np.abs(q))
+        bad = np.abs(y - ref) > LHALF_TOL * scale
+        assert not bad.any(), (int(bad.sum()), float(np.max(np.abs(y - ref))))
+    else:
+        assert _bits_equal(y, ref)
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("op", list(BOX))
+def test_box_scalar_bounds(s, orc, op, n):
+    x, sj, q = _data(n, 200 + n)
+    lam, sigma, delta = 1.0, 1.0, 1.0
+    h = getattr(s, BOX[op])(lam)
+    xd, sd, qd = _dev(x, sj, q)
+    psi = s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd)
+    y = s.prox(psi, qd, sigma).cpu().numpy()
+    ref = getattr(orc, "prox_" + op)(q, x, sj, lam, sigma, -delta, delta)
+    _check_box(op, y, ref, x, sj, q)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 1000, 65_537])
+@pytest.mark.parametrize("op", list(BOX))
+@pytest.mark.parametrize("form", ["vec_vec", "vec_scalar", "scalar_vec"])
+def test_box_vector_bounds_and_mask(s, orc, op, n, form):
+    rng = np.random.default_rng(300 + n)
+    x, sj, q = _data(n, 301 + n)
+    lam, sigma = 0.9, 0.8
+    l = -1.0 - 0.1 * rng.random(n)
+    u = 1.0 + 0.1 * rng.random(n)
+    lo = l if form in ("vec_vec", "vec_scalar") else -1.05
+    uo = u if form in ("vec_vec", "scalar_vec") else 1.05
+    h = getattr(s, BOX[op])(lam)
+    xd, sd, qd = _dev(x, sj, q)
+    ld = _dev(lo)[0] if not np.isscalar(lo) else lo
+    ud = _dev(uo)[0] if not np.isscalar(uo) else uo
+    # all selected
+    psi = s.shifted(s.shifted(h, xd, ld, ud), sd)
+    y = s.prox(psi, qd, sigma).cpu().numpy()
+    _check_box(op, y, getattr(orc, "prox_" + op)(q, x, sj, lam, sigma, lo, uo), x, sj, q)
+    # selected = every other index (test/partial_prox.jl: 1:2:n) and an unsorted duplicated vector (test_allocs.jl:111)
+    for selected in (range(0, n, 2), list(rng.integers(0, n, size=max(1, n // 2)))):
+        mask = orc.mask_from_selected([i + 1 for i in selected], n)
+        psi = s.shifted(s.shifted(h, xd, ld, ud, selected), sd)
+        y = s.prox(psi, qd, sigma).cpu().numpy()
+        _check_box(op, y, getattr(orc, "prox_" + op)(q, x, sj, lam, sigma, lo, uo, mask=mask), x, sj, q)
+
+
+@pytest.mark.parametrize("op", list(BOX))
+def test_box_golden_and_testsbox_through_gpu(s, kats, op):
+    import torch
+    name = {"l1_box": "ShiftedNormL1Box", "l0_box": "ShiftedNormL0Box", "lhalf_box": "ShiftedRootNormLhalfBox"}[op]
+    k = kats["box_golden"]  # test/runtests.jl:449-494
+    x, q = _dev(np.array(k["x"]), np.array(k["q"]))
+    psi = s.shifted(getattr(s, BOX[op])(k["lambda"]), x, k["delta"], s.NormLinf(1.0))
+    y = s.prox(psi, q, k["sigma"]).cpu().numpy()
+    np.testing.assert_allclose(y, k["expected"][name], rtol=k["rtol"], atol=0)
+    assert float(np.max(np.abs(y))) <= k["delta"]
+    t = kats["testsbox"]  # test/testsbox.jl:13-97
+    c = t[name]
+    for qi, xi, lam, sol in zip(c["q"], c["x"], c["lambda"], c["sol"]):
+        xd, qd, sd = _dev(np.array([xi]), np.array([qi]), np.array([t["s"]]))
+        ld, ud = _dev(np.array([t["l"]]), np.array([t["u"]]))
+        psi = s.shifted(getattr(s, BOX[op])(lam), xd, ld, ud)
+        omega = s.shifted(psi, sd)
+        s.prox(omega, qd, t["sigma"])
+        assert abs(float(omega.sol[0]) - sol) <= t["atol"]
+
+
+def test_box_constructor_errors(s):
+    x = _dev(np.zeros(3))[0]
+    l, u = _dev(np.array([0.0, 1.0, 0.0]), np.array([1.0, 0.5, 1.0]))
+    for H in (s.NormL1, s.NormL0):
+        with pytest.raises(ValueError, match="lower bound is greater"):
+            s.shifted(H(1.0), x, l, u)  # shiftedNormL1Box.jl:33-35
+        with pytest.raises(ValueError):
+            s.shifted(H(1.0), x, 1.0, -1.0)
+    s.shifted(s.RootNormLhalf(1.0), x, l, u)  # no check in shiftedRootNormLhalfBox.jl:22-44
+
+
+# ------------------------------------------------------------------ aliasing, views, state updates
+def test_aliasing_and_views(s, orc):
+    import torch
+    n = 4099
+    x, sj, q = _data(n, 7)
+    for op, h in (("l1_box", s.NormL1(1.0)), ("l0_box", s.NormL0(1.0))):
+        xd, sd, qd = _dev(x, sj, q)
+        psi = s.shifted(s.shifted(h, xd, 1.0, s.NormLinf(1.0)), sd)
+        ref = getattr(orc, "prox_" + op)(q, x, sj, 1.0, 1.0, -1.0, 1.0)
+        out = s.prox_bang(qd, psi, qd, 1.0)  # y === q  (test/test_allocs.jl:108-113)
+        assert out is qd and _bits_equal(qd.cpu().numpy(), ref)
+    # ShiftedNormL1 with y === q reproduces the reference's two-pass body: -(xk) - sj
+    xd, sd, qd = _dev(x, sj, q)
+    psi = s.shifted(s.shifted(s.NormL1(1.0), xd), sd)
+    s.prox_bang(qd, psi, qd, 1.0)
+    assert _bits_equal(qd.cpu().numpy(), (-x) - sj)
+    # 8-byte-aligned views (odd offset) take the scalar kernels
+    big = _dev(np.concatenate([[0.0], x]), np.concatenate([[0.0], sj]), np.concatenate([[0.0], q]))
+    xv, sv, qv = (b[1:] for b in big)
+    psi = s.shifted(s.shifted(s.NormL1(1.0), xv, 1.0, s.NormLinf(1.0)), sv)
+    y = torch.empty(n + 1, dtype=torch.float64, device="cuda:0")[1:]
+    s.prox_bang(y, psi, qv, 1.0)
+    assert _bits_equal(y.cpu().numpy(), orc.prox_l1_box(q, x, sj, 1.0, 1.0, -1.0, 1.0))
+    for bad in (qv.float(), qv.cpu(), torch.stack([qv, qv], 1)[:, 0]):
+        with pytest.raises(TypeError):
+            s.prox_bang(y, psi, bad, 1.0)
+    with pytest.raises(IndexError):
+        s.prox_bang(y, psi, qv[:-1], 1.0)
+
+
+def test_shift_and_bounds_updates(s, orc):
+    n = 1000
+    x, sj, q = _data(n, 8)
+    x2, sj2, _ = _data(n, 9)
+    xd, sd, qd, x2d, s2d = _dev(x, sj, q, x2, sj2)
+    psi = s.shifted(s.NormL1(1.0), xd, 0.5, s.NormLinf(1.0))
+    om = s.shifted(psi, sd)
+    assert om.xk is psi.xk is xd and om.sj is sd and bool((psi.sj == 0).all())  # aliasing (runtests.jl:183-185)
+    s.shift_bang(psi, x2d)  # writes INTO the caller's xd
+    assert _bits_equal(xd.cpu().numpy(), x2)
+    s.shift_bang(om, s2d)
+    assert _bits_equal(sd.cpu().numpy(), sj2)
+    s.set_radius_bang(om, 0.25)
+    assert om.l == -0.25 and om.u == 0.25
+    y = s.prox(om, qd, 0.5).cpu().numpy()
+    assert _bits_equal(y, orc.prox_l1_box(q, x2, sj2, 1.0, 0.5, -0.25, 0.25))
+    l, u = -np.abs(x) - 0.1, np.abs(sj) + 0.1
+    ld, ud = _dev(l, u)
+    s.set_bounds_bang(om, ld, ud)
+    assert om.l is ld  # a vector replaces a stored scalar by reference
+    y = s.prox(om, qd, 0.5).cpu().numpy()
+    assert _bits_equal(y, orc.prox_l1_box(q, x2, sj2, 1.0, 0.5, l, u))
+    l2d = _dev(l - 1.0)[0]
+    s.set_bounds_bang(om, l2d, ud)
+    assert om.l is ld and _bits_equal(ld.cpu().numpy(), l - 1.0)  # vector into vector: copied in place
+    assert om.λ == 1.0
+    bi = s.shifted(s.IndBallL0(3), xd, 0.5, s.NormLinf(1.0))
+    s.set_radius_bang(bi, 2.0)
+    assert bi.Δ == 2.0 and bi.r == 3
+
+
+# ------------------------------------------------------------------ top-r selection
+@pytest.mark.parametrize("n", [1, 2, 5, 64, 1000, 4097, 300_001])
+@pytest.mark.parametrize("quant", [None, 8])
+def test_indball_l0(s, orc, n, quant):
+    x, sj, q = _data(n, 400 + n, quant)
+    xd, sd, qd = _dev(x, sj, q)
+    for r in sorted({1, 2, max(1, n // 100), max(1, n // 3), max(1, n - 1), n, n + 7}):
+        psi = s.shifted(s.shifted(s.IndBallL0(r), xd), sd)
+        y = s.prox(psi, qd, 1.0).cpu().numpy()
+        assert _bits_equal(y, orc.prox_indball_l0(q, x, sj, r)), (n, r, quant)
+        psi = s.shifted(s.shifted(s.IndBallL0(r), xd, 0.6, s.NormLinf(1.0)), sd)
+        y = s.prox(psi, qd, 1.0).cpu().numpy()
+        assert _bits_equal(y, orc.prox_indball_l0_binf(q, x, sj, r, 0.6)), (n, r, quant)
+
+
+def test_indball_l0_ties_and_kats(s, orc, kats):
+    T = kats["derived"]["tiebreak"]
+    x, sj, q = (np.array(T[k]) for k in ("x", "s", "q"))
+    xd, sd, qd = _dev(x, sj, q)
+    for r in (2, 3, 4):
+        y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qd, 1.0).cpu().numpy()
+        assert _bits_equal(y, np.array(T["r%d" % r]))
+    # all |v| equal: pure index tie-break over many index digits
+    n = 70_001
+    x, sj = np.zeros(n), np.zeros(n)
+    q = np.where(np.arange(n) % 2 == 0, 1.5, -1.5)
+    xd, sd, qd = _dev(x, sj, q)
+    for r in (1, 4096, 4097, 33_333, n - 1):
+        y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qd, 1.0).cpu().numpy()
+        assert _bits_equal(y, orc.prox_indball_l0(q, x, sj, r))
+        assert np.count_nonzero(y) == r and np.all(y[r:] == 0)
+    # y === q is allowed (y is the reference's scratch too)
+    x, sj, q = _data(5000, 11, 16)
+    xd, sd, qd = _dev(x, sj, q)
+    s.prox_bang(qd, s.shifted(s.shifted(s.IndBallL0(123), xd), sd), qd, 1.0)
+    assert _bits_equal(qd.cpu().numpy(), orc.prox_indball_l0(q, x, sj, 123))
+
+
+# ------------------------------------------------------------------ groups
+def _group_check(y, ref, q, x, sj, offsets):
+    S = (q + x) + sj
+    scale = np.abs(ref).copy()
+    for lo, hi in zip(offsets[:-1], offsets[1:]):
+        scale[lo:hi] = np.maximum(scale[lo:hi], np.linalg.norm(S[lo:hi]))
+    bad = np.abs(y - ref) > GROUP_TOL * np.maximum(scale, 1e-300)
+    assert not bad.any(), (int(bad.sum()), float(np.max(np.abs(y - ref))))
+
+
+@pytest.mark.parametrize("gsize", [64, 128, 256, 512, 1, 7, 100, 3000])
+@pytest.mark.parametrize("binf", [False, True])
+def test_group_uniform(s, orc, gsize, binf):
+    ng = 513 if gsize <= 512 else 9
+    n = ng * gsize
+    x, sj, q = _data(n, 500 + gsize)
+    lam = np.random.default_rng(gsize).uniform(0.5, 1.5, size=ng)
+    sigma, delta = 1.0, 1.0
+    xd, sd, qd = _dev(x, sj, q)
+    h = s.GroupNormL2(lam.tolist(), [range(i, i + gsize) for i in range(0, n, gsize)])
+    if binf:
+        psi = s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd)
+        ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, gsize=gsize)
+    else:
+        psi = s.shifted(s.shifted(h, xd), sd)
+        ref = orc.prox_group_l2(q, x, sj, lam, sigma, gsize=gsize)
+    y = s.prox(psi, qd, sigma).cpu().numpy()
+    _group_check(y, ref, q, x, sj, list(range(0, n + 1, gsize)))
+
+
+@pytest.mark.parametrize("binf", [False, True])
+def test_group_ragged_and_single(s, orc, binf):
+    rng = np.random.default_rng(77)
+    sizes = [1, 5, 64, 129, 1000, 2, 4096, 33]
+    offsets = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(offsets[-1])
+    x, sj, q = _data(n, 78)
+    lam = rng.uniform(0.2, 2.0, size=len(sizes))
+    xd, sd, qd = _dev(x, sj, q)
+    groups = [range(int(a), int(b)) for a, b in zip(offsets[:-1], offsets[1:])]
+    for sigma, delta in ((1.0, 1.0), (0.3, 0.2), (2.5, 5.0)):
+        if binf:
+            psi = s.shifted(s.shifted(s.GroupNormL2(lam.tolist(), groups), xd, delta, s.NormLinf(1.0)), sd)
+            ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, offsets=offsets)
+        else:
+            psi = s.shifted(s.shifted(s.GroupNormL2(lam.tolist(), groups), xd), sd)
+            ref = orc.prox_group_l2(q, x, sj, lam, sigma, offsets=offsets)
+        y = s.prox(psi, qd, sigma).cpu().numpy()
+        _group_check(y, ref, q, x, sj, list(offsets))
+    # NormL2 -> one group [:]  (shiftedGroupNormL2.jl:34-35)
+    if binf:
+        psi = s.shifted(s.NormL2(0.8), xd, 0.7, s.NormLinf(1.0))
+        ref = orc.prox_group_l2_binf(q, x, np.zeros(n), [0.8], 1.1, 0.7, offsets=[0, n])
+    else:
+        psi = s.shifted(s.NormL2(0.8), xd)
+        ref = orc.prox_group_l2(q, x, np.zeros(n), [0.8], 1.1, offsets=[0, n])
+    y = s.prox(psi, qd, 1.1).cpu().numpy()
+    _group_check(y, ref, q, x, np.zeros(n), [0, n])
+
+
+def test_group_binf_goldens_and_edge_branches(s, orc, kats):
+    for name in ("group_l2_binf_single", "group_l2_binf_two"):  # test/runtests.jl:587-606, 658-705
+        k = kats[name]
+        x, q = _dev(np.array(k["x"]), np.array(k["q"]))
+        off = k["offsets"]
+        h = s.GroupNormL2(k["lambda"], [range(a, b) for a, b in zip(off[:-1], off[1:])])
+        y = s.prox(s.shifted(h, x, k["delta"], s.NormLinf(1.0)), q, k["sigma"]).cpu().numpy()
+        np.testing.assert_allclose(y, k["expected"], rtol=k["rtol"], atol=0)
+    # branches of shiftedGroupNormL2Binf.jl:102-109: zero groups, |X| <= Delta everywhere, huge lambda
+    n, g = 128 * 6, 128
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
+    x[:g] = 0; sj[:g] = 0; q[:g] = 0                  # all-zero group
+    x[g:2 * g] *= 0.01                                # |X_i| <= Delta: nothing thresholds at lmin
+    q[2 * g:3 * g] = -(x + sj)[2 * g:3 * g]           # S == 0
+    lam = np.array([1.0, 1.0, 1.0, 1e6, 1e-9, 0.5])   # huge / tiny weights
+    xd, sd, qd = _dev(x, sj, q)
+    h = s.GroupNormL2(lam.tolist(), [range(i, i + g) for i in range(0, n, g)])
+    y = s.prox(s.shifted(s.shifted(h, xd, 1.0, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
+    ref = orc.prox_group_l2_binf(q, x, sj, lam, 1.0, 1.0, gsize=g)
+    assert np.all(np.isfinite(y) == np.isfinite(ref))
+    fin = np.isfinite(ref)
+    _group_check(np.where(fin, y, 0), np.where(fin, ref, 0), q, x, sj, list(range(0, n + 1, g)))
+
+
+def test_group_l2_property_vs_norml2(s):
+    # test/runtests.jl:244-251: ShiftedGroupNormL2 prox == NormL2 prox of q + x, minus x
+    rng = np.random.default_rng(3)
+    x, q = rng.random(6), rng.random(6)
+    lam, nu = rng.random(2), rng.random()
+    xd, qd = _dev(x, q)
+    y = s.prox(s.shifted(s.GroupNormL2(lam.tolist(), [range(0, 3), range(3, 6)]), xd), qd, nu).cpu().numpy()
+    parts = []
+    for g, sl in enumerate((slice(0, 3), slice(3, 6))):
+        v = (q + x)[sl]
+        parts.append(max(1 - nu * lam[g] / np.linalg.norm(v), 0.0) * v)
+    assert np.linalg.norm(y - (np.concatenate(parts) - x)) <= 1e-11
