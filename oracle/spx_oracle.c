@@ -360,19 +360,37 @@ static double froot(const froot_ctx* c, double nn) { /* :87-93 */
   return nn - norm2(c->w, c->m);
 }
 
-/* Roots.fzero(f, a, b) [ext]: bisection to floating-point exhaustion.  Precondition f(a)*f(b) <= 0. */
+/* Roots.fzero(f, a, b) = find_zero(f, (a, b), Bisection()) [ext, Roots.jl ^1.0, unpinned]:
+ *   - the bracket is SORTED first (the reference can hand over lmin > lmax when
+ *     ||S|| + sigma (zlmax + lambda ||X||) < sigma lambda);
+ *   - midpoint = Roots' __middle: the double whose bit pattern is the mean of the two bit patterns;
+ *   - `sign(fa) * sign(fc) < 0 ? b = c : a = c` (a NaN value therefore moves the lower end);
+ *   - stops when no double lies strictly between a and b and returns the end with the smaller |f|
+ *     (`abs(fa) < abs(fb) ? a : b`, so a NaN fa yields b).
+ * A sorted bracket with lmax < sigma*lambda straddles the pole of step(n) at n = sigma*lambda; the
+ * iteration then converges onto the pole from the right-hand side exactly as a sign-bisection does. */
+static double bit_middle(double x, double y) {
+  uint64_t xi, yi;
+  double ax = fabs(x), ay = fabs(y);
+  memcpy(&xi, &ax, 8);
+  memcpy(&yi, &ay, 8);
+  uint64_t mid = (xi + yi) >> 1;
+  double m;
+  memcpy(&m, &mid, 8);
+  return jl_sign(x + y) * m;
+}
 static double orc_bisect(const froot_ctx* c, double a, double fa, double b, double fb) {
+  if (a > b) { double t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
   if (fa == 0.0) return a;
   if (fb == 0.0) return b;
   for (int it = 0; it < 4096; ++it) {
-    double m = a + (b - a) / 2;
+    double m = bit_middle(a, b);
     if (!(a < m && m < b)) break;
     double fm = froot(c, m);
-    if (fm == 0.0) return m;
-    if ((fm < 0) == (fa < 0)) { a = m; fa = fm; }
-    else { b = m; fb = fm; }
+    if (jl_sign(fa) * jl_sign(fm) < 0) { b = m; fb = fm; }
+    else { a = m; fa = fm; }
   }
-  return (fabs(fa) <= fabs(fb)) ? a : b;
+  return (fabs(fa) < fabs(fb)) ? a : b;
 }
 
 /* ShiftedGroupNormL2Binf.prox!  src/shiftedGroupNormL2Binf.jl:67-119 */

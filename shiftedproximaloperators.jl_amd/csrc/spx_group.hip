@@ -80,37 +80,82 @@ struct MemGroup {
 // ---------------------------------------------------------------------------------------------
 // Binf root find.  src/shiftedGroupNormL2Binf.jl:85-108
 //   froot(n) = n - || sigma * softthres(S/sigma - step X, Delta step) - S ||,  step = n / (sigma (n - sl))
-// For an element that is thresholded to zero the term is -S_i; otherwise it equals -c (X_i + Delta sgn a_i)
-// with c = sigma * step = n / (n - sl).  Hence g(n)^2 = A + c^2 B with
-//   A = sum_{inactive} S_i^2,  B = sum_{active} (X_i + Delta sgn a_i)^2,
-// g is non-increasing in n (every |term| is), so froot is strictly increasing: the root in [lmin, lmax]
-// is unique and any bracketing iteration lands on the root the reference's bisection (Roots.fzero)
-// finds.  We use Newton with the analytic slope 1 - g'(n), safeguarded by the bracket (bisection step
-// whenever Newton leaves it), until the step is below 2 ulp; at most SPX_BINF_MAXIT evaluations.
+//
+// Structure used here.  With u = n - sl > 0 and tau = u / n = 1 / (sigma step) in (0, 1) an element is
+// thresholded to zero iff |tau S_i - X_i| <= Delta (its term is then -S_i); otherwise the term equals
+// -(n/u) (X_i + Delta sgn(tau S_i - X_i)).  So
+//   froot(n) = (n/u) * psi(u),   psi(u) = u - phi(u),   phi(u) = sqrt(B(u) + tau^2 A(u)),
+//   A = sum_{inactive} S_i^2,  B = sum_{active} (X_i + Delta sgn(tau S_i - X_i))^2.
+// Every |term| is non-increasing in n, hence froot is strictly increasing on n > sl: the root inside the
+// reference's bracket [lmin, lmax] is unique, and a bracketing iteration of any kind lands on the root
+// the reference's bisection (Roots.fzero) converges to.  psi is solved in u (no cancellation in n - sl,
+// no pole) by a bracket-safeguarded Newton iteration; the result is then POLISHED on the literal froot:
+// the adjacent pair of doubles with froot(a) < 0 < froot(b) is located and the end with the smaller
+// |froot| returned -- exactly the double Roots' bisection-to-exhaustion returns.  All loops are bounded.
 // ---------------------------------------------------------------------------------------------
-#define SPX_BINF_MAXIT 80
+#define SPX_BINF_NEWTON_MAXIT 60
+#define SPX_BINF_WALK_MAXIT 6
 
+// literal froot(n)  (:87-93)
 template <int TEAM, class G>
-__device__ __forceinline__ void binf_eval(const G& grp, double n, double sigma, double sl, double delta, double* lds,
-                                          double& f, double& df) {
-  const double nms = n - sl;
-  const double step = n / (sigma * nms);
+__device__ __forceinline__ double binf_froot(const G& grp, double n, double sigma, double sl, double delta,
+                                             double* lds) {
+  const double step = n / (sigma * (n - sl));
   const double thr = delta * step;
-  double sw = 0.0, sb = 0.0;
+  double sw = 0.0;
   grp.for_each([&](double S, double X, int) {
-    double a = S / sigma - step * X;
-    double w = sigma * softthres(a, thr) - S;  // literal term of the reference's norm
+    double w = sigma * softthres(S / sigma - step * X, thr) - S;
     sw += w * w;
-    double b = (fabs(a) > thr) ? (X + ((a > 0.0) ? delta : -delta)) : 0.0;
-    sb += b * b;
   });
-  team_sum2<TEAM>(sw, sb, lds);
-  const double g = sqrt(sw);
-  f = n - g;
-  // g' = B c c' / g,  c = n / nms,  c' = -sl / nms^2
-  const double c = n / nms;
-  const double gp = (g > 0.0) ? (sb * c * (-sl / (nms * nms)) / g) : 0.0;
-  df = 1.0 - gp;
+  return n - sqrt(team_sum<TEAM>(sw, lds));
+}
+
+// psi(u) and psi'(u)
+template <int TEAM, class G>
+__device__ __forceinline__ void binf_psi(const G& grp, double u, double sl, double delta, double* lds, double& psi,
+                                         double& dpsi) {
+  const double n = sl + u;
+  const double tau = u / n;
+  double sa = 0.0, sb = 0.0;
+  grp.for_each([&](double S, double X, int) {
+    const double z = tau * S - X;
+    const bool act = fabs(z) > delta;
+    const double b = X + ((z > 0.0) ? delta : -delta);
+    sa += act ? 0.0 : S * S;
+    sb += act ? b * b : 0.0;
+  });
+  team_sum2<TEAM>(sa, sb, lds);
+  const double phi = sqrt(sb + tau * tau * sa);
+  psi = u - phi;
+  const double dtau = sl / (n * n);
+  dpsi = 1.0 - ((phi > 0.0) ? (sa * tau * dtau / phi) : 0.0);
+}
+
+__device__ __forceinline__ double next_up(double x) { return __longlong_as_double(__double_as_longlong(x) + 1); }
+__device__ __forceinline__ double next_down(double x) { return __longlong_as_double(__double_as_longlong(x) - 1); }
+// Roots.__middle for positive doubles: the double whose bit pattern is the mean of the two bit patterns
+__device__ __forceinline__ double bit_middle(double a, double b) {
+  const unsigned long long m = ((unsigned long long)__double_as_longlong(fabs(a)) +
+                                (unsigned long long)__double_as_longlong(fabs(b))) >> 1;
+  return jl_sign(a + b) * __longlong_as_double((long long)m);
+}
+
+// Roots.fzero(froot, a, b) literally: sorted bracket, bit-pattern midpoint, sign bisection to exhaustion,
+// the end with the smaller |f| (a NaN value moves the lower end, as `sign(fa) * sign(fc) < 0` is false).
+template <int TEAM, class G>
+__device__ __forceinline__ double binf_bisect(const G& grp, double a, double fa, double b, double fb, double sigma,
+                                              double sl, double delta, double* lds) {
+  if (a > b) { double t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
+  if (fa == 0.0) return a;
+  if (fb == 0.0) return b;
+  for (int it = 0; it < 130; ++it) {
+    const double m = bit_middle(a, b);
+    if (!(a < m && m < b)) break;
+    const double fmid = binf_froot<TEAM>(grp, m, sigma, sl, delta, lds);
+    if (jl_sign(fa) * jl_sign(fmid) < 0) { b = m; fb = fmid; }
+    else { a = m; fa = fmid; }
+  }
+  return (fabs(fa) < fabs(fb)) ? a : b;
 }
 
 // returns true and the root in `root`, or false when fl * fm > 0 (reference writes zeros, :102-103)
@@ -120,10 +165,9 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
   const double eps = 2.220446049250313e-16;
   const double sl = lam * sigma;          // :85
   const double lmin = sl * (1 + eps);     // :94
-  double fl, dfl;
-  binf_eval<TEAM>(grp, lmin, sigma, sl, delta, lds, fl, dfl);  // :95
-  const double ansatz = lmin + 1.0;                           // :97 (epsilon = 1)
-  const double stepa = ansatz / (sigma * (ansatz - sl));      // :98
+  const double fl = binf_froot<TEAM>(grp, lmin, sigma, sl, delta, lds);  // :95
+  const double ansatz = lmin + 1.0;                                      // :97 (epsilon = 1)
+  const double stepa = ansatz / (sigma * (ansatz - sl));                 // :98
   double sz = 0.0, sS = 0.0, sX = 0.0;
   grp.for_each([&](double S, double X, int) {
     double z = softthres(S / sigma - stepa * X, delta * stepa);  // :99
@@ -134,29 +178,58 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
   team_sum2<TEAM>(sz, sS, lds);
   sX = team_sum<TEAM>(sX, lds);
   const double lmax = sqrt(sS) + sigma * (sqrt(sz) + 1.0 * lam * sqrt(sX));  // :100 (|(eps-1)/eps + 1| = 1)
-  double fm, dfm;
-  binf_eval<TEAM>(grp, lmax, sigma, sl, delta, lds, fm, dfm);  // :101
-  if (fl * fm > 0) return false;                               // :102
-  if (fl == 0.0) { root = lmin; return true; }
-  if (fm == 0.0) { root = lmax; return true; }
-  // bracket: f(a) < 0 < f(b) (froot is increasing); start Newton from the well-conditioned end b
-  double a = lmin, b = lmax;
-  if (fl > 0.0) { a = lmax; b = lmin; }  // cannot happen for an increasing f with lmin < lmax; kept for safety
-  double n = lmax, fn = fm, dfn = dfm;
-  for (int it = 0; it < SPX_BINF_MAXIT; ++it) {
-    double nn = n - fn / dfn;
-    const double lo = fmin(a, b), hi = fmax(a, b);
-    if (!(nn > lo && nn < hi)) nn = lo + (hi - lo) / 2;
-    if (!(nn > lo && nn < hi)) break;  // bracket exhausted: no double strictly inside
-    double fnn, dfnn;
-    binf_eval<TEAM>(grp, nn, sigma, sl, delta, lds, fnn, dfnn);
-    const bool small = fabs(nn - n) <= 2 * eps * fabs(nn);
-    n = nn; fn = fnn; dfn = dfnn;
-    if (fnn == 0.0) break;
-    if (fnn < 0.0) a = nn; else b = nn;
-    if (small) break;
+  const double fm = binf_froot<TEAM>(grp, lmax, sigma, sl, delta, lds);     // :101
+  if (fl * fm > 0) return false;                                            // :102
+  if (!(lmin < lmax) || !(fl < 0.0) || !(fm > 0.0)) {
+    // Degenerate bracket (||S|| + sigma (zlmax + lambda ||X||) <= sigma lambda puts the "upper" end at or below
+    // the pole n = sl of step(n)), an exact zero at an end, or a NaN: do literally what Roots.fzero does.
+    root = binf_bisect<TEAM>(grp, lmin, fl, lmax, fm, sigma, sl, delta, lds);
+    return true;
   }
-  root = n;
+  // regular bracket: fl < 0 < fm, sl < lmin < lmax.  Newton on psi(u), u = n - sl in [ulo, uhi].
+  double ulo = lmin - sl, uhi = lmax - sl;
+  double u = uhi, psi, dpsi;
+  binf_psi<TEAM>(grp, u, sl, delta, lds, psi, dpsi);
+  for (int it = 0; it < SPX_BINF_NEWTON_MAXIT; ++it) {
+    double un = u - psi / dpsi;
+    if (!(un > ulo && un < uhi)) un = sqrt(ulo) * sqrt(uhi);  // geometric bisection: the bracket spans decades
+    if (!(un > ulo && un < uhi)) break;
+    double psin, dpsin;
+    binf_psi<TEAM>(grp, un, sl, delta, lds, psin, dpsin);
+    const bool small = fabs(un - u) <= 4 * eps * un;
+    u = un; psi = psin; dpsi = dpsin;
+    if (psin == 0.0 || small) break;
+    if (psin < 0.0) ulo = un; else uhi = un;
+  }
+  // polish on the literal froot: find adjacent doubles a < b with froot(a) < 0 < froot(b)
+  double n0 = sl + u;
+  n0 = fmin(fmax(n0, lmin), lmax);
+  double f0 = binf_froot<TEAM>(grp, n0, sigma, sl, delta, lds);
+  if (f0 == 0.0) { root = n0; return true; }
+  double a = lmin, fa = fl, b = lmax, fb = fm;  // running bracket for the fallback
+  bool found = false;
+  if (f0 < 0.0) {
+    a = n0; fa = f0;
+    for (int k = 0; k < SPX_BINF_WALK_MAXIT && a < lmax; ++k) {
+      const double n1 = next_up(a);
+      const double f1 = binf_froot<TEAM>(grp, n1, sigma, sl, delta, lds);
+      if (f1 < 0.0) { a = n1; fa = f1; }
+      else { b = n1; fb = f1; found = true; break; }
+    }
+  } else {
+    b = n0; fb = f0;
+    for (int k = 0; k < SPX_BINF_WALK_MAXIT && b > lmin; ++k) {
+      const double n1 = next_down(b);
+      const double f1 = binf_froot<TEAM>(grp, n1, sigma, sl, delta, lds);
+      if (f1 > 0.0) { b = n1; fb = f1; }
+      else { a = n1; fa = f1; found = true; break; }
+    }
+  }
+  if (found) {
+    root = (fb == 0.0) ? b : ((fa == 0.0) ? a : ((fabs(fa) < fabs(fb)) ? a : b));
+    return true;
+  }
+  root = binf_bisect<TEAM>(grp, a, fa, b, fb, sigma, sl, delta, lds);  // rare: Newton ended far from the sign change
   return true;
 }
 

@@ -235,8 +235,10 @@ __global__ __launch_bounds__(256) void k_sep_scalar(double* y, const double* q, 
   }
 }
 
-static int g_sep_blocks_per_cu = 8;  // tuning knobs (spx_set_tuning)
-static int g_sep_nt = 0;
+// Tuning knobs (spx_set_tuning).  Defaults from tools/sweep_sep.py on MI355X, n = 1e8 (profiles/r01_sweep_sep.txt):
+// one tile per workgroup (no cap) + non-temporal loads/stores: 6.15 TB/s vs 5.66 TB/s for 16 WG/CU, plain.
+static int g_sep_blocks_per_cu = 0;  // 0 = no cap: grid = number of tiles
+static int g_sep_nt = 1;
 
 template <class Op, bool VECB, bool MASK>
 static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, const double* l,
@@ -244,7 +246,7 @@ static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* xk
   constexpr int UNROLL = 4;
   const int64_t ntiles = (n2 + 256 * UNROLL - 1) / (256 * UNROLL);
   int64_t blocks = ntiles;
-  const int64_t cap = (int64_t)ctx->num_cu * g_sep_blocks_per_cu;
+  const int64_t cap = g_sep_blocks_per_cu > 0 ? (int64_t)ctx->num_cu * g_sep_blocks_per_cu : (int64_t)0x7fffffff;
   if (blocks > cap) blocks = cap;
   if (g_sep_nt)
     hipLaunchKernelGGL((k_sep_vec<Op, UNROLL, VECB, MASK, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y,
@@ -296,7 +298,7 @@ static int run_separable(spx_ctx* ctx, double* y, const double* q, const double*
 // undocumented-in-reference tuning hook used by the kernel benchmarks: key 0 = workgroups per CU of the
 // separable grid, key 1 = non-temporal loads/stores on/off.
 SPX_EXPORT int spx_set_tuning(int key, int value) {
-  if (key == 0 && value >= 1 && value <= 64) { g_sep_blocks_per_cu = value; return SPX_OK; }
+  if (key == 0 && value >= 0 && value <= 1024) { g_sep_blocks_per_cu = value; return SPX_OK; }
   if (key == 1) { g_sep_nt = value ? 1 : 0; return SPX_OK; }
   spx_set_error("invalid argument: unknown tuning key/value");
   return SPX_ERR_INVALID_ARG;
