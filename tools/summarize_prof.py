@@ -9,7 +9,7 @@ if st:
     print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
     rows = list(csv.DictReader(open(st)))
     for r in rows[:12]:
-        print({k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+        print({k: r[k][:110] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
 res = {}
 for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     f = find(sub, "*counter_collection.csv")
