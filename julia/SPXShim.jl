@@ -1,0 +1,181 @@
+# SPXShim.jl -- the reference-side binding a ShiftedProximalOperators.jl maintainer would add
+# (e.g. as a package extension `ext/ShiftedProximalOperatorsSPXExt.jl` loaded when AMDGPU.jl is present).
+#
+# NOT EXECUTED IN THIS REPOSITORY'S PIPELINE: no Julia toolchain exists in the build image or on the GPU
+# box.  It is the `ccall` counterpart of shiftedproximaloperators.jl_amd/_lib.py + shifted.py, which bind
+# exactly the same C symbols (include/spx.h) and ARE exercised by tests/ on the MI355X.
+#
+# Idea: the reference's struct fields are type parameters `<: AbstractVector{R}` (src/shiftedNormL1Box.jl:3-21),
+# so `shifted(h, xk::ROCVector{Float64}, ...)` already builds a ψ whose xk/sj/sol live in HBM -- the
+# constructors need no change.  What cannot run on device arrays is the body of prox! (scalar-indexing loops).
+# This file adds prox! methods that dispatch on ψ with ROCArray storage and forward to libspx.
+
+module SPXShim
+
+using ShiftedProximalOperators
+using ShiftedProximalOperators:
+  ShiftedNormL1, ShiftedNormL0, ShiftedRootNormLhalf, ShiftedNormL1Box, ShiftedNormL0Box,
+  ShiftedRootNormLhalfBox, ShiftedIndBallL0, ShiftedIndBallL0BInf, ShiftedGroupNormL2, ShiftedGroupNormL2Binf
+import ShiftedProximalOperators: prox!
+using AMDGPU  # ROCArray, AMDGPU.stream(), AMDGPU.device_id
+
+const libspx = get(ENV, "LIBSPX", "libspx.so")
+const DVec = ROCVector{Float64}
+
+# ---------------------------------------------------------------------------------------------
+# context: one per (device, HIP stream); enqueue on AMDGPU.jl's current stream so prox! is ordered with
+# the solver's own broadcasts (R2 does `mν∇fk .= -ν .* ∇fk; prox!(s, ψ, mν∇fk, ν)`).
+# ---------------------------------------------------------------------------------------------
+const CTX = Dict{Tuple{Int, Ptr{Cvoid}}, Ptr{Cvoid}}()
+
+function check(status::Cint)
+  status == 0 && return
+  msg = unsafe_string(ccall((:spx_last_error, libspx), Cstring, ()))
+  error("libspx status $status: $msg")
+end
+
+function ctx()
+  dev = AMDGPU.device_id(AMDGPU.device()) - 1
+  st = Ptr{Cvoid}(UInt(AMDGPU.stream().stream))      # hipStream_t of the task-local stream
+  get!(CTX, (dev, st)) do
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:spx_ctx_create_on_stream, libspx), Cint, (Cint, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), dev, st, h))
+    h[]
+  end
+end
+
+dptr(v::DVec) = Ptr{Cdouble}(UInt(pointer(v)))
+dptr(::Nothing) = Ptr{Cdouble}(C_NULL)
+vec_or_nothing(b) = b isa Real ? nothing : b            # `isa(ψ.l, Real) ? ψ.l : ψ.l[i]`
+scal(b) = b isa Real ? Float64(b) : 0.0
+
+# ---------------------------------------------------------------------------------------------
+# separable, unboxed          src/shiftedNormL1.jl:40-54, shiftedNormL0.jl:38-55, shiftedRootNormLhalf.jl:41-63
+# ---------------------------------------------------------------------------------------------
+for (T, sym) in ((:ShiftedNormL1, :spx_prox_l1), (:ShiftedNormL0, :spx_prox_l0),
+                 (:ShiftedRootNormLhalf, :spx_prox_lhalf))
+  @eval function prox!(y::DVec, ψ::$T{Float64, <:DVec, <:DVec, <:DVec}, q::DVec, σ::Float64)
+    n = length(ψ.xk)
+    (length(y) == n && length(q) == n) || throw(BoundsError())
+    check(ccall(($(QuoteNode(sym)), libspx), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cdouble),
+                ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, ψ.λ, σ))
+    return y
+  end
+end
+
+# ---------------------------------------------------------------------------------------------
+# separable, boxed            src/shiftedNormL1Box.jl:89-125, shiftedNormL0Box.jl:89-131,
+#                             shiftedRootNormLhalfBox.jl:86-120
+# `selected` (any AbstractArray{<:Integer}, 1-based) -> device byte mask, built once per ψ and cached;
+# the default 1:length(xk) needs no mask.
+# ---------------------------------------------------------------------------------------------
+const MASKS = IdDict{Any, Any}()   # ψ.selected (shared by a twice-shifted ψ) => ROCVector{UInt8} | nothing
+
+function mask_for(ψ)
+  n = length(ψ.xk)
+  sel = ψ.selected
+  (sel isa AbstractUnitRange && first(sel) <= 1 && last(sel) >= n) && return nothing
+  get!(MASKS, sel) do
+    idx0 = ROCVector{Int64}(collect(Int64, sel) .- 1)            # 0-based for the C ABI
+    m = ROCVector{UInt8}(undef, n)
+    check(ccall((:spx_build_mask, libspx), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int64, Ptr{Int64}, Int64),
+                ctx(), Ptr{UInt8}(UInt(pointer(m))), n, Ptr{Int64}(UInt(pointer(idx0))), length(idx0)))
+    AMDGPU.synchronize()                                         # idx0 may be freed after this
+    m
+  end
+end
+
+for (T, sym) in ((:ShiftedNormL1Box, :spx_prox_l1_box), (:ShiftedNormL0Box, :spx_prox_l0_box),
+                 (:ShiftedRootNormLhalfBox, :spx_prox_lhalf_box))
+  @eval function prox!(y::DVec, ψ::$T{Float64, <:DVec, <:DVec, <:DVec}, q::DVec, σ::Float64)
+    n = length(ψ.xk)
+    (length(y) == n && length(q) == n) || throw(BoundsError())
+    (ψ.l isa Real || ψ.l isa DVec) && (ψ.u isa Real || ψ.u isa DVec) ||
+      return invoke(prox!, Tuple{AbstractVector{Float64}, $T, AbstractVector{Float64}, Float64}, y, ψ, q, σ)
+    m = mask_for(ψ)
+    check(ccall(($(QuoteNode(sym)), libspx), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cdouble,
+                 Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{UInt8}),
+                ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, ψ.λ, σ,
+                dptr(vec_or_nothing(ψ.l)), dptr(vec_or_nothing(ψ.u)), scal(ψ.l), scal(ψ.u),
+                m === nothing ? Ptr{UInt8}(C_NULL) : Ptr{UInt8}(UInt(pointer(m)))))
+    return y
+  end
+end
+
+# ---------------------------------------------------------------------------------------------
+# top-r                       src/shiftedIndBallL0.jl:54-72, shiftedIndBallL0BInf.jl:73-95
+# (ψ.p, the Vector{Int} permutation scratch, is not used: libspx selects, it does not sort)
+# ---------------------------------------------------------------------------------------------
+function prox!(y::DVec, ψ::ShiftedIndBallL0{<:Integer, Float64, <:DVec, <:DVec, <:DVec}, q::DVec, σ::Float64)
+  n = length(ψ.xk)
+  check(ccall((:spx_prox_indball_l0, libspx), Cint,
+              (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Int64),
+              ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, ψ.r))
+  return y
+end
+
+function prox!(y::DVec, ψ::ShiftedIndBallL0BInf{<:Integer, Float64, <:DVec, <:DVec, <:DVec}, q::DVec, σ::Float64)
+  n = length(ψ.xk)
+  check(ccall((:spx_prox_indball_l0_binf, libspx), Cint,
+              (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Int64, Cdouble),
+              ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, ψ.r, ψ.Δ))
+  return y
+end
+
+# ---------------------------------------------------------------------------------------------
+# groups                      src/shiftedGroupNormL2.jl:52-79, shiftedGroupNormL2Binf.jl:67-119
+# ψ.h.idx must be consecutive contiguous ranges (UnitRanges or [:]); anything else falls back to the
+# reference method.  Offsets / weights are uploaded once per h and cached.
+# ---------------------------------------------------------------------------------------------
+const LAYOUTS = IdDict{Any, Any}()
+
+function layout_for(h, n)
+  get!(LAYOUTS, h) do
+    rngs = map(g -> g isa Colon ? (1:n) : g, h.idx)
+    all(g -> g isa AbstractUnitRange, rngs) || return nothing
+    all(i -> first(rngs[i + 1]) == last(rngs[i]) + 1, 1:(length(rngs) - 1)) || return nothing
+    off = Int64[first(rngs[1]) - 1; [last(g) for g in rngs]]      # 0-based CSR offsets
+    sizes = diff(off)
+    uniform = off[1] == 0 && off[end] == n && all(==(sizes[1]), sizes)
+    (offsets = uniform ? nothing : ROCVector{Int64}(off), gsize = uniform ? sizes[1] : 0,
+     ngroups = length(rngs), lambda = ROCVector{Float64}(collect(Float64, h.lambda)))
+  end
+end
+
+function group_call(sym, y, ψ, q, σ, extra...)
+  n = length(ψ.xk)
+  L = layout_for(ψ.h, n)
+  L === nothing && return nothing
+  offp = L.offsets === nothing ? Ptr{Int64}(C_NULL) : Ptr{Int64}(UInt(pointer(L.offsets)))
+  if isempty(extra)
+    check(ccall((:spx_prox_group_l2, libspx), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Ptr{Int64}, Int64, Int64,
+                 Ptr{Cdouble}, Cdouble),
+                ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, offp, L.gsize, L.ngroups, dptr(L.lambda), σ))
+  else
+    check(ccall((:spx_prox_group_l2_binf, libspx), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Ptr{Int64}, Int64, Int64,
+                 Ptr{Cdouble}, Cdouble, Cdouble),
+                ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, offp, L.gsize, L.ngroups, dptr(L.lambda), σ,
+                extra[1]))
+  end
+  return y
+end
+
+function prox!(y::DVec, ψ::ShiftedGroupNormL2{Float64, RR, I, <:DVec, <:DVec, <:DVec}, q::DVec, σ::Float64) where {RR, I}
+  r = group_call(:spx_prox_group_l2, y, ψ, q, σ)
+  r === nothing ? invoke(prox!, Tuple{AbstractVector{Float64}, ShiftedGroupNormL2, AbstractVector{Float64}, Float64}, y, ψ, q, σ) : r
+end
+
+function prox!(y::DVec, ψ::ShiftedGroupNormL2Binf{Float64, RR, I, <:DVec, <:DVec, <:DVec}, q::DVec, σ::Float64) where {RR, I}
+  r = group_call(:spx_prox_group_l2_binf, y, ψ, q, σ, ψ.Δ)
+  r === nothing ? invoke(prox!, Tuple{AbstractVector{Float64}, ShiftedGroupNormL2Binf, AbstractVector{Float64}, Float64}, y, ψ, q, σ) : r
+end
+
+# shift!, set_radius!, set_bounds!, prox (src/ShiftedProximalOperators.jl:72-111,189-190) need no methods:
+# they are broadcasts / field updates on the stored (device) arrays and already work on ROCArrays.
+# The Box constructors' `any(l .> u)` (src/shiftedNormL1Box.jl:33-35) is a device reduction via broadcasting.
+
+end # module
