@@ -78,13 +78,59 @@ struct OpL0Box {  // src/shiftedNormL0Box.jl:96-128
   }
 };
 
-// (2/3) sign(z) |z| (1 + cos(2pi/3 - (2/3) acos(a))),  a = (sl/4) (|z|/3)^(-3/2)
-// src/shiftedRootNormLhalf.jl:48,57 and src/shiftedRootNormLhalfBox.jl:92,106 (real branch, a <= 1)
-__device__ __forceinline__ double lhalf_val(double z, double az, double sl4) {
-  const double twopi3 = 2.0943951023931953;  // 2 * pi / 3 rounded once, as Julia's 2 * pi / 3
-  double a = sl4 * pow(az / 3, -1.5);
-  double phi = acos(a);
-  return 2 * jl_sign(z) / 3 * az * (1 + cos(twopi3 - 2 * phi / 3));
+// ---------------------------------------------------------------------------------------------
+// RootNormLhalf closed form.  Reference (src/shiftedRootNormLhalf.jl:48,57; shiftedRootNormLhalfBox.jl:92,106):
+//   val = (2/3) sign(z) |z| (1 + cos(2 pi/3 - (2/3) acos(a))),   a = (sigma lambda / 4) (|z|/3)^(-3/2),  a <= 1.
+// With phi = acos(-a) = pi - acos(a) and w = cos(phi/3) in [1/2, sqrt(3)/2]:  cos(2 pi/3 - (2/3) acos a) = 2 w^2 - 1,
+// so  val = sign(z) * 4 t w^2  with t = |z|/3, and w is the largest root of 4 w^3 - 3 w + a = 0.
+// Writing w = 1/2 + d:  4 d^3 + 6 d^2 = m := 1 - a  (d ~ sqrt(m/6) near the threshold a = 1).
+// d is obtained by 3 Newton steps on g(d) = 4 d^3 + 6 d^2 - m from a cubic fit d0 = e P(e), e = sqrt(m)
+// (relative error of the fit 5.4e-5 on [0, 1]; Newton squares it: 1e-9, 1e-18).  The divisions by
+// g'(d) = 12 d (d + 1) use the f32 reciprocal: Newton is self-correcting, a 1e-7 error in the slope costs
+// 1e-7 * |last correction| <= 1e-16.  a itself comes from an fp64 rsqrt (hardware seed + 2 Newton steps).
+// Accuracy vs an 80-bit evaluation of the reference formula: <= 6e-16 |z| everywhere, the same as the
+// reference's own double evaluation (tools/lhalf_proto.py); agreement with the CPU restatement is checked to
+// 1e-12 in tests/.  No pow / acos / cos calls: ~55 fp64 VALU ops instead of ~250.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rsqrt_f64(double t) {
+  double y = __builtin_amdgcn_rsq(t);            // v_rsq_f64 seed
+  const double h = 0.5 * t;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    double e = __builtin_fma(-h * y, y, 0.5);    // 1/2 - t y^2 / 2
+    y = __builtin_fma(y, e, y);
+  }
+  return y;
+}
+// sqrt(v) for v >= 0 from the refined rsqrt plus one correction step (faithfully rounded)
+__device__ __forceinline__ double sqrt_f64(double v) {
+  double y = rsqrt_f64(v);
+  double s = v * y;
+  s = __builtin_fma(0.5 * y, __builtin_fma(-s, s, v), s);
+  return (v > 0.0) ? s : 0.0;
+}
+// a = sl4 * (az/3)^(-3/2) and t = az/3
+__device__ __forceinline__ double lhalf_a(double az, double sl4, double& t) {
+  t = az * 0.33333333333333331;
+  const double r = rsqrt_f64(t);
+  return sl4 * (r * r * r);
+}
+// sign(z) * 4 t w^2 for a in [0, 1]
+__device__ __forceinline__ double lhalf_val_from_a(double z, double t, double a) {
+  const double m = fmax(1.0 - a, 0.0);
+  const double e = (double)__builtin_amdgcn_sqrtf((float)m);
+  double d = e * __builtin_fma(e, __builtin_fma(e, __builtin_fma(e, -0.003676457097091405, 0.016543212998449176),
+                                                 -0.05508522799226874), 0.4082262283672896);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double g = __builtin_fma(__builtin_fma(4.0, d, 6.0) * d, d, -m);
+    const double gp = 12.0 * d * (d + 1.0);
+    const double inv = (gp > 0.0) ? (double)__builtin_amdgcn_rcpf((float)gp) : 0.0;
+    d = __builtin_fma(-g, inv, d);
+  }
+  const double w = 0.5 + d;
+  const double v = 4.0 * t * (w * w);
+  return (z < 0.0) ? -v : v;
 }
 struct OpLhalf {  // src/shiftedRootNormLhalf.jl:47-60
   double sl4;     // (sigma * lambda) / 4
@@ -94,47 +140,49 @@ struct OpLhalf {  // src/shiftedRootNormLhalf.jl:47-60
     double xs = x + s;
     double sol = q + xs;  // :50
     double aq = fabs(sol);
-    double yi = (aq <= p) ? 0.0 : lhalf_val(sol, aq, sl4);
-    return yi - xs;  // :59
+    double t;
+    double a = lhalf_a(aq, sl4, t);
+    double val = lhalf_val_from_a(sol, t, fmin(a, 1.0));
+    double yi = (aq <= p) ? 0.0 : val;  // :53-57
+    return yi - xs;                     // :59
   }
 };
 struct OpLhalfBox {  // src/shiftedRootNormLhalfBox.jl:92-117
   double sl4;        // sigma * lambda / 4
-  double lambda, sigma;
+  double lambda;
+  double h2;         // 1 / (2 sigma)
   static constexpr bool kBox = true;
-  __device__ __forceinline__ double rnorm(double tt, double q, double xs) const {  // :95
+  // RNorm(tt) = (tt - q)^2 / 2 / sigma + lambda sqrt|tt + xs|   (:95); used only to pick the argmin
+  __device__ __forceinline__ double rnorm(double tt, double q, double xs) const {
     double d = tt - q;
-    return d * d / 2 / sigma + lambda * sqrt(fabs(tt + xs));
+    return __builtin_fma(lambda, sqrt_f64(fabs(tt + xs)), d * d * h2);
   }
   __device__ __forceinline__ double operator()(double q, double x, double s, double l, double u, bool sel) const {
     double xs = x + s;  // :94
     double xsq = xs + q;
     double axsq = fabs(xsq);
     double tl = l - s, tu = u - s;
-    // candidates 1..3 (:109-111); findmin keeps the FIRST minimum -> strict < when a later one replaces
+    // candidates 1..3 (:109-111); findmin keeps the FIRST minimum -> a later one replaces only on strict <
     double best = rnorm(tl, q, xs);
     double yi = tl;
     double c2 = rnorm(tu, q, xs);
     if (c2 < best) { best = c2; yi = tu; }
     double mx = -x;
-    if (l <= mx && mx <= u) {
-      double c3 = rnorm(-xs, q, xs);
-      if (c3 < best) { best = c3; yi = -xs; }
-    }
+    double c3 = xsq * xsq * h2;  // RNorm(-xs): (-xs - q)^2 = xsq^2 and sqrt|(-xs) + xs| = 0 exactly
+    if (l <= mx && mx <= u && c3 < best) { best = c3; yi = -xs; }
     // candidate 4 (:106,:112): the stationary point.  When the acos argument a exceeds 1 the reference
     // takes the real part of a complex expression, which is not a stationary point; the objective is
     // then V-shaped around v = 0 so that candidate can never be strictly smaller than the first three
-    // (DESIGN.md "RootNormLhalfBox, a > 1") and is skipped here.  a is NaN for xsq == 0 -> skipped too,
-    // as in the reference (`li <= NaN <= ui` is false).
-    double a = sl4 * pow(axsq / 3, -1.5);
+    //  and is skipped here.  a is Inf/NaN for xsq == 0 -> skipped too, as in the
+    // reference (`li <= NaN <= ui` is false).
+    double t;
+    double a = lhalf_a(axsq, sl4, t);
     if (a <= 1.0) {
-      const double twopi3 = 2.0943951023931953;
-      double val = 2 * jl_sign(xsq) / 3 * axsq * (1 + cos(twopi3 - 2 * acos(a) / 3));
+      double val = lhalf_val_from_a(xsq, t, a);
       double vx = val - x;
-      if (l <= vx && vx <= u) {
-        double c4 = rnorm(val - xs, q, xs);
-        if (c4 < best) { best = c4; yi = val - xs; }
-      }
+      double t4 = val - xs;
+      double c4 = rnorm(t4, q, xs);
+      if (l <= vx && vx <= u && c4 < best) { best = c4; yi = t4; }
     }
     return sel ? yi : prox_zero(q, tl, tu);  // :116
   }
@@ -354,5 +402,5 @@ SPX_EXPORT int spx_prox_lhalf_box(spx_ctx* ctx, double* y, const double* q, cons
   int rc = spx_check_common(ctx, y, q, xk, sj, n);
   if (rc) return rc;
   return run_separable(ctx, y, q, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask,
-                       OpLhalfBox{sigma * lambda / 4, lambda, sigma});
+                       OpLhalfBox{sigma * lambda / 4, lambda, 0.5 / sigma});
 }
