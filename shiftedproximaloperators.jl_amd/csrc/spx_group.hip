@@ -5,51 +5,85 @@
 // size); lambda is one fp64 per group.  Algorithmic traffic: 32 B/element + 8 B/group.
 // Roofline: HBM bandwidth; the Binf form adds a per-group scalar root find that runs out of registers.
 //
-// Mapping: one TEAM per group, TEAM = one 64-lane wavefront (small groups) or one 256-lane workgroup
-// (large groups).  Reductions: xor-butterfly over the wavefront (wave_sum), plus an LDS hop for 256-lane
-// teams.  The fast path (uniform group size 64*EPL, EPL <= 8, 16-byte aligned) keeps the whole group in
-// registers: each lane owns EPL/2 (or 1) 16-byte pairs, so q/xk/sj are read once and y written once.
+// Mapping.  Fast path (uniform group size LPG*EPL, 16-byte aligned): a group is owned by LPG lanes of a
+// wavefront (LPG = 16 for the 128-element groups of the BASELINE config, so one wave works on 4 groups at
+// once), each lane keeps EPL elements of S = (q + xk) + sj, X = xk, xk + sj and S/sigma in registers; q/xk/sj
+// are read once with non-temporal 16-byte loads and y is written once.  Sums over a group are DPP
+// butterflies inside a 16-lane row (no LDS).  Packing several groups into a wave amortises the
+// per-group scalar arithmetic of the Binf root find (divisions, square roots), which every lane of a
+// group executes redundantly.  Other shapes: a wavefront or a 256-lane workgroup per group, elements
+// re-read from L1/L2 for every reduction.
 #include <cmath>
 
 #include "spx_common.hpp"
 
 // ---------------------------------------------------------------------------------------------
-// team reductions
+// team reductions: TEAM lanes (8, 16, 32, 64: aligned lane ranges of one wave; 256: the workgroup)
 // ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
 template <int TEAM>
-__device__ __forceinline__ double team_sum(double v, double* lds /* 8 doubles per block, TEAM==256 only */) {
-  v = wave_sum(v);
+__device__ __forceinline__ double lanes_sum(double v) {
+  static_assert(TEAM == 8 || TEAM == 16 || TEAM == 32 || TEAM == 64, "TEAM");
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror: the other quad of each 8
+  if constexpr (TEAM >= 16) v += dpp_f64<0x140>(v);  // row_mirror: the other half of each 16-lane row
+  if constexpr (TEAM >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (TEAM >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+template <int TEAM>
+__device__ __forceinline__ double team_sum(double v, double* lds /* 8 doubles per block, TEAM == 256 only */) {
   if constexpr (TEAM == 256) {
+    v = lanes_sum<64>(v);
     const int w = threadIdx.x >> 6;
     __syncthreads();  // previous use of lds finished
     if ((threadIdx.x & 63) == 0) lds[w] = v;
     __syncthreads();
-    v = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    return (lds[0] + lds[1]) + (lds[2] + lds[3]);
+  } else {
+    return lanes_sum<TEAM>(v);
   }
-  return v;
 }
 template <int TEAM>
 __device__ __forceinline__ void team_sum2(double& a, double& b, double* lds) {
-  a = wave_sum(a);
-  b = wave_sum(b);
   if constexpr (TEAM == 256) {
+    a = lanes_sum<64>(a);
+    b = lanes_sum<64>(b);
     const int w = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { lds[w] = a; lds[4 + w] = b; }
     __syncthreads();
     a = (lds[0] + lds[1]) + (lds[2] + lds[3]);
     b = (lds[4] + lds[5]) + (lds[6] + lds[7]);
+  } else {
+    a = lanes_sum<TEAM>(a);
+    b = lanes_sum<TEAM>(b);
   }
 }
 
 // softthres(x, a) = sign(x) * max(0, |x| - a)          src/shiftedGroupNormL2Binf.jl:82
 __device__ __forceinline__ double softthres(double x, double a) { return jl_sign(x) * jl_max(0.0, fabs(x) - a); }
 
+// 1/x to a few ulp: hardware seed + 2 Newton steps.  Only used inside the self-correcting Newton iteration.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  return y;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-group element access.  Two providers with the same interface:
-//   RegGroup<EPL>  : the group's S = (q + xk) + sj and X = xk live in registers (fast path)
+//   RegGroup<EPL>  : S = (q + xk) + sj and X = xk of this lane's EPL elements live in registers
 //   MemGroup<TEAM> : elements are re-read from global memory (L1/L2 resident for moderate groups)
-// for_each(f) calls f(S_i, X_i, slot) for every element this lane owns.
+// for_each(f) calls f(S_i, X_i) for every element this lane owns.
 // ---------------------------------------------------------------------------------------------
 template <int EPL>
 struct RegGroup {
@@ -57,7 +91,7 @@ struct RegGroup {
   template <class F>
   __device__ __forceinline__ void for_each(F&& f) const {
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) f(S[k], X[k], k);
+    for (int k = 0; k < EPL; ++k) f(S[k], X[k]);
   }
 };
 
@@ -72,7 +106,7 @@ struct MemGroup {
   __device__ __forceinline__ void for_each(F&& f) const {
     for (int64_t i = lo + lane; i < hi; i += TEAM) {
       double x = xk[i];
-      f((q[i] + x) + sj[i], x, 0);
+      f((q[i] + x) + sj[i], x);
     }
   }
 };
@@ -83,31 +117,62 @@ struct MemGroup {
 //
 // Structure used here.  With u = n - sl > 0 and tau = u / n = 1 / (sigma step) in (0, 1) an element is
 // thresholded to zero iff |tau S_i - X_i| <= Delta (its term is then -S_i); otherwise the term equals
-// -(n/u) (X_i + Delta sgn(tau S_i - X_i)).  So
+// -(n/u) b_i,  b_i = X_i + Delta sgn(tau S_i - X_i).  So
 //   froot(n) = (n/u) * psi(u),   psi(u) = u - phi(u),   phi(u) = sqrt(B(u) + tau^2 A(u)),
-//   A = sum_{inactive} S_i^2,  B = sum_{active} (X_i + Delta sgn(tau S_i - X_i))^2.
+//   A = sum_{inactive} S_i^2,  B = sum_{active} b_i^2,
+// and the prox itself is  w_i = S_i - sigma softthres(...) = (n/u) b_i (active) or S_i (inactive)  (:111).
 // Every |term| is non-increasing in n, hence froot is strictly increasing on n > sl: the root inside the
-// reference's bracket [lmin, lmax] is unique, and a bracketing iteration of any kind lands on the root
-// the reference's bisection (Roots.fzero) converges to.  psi is solved in u (no cancellation in n - sl,
-// no pole) by a bracket-safeguarded Newton iteration; the result is then POLISHED on the literal froot:
-// the adjacent pair of doubles with froot(a) < 0 < froot(b) is located and the end with the smaller
-// |froot| returned -- exactly the double Roots' bisection-to-exhaustion returns.  All loops are bounded.
+// reference's bracket [lmin, lmax] is unique, and a bracketing iteration of any kind lands on the root the
+// reference's bisection (Roots.fzero) converges to.  We solve psi(u) = 0 in u (no cancellation in n - sl, no
+// pole) by a bracket-safeguarded Newton iteration.  When the problem is ill-conditioned in n (u < n/1000:
+// a one-ulp change of n moves step by more than 1e-13 relative) the result is POLISHED: the adjacent pair
+// of doubles n with froot < 0 < froot is located and the end with the smaller |froot| returned -- the
+// double Roots' bisection-to-exhaustion returns.  All loops are bounded.
+// The reference's literal expression is kept for the degenerate bracket only (binf_froot_literal).
 // ---------------------------------------------------------------------------------------------
 #define SPX_BINF_NEWTON_MAXIT 60
 #define SPX_BINF_WALK_MAXIT 6
 
 // literal froot(n)  (:87-93)
 template <int TEAM, class G>
-__device__ __forceinline__ double binf_froot(const G& grp, double n, double sigma, double sl, double delta,
-                                             double* lds) {
+__device__ __forceinline__ double binf_froot_literal(const G& grp, double n, double sigma, double sl, double delta,
+                                                     double* lds) {
   const double step = n / (sigma * (n - sl));
   const double thr = delta * step;
   double sw = 0.0;
-  grp.for_each([&](double S, double X, int) {
+  grp.for_each([&](double S, double X) {
     double w = sigma * softthres(S / sigma - step * X, thr) - S;
     sw += w * w;
   });
   return n - sqrt(team_sum<TEAM>(sw, lds));
+}
+
+// Delta with the sign of z
+__device__ __forceinline__ double signed_delta(double delta, double z) {
+  return __hiloint2double((__double2hiint(delta) & 0x7fffffff) | (__double2hiint(z) & 0x80000000), __double2loint(delta));
+}
+
+// sums A (inactive S^2) and B (active b^2) at a given tau
+template <int TEAM, class G>
+__device__ __forceinline__ void binf_ab(const G& grp, double tau, double delta, double* lds, double& sa, double& sb) {
+  sa = 0.0;
+  sb = 0.0;
+  grp.for_each([&](double S, double X) {
+    const double z = __builtin_fma(tau, S, -X);
+    const bool act = fabs(z) > delta;
+    const double b = X + signed_delta(delta, z);
+    sa += act ? 0.0 : S * S;
+    sb += act ? b * b : 0.0;
+  });
+  team_sum2<TEAM>(sa, sb, lds);
+}
+
+__device__ __forceinline__ double sqrt_pos(double v) {  // sqrt for v >= 0: rsq seed + two corrections
+  const double r = __builtin_amdgcn_rsq(v);
+  double s = v * r;
+  s = __builtin_fma(0.5 * r, __builtin_fma(-s, s, v), s);
+  s = __builtin_fma(0.5 * r, __builtin_fma(-s, s, v), s);
+  return (v > 0.0) ? s : 0.0;
 }
 
 // psi(u) and psi'(u)
@@ -115,20 +180,23 @@ template <int TEAM, class G>
 __device__ __forceinline__ void binf_psi(const G& grp, double u, double sl, double delta, double* lds, double& psi,
                                          double& dpsi) {
   const double n = sl + u;
-  const double tau = u / n;
-  double sa = 0.0, sb = 0.0;
-  grp.for_each([&](double S, double X, int) {
-    const double z = tau * S - X;
-    const bool act = fabs(z) > delta;
-    const double b = X + ((z > 0.0) ? delta : -delta);
-    sa += act ? 0.0 : S * S;
-    sb += act ? b * b : 0.0;
-  });
-  team_sum2<TEAM>(sa, sb, lds);
-  const double phi = sqrt(sb + tau * tau * sa);
+  const double rn = fast_rcp(n);
+  const double tau = u * rn;
+  double sa, sb;
+  binf_ab<TEAM>(grp, tau, delta, lds, sa, sb);
+  const double phi = sqrt_pos(__builtin_fma(tau * tau, sa, sb));
   psi = u - phi;
-  const double dtau = sl / (n * n);
-  dpsi = 1.0 - ((phi > 0.0) ? (sa * tau * dtau / phi) : 0.0);
+  const double dtau = sl * rn * rn;
+  dpsi = 1.0 - ((phi > 0.0) ? (sa * tau * dtau * fast_rcp(phi)) : 0.0);
+}
+// sign-accurate froot at the double n:  (n/u) psi(u) with u = fl(n - sl), as the reference's step(n) sees it
+template <int TEAM, class G>
+__device__ __forceinline__ double binf_froot(const G& grp, double n, double sl, double delta, double* lds) {
+  const double u = n - sl;
+  const double tau = u / n;
+  double sa, sb;
+  binf_ab<TEAM>(grp, tau, delta, lds, sa, sb);
+  return n - (n / u) * sqrt(__builtin_fma(tau * tau, sa, sb));
 }
 
 __device__ __forceinline__ double next_up(double x) { return __longlong_as_double(__double_as_longlong(x) + 1); }
@@ -151,7 +219,7 @@ __device__ __forceinline__ double binf_bisect(const G& grp, double a, double fa,
   for (int it = 0; it < 130; ++it) {
     const double m = bit_middle(a, b);
     if (!(a < m && m < b)) break;
-    const double fmid = binf_froot<TEAM>(grp, m, sigma, sl, delta, lds);
+    const double fmid = binf_froot_literal<TEAM>(grp, m, sigma, sl, delta, lds);
     if (jl_sign(fa) * jl_sign(fmid) < 0) { b = m; fb = fmid; }
     else { a = m; fa = fmid; }
   }
@@ -165,33 +233,52 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
   const double eps = 2.220446049250313e-16;
   const double sl = lam * sigma;          // :85
   const double lmin = sl * (1 + eps);     // :94
-  const double fl = binf_froot<TEAM>(grp, lmin, sigma, sl, delta, lds);  // :95
   const double ansatz = lmin + 1.0;                                      // :97 (epsilon = 1)
   const double stepa = ansatz / (sigma * (ansatz - sl));                 // :98
-  double sz = 0.0, sS = 0.0, sX = 0.0;
-  grp.for_each([&](double S, double X, int) {
-    double z = softthres(S / sigma - stepa * X, delta * stepa);  // :99
-    sz += z * z;
-    sS += S * S;
+  const double thra = delta * stepa;
+  const double rsig = 1.0 / sigma;
+  // one fused pass: ||S||, ||X||, zlmax (:99) and the A/B sums of froot(lmin) (:95)
+  const double ul = lmin - sl;
+  const double taul = ul / lmin;
+  double sz = 0.0, sS = 0.0, sX = 0.0, sal = 0.0, sbl = 0.0;
+  grp.for_each([&](double S, double X) {
+    const double za = fabs(__builtin_fma(-stepa, X, S * rsig)) - thra;  // |softthres| = max(0, |.| - thr)
+    sz += (za > 0.0) ? za * za : 0.0;
+    const double s2 = S * S;
+    sS += s2;
     sX += X * X;
+    const double z = __builtin_fma(taul, S, -X);
+    const bool act = fabs(z) > delta;
+    const double b = X + signed_delta(delta, z);
+    sal += act ? 0.0 : s2;
+    sbl += act ? b * b : 0.0;
   });
   team_sum2<TEAM>(sz, sS, lds);
+  team_sum2<TEAM>(sal, sbl, lds);
   sX = team_sum<TEAM>(sX, lds);
   const double lmax = sqrt(sS) + sigma * (sqrt(sz) + 1.0 * lam * sqrt(sX));  // :100 (|(eps-1)/eps + 1| = 1)
-  const double fm = binf_froot<TEAM>(grp, lmax, sigma, sl, delta, lds);     // :101
-  if (fl * fm > 0) return false;                                            // :102
-  if (!(lmin < lmax) || !(fl < 0.0) || !(fm > 0.0)) {
-    // Degenerate bracket (||S|| + sigma (zlmax + lambda ||X||) <= sigma lambda puts the "upper" end at or below
-    // the pole n = sl of step(n)), an exact zero at an end, or a NaN: do literally what Roots.fzero does.
+  double fl = lmin - (lmin / ul) * sqrt(__builtin_fma(taul * taul, sal, sbl));
+  if (!(lmin < lmax) || !(ul > 0.0) || !(fl == fl)) {
+    // Degenerate bracket (||S|| + sigma (zlmax + lambda ||X||) <= sigma lambda puts the "upper" end at or below the
+    // pole n = sl of step(n)), sl == 0, or a NaN: do literally what the reference + Roots.fzero do.
+    fl = binf_froot_literal<TEAM>(grp, lmin, sigma, sl, delta, lds);
+    const double fm = binf_froot_literal<TEAM>(grp, lmax, sigma, sl, delta, lds);
+    if (fl * fm > 0) return false;  // :102
     root = binf_bisect<TEAM>(grp, lmin, fl, lmax, fm, sigma, sl, delta, lds);
     return true;
   }
-  // regular bracket: fl < 0 < fm, sl < lmin < lmax.  Newton on psi(u), u = n - sl in [ulo, uhi].
-  double ulo = lmin - sl, uhi = lmax - sl;
+  // regular bracket sl < lmin < lmax:  fm = froot(lmax) has the sign of psi(uhi)   (:101)
+  double ulo = ul, uhi = lmax - sl;
   double u = uhi, psi, dpsi;
   binf_psi<TEAM>(grp, u, sl, delta, lds, psi, dpsi);
+  const double fm = (lmax / uhi) * psi;
+  if (fl * fm > 0) return false;  // :102
+  if (!(fl < 0.0) || !(fm > 0.0)) {  // an exact zero at an end (or NaN): Roots returns that end
+    root = binf_bisect<TEAM>(grp, lmin, fl, lmax, fm, sigma, sl, delta, lds);
+    return true;
+  }
   for (int it = 0; it < SPX_BINF_NEWTON_MAXIT; ++it) {
-    double un = u - psi / dpsi;
+    double un = u - psi * fast_rcp(dpsi);
     if (!(un > ulo && un < uhi)) un = sqrt(ulo) * sqrt(uhi);  // geometric bisection: the bracket spans decades
     if (!(un > ulo && un < uhi)) break;
     double psin, dpsin;
@@ -201,10 +288,13 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
     if (psin == 0.0 || small) break;
     if (psin < 0.0) ulo = un; else uhi = un;
   }
-  // polish on the literal froot: find adjacent doubles a < b with froot(a) < 0 < froot(b)
-  double n0 = sl + u;
-  n0 = fmin(fmax(n0, lmin), lmax);
-  double f0 = binf_froot<TEAM>(grp, n0, sigma, sl, delta, lds);
+  double n0 = fmin(fmax(sl + u, lmin), lmax);
+  if (u * 1000.0 > n0) {  // well conditioned in n: a few ulp of n cannot move step by more than ~1e-13
+    root = n0;
+    return true;
+  }
+  // polish: find adjacent doubles a < b with froot(a) < 0 < froot(b)
+  double f0 = binf_froot<TEAM>(grp, n0, sl, delta, lds);
   if (f0 == 0.0) { root = n0; return true; }
   double a = lmin, fa = fl, b = lmax, fb = fm;  // running bracket for the fallback
   bool found = false;
@@ -212,7 +302,7 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
     a = n0; fa = f0;
     for (int k = 0; k < SPX_BINF_WALK_MAXIT && a < lmax; ++k) {
       const double n1 = next_up(a);
-      const double f1 = binf_froot<TEAM>(grp, n1, sigma, sl, delta, lds);
+      const double f1 = binf_froot<TEAM>(grp, n1, sl, delta, lds);
       if (f1 < 0.0) { a = n1; fa = f1; }
       else { b = n1; fb = f1; found = true; break; }
     }
@@ -220,7 +310,7 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
     b = n0; fb = f0;
     for (int k = 0; k < SPX_BINF_WALK_MAXIT && b > lmin; ++k) {
       const double n1 = next_down(b);
-      const double f1 = binf_froot<TEAM>(grp, n1, sigma, sl, delta, lds);
+      const double f1 = binf_froot<TEAM>(grp, n1, sl, delta, lds);
       if (f1 > 0.0) { b = n1; fb = f1; }
       else { a = n1; fa = f1; found = true; break; }
     }
@@ -229,44 +319,60 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
     root = (fb == 0.0) ? b : ((fa == 0.0) ? a : ((fabs(fa) < fabs(fb)) ? a : b));
     return true;
   }
-  root = binf_bisect<TEAM>(grp, a, fa, b, fb, sigma, sl, delta, lds);  // rare: Newton ended far from the sign change
+  // rare: Newton ended far from the sign change -> bit-midpoint bisection on the remaining bracket
+  for (int it = 0; it < 130; ++it) {
+    const double m = bit_middle(a, b);
+    if (!(a < m && m < b)) break;
+    const double fmid = binf_froot<TEAM>(grp, m, sl, delta, lds);
+    if (jl_sign(fa) * jl_sign(fmid) < 0) { b = m; fb = fmid; }
+    else { a = m; fa = fmid; }
+  }
+  root = (fabs(fa) < fabs(fb)) ? a : b;
   return true;
 }
 
+// the prox of one element given the root:  alpha w_i with w_i = (n/u) b_i (active) or S_i (inactive)   (:110-113)
+__device__ __forceinline__ double binf_w(double S, double X, double tau, double c, double delta) {
+  const double z = __builtin_fma(tau, S, -X);
+  const double b = X + signed_delta(delta, z);
+  return (fabs(z) > delta) ? c * b : S;
+}
+
 // ---------------------------------------------------------------------------------------------
-// fast path kernel: uniform groups of 64*EPL elements, wave per group, group resident in registers
+// fast path kernel: uniform groups of LPG*EPL elements; LPG lanes own a group, 64/LPG groups per wave;
+// the group is resident in registers.  Lane j of a group owns the 16-byte pairs j, j + LPG, j + 2 LPG, ...
 // ---------------------------------------------------------------------------------------------
-template <int EPL, bool BINF>
+template <int LPG, int EPL, bool BINF>
 __global__ __launch_bounds__(256) void k_group_reg(double* y_, const double* q_, const double* xk_, const double* sj_,
                                                     int64_t ngroups, const double* __restrict__ lambda, double sigma,
                                                     double delta) {
-  static_assert(EPL == 1 || (EPL % 2) == 0, "EPL must be 1 or even");
-  constexpr int GS = 64 * EPL;
+  static_assert((EPL % 2) == 0, "EPL must be even (16-byte pairs)");
+  constexpr int GS = LPG * EPL;
+  constexpr int GPW = 64 / LPG;  // groups per wave
   const int lane = threadIdx.x & 63;
+  const int j = lane % LPG;
+  const int slot = lane / LPG;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t g = wave; g < ngroups; g += nwaves) {
-    RegGroup<EPL> grp;
+  for (int64_t g0 = wave * GPW; g0 < ngroups; g0 += nwaves * GPW) {  // wave-uniform trip count
+    const bool valid = (g0 + slot) < ngroups;
+    const int64_t g = valid ? (g0 + slot) : (ngroups - 1);  // idle slots shadow the last group, no store
     const int64_t base = g * GS;
-    if constexpr (EPL == 1) {
-      double qq = q_[base + lane], xx = xk_[base + lane], ss = sj_[base + lane];
-      grp.S[0] = (qq + xx) + ss;  // shiftedGroupNormL2.jl:65 / shiftedGroupNormL2Binf.jl:80
-      grp.X[0] = xx;
-      grp.XS[0] = xx + ss;
-    } else {
+    RegGroup<EPL> grp;
+    {
       const f64x2* q2 = reinterpret_cast<const f64x2*>(q_ + base);
       const f64x2* x2 = reinterpret_cast<const f64x2*>(xk_ + base);
       const f64x2* s2 = reinterpret_cast<const f64x2*>(sj_ + base);
       f64x2 vq[EPL / 2], vx[EPL / 2], vs[EPL / 2];
 #pragma unroll
       for (int k = 0; k < EPL / 2; ++k) {
-        vq[k] = q2[k * 64 + lane];
-        vx[k] = x2[k * 64 + lane];
-        vs[k] = s2[k * 64 + lane];
+        vq[k] = __builtin_nontemporal_load(q2 + k * LPG + j);
+        vx[k] = __builtin_nontemporal_load(x2 + k * LPG + j);
+        vs[k] = __builtin_nontemporal_load(s2 + k * LPG + j);
       }
 #pragma unroll
       for (int k = 0; k < EPL / 2; ++k) {
-        grp.S[2 * k] = (vq[k].x + vx[k].x) + vs[k].x;
+        grp.S[2 * k] = (vq[k].x + vx[k].x) + vs[k].x;  // shiftedGroupNormL2.jl:65 / shiftedGroupNormL2Binf.jl:80
         grp.S[2 * k + 1] = (vq[k].y + vx[k].y) + vs[k].y;
         grp.X[2 * k] = vx[k].x;
         grp.X[2 * k + 1] = vx[k].y;
@@ -280,37 +386,36 @@ __global__ __launch_bounds__(256) void k_group_reg(double* y_, const double* q_,
       double ss = 0.0;
 #pragma unroll
       for (int k = 0; k < EPL; ++k) ss += grp.S[k] * grp.S[k];
-      const double snorm = sqrt(wave_sum(ss));                                     // shiftedGroupNormL2.jl:69
+      const double snorm = sqrt(lanes_sum<LPG>(ss));                                       // shiftedGroupNormL2.jl:69
       const double alpha = (snorm == 0.0) ? 0.0 : jl_max(1 - sigma * lam / snorm, 0.0);  // :70-73
 #pragma unroll
       for (int k = 0; k < EPL; ++k) out[k] = ((snorm == 0.0) ? 0.0 : alpha * grp.S[k]) - grp.XS[k];  // :74,:77
     } else {
       double root;
-      const bool ok = binf_root<64>(grp, lam, sigma, delta, nullptr, root);
+      const bool ok = binf_root<LPG>(grp, lam, sigma, delta, nullptr, root);
       const double sl = lam * sigma;
       if (!ok || (root - sl) == 0.0) {  // shiftedGroupNormL2Binf.jl:102-103, :107-108
 #pragma unroll
         for (int k = 0; k < EPL; ++k) out[k] = 0.0 - grp.XS[k];
       } else {
-        const double step = root / (sigma * (root - sl));  // :106
+        const double u = root - sl, tau = u / root, c = root / u;  // c = sigma * step (:106)
         double w[EPL], sw = 0.0;
 #pragma unroll
         for (int k = 0; k < EPL; ++k) {
-          w[k] = grp.S[k] - sigma * softthres(grp.S[k] / sigma - step * grp.X[k], delta * step);  // :111
+          w[k] = binf_w(grp.S[k], grp.X[k], tau, c, delta);  // :111
           sw += w[k] * w[k];
         }
-        const double nw = sqrt(wave_sum(sw));
+        const double nw = sqrt(lanes_sum<LPG>(sw));
         const double alpha = jl_max(0.0, 1 - sl / nw);  // l2prox, :83
 #pragma unroll
         for (int k = 0; k < EPL; ++k) out[k] = alpha * w[k] - grp.XS[k];  // :110-116
       }
     }
-    if constexpr (EPL == 1) {
-      y_[base + lane] = out[0];
-    } else {
+    if (valid) {
       f64x2* y2 = reinterpret_cast<f64x2*>(y_ + base);
 #pragma unroll
-      for (int k = 0; k < EPL / 2; ++k) y2[k * 64 + lane] = f64x2{out[2 * k], out[2 * k + 1]};
+      for (int k = 0; k < EPL / 2; ++k)
+        __builtin_nontemporal_store(f64x2{out[2 * k], out[2 * k + 1]}, y2 + k * LPG + j);
     }
   }
 }
@@ -339,7 +444,7 @@ __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, c
     const double lam = lambda[g];
     if constexpr (!BINF) {
       double ss = 0.0;
-      grp.for_each([&](double S, double, int) { ss += S * S; });
+      grp.for_each([&](double S, double) { ss += S * S; });
       const double snorm = sqrt(team_sum<TEAM>(ss, lds));
       const double alpha = (snorm == 0.0) ? 0.0 : jl_max(1 - sigma * lam / snorm, 0.0);
       for (int64_t i = lo + lane; i < hi; i += TEAM) {
@@ -354,10 +459,10 @@ __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, c
       if (!ok || (root - sl) == 0.0) {
         for (int64_t i = lo + lane; i < hi; i += TEAM) y[i] = 0.0 - (xk[i] + sj[i]);
       } else {
-        const double step = root / (sigma * (root - sl));
+        const double u = root - sl, tau = u / root, c = root / u;
         double sw = 0.0;
-        grp.for_each([&](double S, double X, int) {
-          double w = S - sigma * softthres(S / sigma - step * X, delta * step);
+        grp.for_each([&](double S, double X) {
+          double w = binf_w(S, X, tau, c, delta);
           sw += w * w;
         });
         const double nw = sqrt(team_sum<TEAM>(sw, lds));
@@ -365,8 +470,7 @@ __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, c
         for (int64_t i = lo + lane; i < hi; i += TEAM) {
           double x = xk[i], s = sj[i];
           double S = (q[i] + x) + s;
-          double w = S - sigma * softthres(S / sigma - step * x, delta * step);
-          y[i] = alpha * w - (x + s);
+          y[i] = alpha * binf_w(S, x, tau, c, delta) - (x + s);
         }
       }
     }
@@ -395,23 +499,35 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   SPX_HIP(hipSetDevice(ctx->device));
   const int64_t cap_blocks = (int64_t)ctx->num_cu * 8;
   const bool aligned = spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj);
-  if (!offsets && (gsize % 64) == 0 && gsize / 64 <= 8 && (gsize == 64 || (gsize / 64) % 2 == 0) && aligned) {
-    int64_t blocks = (ngroups + 3) / 4;  // 4 waves (groups) per 256-thread block
-    if (blocks > cap_blocks) blocks = cap_blocks;
-    dim3 grid((unsigned)blocks), block(256);
-#define SPX_LAUNCH_REG(EPL)                                                                                       \
-  hipLaunchKernelGGL((k_group_reg<EPL, BINF>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups, lambda, sigma, \
-                     delta)
-    switch (gsize / 64) {
-      case 1: SPX_LAUNCH_REG(1); break;
-      case 2: SPX_LAUNCH_REG(2); break;
-      case 4: SPX_LAUNCH_REG(4); break;
-      case 6: SPX_LAUNCH_REG(6); break;
-      case 8: SPX_LAUNCH_REG(8); break;
+  if (!offsets && aligned) {
+    // register path: gsize = LPG * EPL
+    int lpg = 0;
+    switch (gsize) {
+      case 32: case 64: case 128: lpg = 16; break;
+      case 256: lpg = 32; break;
+      case 384: case 512: lpg = 64; break;
+      default: break;
     }
+    if (lpg) {
+      const int gpw = 64 / lpg;
+      int64_t blocks = (ngroups + 4 * gpw - 1) / (4 * gpw);  // 4 waves per 256-thread block
+      if (blocks > 0x7fffffff) blocks = 0x7fffffff;
+      dim3 grid((unsigned)blocks), block(256);
+#define SPX_LAUNCH_REG(LPG, EPL)                                                                                 \
+  hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups, lambda, \
+                     sigma, delta)
+      switch (gsize) {
+        case 32: SPX_LAUNCH_REG(16, 2); break;
+        case 64: SPX_LAUNCH_REG(16, 4); break;
+        case 128: SPX_LAUNCH_REG(16, 8); break;
+        case 256: SPX_LAUNCH_REG(32, 8); break;
+        case 384: SPX_LAUNCH_REG(64, 6); break;
+        case 512: SPX_LAUNCH_REG(64, 8); break;
+      }
 #undef SPX_LAUNCH_REG
-    SPX_LAUNCH_CHECK();
-    return SPX_OK;
+      SPX_LAUNCH_CHECK();
+      return SPX_OK;
+    }
   }
   // team width: wavefront per group unless groups are large on average
   const double avg = (double)n / (double)ngroups;
