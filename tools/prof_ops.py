@@ -1,0 +1,35 @@
+"""Runs each operator a few times at full size (for rocprofv3 --kernel-trace --stats)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as ge
+s = ge.build()
+dev = torch.device("cuda:0")
+n = int(os.environ.get("SPX_N", "100000000"))
+which = os.environ.get("SPX_OPS", "indball,lhalfbox,group,binf").split(",")
+g = torch.Generator(device=dev).manual_seed(1)
+chi = s.NormLinf(1.0)
+def vecs(m):
+    return (torch.randn(m, dtype=torch.float64, device=dev, generator=g),
+            torch.rand(m, dtype=torch.float64, device=dev, generator=g) - 0.5,
+            torch.randn(m, dtype=torch.float64, device=dev, generator=g))
+xk, sj, q = vecs(n); y = torch.empty_like(q)
+if "indball" in which:
+    psi = s.shifted(s.shifted(s.IndBallL0(n // 100), xk, 1.0, chi), sj)
+    for _ in range(5): s.prox_bang(y, psi, q, 1.0)
+if "lhalfbox" in which:
+    psi = s.shifted(s.shifted(s.RootNormLhalf(1.0), xk, 1.0, chi), sj)
+    for _ in range(5): s.prox_bang(y, psi, q, 1.0)
+if "group" in which or "binf" in which:
+    ng = n // 100; m = ng * 128
+    del xk, sj, q, y
+    xk, sj, q = vecs(m); y = torch.empty_like(q)
+    lam = torch.rand(ng, dtype=torch.float64, device=dev, generator=g) + 0.5
+    h = s.GroupNormL2(lam, [range(i, i + 128) for i in range(0, m, 128)])
+    if "group" in which:
+        psi = s.shifted(s.shifted(h, xk), sj)
+        for _ in range(5): s.prox_bang(y, psi, q, 1.0)
+    if "binf" in which:
+        psi = s.shifted(s.shifted(h, xk, 1.0, chi), sj)
+        for _ in range(5): s.prox_bang(y, psi, q, 1.0)
+torch.cuda.synchronize()
