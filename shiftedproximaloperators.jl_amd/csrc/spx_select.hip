@@ -40,12 +40,27 @@ struct SelState {
   int64_t icut;
   int idx_bits;       // number of significant bits of n - 1
   int pad2;
+  uint64_t t_floor;   // candidate mode: no kept key is below this (0 in the full-vector mode)
+};
+
+// state of the sample-predicted path (see "fast path" below)
+struct FastState {
+  uint64_t t_hi, t_lo;            // candidate band in key space: t_lo <= key <= t_hi; "above": key > t_hi
+  unsigned long long cnt_above;   // number of elements with key > t_hi
+  unsigned long long cand_count;  // number of candidates appended
+  int ok;                         // set by k_s2_verify: the r-th largest is provably inside the band
+  int overflow;                   // a workgroup or the candidate buffer overflowed
 };
 
 struct SelWs {
   SelState st;
+  FastState fs;
   unsigned long long hist[kBins];
 };
+
+constexpr int kSample = 65536;        // sample size (256 chunks of 256 consecutive elements)
+constexpr int kMainChunkPairs = 8192; // 16-byte pairs per workgroup of the main pass
+constexpr int kLdsCand = 1024;        // per-workgroup candidate staging
 
 __device__ __forceinline__ uint64_t key_of(double v) { return (uint64_t)__double_as_longlong(v) & kAbsMask; }
 
@@ -61,6 +76,7 @@ __global__ void k_sel_init(SelWs* ws, int64_t n, int64_t r) {
     s.icut = -1;
     s.t_eq = ~0ull;
     s.pad = s.pad2 = 0;
+    s.t_floor = 0;
     if (r <= 0) {            // nothing kept
       s.phase = 2; s.t_ge = ~0ull; s.quota = 0; s.shift = 0; s.width = 0;
     } else if (r >= n) {     // everything kept
@@ -211,7 +227,8 @@ __global__ __launch_bounds__(256) void k_sel_scan(SelWs* ws) {
     if (st.phase == 0) {
       if ((uint64_t)left == count) {                    // the whole bucket is kept: resolved, no tie
         o.phase = 2;
-        o.t_ge = newprefix << st.shift;
+        const uint64_t lowkey = newprefix << st.shift;
+        o.t_ge = lowkey > st.t_floor ? lowkey : st.t_floor;
       } else if (st.shift == 0) {                       // full key known, more equal keys than quota: tie
         o.t_ge = newprefix + 1;                         // keys are < 2^63: no overflow
         o.t_eq = newprefix;
@@ -279,17 +296,328 @@ __global__ __launch_bounds__(256) void k_sel_final(double* y, const double* xk, 
   }
 }
 
+// =============================================================================================
+// Fast path (large n): sample-predicted band.
+//   1. k_s2_sample   65536 samples of |v| (256 chunks of 256 consecutive elements: 1.5 MB of reads)
+//   2. k_s2_pick     one workgroup: exact order statistics of the sample at ranks p*M -/+ (6 sigma + 16),
+//                    p = r/n, sigma = sqrt(M p (1-p))  ->  key band [t_lo, t_hi] that contains the r-th
+//                    largest |v| of the whole vector except with probability ~1e-9 per side
+//   3. k_s2_main     ONE streaming pass over q, xk, sj (24 B/element, nothing written): counts the
+//                    elements above the band and appends the (key, index) of the ~1% inside it to a
+//                    candidate buffer (LDS staging per workgroup, one global atomic per workgroup)
+//   4. k_s2_verify   cnt_above < r <= cnt_above + candidates ?  -> the selection continues on the
+//                    candidates only (same digit machinery, a few microseconds per pass)
+//   5. k_sel_final_q y[i] from q, xk, sj and the thresholds (24 B read + 8 B written per element)
+// Total 56 B/element instead of >= 80.  The prediction is only a performance device: if the verification
+// fails (or a buffer overflows) the full-vector radix select above runs instead, so the result is exact
+// for any input.  The host reads the 4-byte verdict back (one stream synchronisation per call).
+// y is not touched before step 5 and step 5 reads q[i] before writing y[i]: y may alias q.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_s2_sample(const double* q, const double* xk, const double* sj, int64_t n,
+                                                    double* samp) {
+  const int c = blockIdx.x;  // chunk
+  const int64_t start = (int64_t)((double)c * (double)(n - 256) / 255.0);
+  const int64_t i = start + threadIdx.x;
+  samp[c * 256 + threadIdx.x] = fabs((xk[i] + sj[i]) + q[i]);
+}
+
+// one workgroup of 1024 lanes: rank_hi-th and rank_lo-th largest sample keys (exact), band into ws->fs
+__global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n, int64_t r, SelWs* ws) {
+  __shared__ unsigned int h[2][kBins];
+  __shared__ unsigned long long part[2][256];
+  __shared__ unsigned long long pre[2];
+  __shared__ long long quo[2];
+  __shared__ int active[2];
+  const int t = threadIdx.x;
+  if (t == 0) {
+    const double M = (double)kSample;
+    const double p = (double)r / (double)n;
+    const double k = p * M;
+    const double margin = 6.0 * sqrt(M * p * (1.0 - p)) + 16.0;
+    const long long rank_hi = (long long)floor(k - margin);  // 1-based from the largest
+    const long long rank_lo = (long long)ceil(k + margin);
+    pre[0] = pre[1] = 0;
+    active[0] = rank_hi >= 1;
+    active[1] = rank_lo <= kSample;
+    quo[0] = rank_hi;
+    quo[1] = rank_lo;
+  }
+  __syncthreads();
+  int shift = 64 - kDigitBits, width = kDigitBits;
+  while (true) {
+    for (int b = t; b < 2 * kBins; b += 1024) (&h[0][0])[b] = 0u;
+    __syncthreads();
+    const int hs = shift + width;
+    const uint64_t dmask = ((uint64_t)1 << width) - 1;
+    const uint64_t p0 = pre[0], p1 = pre[1];
+    const bool a0 = active[0], a1 = active[1];
+    for (int i = t; i < kSample; i += 1024) {
+      const uint64_t key = key_of(samp[i]);
+      const uint64_t top = hs >= 64 ? 0ull : (key >> hs);
+      const unsigned d = (unsigned)((key >> shift) & dmask);
+      if (a0 && top == p0) atomicAdd(&h[0][d], 1u);
+      if (a1 && top == p1) atomicAdd(&h[1][d], 1u);
+    }
+    __syncthreads();
+    // scan from the top: lanes 0..255 serve selection 0, lanes 256..511 selection 1
+    constexpr int PER = kBins / 256;
+    const int sel = t >> 8, tt = t & 255;
+    unsigned long long loc[PER], sum = 0;
+    if (t < 512) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) { loc[k] = h[sel][kBins - 1 - (tt * PER + k)]; sum += loc[k]; }
+      part[sel][tt] = sum;
+    }
+    __syncthreads();
+    if (t == 0 || t == 256) {
+      unsigned long long run = 0;
+      for (int k = 0; k < 256; ++k) { unsigned long long c = part[sel][k]; part[sel][k] = run; run += c; }
+    }
+    __syncthreads();
+    if (t < 512 && active[sel]) {
+      unsigned long long run = part[sel][tt];
+      const unsigned long long quota = (unsigned long long)quo[sel];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        if (run < quota && run + loc[k] >= quota) {
+          pre[sel] = (pre[sel] << width) | (uint64_t)(kBins - 1 - (tt * PER + k));
+          quo[sel] = (long long)(quota - run);
+        }
+        run += loc[k];
+      }
+    }
+    __syncthreads();
+    if (shift == 0) break;
+    width = shift < kDigitBits ? shift : kDigitBits;
+    shift -= width;
+  }
+  if (t == 0) {
+    FastState& f = ws->fs;
+    f.t_hi = active[0] ? pre[0] : ~0ull;  // nothing is above an all-ones key
+    f.t_lo = active[1] ? pre[1] : 0ull;
+    f.cnt_above = 0;
+    f.cand_count = 0;
+    f.ok = 0;
+    f.overflow = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_s2_main(const double* q_, const double* xk_, const double* sj_, int64_t n,
+                                                  SelWs* ws, uint64_t* cand_key, int64_t* cand_idx, int64_t cap) {
+  __shared__ uint64_t lk[kLdsCand];
+  __shared__ int64_t li[kLdsCand];
+  __shared__ unsigned int lcnt, labove;
+  __shared__ unsigned long long gbase;
+  if (threadIdx.x == 0) { lcnt = 0; labove = 0; }
+  __syncthreads();
+  const uint64_t t_hi = ws->fs.t_hi, t_lo = ws->fs.t_lo;
+  const f64x2* q = reinterpret_cast<const f64x2*>(q_);
+  const f64x2* xk = reinterpret_cast<const f64x2*>(xk_);
+  const f64x2* sj = reinterpret_cast<const f64x2*>(sj_);
+  const int64_t n2 = n >> 1;
+  const int64_t p0 = (int64_t)blockIdx.x * kMainChunkPairs;
+  unsigned int above = 0;
+  auto visit = [&](double v, int64_t i) {
+    const uint64_t key = key_of(v);
+    if (key > t_hi) {
+      ++above;
+    } else if (key >= t_lo) {
+      const unsigned int slot = atomicAdd(&lcnt, 1u);
+      if (slot < kLdsCand) { lk[slot] = key; li[slot] = i; }
+    }
+  };
+  constexpr int UNROLL = 4;
+  for (int64_t base = p0; base < p0 + kMainChunkPairs && base < n2; base += 256 * UNROLL) {
+    f64x2 a[UNROLL], b[UNROLL], c[UNROLL];
+    bool live[UNROLL];
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) {
+      const int64_t i = base + k * 256 + threadIdx.x;
+      live[k] = i < n2;
+      const int64_t ii = live[k] ? i : (n2 - 1);
+      a[k] = __builtin_nontemporal_load(q + ii);
+      b[k] = __builtin_nontemporal_load(xk + ii);
+      c[k] = __builtin_nontemporal_load(sj + ii);
+    }
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) {
+      if (live[k]) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        visit((b[k].x + c[k].x) + a[k].x, 2 * i);      // shiftedIndBallL0.jl:66  xk .+ sj .+ q
+        visit((b[k].y + c[k].y) + a[k].y, 2 * i + 1);
+      }
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) visit((xk_[n - 1] + sj_[n - 1]) + q_[n - 1], n - 1);
+  // workgroup totals
+  for (int off = 32; off >= 1; off >>= 1) above += __shfl_xor(above, off, 64);
+  if ((threadIdx.x & 63) == 0 && above) atomicAdd(&labove, above);
+  __syncthreads();
+  unsigned int cnt = lcnt;
+  if (threadIdx.x == 0) {
+    if (labove) atomicAdd(&ws->fs.cnt_above, (unsigned long long)labove);
+    if (cnt > kLdsCand) { atomicExch(&ws->fs.overflow, 1); cnt = kLdsCand; }
+    gbase = cnt ? atomicAdd(&ws->fs.cand_count, (unsigned long long)cnt) : 0ull;
+  }
+  __syncthreads();
+  if (cnt > kLdsCand) cnt = kLdsCand;
+  const unsigned long long g0 = gbase;
+  for (unsigned int e = threadIdx.x; e < cnt; e += 256) {
+    if ((int64_t)(g0 + e) < cap) { cand_key[g0 + e] = lk[e]; cand_idx[g0 + e] = li[e]; }
+  }
+}
+
+// verdict + set up the digit machinery on the candidates (first digit = the first one in which the band's
+// ends differ; everything above it is the common prefix)
+__global__ void k_s2_verify(SelWs* ws, int64_t n, int64_t r, int64_t cap) {
+  if (threadIdx.x != 0) return;
+  FastState& f = ws->fs;
+  SelState& s = ws->st;
+  const unsigned long long above = f.cnt_above, cand = f.cand_count;
+  const bool ok = !f.overflow && (int64_t)cand <= cap && above < (unsigned long long)r &&
+                  (unsigned long long)r <= above + cand;
+  f.ok = ok ? 1 : 0;
+  if (!ok) return;
+  s.quota = (int64_t)((unsigned long long)r - above);
+  s.t_floor = f.t_lo;
+  s.t_eq = ~0ull;
+  s.icut = -1;
+  s.t_ge = ~0ull;
+  const uint64_t d = f.t_lo ^ f.t_hi;
+  int idx_bits = s.idx_bits;
+  if (d == 0) {  // one key value in the band: straight to the index tie-break (or everything kept)
+    if ((unsigned long long)s.quota == cand) { s.phase = 2; s.t_ge = f.t_lo; return; }
+    s.t_ge = f.t_lo + 1;
+    s.t_eq = f.t_lo;
+    s.phase = 1;
+    s.prefix = 0;
+    int w = idx_bits % kDigitBits ? idx_bits % kDigitBits : kDigitBits;
+    s.shift = idx_bits - w;
+    s.width = w;
+    return;
+  }
+  const int hb = 63 - __clzll((long long)d);  // highest differing bit
+  int width = hb + 1 < kDigitBits ? hb + 1 : kDigitBits;
+  int shift = hb + 1 - width;
+  s.phase = 0;
+  s.shift = shift;
+  s.width = width;
+  s.prefix = (shift + width >= 64) ? 0ull : (f.t_hi >> (shift + width));
+}
+
+// histogram of the current digit over the candidates
+__global__ __launch_bounds__(256) void k_sel_hist_cand(const uint64_t* cand_key, const int64_t* cand_idx, SelWs* ws) {
+  const SelState st = ws->st;
+  if (st.phase == 2) return;
+  __shared__ unsigned int lh[kBins];
+  for (int b = threadIdx.x; b < kBins; b += blockDim.x) lh[b] = 0u;
+  __syncthreads();
+  const int64_t m = (int64_t)ws->fs.cand_count;
+  const int shift = st.shift;
+  const int hs = st.shift + st.width;
+  const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = tid; e < m; e += stride) {
+    const uint64_t key = cand_key[e];
+    if (st.phase == 0) {
+      if ((hs >= 64 ? 0ull : (key >> hs)) == st.prefix) atomicAdd(&lh[(key >> shift) & dmask], 1u);
+    } else if (key == st.t_eq) {
+      const uint64_t i = (uint64_t)cand_idx[e];
+      if ((i >> hs) == st.prefix) atomicAdd(&lh[(i >> shift) & dmask], 1u);
+    }
+  }
+  flush_hist(lh, ws->hist);
+}
+
+// final pass of the fast path: v recomputed from q, xk, sj (y untouched so far)
+template <bool BINF>
+__global__ __launch_bounds__(256) void k_sel_final_q(double* y_, const double* q_, const double* xk_, const double* sj_,
+                                                      int64_t n, const SelWs* ws, double delta) {
+  const SelState st = ws->st;
+  constexpr int UNROLL = 4;
+  constexpr int64_t TILE = 256 * UNROLL;
+  f64x2* y = reinterpret_cast<f64x2*>(y_);
+  const f64x2* q = reinterpret_cast<const f64x2*>(q_);
+  const f64x2* xk = reinterpret_cast<const f64x2*>(xk_);
+  const f64x2* sj = reinterpret_cast<const f64x2*>(sj_);
+  const int64_t n2 = n >> 1;
+  const int64_t base = (int64_t)blockIdx.x * TILE + threadIdx.x;
+  f64x2 a[UNROLL], b[UNROLL], c[UNROLL];
+#pragma unroll
+  for (int k = 0; k < UNROLL; ++k) {
+    const int64_t i = base + k * 256;
+    const int64_t ii = i < n2 ? i : (n2 - 1);
+    a[k] = __builtin_nontemporal_load(q + ii);
+    b[k] = __builtin_nontemporal_load(xk + ii);
+    c[k] = __builtin_nontemporal_load(sj + ii);
+  }
+#pragma unroll
+  for (int k = 0; k < UNROLL; ++k) {
+    const int64_t i = base + k * 256;
+    if (i < n2) {
+      f64x2 r;
+      r.x = sel_out<BINF>((b[k].x + c[k].x) + a[k].x, 2 * i, b[k].x, c[k].x, st, delta);
+      r.y = sel_out<BINF>((b[k].y + c[k].y) + a[k].y, 2 * i + 1, b[k].y, c[k].y, st, delta);
+      __builtin_nontemporal_store(r, y + i);
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    y_[i] = sel_out<BINF>((xk_[i] + sj_[i]) + q_[i], i, xk_[i], sj_[i], st, delta);
+  }
+}
+
+static int g_sel_fast = 1;  // spx_set_tuning key 2: 0 disables the sample-predicted path
+
 template <bool BINF>
 int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n, int64_t r,
                double delta) {
   int rc = spx_check_common(ctx, y, q, xk, sj, n);
   if (rc) return rc;
   if (n == 0) return SPX_OK;
-  rc = spx_ws_reserve(ctx, sizeof(SelWs) + 256);
-  if (rc) return rc;
   SPX_HIP(hipSetDevice(ctx->device));
-  SelWs* ws = reinterpret_cast<SelWs*>(ctx->ws);
   const int vec = (spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj)) ? 1 : 0;
+  const bool try_fast = g_sel_fast && vec && n >= ((int64_t)1 << 22) && r > 0 && r < n;
+  const int64_t ccap = try_fast ? (n / 16 > (1 << 20) ? n / 16 : (1 << 20)) : 0;  // candidate capacity
+  const size_t off_samp = (sizeof(SelWs) + 255) & ~(size_t)255;
+  const size_t off_ckey = off_samp + (size_t)kSample * sizeof(double);
+  const size_t off_cidx = off_ckey + (size_t)ccap * sizeof(uint64_t);
+  rc = spx_ws_reserve(ctx, off_cidx + (size_t)ccap * sizeof(int64_t) + 256);
+  if (rc) return rc;
+  SelWs* ws = reinterpret_cast<SelWs*>(ctx->ws);
+  if (try_fast) {
+    char* wsb = reinterpret_cast<char*>(ctx->ws);
+    double* samp = reinterpret_cast<double*>(wsb + off_samp);
+    uint64_t* ckey = reinterpret_cast<uint64_t*>(wsb + off_ckey);
+    int64_t* cidx = reinterpret_cast<int64_t*>(wsb + off_cidx);
+    const int64_t n2 = n >> 1;
+    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, ctx->stream, ws, n, r);
+    hipLaunchKernelGGL(k_s2_sample, dim3(256), dim3(256), 0, ctx->stream, q, xk, sj, n, samp);
+    hipLaunchKernelGGL(k_s2_pick, dim3(1), dim3(1024), 0, ctx->stream, (const double*)samp, n, r, ws);
+    hipLaunchKernelGGL(k_s2_main, dim3((unsigned)((n2 + kMainChunkPairs - 1) / kMainChunkPairs)), dim3(256), 0,
+                       ctx->stream, q, xk, sj, n, ws, ckey, cidx, ccap);
+    hipLaunchKernelGGL(k_s2_verify, dim3(1), dim3(64), 0, ctx->stream, ws, n, r, ccap);
+    SPX_LAUNCH_CHECK();
+    int ok = 0;
+    SPX_HIP(hipMemcpyAsync(&ok, &ws->fs.ok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SPX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ok) {
+      int idx_bits = 0;
+      while (idx_bits < 63 && ((int64_t)1 << idx_bits) < n) ++idx_bits;
+      const int passes = (64 + kDigitBits - 1) / kDigitBits + (idx_bits + kDigitBits - 1) / kDigitBits;
+      for (int p = 0; p < passes; ++p) {
+        hipLaunchKernelGGL(k_sel_hist_cand, dim3(512), dim3(256), 0, ctx->stream, (const uint64_t*)ckey,
+                           (const int64_t*)cidx, ws);
+        hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(256), 0, ctx->stream, ws);
+      }
+      hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1023) / 1024)), dim3(256), 0, ctx->stream, y, q,
+                         xk, sj, n, (const SelWs*)ws, delta);
+      SPX_LAUNCH_CHECK();
+      return SPX_OK;
+    }
+    // prediction failed: exact full-vector path below
+  }
   const int64_t work = vec ? (n + 1) / 2 : n;
   int64_t blocks = (work + 255) / 256;
   const int64_t cap = (int64_t)ctx->num_cu * 8;
@@ -315,6 +643,8 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
 }
 
 }  // namespace
+
+void spx_select_set_fast(int on) { g_sel_fast = on ? 1 : 0; }
 
 SPX_EXPORT int spx_prox_indball_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
                                    int64_t n, int64_t r) {

@@ -163,3 +163,40 @@ def test_full_size_groups(s, orc, binf):
         scale = np.maximum(np.abs(ref), np.repeat(nS[lo:hi].cpu().numpy(), gs))
         err = np.abs(yh - ref) / scale
         assert float(err.max()) <= 1e-12, float(err.max())
+
+
+@pytest.mark.parametrize("case", ["normal", "quant", "all_equal", "sorted", "two_values", "spike"])
+def test_indball_fast_path_and_fallback(s, orc, case):
+    """n just above the fast-path threshold (2^22): the sample-predicted band path, its verification and
+    the fallback to the full-vector radix select, bit-exact against the oracle, also with the fast path off."""
+    import ctypes
+    import torch
+    n = (1 << 22) + 12345
+    rng = np.random.default_rng(99)
+    x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
+    if case == "quant":
+        x, sj, q = (np.round(t * 64) / 64 for t in (x, sj, q))
+    elif case == "all_equal":      # band = one key, candidates = everything -> overflow -> fallback
+        x[:] = 0.0; sj[:] = 0.0; q = np.where(rng.random(n) < 0.5, 1.25, -1.25)
+    elif case == "sorted":         # chunked sample sees a monotone ramp
+        q = np.sort(q); x[:] = 0.0; sj[:] = 0.0
+    elif case == "two_values":     # threshold inside a huge tie class
+        x[:] = 0.0; sj[:] = 0.0; q = np.where(rng.random(n) < 0.3, 2.0, 1.0) * np.where(rng.random(n) < 0.5, 1, -1)
+    elif case == "spike":          # the sample misses a tiny cluster of huge values
+        q[1000:1010] = 1e6
+    xd, sd, qd = (torch.from_numpy(t).to("cuda:0") for t in (x, sj, q))
+    L = s._lib.load()
+    for r in (1, 7, n // 1000, n // 3, n - 5):
+        ref = orc.prox_indball_l0_binf(q, x, sj, r, 1.0)
+        for fast in (1, 0):
+            s._lib.check(L.spx_set_tuning(2, fast))
+            try:
+                psi = s.shifted(s.shifted(s.IndBallL0(r), xd, 1.0, s.NormLinf(1.0)), sd)
+                y = s.prox(psi, qd, 1.0).cpu().numpy()
+            finally:
+                s._lib.check(L.spx_set_tuning(2, 1))
+            assert _bits_equal(y, ref), (case, r, fast)
+    # y === q on the fast path
+    ref = orc.prox_indball_l0(q, x, sj, n // 50)
+    s.prox_bang(qd, s.shifted(s.shifted(s.IndBallL0(n // 50), xd), sd), qd, 1.0)
+    assert _bits_equal(qd.cpu().numpy(), ref)
