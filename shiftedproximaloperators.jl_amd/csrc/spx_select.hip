@@ -49,7 +49,9 @@ struct FastState {
   unsigned long long cnt_above;   // number of elements with key > t_hi
   unsigned long long cand_count;  // number of candidates appended
   int ok;                         // set by k_s2_verify: the r-th largest is provably inside the band
+  int key_passes;                 // key-digit passes the candidate selection can need (host reads ok + this)
   int overflow;                   // a workgroup or the candidate buffer overflowed
+  int pad;
 };
 
 struct SelWs {
@@ -63,6 +65,22 @@ constexpr int kMainChunkPairs = 8192; // 16-byte pairs per workgroup of the main
 constexpr int kLdsCand = 1024;        // per-workgroup candidate staging
 
 __device__ __forceinline__ uint64_t key_of(double v) { return (uint64_t)__double_as_longlong(v) & kAbsMask; }
+
+// exclusive prefix sum over 256 consecutive lanes (4 wavefronts: tt = 0..255); wtot = 4 shared slots of that group
+__device__ __forceinline__ unsigned long long scan256_exclusive(unsigned long long v, int tt, unsigned long long* wtot) {
+  const int lane = tt & 63, w = tt >> 6;
+  unsigned long long inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long up = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += up;
+  }
+  if (lane == 63) wtot[w] = inc;
+  __syncthreads();
+  unsigned long long base = 0;
+  for (int k = 0; k < w; ++k) base += wtot[k];
+  return base + inc - v;
+}
 
 __global__ void k_sel_init(SelWs* ws, int64_t n, int64_t r) {
   const int t = threadIdx.x;
@@ -178,7 +196,7 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double* y, int64_t n, in
 // One workgroup: locate the bucket that holds the quota-th element (from the top for keys, from the
 // bottom for indices), advance the state, clear the histogram for the next pass.
 __global__ __launch_bounds__(256) void k_sel_scan(SelWs* ws) {
-  __shared__ unsigned long long part[256];
+  __shared__ unsigned long long part[4];
   __shared__ int s_bucket;
   __shared__ unsigned long long s_before, s_count;
   SelState st = ws->st;
@@ -197,14 +215,7 @@ __global__ __launch_bounds__(256) void k_sel_scan(SelWs* ws) {
     loc[k] = (bin < nb) ? ws->hist[bin] : 0ull;
     sum += loc[k];
   }
-  part[t] = sum;
-  __syncthreads();
-  if (t == 0) {
-    unsigned long long run = 0;
-    for (int k = 0; k < 256; ++k) { unsigned long long c = part[k]; part[k] = run; run += c; }
-  }
-  __syncthreads();
-  unsigned long long run = part[t];
+  unsigned long long run = scan256_exclusive(sum, t, part);
   const unsigned long long quota = (unsigned long long)st.quota;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
@@ -314,17 +325,27 @@ __global__ __launch_bounds__(256) void k_sel_final(double* y, const double* xk, 
 // y is not touched before step 5 and step 5 reads q[i] before writing y[i]: y may alias q.
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_s2_sample(const double* q, const double* xk, const double* sj, int64_t n,
-                                                    double* samp) {
+                                                    double* samp, SelWs* ws) {
+  // also histograms the top key digit of the sample into ws->hist (zeroed by k_sel_init): that digit is
+  // mostly exponent bits, a handful of hot bins, which would serialise a single workgroup's LDS atomics
+  __shared__ unsigned int lh[kBins];
+  for (int b = threadIdx.x; b < kBins; b += blockDim.x) lh[b] = 0u;
+  __syncthreads();
   const int c = blockIdx.x;  // chunk
   const int64_t start = (int64_t)((double)c * (double)(n - 256) / 255.0);
   const int64_t i = start + threadIdx.x;
-  samp[c * 256 + threadIdx.x] = fabs((xk[i] + sj[i]) + q[i]);
+  const double a = fabs((xk[i] + sj[i]) + q[i]);
+  samp[c * 256 + threadIdx.x] = a;
+  atomicAdd(&lh[key_of(a) >> (64 - kDigitBits)], 1u);
+  flush_hist(lh, ws->hist);
 }
 
-// one workgroup of 1024 lanes: rank_hi-th and rank_lo-th largest sample keys (exact), band into ws->fs
+// One workgroup of 1024 lanes: brackets the sample's rank_hi-th and rank_lo-th largest keys to 36 bits
+// (three 12-bit digits; the first comes from the histogram k_s2_sample built) and writes the band.
+constexpr int kPickDigits = 3;
 __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n, int64_t r, SelWs* ws) {
   __shared__ unsigned int h[2][kBins];
-  __shared__ unsigned long long part[2][256];
+  __shared__ unsigned long long part[4][4];  // per 256-lane group
   __shared__ unsigned long long pre[2];
   __shared__ long long quo[2];
   __shared__ int active[2];
@@ -342,40 +363,44 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
     quo[0] = rank_hi;
     quo[1] = rank_lo;
   }
-  __syncthreads();
-  int shift = 64 - kDigitBits, width = kDigitBits;
-  while (true) {
-    for (int b = t; b < 2 * kBins; b += 1024) (&h[0][0])[b] = 0u;
+  int shift = 64 - kDigitBits;
+  const int width = kDigitBits;
+  for (int digit = 0; digit < kPickDigits; ++digit) {
     __syncthreads();
-    const int hs = shift + width;
-    const uint64_t dmask = ((uint64_t)1 << width) - 1;
-    const uint64_t p0 = pre[0], p1 = pre[1];
-    const bool a0 = active[0], a1 = active[1];
-    for (int i = t; i < kSample; i += 1024) {
-      const uint64_t key = key_of(samp[i]);
-      const uint64_t top = hs >= 64 ? 0ull : (key >> hs);
-      const unsigned d = (unsigned)((key >> shift) & dmask);
-      if (a0 && top == p0) atomicAdd(&h[0][d], 1u);
-      if (a1 && top == p1) atomicAdd(&h[1][d], 1u);
+    if (digit == 0) {
+      for (int b = t; b < kBins; b += 1024) { const unsigned int c = (unsigned int)ws->hist[b]; h[0][b] = c; h[1][b] = c; }
+    } else {
+      for (int b = t; b < 2 * kBins; b += 1024) (&h[0][0])[b] = 0u;
+      __syncthreads();
+      const int hs = shift + width;
+      const uint64_t p0 = pre[0], p1 = pre[1];
+      const bool a0 = active[0], a1 = active[1];
+      for (int i0 = t; i0 < kSample; i0 += 1024 * 8) {  // 8 independent loads in flight per lane
+        double sv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sv[k] = samp[i0 + 1024 * k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint64_t key = key_of(sv[k]);
+          const uint64_t top = key >> hs;
+          const unsigned d = (unsigned)((key >> shift) & (kBins - 1));
+          if (a0 && top == p0) atomicAdd(&h[0][d], 1u);
+          if (a1 && top == p1) atomicAdd(&h[1][d], 1u);
+        }
+      }
     }
     __syncthreads();
     // scan from the top: lanes 0..255 serve selection 0, lanes 256..511 selection 1
     constexpr int PER = kBins / 256;
-    const int sel = t >> 8, tt = t & 255;
+    const int sel = (t >> 8) & 1, tt = t & 255, grp256 = t >> 8;
     unsigned long long loc[PER], sum = 0;
     if (t < 512) {
 #pragma unroll
       for (int k = 0; k < PER; ++k) { loc[k] = h[sel][kBins - 1 - (tt * PER + k)]; sum += loc[k]; }
-      part[sel][tt] = sum;
     }
-    __syncthreads();
-    if (t == 0 || t == 256) {
-      unsigned long long run = 0;
-      for (int k = 0; k < 256; ++k) { unsigned long long c = part[sel][k]; part[sel][k] = run; run += c; }
-    }
-    __syncthreads();
+    const unsigned long long run0 = scan256_exclusive(sum, tt, part[grp256]);  // every 256-lane group has its own slots
     if (t < 512 && active[sel]) {
-      unsigned long long run = part[sel][tt];
+      unsigned long long run = run0;
       const unsigned long long quota = (unsigned long long)quo[sel];
 #pragma unroll
       for (int k = 0; k < PER; ++k) {
@@ -386,19 +411,21 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
         run += loc[k];
       }
     }
-    __syncthreads();
-    if (shift == 0) break;
-    width = shift < kDigitBits ? shift : kDigitBits;
     shift -= width;
   }
+  __syncthreads();
+  for (int b = t; b < kBins; b += 1024) ws->hist[b] = 0ull;  // clean for the candidate passes
   if (t == 0) {
     FastState& f = ws->fs;
-    f.t_hi = active[0] ? pre[0] : ~0ull;  // nothing is above an all-ones key
-    f.t_lo = active[1] ? pre[1] : 0ull;
+    const int low = 64 - kPickDigits * kDigitBits;  // undecided low bits: take the whole bucket
+    f.t_hi = active[0] ? ((pre[0] << low) | (((uint64_t)1 << low) - 1)) : ~0ull;  // nothing is above all-ones
+    f.t_lo = active[1] ? (pre[1] << low) : 0ull;
     f.cnt_above = 0;
     f.cand_count = 0;
     f.ok = 0;
+    f.key_passes = 0;
     f.overflow = 0;
+    f.pad = 0;
   }
 }
 
@@ -477,6 +504,7 @@ __global__ void k_s2_verify(SelWs* ws, int64_t n, int64_t r, int64_t cap) {
   const bool ok = !f.overflow && (int64_t)cand <= cap && above < (unsigned long long)r &&
                   (unsigned long long)r <= above + cand;
   f.ok = ok ? 1 : 0;
+  f.key_passes = 0;
   if (!ok) return;
   s.quota = (int64_t)((unsigned long long)r - above);
   s.t_floor = f.t_lo;
@@ -497,6 +525,7 @@ __global__ void k_s2_verify(SelWs* ws, int64_t n, int64_t r, int64_t cap) {
     return;
   }
   const int hb = 63 - __clzll((long long)d);  // highest differing bit
+  f.key_passes = (hb + 1 + kDigitBits - 1) / kDigitBits;
   int width = hb + 1 < kDigitBits ? hb + 1 : kDigitBits;
   int shift = hb + 1 - width;
   s.phase = 0;
@@ -593,19 +622,20 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     int64_t* cidx = reinterpret_cast<int64_t*>(wsb + off_cidx);
     const int64_t n2 = n >> 1;
     hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, ctx->stream, ws, n, r);
-    hipLaunchKernelGGL(k_s2_sample, dim3(256), dim3(256), 0, ctx->stream, q, xk, sj, n, samp);
+    hipLaunchKernelGGL(k_s2_sample, dim3(256), dim3(256), 0, ctx->stream, q, xk, sj, n, samp, ws);
     hipLaunchKernelGGL(k_s2_pick, dim3(1), dim3(1024), 0, ctx->stream, (const double*)samp, n, r, ws);
     hipLaunchKernelGGL(k_s2_main, dim3((unsigned)((n2 + kMainChunkPairs - 1) / kMainChunkPairs)), dim3(256), 0,
                        ctx->stream, q, xk, sj, n, ws, ckey, cidx, ccap);
     hipLaunchKernelGGL(k_s2_verify, dim3(1), dim3(64), 0, ctx->stream, ws, n, r, ccap);
     SPX_LAUNCH_CHECK();
-    int ok = 0;
-    SPX_HIP(hipMemcpyAsync(&ok, &ws->fs.ok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    int verdict[2] = {0, 0};  // {ok, key_passes}
+    SPX_HIP(hipMemcpyAsync(verdict, &ws->fs.ok, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SPX_HIP(hipStreamSynchronize(ctx->stream));
-    if (ok) {
+    if (verdict[0]) {
       int idx_bits = 0;
       while (idx_bits < 63 && ((int64_t)1 << idx_bits) < n) ++idx_bits;
-      const int passes = (64 + kDigitBits - 1) / kDigitBits + (idx_bits + kDigitBits - 1) / kDigitBits;
+      int kp = verdict[1] < 0 ? 0 : (verdict[1] > 6 ? 6 : verdict[1]);
+      const int passes = kp + (idx_bits + kDigitBits - 1) / kDigitBits;
       for (int p = 0; p < passes; ++p) {
         hipLaunchKernelGGL(k_sel_hist_cand, dim3(512), dim3(256), 0, ctx->stream, (const uint64_t*)ckey,
                            (const int64_t*)cidx, ws);
