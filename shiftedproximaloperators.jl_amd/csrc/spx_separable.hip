@@ -84,7 +84,7 @@ struct OpL0Box {  // src/shiftedNormL0Box.jl:96-128
 // With phi = acos(-a) = pi - acos(a) and w = cos(phi/3) in [1/2, sqrt(3)/2]:  cos(2 pi/3 - (2/3) acos a) = 2 w^2 - 1,
 // so  val = sign(z) * 4 t w^2  with t = |z|/3, and w is the largest root of 4 w^3 - 3 w + a = 0.
 // Writing w = 1/2 + d:  4 d^3 + 6 d^2 = m := 1 - a  (d ~ sqrt(m/6) near the threshold a = 1).
-// d is obtained by 3 Newton steps on g(d) = 4 d^3 + 6 d^2 - m from a cubic fit d0 = e P(e), e = sqrt(m)
+// d is obtained by 2 Newton steps on g(d) = 4 d^3 + 6 d^2 - m from a cubic fit d0 = e P(e), e = sqrt(m)
 // (relative error of the fit 5.4e-5 on [0, 1]; Newton squares it: 1e-9, 1e-18).  The divisions by
 // g'(d) = 12 d (d + 1) use the f32 reciprocal: Newton is self-correcting, a 1e-7 error in the slope costs
 // 1e-7 * |last correction| <= 1e-16.  a itself comes from an fp64 rsqrt (hardware seed + 2 Newton steps).
@@ -92,6 +92,9 @@ struct OpL0Box {  // src/shiftedNormL0Box.jl:96-128
 // reference's own double evaluation (tools/lhalf_proto.py); agreement with the CPU restatement is checked to
 // 1e-12 in tests/.  No pow / acos / cos calls: ~55 fp64 VALU ops instead of ~250.
 // ---------------------------------------------------------------------------------------------
+#ifndef SPX_LHALF_NEWTON
+#define SPX_LHALF_NEWTON 2  // fit 5.4e-5 -> 1.5e-9 -> 1e-18 (tools/lhalf_proto.py: 2 and 3 steps give identical errors)
+#endif
 __device__ __forceinline__ double rsqrt_f64(double t) {
   double y = __builtin_amdgcn_rsq(t);            // v_rsq_f64 seed
   const double h = 0.5 * t;
@@ -102,11 +105,16 @@ __device__ __forceinline__ double rsqrt_f64(double t) {
   }
   return y;
 }
-// sqrt(v) for v >= 0 from the refined rsqrt plus one correction step (faithfully rounded)
+// sqrt(v) for v >= 0: coupled Goldschmidt step on (s, h) = (v y, y / 2) from the hardware rsq seed, then one
+// residual correction (faithfully rounded; 8 VALU ops)
 __device__ __forceinline__ double sqrt_f64(double v) {
-  double y = rsqrt_f64(v);
+  const double y = __builtin_amdgcn_rsq(v);
   double s = v * y;
-  s = __builtin_fma(0.5 * y, __builtin_fma(-s, s, v), s);
+  double h = 0.5 * y;
+  const double r = __builtin_fma(-s, h, 0.5);
+  s = __builtin_fma(s, r, s);
+  h = __builtin_fma(h, r, h);
+  s = __builtin_fma(__builtin_fma(-s, s, v), h, s);
   return (v > 0.0) ? s : 0.0;
 }
 // a = sl4 * (az/3)^(-3/2) and t = az/3
@@ -122,7 +130,7 @@ __device__ __forceinline__ double lhalf_val_from_a(double z, double t, double a)
   double d = e * __builtin_fma(e, __builtin_fma(e, __builtin_fma(e, -0.003676457097091405, 0.016543212998449176),
                                                  -0.05508522799226874), 0.4082262283672896);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < SPX_LHALF_NEWTON; ++k) {
     const double g = __builtin_fma(__builtin_fma(4.0, d, 6.0) * d, d, -m);
     const double gp = 12.0 * d * (d + 1.0);
     const double inv = (gp > 0.0) ? (double)__builtin_amdgcn_rcpf((float)gp) : 0.0;
