@@ -13,7 +13,7 @@ owns its own contiguous n-element shard and there is NO data-path collective ("r
 SURVEY.md 8e); the only collectives are the barrier and a MAX over ranks of the elapsed time.
 
 One JSON line on rank 0: metric/value/... plus
-  roofline      -- dominant kernel (k_sep_vec<OpL1Box>): algorithmic bytes (32 B/element) / average launch
+  roofline      -- dominant kernel (k_sep_lds<OpL1Box>): algorithmic bytes (32 B/element) / average launch
                    duration measured with HIP events on the launching stream over the timed region
   cpu_baseline  -- the CPU oracle (literal single-thread C restatement of the reference's Julia loop; the
                    reference itself cannot run here: no Julia) timed on rank 0's host core
@@ -116,7 +116,7 @@ def main():
         "config": {"workload": "ShiftedNormL1Box prox!, n=%d fp64 per GPU, Delta=1.0 scalar bounds, all selected, "
                                "twice shifted, lambda=sigma=1 (BASELINE configs[1])" % n,
                    "elements_per_gpu": n, "parallelism": "replicas (independent shards, no collective)"},
-        "roofline": {"bound": "hbm", "kernel": "k_sep_vec<OpL1Box,4,false,false>",
+        "roofline": {"bound": "hbm", "kernel": "k_sep_lds<OpL1Box,6,false,false>",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "avg_launch_ms": round(launch_ms, 5), "algorithmic_bytes_per_launch": BYTES_PER_ELEM * n,

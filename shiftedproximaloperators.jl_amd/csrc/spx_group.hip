@@ -73,10 +73,10 @@ __device__ __forceinline__ double softthres(double x, double a) { return jl_sign
 
 // 1/x to a few ulp: hardware seed + 2 Newton steps.  Only used inside the self-correcting Newton iteration.
 __device__ __forceinline__ double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
+  const double y0 = __builtin_amdgcn_rcp(x);  // +-inf for +-0, +-0 for +-inf
+  double y = __builtin_fma(__builtin_fma(-x, y0, 1.0), y0, y0);
   y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
-  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
-  return y;
+  return (y == y) ? y : y0;  // the Newton steps turn 1/0 and 1/inf into NaN: keep the seed there
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -233,13 +233,15 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
   const double eps = 2.220446049250313e-16;
   const double sl = lam * sigma;          // :85
   const double lmin = sl * (1 + eps);     // :94
+  // lmax, zlmax and froot(lmin) only steer the bracket (their exact rounding never reaches y): the wave-uniform
+  // divisions and square roots below use the few-ulp fast forms
   const double ansatz = lmin + 1.0;                                      // :97 (epsilon = 1)
-  const double stepa = ansatz / (sigma * (ansatz - sl));                 // :98
+  const double rsig = fast_rcp(sigma);
+  const double stepa = ansatz * rsig * fast_rcp(ansatz - sl);            // :98
   const double thra = delta * stepa;
-  const double rsig = 1.0 / sigma;
   // one fused pass: ||S||, ||X||, zlmax (:99) and the A/B sums of froot(lmin) (:95)
   const double ul = lmin - sl;
-  const double taul = ul / lmin;
+  const double taul = ul * fast_rcp(lmin);
   double sz = 0.0, sS = 0.0, sX = 0.0, sal = 0.0, sbl = 0.0;
   grp.for_each([&](double S, double X) {
     const double za = fabs(__builtin_fma(-stepa, X, S * rsig)) - thra;  // |softthres| = max(0, |.| - thr)
@@ -256,8 +258,9 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
   team_sum2<TEAM>(sz, sS, lds);
   team_sum2<TEAM>(sal, sbl, lds);
   sX = team_sum<TEAM>(sX, lds);
-  const double lmax = sqrt(sS) + sigma * (sqrt(sz) + 1.0 * lam * sqrt(sX));  // :100 (|(eps-1)/eps + 1| = 1)
-  double fl = lmin - (lmin / ul) * sqrt(__builtin_fma(taul * taul, sal, sbl));
+  const double nS = sqrt_pos(sS), nX = sqrt_pos(sX);
+  const double lmax = nS + sigma * (sqrt_pos(sz) + 1.0 * lam * nX);  // :100 (|(eps-1)/eps + 1| = 1)
+  double fl = lmin - (lmin * fast_rcp(ul)) * sqrt_pos(__builtin_fma(taul * taul, sal, sbl));
   if (!(lmin < lmax) || !(ul > 0.0) || !(fl == fl)) {
     // Degenerate bracket (||S|| + sigma (zlmax + lambda ||X||) <= sigma lambda puts the "upper" end at or below the
     // pole n = sl of step(n)), sl == 0, or a NaN: do literally what the reference + Roots.fzero do.
@@ -267,16 +270,32 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
     root = binf_bisect<TEAM>(grp, lmin, fl, lmax, fm, sigma, sl, delta, lds);
     return true;
   }
-  // regular bracket sl < lmin < lmax:  fm = froot(lmax) has the sign of psi(uhi)   (:101)
+  // regular bracket sl < lmin < lmax:  fm = froot(lmax) has the sign of psi(uhi)   (:101).
+  // |b_i| <= max(|S_i|, |X_i|) gives phi(u) <= ub := sqrt(||S||^2 + ||X||^2) for every u, so the root is <= ub:
+  // if uhi >= ub then psi(uhi) >= 0 is known without evaluating it and Newton starts from ub instead.
   double ulo = ul, uhi = lmax - sl;
-  double u = uhi, psi, dpsi;
-  binf_psi<TEAM>(grp, u, sl, delta, lds, psi, dpsi);
-  const double fm = (lmax / uhi) * psi;
+  const double ub = sqrt_pos(sS + sX) * (1.0 + 8 * eps);
+  double u, psi, dpsi, fm;
+  if (uhi > ub && ub > ulo) {
+    uhi = ub;
+    u = ub;
+    binf_psi<TEAM>(grp, u, sl, delta, lds, psi, dpsi);
+    fm = (psi > 0.0) ? psi : 1.0;  // psi(ub) >= 0 up to rounding; froot(lmax) > 0 follows from monotonicity
+    if (!(psi > 0.0)) { psi = 0.0; }
+  } else {
+    u = uhi;
+    binf_psi<TEAM>(grp, u, sl, delta, lds, psi, dpsi);
+    fm = (lmax / uhi) * psi;
+  }
   if (fl * fm > 0) return false;  // :102
   if (!(fl < 0.0) || !(fm > 0.0)) {  // an exact zero at an end (or NaN): Roots returns that end
-    root = binf_bisect<TEAM>(grp, lmin, fl, lmax, fm, sigma, sl, delta, lds);
+    const double fll = binf_froot_literal<TEAM>(grp, lmin, sigma, sl, delta, lds);
+    const double fml = binf_froot_literal<TEAM>(grp, lmax, sigma, sl, delta, lds);
+    if (fll * fml > 0) return false;
+    root = binf_bisect<TEAM>(grp, lmin, fll, lmax, fml, sigma, sl, delta, lds);
     return true;
   }
+  if (psi == 0.0) { root = fmin(fmax(sl + u, lmin), lmax); return true; }
   for (int it = 0; it < SPX_BINF_NEWTON_MAXIT; ++it) {
     double un = u - psi * fast_rcp(dpsi);
     if (!(un > ulo && un < uhi)) un = sqrt(ulo) * sqrt(uhi);  // geometric bisection: the bracket spans decades
@@ -398,15 +417,15 @@ __global__ __launch_bounds__(256) void k_group_reg(double* y_, const double* q_,
 #pragma unroll
         for (int k = 0; k < EPL; ++k) out[k] = 0.0 - grp.XS[k];
       } else {
-        const double u = root - sl, tau = u / root, c = root / u;  // c = sigma * step (:106)
+        const double u = root - sl, tau = u * fast_rcp(root), c = root * fast_rcp(u);  // c = sigma * step (:106)
         double w[EPL], sw = 0.0;
 #pragma unroll
         for (int k = 0; k < EPL; ++k) {
           w[k] = binf_w(grp.S[k], grp.X[k], tau, c, delta);  // :111
           sw += w[k] * w[k];
         }
-        const double nw = sqrt(lanes_sum<LPG>(sw));
-        const double alpha = jl_max(0.0, 1 - sl / nw);  // l2prox, :83
+        const double nw = sqrt_pos(lanes_sum<LPG>(sw));
+        const double alpha = jl_max(0.0, 1 - sl * fast_rcp(nw));  // l2prox, :83
 #pragma unroll
         for (int k = 0; k < EPL; ++k) out[k] = alpha * w[k] - grp.XS[k];  // :110-116
       }

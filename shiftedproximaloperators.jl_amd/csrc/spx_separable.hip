@@ -22,6 +22,7 @@
 struct OpL1 {  // src/shiftedNormL1.jl:46-51
   double ls;   // lambda * sigma
   static constexpr bool kBox = false;
+  static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
   __device__ __forceinline__ double operator()(double q, double x, double s, double, double, bool) const {
     double t = (-x) - s;                          // :47  @. y = -xk - sj
     return jl_min(jl_max(t, q - ls), q + ls);     // :50
@@ -29,6 +30,7 @@ struct OpL1 {  // src/shiftedNormL1.jl:46-51
 };
 struct OpL1Aliased {  // y === q in the reference: the broadcast at :47 overwrites q before :50 reads it
   static constexpr bool kBox = false;
+  static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
   __device__ __forceinline__ double operator()(double, double x, double s, double, double, bool) const {
     return (-x) - s;  // min(max(t, t - ls), t + ls) == t bit for bit whenever ls >= 0
   }
@@ -36,6 +38,7 @@ struct OpL1Aliased {  // y === q in the reference: the broadcast at :47 overwrit
 struct OpL0 {  // src/shiftedNormL0.jl:45-52
   double c;    // sqrt(2 * lambda * sigma)
   static constexpr bool kBox = false;
+  static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
   __device__ __forceinline__ double operator()(double q, double x, double s, double, double, bool) const {
     double xps = x + s;
     return (fabs(xps + q) <= c) ? -xps : q;
@@ -44,6 +47,7 @@ struct OpL0 {  // src/shiftedNormL0.jl:45-52
 struct OpL1Box {  // src/shiftedNormL1Box.jl:96-122
   double sl;      // sigma * lambda
   static constexpr bool kBox = true;
+  static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
   __device__ __forceinline__ double operator()(double q, double x, double s, double l, double u, bool sel) const {
     double xs = x + s;
     double xsq = xs + q;
@@ -55,6 +59,7 @@ struct OpL1Box {  // src/shiftedNormL1Box.jl:96-122
 struct OpL0Box {  // src/shiftedNormL0Box.jl:96-128
   double c;       // 2 * lambda * sigma
   static constexpr bool kBox = true;
+  static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
   __device__ __forceinline__ double operator()(double q, double x, double s, double l, double u, bool sel) const {
     double sq = s + q;
     double xs = x + s;
@@ -144,6 +149,7 @@ struct OpLhalf {  // src/shiftedRootNormLhalf.jl:47-60
   double sl4;     // (sigma * lambda) / 4
   double p;       // 54^(1/3) * (2 sigma lambda)^(2/3) / 4
   static constexpr bool kBox = false;
+  static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
   __device__ __forceinline__ double operator()(double q, double x, double s, double, double, bool) const {
     double xs = x + s;
     double sol = q + xs;  // :50
@@ -160,6 +166,7 @@ struct OpLhalfBox {  // src/shiftedRootNormLhalfBox.jl:92-117
   double lambda;
   double h2;         // 1 / (2 sigma)
   static constexpr bool kBox = true;
+  static constexpr int kLdsKiB = 0;  // 0: register-staged skeleton (VALU-heavy: needs the occupancy; 5.97 vs 5.68 TB/s)
   // RNorm(tt) = (tt - q)^2 / 2 / sigma + lambda sqrt|tt + xs|   (:95); used only to pick the argmin
   __device__ __forceinline__ double rnorm(double tt, double q, double xs) const {
     double d = tt - q;
@@ -276,6 +283,74 @@ __global__ __launch_bounds__(256) void k_sep_vec(double* y_, const double* q_, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-staged skeleton (the default): each wavefront owns a contiguous chunk of UNROLL KiB per input vector and
+// stages it through LDS with `global_load_lds_dwordx4 ... nt` -- LDS-DMA: no VGPR destination, one contiguous
+// 1 KiB piece per wave instruction -- then waits once (vmcnt(0)), reads its own 16 bytes per piece back with
+// ds_read_b128 (lane-private slots: conflict-free, no barrier: nothing is shared between waves), evaluates
+// the operator and writes y with non-temporal 16-byte stores.  3*UNROLL KiB are in flight per wave without
+// holding registers; UNROLL = 6 -> 72 KiB of LDS per 4-wave workgroup -> two workgroups (144 KiB in flight)
+// per CU.  Measured on MI355X (tools/exp/exp_stream.hip, n = 1e8, same process, interleaved rounds):
+// 6.45-6.57 TB/s against 6.11-6.30 TB/s for the register-staged form above; 7 KiB per wave and more (one
+// workgroup per CU) or a piece-by-piece pipelined wait lose 10-20 %.
+// All loads of a wave have landed before its first store, and waves touch disjoint ranges: y may alias q.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void dma16_nt(const f64x2* g, char* wave_lds_piece) {
+  __builtin_amdgcn_global_load_lds((const void*)g, (lds_void*)wave_lds_piece, 16, 0, 2);  // aux = 2: nt
+}
+
+template <class Op, int UNROLL, bool VECB, bool MASK>
+__global__ __launch_bounds__(256) void k_sep_lds(double* y_, const double* q_, const double* xk_, const double* sj_,
+                                                  const double* l_, const double* u_, const uint8_t* mask_,
+                                                  double ls, double us, int64_t n2, Op op) {
+  constexpr int NARR = 3 + ((VECB && Op::kBox) ? 2 : 0);
+  __shared__ __attribute__((aligned(16))) char lds[4 * NARR * UNROLL * 1024];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  char* wl = lds + wave * (NARR * UNROLL * 1024);
+  f64x2* y = reinterpret_cast<f64x2*>(y_);
+  const f64x2* q = reinterpret_cast<const f64x2*>(q_);
+  const f64x2* xk = reinterpret_cast<const f64x2*>(xk_);
+  const f64x2* sj = reinterpret_cast<const f64x2*>(sj_);
+  const f64x2* lv = reinterpret_cast<const f64x2*>(l_);
+  const f64x2* uv = reinterpret_cast<const f64x2*>(u_);
+  const uint16_t* mk = reinterpret_cast<const uint16_t*>(mask_);
+  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * (64 * UNROLL) + lane;  // this lane's first pair
+  uint16_t vm[UNROLL];
+#pragma unroll
+  for (int k = 0; k < UNROLL; ++k) {
+    int64_t i = base + k * 64;
+    if (i >= n2) i = n2 - 1;  // tail: load something valid, the store is guarded
+    dma16_nt(q + i, wl + (0 * UNROLL + k) * 1024);
+    dma16_nt(xk + i, wl + (1 * UNROLL + k) * 1024);
+    dma16_nt(sj + i, wl + (2 * UNROLL + k) * 1024);
+    if constexpr (VECB && Op::kBox) {
+      if (l_) dma16_nt(lv + i, wl + (3 * UNROLL + k) * 1024);
+      if (u_) dma16_nt(uv + i, wl + (4 * UNROLL + k) * 1024);
+    }
+    if constexpr (MASK && Op::kBox) vm[k] = mk[i];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every piece of this wave has landed in LDS
+#pragma unroll
+  for (int k = 0; k < UNROLL; ++k) {
+    const int64_t i = base + k * 64;
+    const f64x2 a = *reinterpret_cast<const f64x2*>(wl + (0 * UNROLL + k) * 1024 + lane * 16);
+    const f64x2 b = *reinterpret_cast<const f64x2*>(wl + (1 * UNROLL + k) * 1024 + lane * 16);
+    const f64x2 c = *reinterpret_cast<const f64x2*>(wl + (2 * UNROLL + k) * 1024 + lane * 16);
+    double l0 = ls, l1 = ls, u0 = us, u1 = us;
+    bool s0 = true, s1 = true;
+    if constexpr (VECB && Op::kBox) {
+      if (l_) { const f64x2 t = *reinterpret_cast<const f64x2*>(wl + (3 * UNROLL + k) * 1024 + lane * 16); l0 = t.x; l1 = t.y; }
+      if (u_) { const f64x2 t = *reinterpret_cast<const f64x2*>(wl + (4 * UNROLL + k) * 1024 + lane * 16); u0 = t.x; u1 = t.y; }
+    }
+    if constexpr (MASK && Op::kBox) { s0 = (vm[k] & 0xff) != 0; s1 = (vm[k] >> 8) != 0; }
+    f64x2 r;
+    r.x = op(a.x, b.x, c.x, l0, u0, s0);
+    r.y = op(a.y, b.y, c.y, l1, u1, s1);
+    if (i < n2) __builtin_nontemporal_store(r, y + i);
+  }
+}
+
 // scalar path: unaligned vectors, and the odd last element of the vector path ([begin, n))
 template <class Op>
 __global__ __launch_bounds__(256) void k_sep_scalar(double* y, const double* q, const double* xk, const double* sj,
@@ -297,9 +372,20 @@ void spx_select_set_fast(int on);  // spx_select.hip
 static int g_sep_blocks_per_cu = 0;  // 0 = no cap: grid = number of tiles
 static int g_sep_nt = 1;
 
+static int g_sep_lds = 1;  // 1 = LDS-staged skeleton (default), 0 = register-staged
+
 template <class Op, bool VECB, bool MASK>
 static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, const double* l,
                       const double* u, const uint8_t* mask, double ls, double us, int64_t n2, Op op) {
+  if constexpr (Op::kLdsKiB > 0) if (g_sep_lds) {
+    // 3 input vectors: 6 KiB per wave and vector -> 72 KiB per workgroup; 5 vectors (vector bounds): 3 KiB -> 60 KiB
+    constexpr int U = (VECB && Op::kBox) ? (Op::kLdsKiB > 3 ? 3 : Op::kLdsKiB) : Op::kLdsKiB;
+    const int64_t blocks = (n2 + 256 * U - 1) / (256 * U);
+    hipLaunchKernelGGL((k_sep_lds<Op, U, VECB, MASK>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj,
+                       l, u, mask, ls, us, n2, op);
+    SPX_LAUNCH_CHECK();
+    return SPX_OK;
+  }
   constexpr int UNROLL = 4;
   const int64_t ntiles = (n2 + 256 * UNROLL - 1) / (256 * UNROLL);
   int64_t blocks = ntiles;
@@ -358,6 +444,7 @@ SPX_EXPORT int spx_set_tuning(int key, int value) {
   if (key == 0 && value >= 0 && value <= 1024) { g_sep_blocks_per_cu = value; return SPX_OK; }
   if (key == 1) { g_sep_nt = value ? 1 : 0; return SPX_OK; }
   if (key == 2) { spx_select_set_fast(value); return SPX_OK; }
+  if (key == 3) { g_sep_lds = value ? 1 : 0; return SPX_OK; }
   spx_set_error("invalid argument: unknown tuning key/value");
   return SPX_ERR_INVALID_ARG;
 }

@@ -22,7 +22,7 @@ for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     print("== %s per dispatch (raw counter units) ==" % ctr)
     for k, v in vals.items():
         print("  %-90s n=%d mean=%.6g" % (k[:90], len(v), sum(v) / len(v)))
-        if "k_sep_vec" in k and "OpL1Box" in k:
+        if "k_sep_" in k and "OpL1Box" in k:
             res[ctr] = sum(v) / len(v)
 if res:
     print("raw", json.dumps(res))

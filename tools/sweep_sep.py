@@ -1,5 +1,6 @@
-"""Kernel tuning sweep for the separable skeleton (interleaved rounds in one process, guide rule 24)."""
-import ctypes, sys, os, json
+"""Separable-skeleton A/B: register-staged (tuning key 3 = 0) vs LDS-staged (1), all separable operators,
+interleaved rounds in one process (guide rule 24)."""
+import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import __graft_entry__ as ge
@@ -10,25 +11,32 @@ g = torch.Generator(device=dev).manual_seed(1)
 xk = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
 sj = torch.rand(n, dtype=torch.float64, device=dev, generator=g) - 0.5
 q = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+lv = -1.0 - 0.1 * torch.rand(n, dtype=torch.float64, device=dev, generator=g)
+uv = 1.0 + 0.1 * torch.rand(n, dtype=torch.float64, device=dev, generator=g)
 y = torch.empty_like(q)
 ctx = s.context(dev)
-ops = {"l1box": s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, s.NormLinf(1.0)), sj),
-       "l1": s.shifted(s.shifted(s.NormL1(1.0), xk), sj),
-       "l0box": s.shifted(s.shifted(s.NormL0(1.0), xk, 1.0, s.NormLinf(1.0)), sj)}
+chi = s.NormLinf(1.0)
+ops = {"l1box": (32, s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj)),
+       "l1": (32, s.shifted(s.shifted(s.NormL1(1.0), xk), sj)),
+       "l0box": (32, s.shifted(s.shifted(s.NormL0(1.0), xk, 1.0, chi), sj)),
+       "lhalf": (32, s.shifted(s.shifted(s.RootNormLhalf(1.0), xk), sj)),
+       "lhalfbox": (32, s.shifted(s.shifted(s.RootNormLhalf(1.0), xk, 1.0, chi), sj)),
+       "l1box_vecbounds": (48, s.shifted(s.shifted(s.NormL1(1.0), xk, lv, uv), sj)),
+       "l1box_mask": (33, s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi, range(0, n, 2)), sj))}
 def t(psi, iters=20):
     ms = ctypes.c_float()
     L.spx_timer_start(ctx)
     for _ in range(iters): s.prox_bang(y, psi, q, 1.0)
     L.spx_timer_stop(ctx, ctypes.byref(ms))
     return ms.value / iters
-configs = [(b, nt) for b in (16, 64, 128, 256, 0) for nt in (0, 1)]
 res = {}
 for rnd in range(5):
-    for name, psi in ops.items():
-        for b, nt in configs:
-            L.spx_set_tuning(0, b); L.spx_set_tuning(1, nt)
+    for name, (bpe, psi) in ops.items():
+        for lds in (0, 1):
+            L.spx_set_tuning(3, lds)
             if rnd == 0: t(psi, 3)
-            res.setdefault((name, b, nt), []).append(t(psi))
+            res.setdefault((name, lds), []).append(t(psi))
+L.spx_set_tuning(3, 1)
 for k in sorted(res):
     v = sorted(res[k]); med = v[len(v)//2]
-    print("%-6s blocks/CU=%2d nt=%d  median %.4f ms  min %.4f ms  -> %.0f GB/s (median)" % (k[0], k[1], k[2], med, v[0], 32*n/med/1e6))
+    print("%-16s %-9s median %.4f ms  min %.4f ms  -> %.0f GB/s" % (k[0], "lds" if k[1] else "registers", med, v[0], ops[k[0]][0]*n/med/1e6))
