@@ -6,7 +6,7 @@ Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
     twice shifted (xk ~ N(0,1), sj ~ U(-1/2, 1/2)), q ~ N(0,1), lambda = sigma = 1.  Synthetic data.
 A "step" is one prox! call over the whole n-vector.  Inputs are resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n N_ELEMS] [--no-cpu] [--no-extra]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--elements N] [--no-cpu] [--no-extra]
 
 Multi-GPU (launched by torch.distributed.run, one rank per GPU): the operators are separable, so every rank
 owns its own contiguous n-element shard and there is NO data-path collective ("replicas / weak scaling",
@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=100_000_000)
+    ap.add_argument("--elements", dest="n", type=int, default=100_000_000, help="elements per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary operators")
     args = ap.parse_args()
@@ -50,11 +50,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; libspx has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SPX_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices,
+    # barrier / MAX go over gloo); the driver's runs use nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("SPX_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
     s = ge.build()
@@ -89,7 +97,7 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([wall, ms.value], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall, ms.value], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(t[0]), float(t[1])
     else:
@@ -101,7 +109,7 @@ def main():
     achieved = BYTES_PER_ELEM * n / (launch_ms * 1e-3) / 1e9
 
     out = {
-        "metric": "prox! throughput (ShiftedNormL1Box, n=1e8 fp64 per GPU)",
+        "metric": "prox! throughput (ShiftedNormL1Box, n=%.0e fp64 per GPU)" % n,
         "value": round(value, 3),
         "unit": "G-elements/s",
         "n_gpus": world,
@@ -120,7 +128,7 @@ def main():
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "avg_launch_ms": round(launch_ms, 5), "algorithmic_bytes_per_launch": BYTES_PER_ELEM * n,
-                     "traffic": _pmc_traffic()},
+                     "traffic": _pmc_traffic(n)},
     }
 
     if rank == 0 and not args.no_extra:
@@ -134,12 +142,14 @@ def main():
         dist.destroy_process_group()
 
 
-def _pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*traffic*.json), or None."""
+def _pmc_traffic(n):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic_l1box.json, taken with
+    tools/profile.sh on this very command at the default size), or None for another size."""
     p = os.path.join(ROOT, "profiles", "traffic_l1box.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get("hbm_bytes_per_launch")
+            d = json.load(open(p))
+            return d.get("hbm_bytes_per_launch") if d.get("n") == n else None
         except Exception:
             return None
     return None
