@@ -51,7 +51,7 @@ struct FastState {
   int ok;                         // set by k_s2_verify: the r-th largest is provably inside the band
   int key_passes;                 // key-digit passes the candidate selection can need (host reads ok + this)
   int overflow;                   // a workgroup or the candidate buffer overflowed
-  int pad;
+  unsigned int list_count;        // entries appended to the short list by k_s2_compact
 };
 
 struct SelWs {
@@ -63,6 +63,7 @@ struct SelWs {
 constexpr int kSample = 65536;        // sample size (256 chunks of 256 consecutive elements)
 constexpr int kMainChunkPairs = 8192; // 16-byte pairs per workgroup of the main pass
 constexpr int kLdsCand = 1024;        // per-workgroup candidate staging
+constexpr int kShortList = 4096;      // candidates left after the first digit that k_s2_finish resolves in LDS
 
 __device__ __forceinline__ uint64_t key_of(double v) { return (uint64_t)__double_as_longlong(v) & kAbsMask; }
 
@@ -193,48 +194,51 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double* y, int64_t n, in
   flush_hist(lh, ws->hist);
 }
 
-// One workgroup: locate the bucket that holds the quota-th element (from the top for keys, from the
-// bottom for indices), advance the state, clear the histogram for the next pass.
-__global__ __launch_bounds__(256) void k_sel_scan(SelWs* ws) {
-  __shared__ unsigned long long part[4];
-  __shared__ int s_bucket;
-  __shared__ unsigned long long s_before, s_count;
-  SelState st = ws->st;
-  if (st.phase == 2) return;
+// Locates the bucket that holds the quota-th element (from the top for keys, from the bottom for indices) in a
+// 4096-bin histogram and advances the selection state.  Called by all lanes of a workgroup (>= 256 lanes);
+// lanes 0..255 do the work.  `scratch` = 8 unsigned long long of shared memory.  The new state is returned in
+// *out by lane 0 (out may be global or shared memory); no barrier after that write.
+template <class Hist>
+__device__ __forceinline__ void sel_scan_step(const Hist& hist, const SelState st, SelState* out,
+                                              unsigned long long* scratch) {
   const int t = threadIdx.x;
+  const int tt = t & 255;
+  const bool worker = t < 256;
   const int nb = 1 << st.width;
   const bool desc = (st.phase == 0);
-  // thread t owns the 16 consecutive bins [16 t, 16 t + 16) of the scan order
-  constexpr int PER = kBins / 256;
+  constexpr int PER = kBins / 256;  // lane tt owns PER consecutive bins of the scan order
   unsigned long long loc[PER];
   unsigned long long sum = 0;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    const int pos = t * PER + k;                       // position in scan order
-    const int bin = desc ? (kBins - 1 - pos) : pos;    // descending keys / ascending indices
-    loc[k] = (bin < nb) ? ws->hist[bin] : 0ull;
+    const int pos = tt * PER + k;
+    const int bin = desc ? (kBins - 1 - pos) : pos;  // descending keys / ascending indices
+    loc[k] = (worker && bin < nb) ? (unsigned long long)hist[bin] : 0ull;
     sum += loc[k];
   }
-  unsigned long long run = scan256_exclusive(sum, t, part);
+  unsigned long long run = scan256_exclusive(sum, tt, scratch + (t >> 8 ? 4 : 0));
   const unsigned long long quota = (unsigned long long)st.quota;
+  unsigned long long* found = scratch + 4;  // [4] bucket, [5] before, [6] count  (lanes >= 256 used [4..7] only as wtot)
+  __syncthreads();
+  if (worker) {
 #pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    if (run < quota && run + loc[k] >= quota) {
-      const int pos = t * PER + k;
-      s_bucket = desc ? (kBins - 1 - pos) : pos;
-      s_before = run;
-      s_count = loc[k];
+    for (int k = 0; k < PER; ++k) {
+      if (run < quota && run + loc[k] >= quota) {
+        const int pos = tt * PER + k;
+        found[0] = (unsigned long long)(desc ? (kBins - 1 - pos) : pos);
+        found[1] = run;
+        found[2] = loc[k];
+      }
+      run += loc[k];
     }
-    run += loc[k];
   }
   __syncthreads();
-  for (int b = t; b < kBins; b += blockDim.x) ws->hist[b] = 0ull;
   if (t == 0) {
-    const uint64_t bucket = (uint64_t)s_bucket;
-    const int64_t left = (int64_t)(quota - s_before);   // to be taken from this bucket
-    const uint64_t count = s_count;
+    const uint64_t bucket = found[0];
+    const int64_t left = (int64_t)(quota - found[1]);  // to be taken from this bucket
+    const uint64_t count = found[2];
     const uint64_t newprefix = (st.width >= 64 ? 0ull : (st.prefix << st.width)) | bucket;
-    SelState& o = ws->st;
+    SelState o = st;
     if (st.phase == 0) {
       if ((uint64_t)left == count) {                    // the whole bucket is kept: resolved, no tie
         o.phase = 2;
@@ -270,7 +274,18 @@ __global__ __launch_bounds__(256) void k_sel_scan(SelWs* ws) {
         o.width = w;
       }
     }
+    *out = o;
   }
+}
+
+// One workgroup: scan step on the global histogram, then clear it for the next pass.
+__global__ __launch_bounds__(256) void k_sel_scan(SelWs* ws) {
+  __shared__ unsigned long long scratch[8];
+  const SelState st = ws->st;
+  if (st.phase == 2) return;
+  sel_scan_step(ws->hist, st, &ws->st, scratch);
+  __syncthreads();  // every lane has read its bins (inside the step) before they are cleared
+  for (int b = threadIdx.x; b < kBins; b += blockDim.x) ws->hist[b] = 0ull;
 }
 
 template <bool BINF>
@@ -321,7 +336,8 @@ __global__ __launch_bounds__(256) void k_sel_final(double* y, const double* xk, 
 //   5. k_sel_final_q y[i] from q, xk, sj and the thresholds (24 B read + 8 B written per element)
 // Total 56 B/element instead of >= 80.  The prediction is only a performance device: if the verification
 // fails (or a buffer overflows) the full-vector radix select above runs instead, so the result is exact
-// for any input.  The host reads the 4-byte verdict back (one stream synchronisation per call).
+// for any input.  The host reads the 4-byte verdict back once, after the final pass has been queued
+// speculatively (the final pass returns at once if the verdict is negative).
 // y is not touched before step 5 and step 5 reads q[i] before writing y[i]: y may alias q.
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_s2_sample(const double* q, const double* xk, const double* sj, int64_t n,
@@ -425,7 +441,7 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
     f.ok = 0;
     f.key_passes = 0;
     f.overflow = 0;
-    f.pad = 0;
+    f.list_count = 0;
   }
 }
 
@@ -537,7 +553,7 @@ __global__ void k_s2_verify(SelWs* ws, int64_t n, int64_t r, int64_t cap) {
 // histogram of the current digit over the candidates
 __global__ __launch_bounds__(256) void k_sel_hist_cand(const uint64_t* cand_key, const int64_t* cand_idx, SelWs* ws) {
   const SelState st = ws->st;
-  if (st.phase == 2) return;
+  if (!ws->fs.ok || st.phase == 2) return;
   __shared__ unsigned int lh[kBins];
   for (int b = threadIdx.x; b < kBins; b += blockDim.x) lh[b] = 0u;
   __syncthreads();
@@ -559,10 +575,74 @@ __global__ __launch_bounds__(256) void k_sel_hist_cand(const uint64_t* cand_key,
   flush_hist(lh, ws->hist);
 }
 
+// after the first candidate digit: the candidates still in play (same decided prefix, or tied key) -> short list
+__global__ __launch_bounds__(256) void k_s2_compact(const uint64_t* cand_key, const int64_t* cand_idx, SelWs* ws,
+                                                     uint64_t* list_key, int64_t* list_idx) {
+  const SelState st = ws->st;
+  if (!ws->fs.ok || st.phase == 2) return;
+  const int64_t m = (int64_t)ws->fs.cand_count;
+  const int hs = st.shift + st.width;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = tid; e < m; e += stride) {
+    const uint64_t key = cand_key[e];
+    const int64_t i = cand_idx[e];
+    const bool in = (st.phase == 0) ? ((hs >= 64 ? 0ull : (key >> hs)) == st.prefix)
+                                    : (key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix);
+    if (in) {
+      const unsigned int slot = atomicAdd(&ws->fs.list_count, 1u);
+      if (slot < (unsigned)kShortList) { list_key[slot] = key; list_idx[slot] = i; }
+    }
+  }
+}
+
+// one workgroup: finishes the selection on the short list, entirely in LDS
+__global__ __launch_bounds__(1024) void k_s2_finish(SelWs* ws, const uint64_t* list_key, const int64_t* list_idx) {
+  __shared__ uint64_t lk[kShortList];
+  __shared__ int64_t li[kShortList];
+  __shared__ unsigned int h[kBins];
+  __shared__ unsigned long long scratch[8];
+  __shared__ SelState sst;
+  const int t = threadIdx.x;
+  if (!ws->fs.ok) return;
+  if (t == 0) sst = ws->st;
+  __syncthreads();
+  if (sst.phase == 2) return;
+  const unsigned int m = ws->fs.list_count;
+  if (m > (unsigned)kShortList) {  // too many survivors (heavy ties): let the full-vector path do it
+    if (t == 0) ws->fs.ok = 0;
+    return;
+  }
+  for (unsigned int e = t; e < m; e += 1024) { lk[e] = list_key[e]; li[e] = list_idx[e]; }
+  for (int guard = 0; guard < 16; ++guard) {  // <= 6 key digits + <= 6 index digits
+    __syncthreads();
+    const SelState st = sst;
+    if (st.phase == 2) break;
+    for (int b = t; b < kBins; b += 1024) h[b] = 0u;
+    __syncthreads();
+    const int hs = st.shift + st.width;
+    const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
+    for (unsigned int e = t; e < m; e += 1024) {
+      const uint64_t key = lk[e];
+      if (st.phase == 0) {
+        if ((hs >= 64 ? 0ull : (key >> hs)) == st.prefix) atomicAdd(&h[(key >> st.shift) & dmask], 1u);
+      } else if (key == st.t_eq) {
+        const uint64_t i = (uint64_t)li[e];
+        if ((i >> hs) == st.prefix) atomicAdd(&h[(i >> st.shift) & dmask], 1u);
+      }
+    }
+    __syncthreads();
+    sel_scan_step(h, st, &sst, scratch);
+  }
+  __syncthreads();
+  if (t == 0) ws->st = sst;
+}
+
 // final pass of the fast path: v recomputed from q, xk, sj (y untouched so far)
 template <bool BINF>
 __global__ __launch_bounds__(256) void k_sel_final_q(double* y_, const double* q_, const double* xk_, const double* sj_,
                                                       int64_t n, const SelWs* ws, double delta) {
+  if (!ws->fs.ok) return;  // prediction not verified: the host runs the full-vector path afterwards
   const SelState st = ws->st;
   constexpr int UNROLL = 4;
   constexpr int64_t TILE = 256 * UNROLL;
@@ -612,7 +692,9 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   const size_t off_samp = (sizeof(SelWs) + 255) & ~(size_t)255;
   const size_t off_ckey = off_samp + (size_t)kSample * sizeof(double);
   const size_t off_cidx = off_ckey + (size_t)ccap * sizeof(uint64_t);
-  rc = spx_ws_reserve(ctx, off_cidx + (size_t)ccap * sizeof(int64_t) + 256);
+  const size_t off_lkey = off_cidx + (size_t)ccap * sizeof(int64_t);
+  const size_t off_lidx = off_lkey + (size_t)kShortList * sizeof(uint64_t);
+  rc = spx_ws_reserve(ctx, off_lidx + (size_t)kShortList * sizeof(int64_t) + 256);
   if (rc) return rc;
   SelWs* ws = reinterpret_cast<SelWs*>(ctx->ws);
   if (try_fast) {
@@ -620,6 +702,8 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     double* samp = reinterpret_cast<double*>(wsb + off_samp);
     uint64_t* ckey = reinterpret_cast<uint64_t*>(wsb + off_ckey);
     int64_t* cidx = reinterpret_cast<int64_t*>(wsb + off_cidx);
+    uint64_t* lkey = reinterpret_cast<uint64_t*>(wsb + off_lkey);
+    int64_t* lidx = reinterpret_cast<int64_t*>(wsb + off_lidx);
     const int64_t n2 = n >> 1;
     hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, ctx->stream, ws, n, r);
     hipLaunchKernelGGL(k_s2_sample, dim3(256), dim3(256), 0, ctx->stream, q, xk, sj, n, samp, ws);
@@ -627,25 +711,21 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     hipLaunchKernelGGL(k_s2_main, dim3((unsigned)((n2 + kMainChunkPairs - 1) / kMainChunkPairs)), dim3(256), 0,
                        ctx->stream, q, xk, sj, n, ws, ckey, cidx, ccap);
     hipLaunchKernelGGL(k_s2_verify, dim3(1), dim3(64), 0, ctx->stream, ws, n, r, ccap);
+    // first candidate digit with all CUs, survivors -> short list, rest of the selection in one workgroup
+    hipLaunchKernelGGL(k_sel_hist_cand, dim3(512), dim3(256), 0, ctx->stream, (const uint64_t*)ckey, (const int64_t*)cidx,
+                       ws);
+    hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(256), 0, ctx->stream, ws);
+    hipLaunchKernelGGL(k_s2_compact, dim3(512), dim3(256), 0, ctx->stream, (const uint64_t*)ckey, (const int64_t*)cidx,
+                       ws, lkey, lidx);
+    hipLaunchKernelGGL(k_s2_finish, dim3(1), dim3(1024), 0, ctx->stream, ws, (const uint64_t*)lkey, (const int64_t*)lidx);
+    hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1023) / 1024)), dim3(256), 0, ctx->stream, y, q, xk,
+                       sj, n, (const SelWs*)ws, delta);
     SPX_LAUNCH_CHECK();
-    int verdict[2] = {0, 0};  // {ok, key_passes}
-    SPX_HIP(hipMemcpyAsync(verdict, &ws->fs.ok, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    // the verdict is read back AFTER the speculative final pass has been queued: the GPU never idles on the host
+    int ok = 0;
+    SPX_HIP(hipMemcpyAsync(&ok, &ws->fs.ok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SPX_HIP(hipStreamSynchronize(ctx->stream));
-    if (verdict[0]) {
-      int idx_bits = 0;
-      while (idx_bits < 63 && ((int64_t)1 << idx_bits) < n) ++idx_bits;
-      int kp = verdict[1] < 0 ? 0 : (verdict[1] > 6 ? 6 : verdict[1]);
-      const int passes = kp + (idx_bits + kDigitBits - 1) / kDigitBits;
-      for (int p = 0; p < passes; ++p) {
-        hipLaunchKernelGGL(k_sel_hist_cand, dim3(512), dim3(256), 0, ctx->stream, (const uint64_t*)ckey,
-                           (const int64_t*)cidx, ws);
-        hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(256), 0, ctx->stream, ws);
-      }
-      hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1023) / 1024)), dim3(256), 0, ctx->stream, y, q,
-                         xk, sj, n, (const SelWs*)ws, delta);
-      SPX_LAUNCH_CHECK();
-      return SPX_OK;
-    }
+    if (ok) return SPX_OK;
     // prediction failed: exact full-vector path below
   }
   const int64_t work = vec ? (n + 1) / 2 : n;
