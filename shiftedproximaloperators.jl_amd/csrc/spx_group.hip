@@ -152,6 +152,12 @@ __device__ __forceinline__ double signed_delta(double delta, double z) {
   return __hiloint2double((__double2hiint(delta) & 0x7fffffff) | (__double2hiint(z) & 0x80000000), __double2loint(delta));
 }
 
+// v if keep, else (essentially) zero: clears the high dword only -> one v_cndmask instead of two; the leftover
+// low dword is a denormal below 2^-1042, invisible in the sums below
+__device__ __forceinline__ double keep_if(double v, bool keep) {
+  return __hiloint2double(keep ? __double2hiint(v) : 0, __double2loint(v));
+}
+
 // sums A (inactive S^2) and B (active b^2) at a given tau
 template <int TEAM, class G>
 __device__ __forceinline__ void binf_ab(const G& grp, double tau, double delta, double* lds, double& sa, double& sb) {
@@ -161,8 +167,8 @@ __device__ __forceinline__ void binf_ab(const G& grp, double tau, double delta, 
     const double z = __builtin_fma(tau, S, -X);
     const bool act = fabs(z) > delta;
     const double b = X + signed_delta(delta, z);
-    sa += act ? 0.0 : S * S;
-    sb += act ? b * b : 0.0;
+    sa += keep_if(S * S, !act);
+    sb += keep_if(b * b, act);
   });
   team_sum2<TEAM>(sa, sb, lds);
 }
@@ -272,40 +278,60 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
   }
   // regular bracket sl < lmin < lmax:  fm = froot(lmax) has the sign of psi(uhi)   (:101).
   // |b_i| <= max(|S_i|, |X_i|) gives phi(u) <= ub := sqrt(||S||^2 + ||X||^2) for every u, so the root is <= ub:
-  // if uhi >= ub then psi(uhi) >= 0 is known without evaluating it and Newton starts from ub instead.
+  // if uhi >= ub then psi(uhi) >= 0 is known without evaluating it and the iteration starts from ub instead.
+  //
+  // Iteration: psi is piecewise smooth -- on a fixed active set it is u - sqrt(B + A tau(u)^2) with constant
+  // A, B.  Each pass over the group yields (A, B) of the current u; the root of THAT piece is then found by a
+  // scalar Newton iteration (no element work), and the next pass checks it: if the sums come back bit-identical
+  // the active set did not change and u is the root; otherwise continue from the new piece.  2-3 passes on
+  // the BASELINE data instead of 5-6 for Newton on psi itself; bracket-safeguarded, bounded.
   double ulo = ul, uhi = lmax - sl;
   const double ub = sqrt_pos(sS + sX) * (1.0 + 8 * eps);
-  double u, psi, dpsi, fm;
-  if (uhi > ub && ub > ulo) {
-    uhi = ub;
-    u = ub;
-    binf_psi<TEAM>(grp, u, sl, delta, lds, psi, dpsi);
-    fm = (psi > 0.0) ? psi : 1.0;  // psi(ub) >= 0 up to rounding; froot(lmax) > 0 follows from monotonicity
-    if (!(psi > 0.0)) { psi = 0.0; }
-  } else {
-    u = uhi;
-    binf_psi<TEAM>(grp, u, sl, delta, lds, psi, dpsi);
-    fm = (lmax / uhi) * psi;
+  const bool from_bound = (uhi > ub && ub > ulo);
+  if (from_bound) uhi = ub;
+  double u = uhi;
+  double sa, sb, psi;
+  {
+    const double tau = u * fast_rcp(sl + u);
+    binf_ab<TEAM>(grp, tau, delta, lds, sa, sb);
+    psi = u - sqrt_pos(__builtin_fma(tau * tau, sa, sb));
   }
-  if (fl * fm > 0) return false;  // :102
-  if (!(fl < 0.0) || !(fm > 0.0)) {  // an exact zero at an end (or NaN): Roots returns that end
-    const double fll = binf_froot_literal<TEAM>(grp, lmin, sigma, sl, delta, lds);
-    const double fml = binf_froot_literal<TEAM>(grp, lmax, sigma, sl, delta, lds);
-    if (fll * fml > 0) return false;
-    root = binf_bisect<TEAM>(grp, lmin, fll, lmax, fml, sigma, sl, delta, lds);
-    return true;
+  {
+    const double fm = from_bound ? ((psi > 0.0) ? psi : 1.0) : (lmax * fast_rcp(u)) * psi;
+    if (fl * fm > 0) return false;  // :102
+    if (!(fl < 0.0) || !(fm > 0.0)) {  // an exact zero at an end (or NaN): Roots returns that end
+      const double fll = binf_froot_literal<TEAM>(grp, lmin, sigma, sl, delta, lds);
+      const double fml = binf_froot_literal<TEAM>(grp, lmax, sigma, sl, delta, lds);
+      if (fll * fml > 0) return false;
+      root = binf_bisect<TEAM>(grp, lmin, fll, lmax, fml, sigma, sl, delta, lds);
+      return true;
+    }
   }
-  if (psi == 0.0) { root = fmin(fmax(sl + u, lmin), lmax); return true; }
+  double pa = -1.0, pb = -1.0;  // sums of the piece solved last (A, B >= 0 always)
   for (int it = 0; it < SPX_BINF_NEWTON_MAXIT; ++it) {
-    double un = u - psi * fast_rcp(dpsi);
-    if (!(un > ulo && un < uhi)) un = sqrt(ulo) * sqrt(uhi);  // geometric bisection: the bracket spans decades
-    if (!(un > ulo && un < uhi)) break;
-    double psin, dpsin;
-    binf_psi<TEAM>(grp, un, sl, delta, lds, psin, dpsin);
-    const bool small = fabs(un - u) <= 4 * eps * un;
-    u = un; psi = psin; dpsi = dpsin;
-    if (psin == 0.0 || small) break;
-    if (psin < 0.0) ulo = un; else uhi = un;
+    if (psi == 0.0 || (sa == pa && sb == pb)) break;  // exact hit, or the piece just solved is confirmed
+    if (psi < 0.0) ulo = u; else uhi = u;
+    // root of the current piece: g(v) = v - sqrt(sb + sa (v / (sl + v))^2), scalar Newton from u
+    double v = u;
+    for (int k = 0; k < 12; ++k) {
+      const double rn = fast_rcp(sl + v);
+      const double t = v * rn;
+      const double ph = sqrt_pos(__builtin_fma(t * t, sa, sb));
+      const double g = v - ph;
+      const double gp = 1.0 - ((ph > 0.0) ? sa * t * (sl * rn * rn) * fast_rcp(ph) : 0.0);
+      const double vn = v - g * fast_rcp(gp);
+      const bool done = fabs(vn - v) <= 2 * eps * fabs(vn);
+      v = vn;
+      if (done) break;
+    }
+    if (!(v > ulo && v < uhi)) v = sqrt_pos(ulo) * sqrt_pos(uhi);  // safeguard: geometric bisection of the bracket
+    if (!(v > ulo && v < uhi)) break;
+    const bool small = fabs(v - u) <= 4 * eps * v;
+    pa = sa; pb = sb; u = v;
+    if (small) break;
+    const double tau = u * fast_rcp(sl + u);
+    binf_ab<TEAM>(grp, tau, delta, lds, sa, sb);
+    psi = u - sqrt_pos(__builtin_fma(tau * tau, sa, sb));
   }
   double n0 = fmin(fmax(sl + u, lmin), lmax);
   if (u * 1000.0 > n0) {  // well conditioned in n: a few ulp of n cannot move step by more than ~1e-13
@@ -315,7 +341,7 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
   // polish: find adjacent doubles a < b with froot(a) < 0 < froot(b)
   double f0 = binf_froot<TEAM>(grp, n0, sl, delta, lds);
   if (f0 == 0.0) { root = n0; return true; }
-  double a = lmin, fa = fl, b = lmax, fb = fm;  // running bracket for the fallback
+  double a = fmax(sl + ulo, lmin), fa = -1.0, b = fmin(sl + uhi, lmax), fb = 1.0;  // running bracket (signs known)
   bool found = false;
   if (f0 < 0.0) {
     a = n0; fa = f0;
@@ -361,8 +387,11 @@ __device__ __forceinline__ double binf_w(double S, double X, double tau, double 
 // fast path kernel: uniform groups of LPG*EPL elements; LPG lanes own a group, 64/LPG groups per wave;
 // the group is resident in registers.  Lane j of a group owns the 16-byte pairs j, j + LPG, j + 2 LPG, ...
 // ---------------------------------------------------------------------------------------------
+#ifndef SPX_GROUP_WAVES
+#define SPX_GROUP_WAVES 3  // min waves/SIMD (VGPR cap).  Binf 1e6x128: 3 (162 VGPRs, no spill) 0.84 ms; 4 (128, cold paths spill) 0.93 ms; 5: 1.49 ms
+#endif
 template <int LPG, int EPL, bool BINF>
-__global__ __launch_bounds__(256) void k_group_reg(double* y_, const double* q_, const double* xk_, const double* sj_,
+__global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, const double* q_, const double* xk_, const double* sj_,
                                                     int64_t ngroups, const double* __restrict__ lambda, double sigma,
                                                     double delta) {
   static_assert((EPL % 2) == 0, "EPL must be even (16-byte pairs)");
