@@ -232,10 +232,40 @@ __device__ __forceinline__ double binf_bisect(const G& grp, double a, double fa,
   return (fabs(fa) < fabs(fb)) ? a : b;
 }
 
-// returns true and the root in `root`, or false when fl * fm > 0 (reference writes zeros, :102-103)
+// The reference's own evaluation, literally: froot at both ends (:95,:101), `fl * fm > 0` -> zeros (:102), else
+// Roots.fzero (:105).  Used for degenerate brackets, exact zeros at an end and NaNs, where the A/B form of the
+// fast path (which assumes n > sl) does not describe what the reference computes.
 template <int TEAM, class G>
-__device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma, double delta, double* lds,
-                                          double& root) {
+__device__ __forceinline__ bool binf_literal_root(const G& grp, double lam, double sigma, double delta, double* lds,
+                                                  double& root) {
+  const double eps = 2.220446049250313e-16;
+  const double sl = lam * sigma;
+  const double lmin = sl * (1 + eps);                                     // :94
+  const double fl = binf_froot_literal<TEAM>(grp, lmin, sigma, sl, delta, lds);  // :95
+  const double ansatz = lmin + 1.0;                                       // :97
+  const double step = ansatz / (sigma * (ansatz - sl));                   // :98
+  double sz = 0.0, sS = 0.0, sX = 0.0;
+  grp.for_each([&](double S, double X) {
+    const double z = softthres(S / sigma - step * X, delta * step);       // :99
+    sz += z * z;
+    sS += S * S;
+    sX += X * X;
+  });
+  team_sum2<TEAM>(sz, sS, lds);
+  sX = team_sum<TEAM>(sX, lds);
+  const double lmax = sqrt(sS) + sigma * (sqrt(sz) + 1.0 * lam * sqrt(sX));  // :100
+  const double fm = binf_froot_literal<TEAM>(grp, lmax, sigma, sl, delta, lds);  // :101
+  if (fl * fm > 0) return false;                                          // :102
+  root = binf_bisect<TEAM>(grp, lmin, fl, lmax, fm, sigma, sl, delta, lds);  // :105
+  return true;
+}
+
+enum { BINF_ZERO = 0, BINF_ROOT = 1, BINF_LITERAL = 2 };
+// BINF_ROOT: root (> sl) in `root`;  BINF_ZERO: fl * fm > 0, the reference writes zeros (:102-103);
+// BINF_LITERAL: degenerate bracket / exact zero at an end / NaN -> the caller must run binf_literal_root.
+template <int TEAM, class G>
+__device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma, double delta, double* lds,
+                                         double& root) {
   const double eps = 2.220446049250313e-16;
   const double sl = lam * sigma;          // :85
   const double lmin = sl * (1 + eps);     // :94
@@ -267,15 +297,7 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
   const double nS = sqrt_pos(sS), nX = sqrt_pos(sX);
   const double lmax = nS + sigma * (sqrt_pos(sz) + 1.0 * lam * nX);  // :100 (|(eps-1)/eps + 1| = 1)
   double fl = lmin - (lmin * fast_rcp(ul)) * sqrt_pos(__builtin_fma(taul * taul, sal, sbl));
-  if (!(lmin < lmax) || !(ul > 0.0) || !(fl == fl)) {
-    // Degenerate bracket (||S|| + sigma (zlmax + lambda ||X||) <= sigma lambda puts the "upper" end at or below the
-    // pole n = sl of step(n)), sl == 0, or a NaN: do literally what the reference + Roots.fzero do.
-    fl = binf_froot_literal<TEAM>(grp, lmin, sigma, sl, delta, lds);
-    const double fm = binf_froot_literal<TEAM>(grp, lmax, sigma, sl, delta, lds);
-    if (fl * fm > 0) return false;  // :102
-    root = binf_bisect<TEAM>(grp, lmin, fl, lmax, fm, sigma, sl, delta, lds);
-    return true;
-  }
+  if (!(lmin < lmax) || !(ul > 0.0) || !(fl == fl)) return BINF_LITERAL;  // degenerate bracket, sl == 0, NaN
   // regular bracket sl < lmin < lmax:  fm = froot(lmax) has the sign of psi(uhi)   (:101).
   // |b_i| <= max(|S_i|, |X_i|) gives phi(u) <= ub := sqrt(||S||^2 + ||X||^2) for every u, so the root is <= ub:
   // if uhi >= ub then psi(uhi) >= 0 is known without evaluating it and the iteration starts from ub instead.
@@ -298,14 +320,8 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
   }
   {
     const double fm = from_bound ? ((psi > 0.0) ? psi : 1.0) : (lmax * fast_rcp(u)) * psi;
-    if (fl * fm > 0) return false;  // :102
-    if (!(fl < 0.0) || !(fm > 0.0)) {  // an exact zero at an end (or NaN): Roots returns that end
-      const double fll = binf_froot_literal<TEAM>(grp, lmin, sigma, sl, delta, lds);
-      const double fml = binf_froot_literal<TEAM>(grp, lmax, sigma, sl, delta, lds);
-      if (fll * fml > 0) return false;
-      root = binf_bisect<TEAM>(grp, lmin, fll, lmax, fml, sigma, sl, delta, lds);
-      return true;
-    }
+    if (fl * fm > 0) return BINF_ZERO;                      // :102
+    if (!(fl < 0.0) || !(fm > 0.0)) return BINF_LITERAL;    // an exact zero at an end (or NaN)
   }
   double pa = -1.0, pb = -1.0;  // sums of the piece solved last (A, B >= 0 always)
   for (int it = 0; it < SPX_BINF_NEWTON_MAXIT; ++it) {
@@ -336,11 +352,11 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
   double n0 = fmin(fmax(sl + u, lmin), lmax);
   if (u * 1000.0 > n0) {  // well conditioned in n: a few ulp of n cannot move step by more than ~1e-13
     root = n0;
-    return true;
+    return BINF_ROOT;
   }
   // polish: find adjacent doubles a < b with froot(a) < 0 < froot(b)
   double f0 = binf_froot<TEAM>(grp, n0, sl, delta, lds);
-  if (f0 == 0.0) { root = n0; return true; }
+  if (f0 == 0.0) { root = n0; return BINF_ROOT; }
   double a = fmax(sl + ulo, lmin), fa = -1.0, b = fmin(sl + uhi, lmax), fb = 1.0;  // running bracket (signs known)
   bool found = false;
   if (f0 < 0.0) {
@@ -362,7 +378,7 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
   }
   if (found) {
     root = (fb == 0.0) ? b : ((fa == 0.0) ? a : ((fabs(fa) < fabs(fb)) ? a : b));
-    return true;
+    return BINF_ROOT;
   }
   // rare: Newton ended far from the sign change -> bit-midpoint bisection on the remaining bracket
   for (int it = 0; it < 130; ++it) {
@@ -373,7 +389,7 @@ __device__ __forceinline__ bool binf_root(const G& grp, double lam, double sigma
     else { a = m; fa = fmid; }
   }
   root = (fabs(fa) < fabs(fb)) ? a : b;
-  return true;
+  return BINF_ROOT;
 }
 
 // the prox of one element given the root:  alpha w_i with w_i = (n/u) b_i (active) or S_i (inactive)   (:110-113)
@@ -393,7 +409,7 @@ __device__ __forceinline__ double binf_w(double S, double X, double tau, double 
 template <int LPG, int EPL, bool BINF>
 __global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, const double* q_, const double* xk_, const double* sj_,
                                                     int64_t ngroups, const double* __restrict__ lambda, double sigma,
-                                                    double delta) {
+                                                    double delta, long long* deferred /* [0] = count, [1..] = groups */) {
   static_assert((EPL % 2) == 0, "EPL must be even (16-byte pairs)");
   constexpr int GS = LPG * EPL;
   constexpr int GPW = 64 / LPG;  // groups per wave
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, 
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t g0 = wave * GPW; g0 < ngroups; g0 += nwaves * GPW) {  // wave-uniform trip count
-    const bool valid = (g0 + slot) < ngroups;
+    bool valid = (g0 + slot) < ngroups;
     const int64_t g = valid ? (g0 + slot) : (ngroups - 1);  // idle slots shadow the last group, no store
     const int64_t base = g * GS;
     RegGroup<EPL> grp;
@@ -440,9 +456,15 @@ __global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, 
       for (int k = 0; k < EPL; ++k) out[k] = ((snorm == 0.0) ? 0.0 : alpha * grp.S[k]) - grp.XS[k];  // :74,:77
     } else {
       double root;
-      const bool ok = binf_root<LPG>(grp, lam, sigma, delta, nullptr, root);
+      const int status = binf_root<LPG>(grp, lam, sigma, delta, nullptr, root);
       const double sl = lam * sigma;
-      if (!ok || (root - sl) == 0.0) {  // shiftedGroupNormL2Binf.jl:102-103, :107-108
+      if (status == BINF_LITERAL) {
+        // rare (degenerate bracket / exact zero / NaN): handed to k_group_list, which evaluates the reference's
+        // expressions literally; keeping that code out of this kernel saves ~40 VGPRs
+        if (valid && j == 0) deferred[1 + atomicAdd((unsigned long long*)deferred, 1ull)] = g;
+        valid = false;
+      }
+      if (status != BINF_ROOT || (root - sl) == 0.0) {  // shiftedGroupNormL2Binf.jl:102-103, :107-108
 #pragma unroll
         for (int k = 0; k < EPL; ++k) out[k] = 0.0 - grp.XS[k];
       } else {
@@ -476,13 +498,15 @@ template <int TEAM, bool BINF>
 __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, const double* xk, const double* sj,
                                                     int64_t n, const int64_t* __restrict__ offsets, int64_t gsize,
                                                     int64_t ngroups, const double* __restrict__ lambda, double sigma,
-                                                    double delta) {
+                                                    double delta, const long long* list /* NULL, or [0] = count, [1..] */) {
   __shared__ double lds[8];
   constexpr int TPB = 256 / TEAM;  // teams per block
   const int lane = threadIdx.x % TEAM;
   const int64_t team = (int64_t)blockIdx.x * TPB + threadIdx.x / TEAM;
   const int64_t nteams = (int64_t)gridDim.x * TPB;
-  for (int64_t g = team; g < ngroups; g += nteams) {  // for TEAM == 256 the trip count is block-uniform
+  const int64_t ntodo = list ? (int64_t)list[0] : ngroups;
+  for (int64_t t = team; t < ntodo; t += nteams) {  // for TEAM == 256 the trip count is block-uniform
+    const int64_t g = list ? (int64_t)list[1 + t] : t;
     int64_t lo, hi;
     if (offsets) { lo = offsets[g]; hi = offsets[g + 1]; }
     else { lo = g * gsize; hi = lo + gsize; }
@@ -502,9 +526,29 @@ __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, c
       }
     } else {
       double root;
-      const bool ok = binf_root<TEAM>(grp, lam, sigma, delta, lds, root);
+      int status = list ? BINF_LITERAL : binf_root<TEAM>(grp, lam, sigma, delta, lds, root);
       const double sl = lam * sigma;
-      if (!ok || (root - sl) == 0.0) {
+      if (status == BINF_LITERAL) {
+        // the reference, literally, including its last step (:106-113) -- the root may lie below sl here
+        const bool ok = binf_literal_root<TEAM>(grp, lam, sigma, delta, lds, root);
+        if (!ok || (root - sl) == 0.0) {
+          for (int64_t i = lo + lane; i < hi; i += TEAM) y[i] = 0.0 - (xk[i] + sj[i]);
+        } else {
+          const double step = root / (sigma * (root - sl));
+          double sw = 0.0;
+          grp.for_each([&](double S, double X) {
+            double w = S - sigma * softthres(S / sigma - step * X, delta * step);
+            sw += w * w;
+          });
+          const double nw = sqrt(team_sum<TEAM>(sw, lds));
+          const double alpha = jl_max(0.0, 1 - sl / nw);
+          for (int64_t i = lo + lane; i < hi; i += TEAM) {
+            double x = xk[i], s = sj[i];
+            double S = (q[i] + x) + s;
+            y[i] = alpha * (S - sigma * softthres(S / sigma - step * x, delta * step)) - (x + s);
+          }
+        }
+      } else if (status == BINF_ZERO || (root - sl) == 0.0) {
         for (int64_t i = lo + lane; i < hi; i += TEAM) y[i] = 0.0 - (xk[i] + sj[i]);
       } else {
         const double u = root - sl, tau = u / root, c = root / u;
@@ -561,9 +605,16 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
       int64_t blocks = (ngroups + 4 * gpw - 1) / (4 * gpw);  // 4 waves per 256-thread block
       if (blocks > 0x7fffffff) blocks = 0x7fffffff;
       dim3 grid((unsigned)blocks), block(256);
+      long long* deferred = nullptr;
+      if (BINF) {  // list of the groups whose bracket needs the reference's literal evaluation
+        rc = spx_ws_reserve(ctx, (size_t)(ngroups + 1) * sizeof(long long) + 256);
+        if (rc) return rc;
+        deferred = reinterpret_cast<long long*>(ctx->ws);
+        SPX_HIP(hipMemsetAsync(deferred, 0, sizeof(long long), ctx->stream));
+      }
 #define SPX_LAUNCH_REG(LPG, EPL)                                                                                 \
   hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups, lambda, \
-                     sigma, delta)
+                     sigma, delta, deferred)
       switch (gsize) {
         case 32: SPX_LAUNCH_REG(16, 2); break;
         case 64: SPX_LAUNCH_REG(16, 4); break;
@@ -573,6 +624,11 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
         case 512: SPX_LAUNCH_REG(64, 8); break;
       }
 #undef SPX_LAUNCH_REG
+      if (BINF) {  // usually an empty list: the kernel returns at once
+        hipLaunchKernelGGL((k_group_mem<64, BINF>), dim3((unsigned)(ctx->num_cu * 2)), dim3(256), 0, ctx->stream, y, q, xk,
+                           sj, n, (const int64_t*)nullptr, gsize, ngroups, lambda, sigma, delta,
+                           (const long long*)deferred);
+      }
       SPX_LAUNCH_CHECK();
       return SPX_OK;
     }
@@ -583,11 +639,11 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     int64_t blocks = (ngroups + 3) / 4;
     if (blocks > cap_blocks) blocks = cap_blocks;
     hipLaunchKernelGGL((k_group_mem<64, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n,
-                       offsets, gsize, ngroups, lambda, sigma, delta);
+                       offsets, gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr);
   } else {
     int64_t blocks = ngroups < cap_blocks ? ngroups : cap_blocks;
     hipLaunchKernelGGL((k_group_mem<256, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n,
-                       offsets, gsize, ngroups, lambda, sigma, delta);
+                       offsets, gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr);
   }
   SPX_LAUNCH_CHECK();
   return SPX_OK;
