@@ -203,6 +203,17 @@ def _extra(s, L, ctx, dev, n, torch):
     uv = 1.0 + 0.1 * torch.rand(n, dtype=torch.float64, device=dev, generator=gen)
     line("ShiftedNormL1Box_vector_bounds", s.shifted(s.shifted(s.NormL1(1.0), xk, lv, uv), sj), 48, n, y, q)
     del lv, uv
+    # iprox!: g, d, xk, sj -> y, 40 B/element
+    d = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) + 0.5
+
+    def iline(name, psi):
+        ms = _time_op(s, L, ctx, lambda: s.iprox_bang(y, psi, q, d, check=False))
+        res[name] = {"ms": round(ms, 4), "gelem_s": round(n / ms / 1e6, 2), "gbs_algorithmic": round(40 * n / ms / 1e6, 1),
+                     "frac_of_peak": round(40 * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+    iline("iprox_ShiftedNormL1Box", s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj))
+    iline("iprox_ShiftedNormL0Box", s.shifted(s.shifted(s.NormL0(1.0), xk, 1.0, chi), sj))
+    del d
     r = max(1, n // 100)
     line("ShiftedIndBallL0BInf_r=n/100", s.shifted(s.shifted(s.IndBallL0(r), xk, 1.0, chi), sj), 32, n, y, q)
     # group config: (n // 100) groups of 128  (10^6 x 128 at n = 10^8)

@@ -41,7 +41,8 @@ typedef enum spx_status {
   SPX_ERR_BOUNDS = 2,      /* reserved for "at least one lower bound is greater than the upper"   */
   SPX_ERR_HIP = 3,         /* a HIP runtime call failed (message has the HIP error string)        */
   SPX_ERR_ALLOC = 4,       /* workspace allocation failed                                         */
-  SPX_ERR_NO_DEVICE = 5    /* no usable gfx950 device                                             */
+  SPX_ERR_NO_DEVICE = 5,   /* no usable gfx950 device                                             */
+  SPX_ERR_ASSERT = 6       /* the reference's `@assert d[i] > 0` failed (unboxed iprox!)           */
 } spx_status;
 
 typedef struct spx_ctx spx_ctx; /* opaque: device id, HIP stream, library-owned scratch */
@@ -105,6 +106,26 @@ int spx_prox_lhalf_box(spx_ctx* ctx, double* y, const double* q, const double* x
                        int64_t n, double lambda, double sigma, const double* l_vec,
                        const double* u_vec, double l_scalar, double u_scalar,
                        const uint8_t* sel_mask);
+
+/* ---- iprox!: argmin 1/2 y'Dy + g'y + psi(y), D = diag(d)  (src/ShiftedProximalOperators.jl:154-180) ------ */
+/* Separable; reads g, d, xk, sj (40 B/element).  y may alias g.
+ * Unboxed forms: the reference asserts d[i] > 0.  check_d != 0: the call synchronises and returns SPX_ERR_ASSERT
+ * if some d[i] <= 0 (y is then unspecified, as after the reference's exception); check_d == 0: asynchronous, no check. */
+/* ShiftedNormL1.iprox!     src/shiftedNormL1.jl:60-75 */
+int spx_iprox_l1(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk,
+                 const double* sj, int64_t n, double lambda, int check_d);
+/* ShiftedNormL0.iprox!     src/shiftedNormL0.jl:61-80 */
+int spx_iprox_l0(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk,
+                 const double* sj, int64_t n, double lambda, int check_d);
+/* ShiftedNormL1Box.iprox!  src/shiftedNormL1Box.jl:131-225; unselected entries: iprox_zero
+ * (src/ShiftedProximalOperators.jl:217-236) */
+int spx_iprox_l1_box(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk,
+                     const double* sj, int64_t n, double lambda, const double* l_vec,
+                     const double* u_vec, double l_scalar, double u_scalar, const uint8_t* sel_mask);
+/* ShiftedNormL0Box.iprox!  src/shiftedNormL0Box.jl:137-231 */
+int spx_iprox_l0_box(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk,
+                     const double* sj, int64_t n, double lambda, const double* l_vec,
+                     const double* u_vec, double l_scalar, double u_scalar, const uint8_t* sel_mask);
 
 /* ---- top-r selection ------------------------------------------------------------------- */
 /* ShiftedIndBallL0.prox!     src/shiftedIndBallL0.jl:54-72 : keep the r entries of (xk+sj)+q largest in

@@ -16,7 +16,7 @@ using ShiftedProximalOperators
 using ShiftedProximalOperators:
   ShiftedNormL1, ShiftedNormL0, ShiftedRootNormLhalf, ShiftedNormL1Box, ShiftedNormL0Box,
   ShiftedRootNormLhalfBox, ShiftedIndBallL0, ShiftedIndBallL0BInf, ShiftedGroupNormL2, ShiftedGroupNormL2Binf
-import ShiftedProximalOperators: prox!
+import ShiftedProximalOperators: prox!, iprox!
 using AMDGPU  # ROCArray, AMDGPU.stream(), AMDGPU.device_id
 
 const libspx = get(ENV, "LIBSPX", "libspx.so")
@@ -98,6 +98,35 @@ for (T, sym) in ((:ShiftedNormL1Box, :spx_prox_l1_box), (:ShiftedNormL0Box, :spx
                 (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cdouble,
                  Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{UInt8}),
                 ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, ψ.λ, σ,
+                dptr(vec_or_nothing(ψ.l)), dptr(vec_or_nothing(ψ.u)), scal(ψ.l), scal(ψ.u),
+                m === nothing ? Ptr{UInt8}(C_NULL) : Ptr{UInt8}(UInt(pointer(m)))))
+    return y
+  end
+end
+
+# ---------------------------------------------------------------------------------------------
+# iprox!                      src/shiftedNormL1.jl:60-75, shiftedNormL0.jl:61-80, shiftedNormL1Box.jl:131-225,
+#                             shiftedNormL0Box.jl:137-231
+# ---------------------------------------------------------------------------------------------
+for (T, sym) in ((:ShiftedNormL1, :spx_iprox_l1), (:ShiftedNormL0, :spx_iprox_l0))
+  @eval function iprox!(y::DVec, ψ::$T{Float64, <:DVec, <:DVec, <:DVec}, g::DVec, d::DVec)
+    n = length(ψ.xk)
+    st = ccall(($(QuoteNode(sym)), libspx), Cint,
+               (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cint),
+               ctx(), dptr(y), dptr(g), dptr(d), dptr(ψ.xk), dptr(ψ.sj), n, ψ.λ, 1)
+    st == 6 && throw(AssertionError("d[i] > 0"))   # SPX_ERR_ASSERT
+    check(st)
+    return y
+  end
+end
+for (T, sym) in ((:ShiftedNormL1Box, :spx_iprox_l1_box), (:ShiftedNormL0Box, :spx_iprox_l0_box))
+  @eval function iprox!(y::DVec, ψ::$T{Float64, <:DVec, <:DVec, <:DVec}, g::DVec, d::DVec)
+    n = length(ψ.xk)
+    m = mask_for(ψ)
+    check(ccall(($(QuoteNode(sym)), libspx), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble,
+                 Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{UInt8}),
+                ctx(), dptr(y), dptr(g), dptr(d), dptr(ψ.xk), dptr(ψ.sj), n, ψ.λ,
                 dptr(vec_or_nothing(ψ.l)), dptr(vec_or_nothing(ψ.u)), scal(ψ.l), scal(ψ.u),
                 m === nothing ? Ptr{UInt8}(C_NULL) : Ptr{UInt8}(UInt(pointer(m)))))
     return y

@@ -50,6 +50,17 @@ def lib():
         L.orc_prox_indball_l0_binf.argtypes = base + [i64, d]
         L.orc_prox_group_l2.argtypes = base + [ip, i64, i64, dp, d]
         L.orc_prox_group_l2_binf.argtypes = base + [ip, i64, i64, dp, d, d]
+        ib = [dp, dp, dp, dp, dp, i64, d]
+        L.orc_iprox_l1.argtypes = ib
+        L.orc_iprox_l0.argtypes = ib
+        L.orc_iprox_l1.restype = i64
+        L.orc_iprox_l0.restype = i64
+        L.orc_iprox_l1_box.argtypes = ib + [dp, dp, d, d, up]
+        L.orc_iprox_l0_box.argtypes = ib + [dp, dp, d, d, up]
+        L.orc_iprox_l1_box.restype = None
+        L.orc_iprox_l0_box.restype = None
+        L.orc_iprox_zero.argtypes = [d, d, d, d]
+        L.orc_iprox_zero.restype = d
         L.orc_rootnormlhalf_prox.argtypes = [dp, dp, i64, d, d]
         L.orc_rootnormlhalf_prox.restype = d
         for name in ("orc_prox_l1", "orc_prox_l0", "orc_prox_lhalf", "orc_prox_l1_box", "orc_prox_l0_box",
@@ -193,3 +204,52 @@ def rootnormlhalf_prox(x, lam, gamma):
     y = np.empty_like(x)
     val = lib().orc_rootnormlhalf_prox(_dp(y), _dp(x), x.shape[0], lam, gamma)
     return y, val
+
+
+# ---- iprox! (indefinite prox) ---------------------------------------------------------------
+class AssertionErrorAt(AssertionError):
+    """The reference's `@assert d[i] > 0` (0-based index in .index; y holds the entries written before it)."""
+
+    def __init__(self, index, y):
+        super().__init__("AssertionError: d[i] > 0 at i = %d" % index)
+        self.index, self.y = index, y
+
+
+def _iprox_unboxed(fn, g, d, xk, sj, lam):
+    g, xk, sj, n, y = _prep(g, xk, sj)
+    d = _f64(d)
+    assert d.shape[0] == n
+    bad = fn(_dp(y), _dp(g), _dp(d), _dp(xk), _dp(sj), n, lam)
+    if bad >= 0:
+        raise AssertionErrorAt(int(bad), y)
+    return y
+
+
+def iprox_l1(g, d, xk, sj, lam):
+    return _iprox_unboxed(lib().orc_iprox_l1, g, d, xk, sj, lam)
+
+
+def iprox_l0(g, d, xk, sj, lam):
+    return _iprox_unboxed(lib().orc_iprox_l0, g, d, xk, sj, lam)
+
+
+def _iprox_box(fn, g, d, xk, sj, lam, l, u, mask):
+    g, xk, sj, n, y = _prep(g, xk, sj)
+    d = _f64(d)
+    assert d.shape[0] == n
+    lv, uv, ls, us = _bounds(l, u, n)
+    m, mp = _mask(mask, n)
+    fn(_dp(y), _dp(g), _dp(d), _dp(xk), _dp(sj), n, lam, _dp(lv), _dp(uv), ls, us, mp)
+    return y
+
+
+def iprox_l1_box(g, d, xk, sj, lam, l, u, mask=None):
+    return _iprox_box(lib().orc_iprox_l1_box, g, d, xk, sj, lam, l, u, mask)
+
+
+def iprox_l0_box(g, d, xk, sj, lam, l, u, mask=None):
+    return _iprox_box(lib().orc_iprox_l0_box, g, d, xk, sj, lam, l, u, mask)
+
+
+def iprox_zero(d, g, l, u):
+    return lib().orc_iprox_zero(float(d), float(g), float(l), float(u))

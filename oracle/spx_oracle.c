@@ -438,6 +438,193 @@ ORC_API void orc_prox_group_l2_binf(double* y, const double* q, const double* xk
   free(w);
 }
 
+/* ==========================================================================================
+ * iprox!  (SURVEY.md 8f rank 1): indefinite prox  argmin 1/2 y'Dy + g'y + psi(y), D = diag(d)
+ * ========================================================================================== */
+
+/* iprox_zero(d, g, l, u)  src/ShiftedProximalOperators.jl:217-236 */
+static inline double iprox_zero(double d, double g, double l, double u) {
+  const double eps = 2.220446049250313e-16;
+  if (d > eps) {
+    double argmin_quad = -g / d;
+    return jl_min(jl_max(argmin_quad, l), u);
+  } else if (d < -eps) {
+    double d_2 = d / 2;
+    double val_l = d_2 * (l * l) + g * l;
+    double val_u = d_2 * (u * u) + g * u;
+    return (val_l < val_u) ? l : u;
+  } else {
+    if (g > 0.0) return l;
+    if (g < 0.0) return u;
+    return 0.0;
+  }
+}
+
+/* ShiftedNormL1.iprox!  src/shiftedNormL1.jl:60-75.  Returns -1, or the (0-based) index of the first element
+ * with d[i] <= 0, where the reference's `@assert d[i] > 0` throws (entries before it are already written). */
+ORC_API int64_t orc_iprox_l1(double* y, const double* g, const double* d, const double* xk, const double* sj,
+                             int64_t n, double lambda) {
+  for (int64_t i = 0; i < n; ++i) y[i] = (-xk[i]) - sj[i]; /* :67 */
+  for (int64_t i = 0; i < n; ++i) {
+    if (!(d[i] > 0)) return i; /* :70 */
+    y[i] = jl_min(jl_max(y[i], -g[i] / d[i] - lambda / d[i]), -g[i] / d[i] + lambda / d[i]); /* :71 */
+  }
+  return -1;
+}
+
+/* ShiftedNormL0.iprox!  src/shiftedNormL0.jl:61-80 */
+ORC_API int64_t orc_iprox_l0(double* y, const double* g, const double* d, const double* xk, const double* sj,
+                             int64_t n, double lambda) {
+  for (int64_t i = 0; i < n; ++i) {
+    double di = d[i];
+    if (!(di > 0)) return i; /* :70 */
+    double ci = sqrt(2 * lambda * di);
+    double xps = xk[i] + sj[i];
+    y[i] = (fabs(di * xps - g[i]) <= ci) ? -xps : (-g[i] / di);
+  }
+  return -1;
+}
+
+/* ShiftedNormL1Box.iprox!  src/shiftedNormL1Box.jl:131-225 */
+ORC_API void orc_iprox_l1_box(double* y, const double* g, const double* d, const double* xk, const double* sj,
+                              int64_t n, double lambda, const double* lvec, const double* uvec, double lscal,
+                              double uscal, const uint8_t* mask) {
+  const double eps = 2.220446049250313e-16;
+  for (int64_t i = 0; i < n; ++i) {
+    double li = lvec ? lvec[i] : lscal;
+    double ui = uvec ? uvec[i] : uscal;
+    double di = d[i], gi = g[i], si = sj[i], xi = xk[i];
+    double xs = xi + si;
+    if (!is_selected(mask, i)) { y[i] = iprox_zero(di, gi, li - si, ui - si); continue; } /* :221 */
+    double left = li - si, right = ui - si;
+    double yi;
+    if (fabs(di) <= eps) { /* :152 */
+      if (fabs(gi) <= lambda) yi = jl_min(jl_max(left, -xs), right);
+      else yi = (gi > 0) ? left : right;
+    } else if (di > eps) { /* :161 */
+      double di_2 = di / 2;
+      double lx = li + xi, ux = ui + xi;
+      double gi2_di = gi / di_2;
+      double fi2_di = gi2_di - 2 * xs;
+      double l2_di = lambda / di_2;
+      double val_left = lx * lx + fi2_di * lx + l2_di * fabs(lx);
+      double val_right = ux * ux + fi2_di * ux + l2_di * fabs(ux);
+      double val_min = jl_min(val_left, val_right);
+      yi = (val_left < val_right) ? left : right;
+      if (lx >= 0.0) {
+        double a = -(gi + lambda) / di;
+        if (left <= a && a <= right) yi = a;
+      } else if (0.0 >= ux) {
+        double a = (lambda - gi) / di;
+        if (left <= a && a <= right) yi = a;
+      } else {
+        double y1 = -(gi + lambda) / di;
+        double y2 = (lambda - gi) / di;
+        if (left <= y1 && y1 <= right) {
+          double v1 = xs + y1;
+          double q1 = v1 * v1 + fi2_di * v1 + l2_di * fabs(v1);
+          if (q1 < val_min) yi = y1;
+          val_min = jl_min(q1, val_min);
+        }
+        if (left <= y2 && y2 <= right) {
+          double v2 = xs + y2;
+          double q2 = v2 * v2 + fi2_di * v2 + l2_di * fabs(v2);
+          if (q2 < val_min) yi = y2;
+          val_min = jl_min(q2, val_min);
+        }
+        if (0.0 < val_min) yi = -xs; /* val_0 = 0 */
+      }
+    } else { /* di <= -eps, :199 */
+      double di_2 = di / 2;
+      double gi2_di = gi / di_2;
+      double fi2_di = gi2_di - 2 * xs;
+      double l2_di = lambda / di_2;
+      double lx = li + xi, ux = ui + xi;
+      double val_left = lx * lx + fi2_di * lx + l2_di * fabs(lx);
+      double val_right = ux * ux + fi2_di * ux + l2_di * fabs(ux);
+      double val_max = jl_max(val_left, val_right);
+      yi = (val_left > val_right) ? left : right;
+      double mxi = -xi;
+      if (li <= mxi && mxi <= ui) {
+        if (0.0 > val_max) yi = -xs;
+      }
+    }
+    y[i] = yi;
+  }
+}
+
+/* ShiftedNormL0Box.iprox!  src/shiftedNormL0Box.jl:137-231 */
+ORC_API void orc_iprox_l0_box(double* y, const double* g, const double* d, const double* xk, const double* sj,
+                              int64_t n, double lambda, const double* lvec, const double* uvec, double lscal,
+                              double uscal, const uint8_t* mask) {
+  const double eps = 2.220446049250313e-16;
+  for (int64_t i = 0; i < n; ++i) {
+    double li = lvec ? lvec[i] : lscal;
+    double ui = uvec ? uvec[i] : uscal;
+    double di = d[i], gi = g[i], si = sj[i], xi = xk[i];
+    double xs = xi + si;
+    double mxi = -xi;
+    int zero_ok = (li <= mxi && mxi <= ui);
+    if (!is_selected(mask, i)) { y[i] = iprox_zero(di, gi, li - si, ui - si); continue; } /* :227 */
+    double yi;
+    if (fabs(di) < eps) { /* :154 */
+      if (gi == 0.0) {
+        yi = zero_ok ? -xs : 0.0;
+      } else {
+        double val_min;
+        if (gi > 0.0) {
+          double left = li - si;
+          val_min = gi * left + ((xi == -li) ? 0.0 : lambda);
+          yi = left;
+        } else {
+          double right = ui - si;
+          val_min = gi * right + ((xi == -ui) ? 0.0 : lambda);
+          yi = right;
+        }
+        if (zero_ok) {
+          double val_0 = -gi * xs;
+          if (val_0 < val_min) yi = -xs;
+        }
+      }
+    } else {
+      double di_2 = di / 2;
+      double left = li - si, right = ui - si;
+      double lx = li + xi, ux = ui + xi;
+      double gi2_di = gi / di_2;
+      double fi2_di = gi2_di - 2 * xs;
+      double l2_di = lambda / di_2;
+      if (di >= eps) { /* :190 */
+        double aqy = -gi / di;
+        double aqv = aqy + xs;
+        double val_min;
+        if (lx <= aqv && aqv <= ux) {
+          val_min = (aqv == 0.0) ? (-(aqv * aqv)) : (-(aqv * aqv) + l2_di);
+          yi = aqy;
+        } else {
+          double val_left = (lx == 0.0) ? 0.0 : (lx * lx + fi2_di * lx + l2_di);
+          double val_right = (ux == 0.0) ? 0.0 : (ux * ux + fi2_di * ux + l2_di);
+          yi = (val_left < val_right) ? left : right;
+          val_min = jl_min(val_left, val_right);
+        }
+        if (zero_ok) {
+          if (0.0 < val_min) yi = -xs;
+        }
+      } else { /* :213 */
+        double val_left = (lx == 0.0) ? 0.0 : (lx * lx + fi2_di * lx + l2_di);
+        double val_right = (ux == 0.0) ? 0.0 : (ux * ux + fi2_di * ux + l2_di);
+        yi = (val_left > val_right) ? left : right;
+        double val_max = jl_max(val_left, val_right);
+        if (zero_ok) {
+          if (0.0 > val_max) yi = -xs;
+        }
+      }
+    }
+    y[i] = yi;
+  }
+}
+
+ORC_API double orc_iprox_zero(double d, double g, double l, double u) { return iprox_zero(d, g, l, u); }
+
 /* Objective value 1/(2 sigma) (t-q)^2 + lambda*h(x+s+t) helpers for the brute-force second oracle
  * live in tests/ (numpy); nothing else is exported from here. */
-ORC_API int orc_abi_version(void) { return 1; }
+ORC_API int orc_abi_version(void) { return 2; }

@@ -28,6 +28,10 @@ SIGNATURES = {
     "spx_prox_l1_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p],
     "spx_prox_l0_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p],
     "spx_prox_lhalf_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p],
+    "spx_iprox_l1": [_p, _p, _p, _p, _p, _p, _i64, _d, _int],
+    "spx_iprox_l0": [_p, _p, _p, _p, _p, _p, _i64, _d, _int],
+    "spx_iprox_l1_box": [_p, _p, _p, _p, _p, _p, _i64, _d, _p, _p, _d, _d, _p],
+    "spx_iprox_l0_box": [_p, _p, _p, _p, _p, _p, _i64, _d, _p, _p, _d, _d, _p],
     "spx_prox_indball_l0": [_p, _p, _p, _p, _p, _i64, _i64],
     "spx_prox_indball_l0_binf": [_p, _p, _p, _p, _p, _i64, _i64, _d],
     "spx_prox_group_l2": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _d],

@@ -23,6 +23,7 @@ struct OpL1 {  // src/shiftedNormL1.jl:46-51
   double ls;   // lambda * sigma
   static constexpr bool kBox = false;
   static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
+  static constexpr int kNIn = 3;     // input vectors besides bounds: q, xk, sj
   __device__ __forceinline__ double operator()(double q, double x, double s, double, double, bool) const {
     double t = (-x) - s;                          // :47  @. y = -xk - sj
     return jl_min(jl_max(t, q - ls), q + ls);     // :50
@@ -31,6 +32,7 @@ struct OpL1 {  // src/shiftedNormL1.jl:46-51
 struct OpL1Aliased {  // y === q in the reference: the broadcast at :47 overwrites q before :50 reads it
   static constexpr bool kBox = false;
   static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
+  static constexpr int kNIn = 3;     // input vectors besides bounds: q, xk, sj
   __device__ __forceinline__ double operator()(double, double x, double s, double, double, bool) const {
     return (-x) - s;  // min(max(t, t - ls), t + ls) == t bit for bit whenever ls >= 0
   }
@@ -39,6 +41,7 @@ struct OpL0 {  // src/shiftedNormL0.jl:45-52
   double c;    // sqrt(2 * lambda * sigma)
   static constexpr bool kBox = false;
   static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
+  static constexpr int kNIn = 3;     // input vectors besides bounds: q, xk, sj
   __device__ __forceinline__ double operator()(double q, double x, double s, double, double, bool) const {
     double xps = x + s;
     return (fabs(xps + q) <= c) ? -xps : q;
@@ -48,6 +51,7 @@ struct OpL1Box {  // src/shiftedNormL1Box.jl:96-122
   double sl;      // sigma * lambda
   static constexpr bool kBox = true;
   static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
+  static constexpr int kNIn = 3;     // input vectors besides bounds: q, xk, sj
   __device__ __forceinline__ double operator()(double q, double x, double s, double l, double u, bool sel) const {
     double xs = x + s;
     double xsq = xs + q;
@@ -60,6 +64,7 @@ struct OpL0Box {  // src/shiftedNormL0Box.jl:96-128
   double c;       // 2 * lambda * sigma
   static constexpr bool kBox = true;
   static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
+  static constexpr int kNIn = 3;     // input vectors besides bounds: q, xk, sj
   __device__ __forceinline__ double operator()(double q, double x, double s, double l, double u, bool sel) const {
     double sq = s + q;
     double xs = x + s;
@@ -150,6 +155,7 @@ struct OpLhalf {  // src/shiftedRootNormLhalf.jl:47-60
   double p;       // 54^(1/3) * (2 sigma lambda)^(2/3) / 4
   static constexpr bool kBox = false;
   static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
+  static constexpr int kNIn = 3;     // input vectors besides bounds: q, xk, sj
   __device__ __forceinline__ double operator()(double q, double x, double s, double, double, bool) const {
     double xs = x + s;
     double sol = q + xs;  // :50
@@ -167,6 +173,7 @@ struct OpLhalfBox {  // src/shiftedRootNormLhalfBox.jl:92-117
   double h2;         // 1 / (2 sigma)
   static constexpr bool kBox = true;
   static constexpr int kLdsKiB = 0;  // 0: register-staged skeleton (VALU-heavy: needs the occupancy; 5.97 vs 5.68 TB/s)
+  static constexpr int kNIn = 3;
   // RNorm(tt) = (tt - q)^2 / 2 / sigma + lambda sqrt|tt + xs|   (:95); used only to pick the argmin
   __device__ __forceinline__ double rnorm(double tt, double q, double xs) const {
     double d = tt - q;
@@ -204,6 +211,158 @@ struct OpLhalfBox {  // src/shiftedRootNormLhalfBox.jl:92-117
 };
 
 // ---------------------------------------------------------------------------------------------
+// iprox!  (SURVEY.md 8f rank 1): argmin 1/2 y'Dy + g'y + psi(y), D = diag(d).  Four input vectors (g, d, xk, sj):
+// 40 B/element.  Only +, -, *, /, sqrt and comparisons: bit-exact against the reference formulas.
+// ---------------------------------------------------------------------------------------------
+// iprox_zero(d, g, l, u)   src/ShiftedProximalOperators.jl:217-236
+__device__ __forceinline__ double iprox_zero(double d, double g, double l, double u) {
+  const double eps = 2.220446049250313e-16;
+  const double a = jl_min(jl_max(-g / d, l), u);                       // d > eps
+  const double d_2 = d / 2;
+  const double b = ((d_2 * (l * l) + g * l) < (d_2 * (u * u) + g * u)) ? l : u;  // d < -eps
+  const double c = (g > 0.0) ? l : ((g < 0.0) ? u : 0.0);              // |d| <= eps
+  return (d > eps) ? a : ((d < -eps) ? b : c);
+}
+struct OpIproxL1 {  // src/shiftedNormL1.jl:60-75
+  double lambda;
+  int* flag;  // set when some d[i] <= 0 (the reference's `@assert d[i] > 0`)
+  static constexpr bool kBox = false;
+  static constexpr int kLdsKiB = 4;
+  static constexpr int kNIn = 4;
+  __device__ __forceinline__ double call4(double g, double d, double x, double s, double, double, bool) const {
+    if (!(d > 0.0)) atomicOr(flag, 1);
+    const double t = (-x) - s;                                                       // :67
+    return jl_min(jl_max(t, -g / d - lambda / d), -g / d + lambda / d);              // :71
+  }
+};
+struct OpIproxL0 {  // src/shiftedNormL0.jl:61-80
+  double lambda;
+  int* flag;
+  static constexpr bool kBox = false;
+  static constexpr int kLdsKiB = 4;
+  static constexpr int kNIn = 4;
+  __device__ __forceinline__ double call4(double g, double d, double x, double s, double, double, bool) const {
+    if (!(d > 0.0)) atomicOr(flag, 1);
+    const double ci = sqrt(2 * lambda * d);                                          // :71
+    const double xps = x + s;
+    return (fabs(d * xps - g) <= ci) ? -xps : (-g / d);                              // :73-77
+  }
+};
+struct OpIproxL1Box {  // src/shiftedNormL1Box.jl:131-225
+  double lambda;
+  static constexpr bool kBox = true;
+  static constexpr int kLdsKiB = 4;
+  static constexpr int kNIn = 4;
+  __device__ __forceinline__ double call4(double g, double d, double x, double s, double l, double u, bool sel) const {
+    const double eps = 2.220446049250313e-16;
+    const double xs = x + s;
+    const double left = l - s, right = u - s;
+    double yi;
+    if (fabs(d) <= eps) {  // :152
+      yi = (fabs(g) <= lambda) ? jl_min(jl_max(left, -xs), right) : ((g > 0) ? left : right);
+    } else {
+      const double d_2 = d / 2;
+      const double lx = l + x, ux = u + x;
+      const double g2_d = g / d_2;
+      const double f2_d = g2_d - 2 * xs;
+      const double l2_d = lambda / d_2;
+      const double val_left = lx * lx + f2_d * lx + l2_d * fabs(lx);
+      const double val_right = ux * ux + f2_d * ux + l2_d * fabs(ux);
+      if (d > eps) {  // :161
+        double val_min = jl_min(val_left, val_right);
+        yi = (val_left < val_right) ? left : right;
+        const double y1 = -(g + lambda) / d;
+        const double y2 = (lambda - g) / d;
+        if (lx >= 0.0) {
+          if (left <= y1 && y1 <= right) yi = y1;
+        } else if (0.0 >= ux) {
+          if (left <= y2 && y2 <= right) yi = y2;
+        } else {
+          if (left <= y1 && y1 <= right) {
+            const double v1 = xs + y1;
+            const double q1 = v1 * v1 + f2_d * v1 + l2_d * fabs(v1);
+            if (q1 < val_min) yi = y1;
+            val_min = jl_min(q1, val_min);
+          }
+          if (left <= y2 && y2 <= right) {
+            const double v2 = xs + y2;
+            const double q2 = v2 * v2 + f2_d * v2 + l2_d * fabs(v2);
+            if (q2 < val_min) yi = y2;
+            val_min = jl_min(q2, val_min);
+          }
+          if (0.0 < val_min) yi = -xs;  // val_0 = 0
+        }
+      } else {  // d <= -eps, :199
+        const double val_max = jl_max(val_left, val_right);
+        yi = (val_left > val_right) ? left : right;
+        const double mx = -x;
+        if (l <= mx && mx <= u && 0.0 > val_max) yi = -xs;
+      }
+    }
+    return sel ? yi : iprox_zero(d, g, left, right);  // :221
+  }
+};
+struct OpIproxL0Box {  // src/shiftedNormL0Box.jl:137-231
+  double lambda;
+  static constexpr bool kBox = true;
+  static constexpr int kLdsKiB = 4;
+  static constexpr int kNIn = 4;
+  __device__ __forceinline__ double call4(double g, double d, double x, double s, double l, double u, bool sel) const {
+    const double eps = 2.220446049250313e-16;
+    const double xs = x + s;
+    const double mx = -x;
+    const bool zero_ok = (l <= mx && mx <= u);
+    const double left = l - s, right = u - s;
+    double yi;
+    if (fabs(d) < eps) {  // :154
+      if (g == 0.0) {
+        yi = zero_ok ? -xs : 0.0;
+      } else {
+        const bool pos = g > 0.0;
+        const double t = pos ? left : right;
+        const double val_min = g * t + ((x == (pos ? -l : -u)) ? 0.0 : lambda);
+        yi = t;
+        if (zero_ok && (-g * xs) < val_min) yi = -xs;
+      }
+    } else {
+      const double d_2 = d / 2;
+      const double lx = l + x, ux = u + x;
+      const double g2_d = g / d_2;
+      const double f2_d = g2_d - 2 * xs;
+      const double l2_d = lambda / d_2;
+      const double val_left = (lx == 0.0) ? 0.0 : (lx * lx + f2_d * lx + l2_d);
+      const double val_right = (ux == 0.0) ? 0.0 : (ux * ux + f2_d * ux + l2_d);
+      if (d >= eps) {  // :190
+        const double aqy = -g / d;
+        const double aqv = aqy + xs;
+        double val_min;
+        if (lx <= aqv && aqv <= ux) {
+          val_min = (aqv == 0.0) ? (-(aqv * aqv)) : (-(aqv * aqv) + l2_d);
+          yi = aqy;
+        } else {
+          yi = (val_left < val_right) ? left : right;
+          val_min = jl_min(val_left, val_right);
+        }
+        if (zero_ok && 0.0 < val_min) yi = -xs;
+      } else {  // :213
+        yi = (val_left > val_right) ? left : right;
+        const double val_max = jl_max(val_left, val_right);
+        if (zero_ok && 0.0 > val_max) yi = -xs;
+      }
+    }
+    return sel ? yi : iprox_zero(d, g, left, right);  // :227
+  }
+};
+
+// uniform call: 3-input operators ignore d
+template <class Op>
+__device__ __forceinline__ double apply_op(const Op& op, double q, double d, double x, double s, double l, double u,
+                                           bool sel) {
+  if constexpr (Op::kNIn == 4) return op.call4(q, d, x, s, l, u, sel);
+  else return op(q, x, s, l, u, sel);
+}
+
+// ---------------------------------------------------------------------------------------------
 // streaming skeleton
 // ---------------------------------------------------------------------------------------------
 template <bool NT>
@@ -219,9 +378,10 @@ __device__ __forceinline__ void st2(f64x2* p, f64x2 v) {
 
 // n2 = number of 16-byte pairs.  VECB: l/u are vectors.  MASK: sel mask present.
 template <class Op, int UNROLL, bool VECB, bool MASK, bool NT>
-__global__ __launch_bounds__(256) void k_sep_vec(double* y_, const double* q_, const double* xk_, const double* sj_,
-                                                  const double* l_, const double* u_, const uint8_t* mask_,
-                                                  double ls, double us, int64_t n2, Op op) {
+__global__ __launch_bounds__(256) void k_sep_vec(double* y_, const double* q_, const double* d_, const double* xk_,
+                                                  const double* sj_, const double* l_, const double* u_,
+                                                  const uint8_t* mask_, double ls, double us, int64_t n2, Op op) {
+  const f64x2* dv = reinterpret_cast<const f64x2*>(d_);
   constexpr int64_t TILE = 256 * UNROLL;
   f64x2* y = reinterpret_cast<f64x2*>(y_);
   const f64x2* q = reinterpret_cast<const f64x2*>(q_);
@@ -233,13 +393,14 @@ __global__ __launch_bounds__(256) void k_sep_vec(double* y_, const double* q_, c
   const int64_t ntiles = (n2 + TILE - 1) / TILE;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t base = tile * TILE + threadIdx.x;
-    f64x2 vq[UNROLL], vx[UNROLL], vs[UNROLL], vl[UNROLL], vu[UNROLL];
+    f64x2 vq[UNROLL], vx[UNROLL], vs[UNROLL], vl[UNROLL], vu[UNROLL], vd[UNROLL];
     uint16_t vm[UNROLL];
     if (base - threadIdx.x + TILE <= n2) {
 #pragma unroll
       for (int k = 0; k < UNROLL; ++k) {
         const int64_t i = base + k * 256;
         vq[k] = ld2<NT>(q + i);
+        if constexpr (Op::kNIn == 4) vd[k] = ld2<NT>(dv + i); else vd[k] = f64x2{0.0, 0.0};
         vx[k] = ld2<NT>(xk + i);
         vs[k] = ld2<NT>(sj + i);
         if constexpr (VECB && Op::kBox) {
@@ -256,8 +417,8 @@ __global__ __launch_bounds__(256) void k_sep_vec(double* y_, const double* q_, c
         if constexpr (VECB && Op::kBox) { l0 = vl[k].x; l1 = vl[k].y; u0 = vu[k].x; u1 = vu[k].y; }
         if constexpr (MASK && Op::kBox) { s0 = (vm[k] & 0xff) != 0; s1 = (vm[k] >> 8) != 0; }
         f64x2 r;
-        r.x = op(vq[k].x, vx[k].x, vs[k].x, l0, u0, s0);
-        r.y = op(vq[k].y, vx[k].y, vs[k].y, l1, u1, s1);
+        r.x = apply_op(op, vq[k].x, vd[k].x, vx[k].x, vs[k].x, l0, u0, s0);
+        r.y = apply_op(op, vq[k].y, vd[k].y, vx[k].y, vs[k].y, l1, u1, s1);
         st2<NT>(y + i, r);
       }
     } else {  // last, partial tile
@@ -266,6 +427,8 @@ __global__ __launch_bounds__(256) void k_sep_vec(double* y_, const double* q_, c
         const int64_t i = base + k * 256;
         if (i < n2) {
           f64x2 a = q[i], b = xk[i], c = sj[i];
+          f64x2 dd = f64x2{0.0, 0.0};
+          if constexpr (Op::kNIn == 4) dd = dv[i];
           double l0 = ls, l1 = ls, u0 = us, u1 = us;
           bool s0 = true, s1 = true;
           if constexpr (VECB && Op::kBox) {
@@ -274,8 +437,8 @@ __global__ __launch_bounds__(256) void k_sep_vec(double* y_, const double* q_, c
           }
           if constexpr (MASK && Op::kBox) { uint16_t m = mk[i]; s0 = (m & 0xff) != 0; s1 = (m >> 8) != 0; }
           f64x2 r;
-          r.x = op(a.x, b.x, c.x, l0, u0, s0);
-          r.y = op(a.y, b.y, c.y, l1, u1, s1);
+          r.x = apply_op(op, a.x, dd.x, b.x, c.x, l0, u0, s0);
+          r.y = apply_op(op, a.y, dd.y, b.y, c.y, l1, u1, s1);
           y[i] = r;
         }
       }
@@ -301,10 +464,11 @@ __device__ __forceinline__ void dma16_nt(const f64x2* g, char* wave_lds_piece) {
 }
 
 template <class Op, int UNROLL, bool VECB, bool MASK>
-__global__ __launch_bounds__(256) void k_sep_lds(double* y_, const double* q_, const double* xk_, const double* sj_,
-                                                  const double* l_, const double* u_, const uint8_t* mask_,
-                                                  double ls, double us, int64_t n2, Op op) {
-  constexpr int NARR = 3 + ((VECB && Op::kBox) ? 2 : 0);
+__global__ __launch_bounds__(256) void k_sep_lds(double* y_, const double* q_, const double* d_, const double* xk_,
+                                                  const double* sj_, const double* l_, const double* u_,
+                                                  const uint8_t* mask_, double ls, double us, int64_t n2, Op op) {
+  constexpr int NARR = Op::kNIn + ((VECB && Op::kBox) ? 2 : 0);
+  const f64x2* dv = reinterpret_cast<const f64x2*>(d_);
   __shared__ __attribute__((aligned(16))) char lds[4 * NARR * UNROLL * 1024];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   char* wl = lds + wave * (NARR * UNROLL * 1024);
@@ -324,9 +488,10 @@ __global__ __launch_bounds__(256) void k_sep_lds(double* y_, const double* q_, c
     dma16_nt(q + i, wl + (0 * UNROLL + k) * 1024);
     dma16_nt(xk + i, wl + (1 * UNROLL + k) * 1024);
     dma16_nt(sj + i, wl + (2 * UNROLL + k) * 1024);
+    if constexpr (Op::kNIn == 4) dma16_nt(dv + i, wl + (3 * UNROLL + k) * 1024);
     if constexpr (VECB && Op::kBox) {
-      if (l_) dma16_nt(lv + i, wl + (3 * UNROLL + k) * 1024);
-      if (u_) dma16_nt(uv + i, wl + (4 * UNROLL + k) * 1024);
+      if (l_) dma16_nt(lv + i, wl + ((Op::kNIn + 0) * UNROLL + k) * 1024);
+      if (u_) dma16_nt(uv + i, wl + ((Op::kNIn + 1) * UNROLL + k) * 1024);
     }
     if constexpr (MASK && Op::kBox) vm[k] = mk[i];
   }
@@ -339,30 +504,35 @@ __global__ __launch_bounds__(256) void k_sep_lds(double* y_, const double* q_, c
     const f64x2 c = *reinterpret_cast<const f64x2*>(wl + (2 * UNROLL + k) * 1024 + lane * 16);
     double l0 = ls, l1 = ls, u0 = us, u1 = us;
     bool s0 = true, s1 = true;
+    f64x2 dd = f64x2{0.0, 0.0};
+    if constexpr (Op::kNIn == 4) dd = *reinterpret_cast<const f64x2*>(wl + (3 * UNROLL + k) * 1024 + lane * 16);
     if constexpr (VECB && Op::kBox) {
-      if (l_) { const f64x2 t = *reinterpret_cast<const f64x2*>(wl + (3 * UNROLL + k) * 1024 + lane * 16); l0 = t.x; l1 = t.y; }
-      if (u_) { const f64x2 t = *reinterpret_cast<const f64x2*>(wl + (4 * UNROLL + k) * 1024 + lane * 16); u0 = t.x; u1 = t.y; }
+      if (l_) { const f64x2 t = *reinterpret_cast<const f64x2*>(wl + ((Op::kNIn + 0) * UNROLL + k) * 1024 + lane * 16); l0 = t.x; l1 = t.y; }
+      if (u_) { const f64x2 t = *reinterpret_cast<const f64x2*>(wl + ((Op::kNIn + 1) * UNROLL + k) * 1024 + lane * 16); u0 = t.x; u1 = t.y; }
     }
     if constexpr (MASK && Op::kBox) { s0 = (vm[k] & 0xff) != 0; s1 = (vm[k] >> 8) != 0; }
     f64x2 r;
-    r.x = op(a.x, b.x, c.x, l0, u0, s0);
-    r.y = op(a.y, b.y, c.y, l1, u1, s1);
+    r.x = apply_op(op, a.x, dd.x, b.x, c.x, l0, u0, s0);
+    r.y = apply_op(op, a.y, dd.y, b.y, c.y, l1, u1, s1);
     if (i < n2) __builtin_nontemporal_store(r, y + i);
   }
 }
 
 // scalar path: unaligned vectors, and the odd last element of the vector path ([begin, n))
 template <class Op>
-__global__ __launch_bounds__(256) void k_sep_scalar(double* y, const double* q, const double* xk, const double* sj,
-                                                     const double* l_, const double* u_, const uint8_t* mask,
-                                                     double ls, double us, int64_t begin, int64_t n, Op op) {
+__global__ __launch_bounds__(256) void k_sep_scalar(double* y, const double* q, const double* d_, const double* xk,
+                                                     const double* sj, const double* l_, const double* u_,
+                                                     const uint8_t* mask, double ls, double us, int64_t begin,
+                                                     int64_t n, Op op) {
   int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     double li = l_ ? l_[i] : ls;
     double ui = u_ ? u_[i] : us;
     bool sel = mask ? (mask[i] != 0) : true;
-    y[i] = op(q[i], xk[i], sj[i], li, ui, sel);
+    double di = 0.0;
+    if constexpr (Op::kNIn == 4) di = d_[i];
+    y[i] = apply_op(op, q[i], di, xk[i], sj[i], li, ui, sel);
   }
 }
 
@@ -375,14 +545,14 @@ static int g_sep_nt = 1;
 static int g_sep_lds = 1;  // 1 = LDS-staged skeleton (default), 0 = register-staged
 
 template <class Op, bool VECB, bool MASK>
-static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, const double* l,
-                      const double* u, const uint8_t* mask, double ls, double us, int64_t n2, Op op) {
+static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d, const double* xk, const double* sj,
+                      const double* l, const double* u, const uint8_t* mask, double ls, double us, int64_t n2, Op op) {
   if constexpr (Op::kLdsKiB > 0) if (g_sep_lds) {
     // 3 input vectors: 6 KiB per wave and vector -> 72 KiB per workgroup; 5 vectors (vector bounds): 3 KiB -> 60 KiB
-    constexpr int U = (VECB && Op::kBox) ? (Op::kLdsKiB > 3 ? 3 : Op::kLdsKiB) : Op::kLdsKiB;
+    constexpr int U = (VECB && Op::kBox) ? (Op::kLdsKiB > 3 ? 3 : Op::kLdsKiB) : Op::kLdsKiB;  // <= 72 KiB per workgroup
     const int64_t blocks = (n2 + 256 * U - 1) / (256 * U);
-    hipLaunchKernelGGL((k_sep_lds<Op, U, VECB, MASK>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj,
-                       l, u, mask, ls, us, n2, op);
+    hipLaunchKernelGGL((k_sep_lds<Op, U, VECB, MASK>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, d, xk,
+                       sj, l, u, mask, ls, us, n2, op);
     SPX_LAUNCH_CHECK();
     return SPX_OK;
   }
@@ -393,20 +563,21 @@ static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* xk
   if (blocks > cap) blocks = cap;
   if (g_sep_nt)
     hipLaunchKernelGGL((k_sep_vec<Op, UNROLL, VECB, MASK, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y,
-                       q, xk, sj, l, u, mask, ls, us, n2, op);
+                       q, d, xk, sj, l, u, mask, ls, us, n2, op);
   else
     hipLaunchKernelGGL((k_sep_vec<Op, UNROLL, VECB, MASK, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                       y, q, xk, sj, l, u, mask, ls, us, n2, op);
+                       y, q, d, xk, sj, l, u, mask, ls, us, n2, op);
   SPX_LAUNCH_CHECK();
   return SPX_OK;
 }
 
 template <class Op>
 static int run_separable(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
-                         const double* l, const double* u, double ls, double us, const uint8_t* mask, Op op) {
+                         const double* l, const double* u, double ls, double us, const uint8_t* mask, Op op,
+                         const double* d = nullptr) {
   if (n == 0) return SPX_OK;
   SPX_HIP(hipSetDevice(ctx->device));
-  bool vec_ok = spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj) &&
+  bool vec_ok = spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj) && (!d || spx_aligned16(d)) &&
                 (!l || spx_aligned16(l)) && (!u || spx_aligned16(u)) &&
                 (!mask || (reinterpret_cast<uintptr_t>(mask) & 1u) == 0);
   int64_t done = 0;
@@ -416,12 +587,12 @@ static int run_separable(spx_ctx* ctx, double* y, const double* q, const double*
     if constexpr (Op::kBox) {
       const bool vecb = (l || u);
       const bool msk = (mask != nullptr);
-      if (vecb && msk) rc = launch_vec<Op, true, true>(ctx, y, q, xk, sj, l, u, mask, ls, us, n2, op);
-      else if (vecb) rc = launch_vec<Op, true, false>(ctx, y, q, xk, sj, l, u, mask, ls, us, n2, op);
-      else if (msk) rc = launch_vec<Op, false, true>(ctx, y, q, xk, sj, l, u, mask, ls, us, n2, op);
-      else rc = launch_vec<Op, false, false>(ctx, y, q, xk, sj, l, u, mask, ls, us, n2, op);
+      if (vecb && msk) rc = launch_vec<Op, true, true>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op);
+      else if (vecb) rc = launch_vec<Op, true, false>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op);
+      else if (msk) rc = launch_vec<Op, false, true>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op);
+      else rc = launch_vec<Op, false, false>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op);
     } else {
-      rc = launch_vec<Op, false, false>(ctx, y, q, xk, sj, l, u, mask, ls, us, n2, op);
+      rc = launch_vec<Op, false, false>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op);
     }
     if (rc) return rc;
     done = 2 * n2;
@@ -431,7 +602,7 @@ static int run_separable(spx_ctx* ctx, double* y, const double* q, const double*
     int64_t blocks = (rem + 255) / 256;
     const int64_t cap = (int64_t)ctx->num_cu * 8;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((k_sep_scalar<Op>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj, l, u,
+    hipLaunchKernelGGL((k_sep_scalar<Op>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, d, xk, sj, l, u,
                        mask, ls, us, done, n, op);
     SPX_LAUNCH_CHECK();
   }
@@ -500,4 +671,56 @@ SPX_EXPORT int spx_prox_lhalf_box(spx_ctx* ctx, double* y, const double* q, cons
   if (rc) return rc;
   return run_separable(ctx, y, q, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask,
                        OpLhalfBox{sigma * lambda / 4, lambda, 0.5 / sigma});
+}
+
+// ---------------------------------------------------------------------------------------------
+// iprox! entry points
+// ---------------------------------------------------------------------------------------------
+template <class Op>
+static int run_iprox_unboxed(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk,
+                             const double* sj, int64_t n, double lambda, int check_d) {
+  int rc = spx_check_common(ctx, y, g, xk, sj, n);
+  if (rc) return rc;
+  SPX_REQUIRE(n == 0 || d != nullptr, "d is NULL");
+  if (n == 0) return SPX_OK;
+  rc = spx_ws_reserve(ctx, 256);
+  if (rc) return rc;
+  SPX_HIP(hipSetDevice(ctx->device));
+  int* flag = reinterpret_cast<int*>(ctx->ws);
+  SPX_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+  rc = run_separable(ctx, y, g, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, Op{lambda, flag}, d);
+  if (rc || !check_d) return rc;
+  int bad = 0;
+  SPX_HIP(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  SPX_HIP(hipStreamSynchronize(ctx->stream));
+  if (bad) {
+    spx_set_error("AssertionError: d[i] > 0");
+    return SPX_ERR_ASSERT;
+  }
+  return SPX_OK;
+}
+
+SPX_EXPORT int spx_iprox_l1(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk,
+                            const double* sj, int64_t n, double lambda, int check_d) {
+  return run_iprox_unboxed<OpIproxL1>(ctx, y, g, d, xk, sj, n, lambda, check_d);
+}
+SPX_EXPORT int spx_iprox_l0(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk,
+                            const double* sj, int64_t n, double lambda, int check_d) {
+  return run_iprox_unboxed<OpIproxL0>(ctx, y, g, d, xk, sj, n, lambda, check_d);
+}
+SPX_EXPORT int spx_iprox_l1_box(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk,
+                                const double* sj, int64_t n, double lambda, const double* l_vec, const double* u_vec,
+                                double l_scalar, double u_scalar, const uint8_t* sel_mask) {
+  int rc = spx_check_common(ctx, y, g, xk, sj, n);
+  if (rc) return rc;
+  SPX_REQUIRE(n == 0 || d != nullptr, "d is NULL");
+  return run_separable(ctx, y, g, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask, OpIproxL1Box{lambda}, d);
+}
+SPX_EXPORT int spx_iprox_l0_box(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk,
+                                const double* sj, int64_t n, double lambda, const double* l_vec, const double* u_vec,
+                                double l_scalar, double u_scalar, const uint8_t* sel_mask) {
+  int rc = spx_check_common(ctx, y, g, xk, sj, n);
+  if (rc) return rc;
+  SPX_REQUIRE(n == 0 || d != nullptr, "d is NULL");
+  return run_separable(ctx, y, g, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask, OpIproxL0Box{lambda}, d);
 }

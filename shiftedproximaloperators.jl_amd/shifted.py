@@ -8,6 +8,7 @@ spelled `f_bang` here):
     ψ = shifted(h, xk, l, u[, selected])   # ... + indicator of the box [l, u] (scalars or vectors)
     ω = shifted(ψ, sj)                 # second shift, shares ψ.xk / l / u / selected, borrows sj
     prox_bang(y, ψ, q, σ) -> y         # prox!   src/ShiftedProximalOperators.jl:135-152
+    iprox_bang(y, ψ, g, d) -> y        # iprox!  :154-180 (ShiftedNormL1/L0 and their Box forms)
     prox(ψ, q, σ) -> ψ.sol             # prox    :189-190
     shift_bang(ψ, v), set_radius_bang(ψ, Δ), set_bounds_bang(ψ, l, u)        # :72-111
 
@@ -89,21 +90,36 @@ class ShiftedProximableFunction:
     def _prox(self, L, ctx, y, q, sigma):
         raise NotImplementedError
 
+    def _iprox(self, L, ctx, y, g, d, check):
+        raise TypeError("MethodError: no method matching iprox!(::%s, ...)" % type(self).__name__)
+
 
 class _Unboxed(ShiftedProximableFunction):
     _fn = None
+    _ifn = None
 
     def _prox(self, L, ctx, y, q, sigma):
         fn = getattr(L, self._fn)
         _lib.check(fn(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), y.numel(), self.h.lam, sigma))
 
+    def _iprox(self, L, ctx, y, g, d, check):
+        if self._ifn is None:
+            return super()._iprox(L, ctx, y, g, d, check)
+        st = getattr(L, self._ifn)(ctx, _ptr(y), _ptr(g), _ptr(d), _ptr(self.xk), _ptr(self.sj), y.numel(),
+                                   self.h.lam, 1 if check else 0)
+        if st == 6:  # SPX_ERR_ASSERT: the reference's `@assert d[i] > 0`
+            raise AssertionError("d[i] > 0")
+        _lib.check(st)
+
 
 class ShiftedNormL1(_Unboxed):  # src/shiftedNormL1.jl
     _fn = "spx_prox_l1"
+    _ifn = "spx_iprox_l1"
 
 
 class ShiftedNormL0(_Unboxed):  # src/shiftedNormL0.jl
     _fn = "spx_prox_l0"
+    _ifn = "spx_iprox_l0"
 
 
 class ShiftedRootNormLhalf(_Unboxed):  # src/shiftedRootNormLhalf.jl
@@ -148,10 +164,28 @@ class _Boxed(ShiftedProximableFunction):
 
 class ShiftedNormL1Box(_Boxed):  # src/shiftedNormL1Box.jl
     _fn = "spx_prox_l1_box"
+    _ifn = "spx_iprox_l1_box"
 
 
 class ShiftedNormL0Box(_Boxed):  # src/shiftedNormL0Box.jl
     _fn = "spx_prox_l0_box"
+    _ifn = "spx_iprox_l0_box"
+
+
+def _boxed_iprox(self, L, ctx, y, g, d, check):
+    if self._ifn is None:
+        return ShiftedProximableFunction._iprox(self, L, ctx, y, g, d, check)
+    n = y.numel()
+    lv = None if _is_real(self.l) else _vec(self.l, "l", n)
+    uv = None if _is_real(self.u) else _vec(self.u, "u", n)
+    _lib.check(getattr(L, self._ifn)(ctx, _ptr(y), _ptr(g), _ptr(d), _ptr(self.xk), _ptr(self.sj), n, self.h.lam,
+                                     _ptr(lv), _ptr(uv), float(self.l) if lv is None else 0.0,
+                                     float(self.u) if uv is None else 0.0,
+                                     _ptr(self._mask[0]) if self._mask is not None else ctypes.c_void_p(0)))
+
+
+_Boxed._ifn = None
+_Boxed._iprox = _boxed_iprox
 
 
 class ShiftedRootNormLhalfBox(_Boxed):  # src/shiftedRootNormLhalfBox.jl (no l > u check, :22-44)
@@ -331,6 +365,25 @@ def prox_bang(y, ψ, q, σ):
 def prox(ψ, q, σ):
     """prox(ψ, q, σ) = prox!(ψ.sol, ψ, q, σ)   (src/ShiftedProximalOperators.jl:189-190)"""
     return prox_bang(ψ.sol, ψ, q, σ)
+
+
+def iprox_bang(y, ψ, g, d, check=True):
+    """iprox!(y, ψ, g, d): y <- argmin_t ½ tᵀDt + gᵀt + ψ(t), D = diag(d); returns y.  Defined for ShiftedNormL1/L0 and
+    their Box forms (as in the reference).  The unboxed forms assert d .> 0 like the reference (`check=True`
+    synchronises to raise AssertionError; pass check=False to stay asynchronous)."""
+    if not isinstance(ψ, ShiftedProximableFunction):
+        raise TypeError("ψ must be a ShiftedProximableFunction")
+    n = ψ.xk.numel()
+    _vec(g, "g", n)
+    _vec(d, "d", n)
+    _vec(y, "y", n)
+    ψ._iprox(_lib.load(), _ctx(y.device), y, g, d, check)
+    return y
+
+
+def iprox(ψ, g, d):
+    """iprox(ψ, g, d) = iprox!(ψ.sol, ψ, g, d)   (src/ShiftedProximalOperators.jl:180)"""
+    return iprox_bang(ψ.sol, ψ, g, d)
 
 
 def shift_bang(ψ, shift):

@@ -71,6 +71,24 @@ kats = {
         "cite": "test/runtests.jl:213-251,286-329 (property: ShiftedGroupNormL2 prox == per-group NormL2 prox of q+x, minus x; 2-norm <= 1e-11)",
         "tol": 1e-11,
     },
+    "iprox_testsbox": {
+        "cite": "test/testsbox.jl:101-304 (14 scalar cases per operator; psi=shifted(h,x,l,u); omega=shifted(psi,s); iprox(omega,g,d); exact ==)",
+        "l": -2.0, "u": 1.0, "s": -1.0,
+        "ShiftedNormL0Box": {
+            "d": [0.0, 0.0, 0.0, 0.0, 0.0, 2.0, 2.0, 2.0, 2.0, 2.0, 2.0, -2.0, -2.0, -2.0],
+            "g": [0.0, 0.0, 2.0, 2.0, -2.0, 1.0, 0.0, 1.0, 10.0, -10.0, 4.0, -10.0, 10.0, -4.0],
+            "x": [0.0, -10.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0],
+            "lambda": [1.0, 1.0, 1.0, 10.0, 1.0, 1.0, 0.1, 10.0, 1.0, 1.0, 10.0, 1.0, 1.0, 10.0],
+            "sol": [1.0, 0.0, -1.0, 1.0, 2.0, -0.5, 0.0, 1.0, -1.0, 2.0, 1.0, 2.0, -1.0, 1.0],
+        },
+        "ShiftedNormL1Box": {
+            "d": [0.0, 0.0, 0.0, 0.0, 0.0, 2.0, 2.0, 2.0, 2.0, 2.0, 2.0, -2.0, -2.0, -2.0],
+            "g": [0.5, 0.5, 0.5, 2.0, -2.0, 0.0, 1.0, 1.0, -1.0, 1.0, 1.0, 0.0, 1.0, 1.0],
+            "x": [0.0, 4.0, -2.0, 0.0, 0.0, 4.0, -2.0, 1.0, 0.5, 0.5, 3.0, 1.0, 1.0, 1.0],
+            "lambda": [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 10.0, 1.0],
+            "sol": [1.0, -1.0, 2.0, -1.0, 2.0, -0.5, 0.0, 0.0, 0.5, 0.0, -1.0, 2.0, 0.0, -1.0],
+        },
+    },
     "derived": {
         "provenance": "NOT from the reference: hand-derivable answers (SURVEY.md Appendix B) for operators whose prox values the reference tests leave as TODO (runtests.jl:179-180,382-383,772-773)",
         "setA_unboxed": {

@@ -368,3 +368,86 @@ def test_group_l2_property_vs_norml2(s):
         v = (q + x)[sl]
         parts.append(max(1 - nu * lam[g] / np.linalg.norm(v), 0.0) * v)
     assert np.linalg.norm(y - (np.concatenate(parts) - x)) <= 1e-11
+
+
+@pytest.mark.parametrize("gsize", [1, 2, 3, 32, 128])
+def test_group_binf_degenerate_bracket(s, orc, gsize):
+    """lmax = ||S|| + sigma (zlmax + lambda ||X||) below sigma*lambda: the reference hands Roots.fzero a reversed bracket
+    that straddles the pole of step(n); the root it returns can lie BELOW sigma*lambda.  Both the small-group kernel and
+    the deferred list of the register kernel must reproduce the reference's literal arithmetic there."""
+    rng = np.random.default_rng(1000 + gsize)
+    ng = 4000
+    n = ng * gsize
+    scale = 0.6 / np.sqrt(gsize)
+    x = rng.normal(size=n) * scale
+    sj = rng.uniform(-0.5, 0.5, size=n) * scale
+    q = rng.normal(size=n) * scale
+    lam = rng.choice([2.0, 10.0, 0.7], size=ng)
+    sigma, delta = 2.0, 0.3 * scale
+    ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, gsize=gsize)
+    # the test is only meaningful if the regime actually occurs: count groups whose bracket is reversed
+    S = ((q + x) + sj).reshape(ng, gsize)
+    nX = np.linalg.norm(x.reshape(ng, gsize), axis=1)
+    assert np.sum(np.linalg.norm(S, axis=1) + sigma * lam * nX < sigma * lam) > ng // 10
+    xd, sd, qd = _dev(x, sj, q)
+    h = s.GroupNormL2(lam.tolist(), [range(i, i + gsize) for i in range(0, n, gsize)])
+    y = s.prox(s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd), qd, sigma).cpu().numpy()
+    assert np.all(np.isfinite(y) == np.isfinite(ref))
+    fin = np.isfinite(ref)
+    scale_g = np.repeat(np.maximum(np.linalg.norm(S, axis=1), 1e-300), gsize)
+    err = np.abs(np.where(fin, y - ref, 0.0)) / np.maximum(np.abs(np.where(fin, ref, 0.0)), scale_g)
+    # roots next to the pole amplify last-bit differences of the norm: allow 1e-9 there, 1e-12 elsewhere
+    assert np.quantile(err, 0.99) <= 1e-12 and err.max() <= 1e-6, (float(np.quantile(err, 0.99)), float(err.max()))
+
+
+# ------------------------------------------------------------------ iprox! (SURVEY 8f rank 1)
+@pytest.mark.parametrize("op", ["ShiftedNormL0Box", "ShiftedNormL1Box"])
+def test_iprox_testsbox_through_gpu(s, kats, op):
+    # test/testsbox.jl:101-304: 14 cases per operator, exact ==
+    t = kats["iprox_testsbox"]
+    c = t[op]
+    H = s.NormL0 if op == "ShiftedNormL0Box" else s.NormL1
+    for d, g, x, lam, sol in zip(c["d"], c["g"], c["x"], c["lambda"], c["sol"]):
+        xd, gd, dd, sd = _dev(np.array([x]), np.array([g]), np.array([d]), np.array([t["s"]]))
+        ld, ud = _dev(np.array([t["l"]]), np.array([t["u"]]))
+        omega = s.shifted(s.shifted(H(lam), xd, ld, ud), sd)
+        s.iprox(omega, gd, dd)
+        assert float(omega.sol[0]) == sol
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 1000, 65_537, 1_000_003])
+@pytest.mark.parametrize("op", ["l1", "l0", "l1_box", "l0_box"])
+def test_iprox_parity(s, orc, op, n):
+    rng = np.random.default_rng(600 + n)
+    x, sj, g = _data(n, 601 + n)
+    lam = 0.9
+    box = op.endswith("box")
+    if box:  # all three regimes of d, incl. |d| <= eps and exact zeros, and g == 0
+        d = rng.choice([1.0, -1.0, 0.0, 1e-17], size=n) * rng.uniform(0.2, 3.0, size=n)
+        g = np.where(rng.random(n) < 0.05, 0.0, g)
+    else:
+        d = rng.uniform(0.1, 3.0, size=n)
+    xd, sd, gd, dd = _dev(x, sj, g, d)
+    H = s.NormL1 if "l1" in op else s.NormL0
+    if box:
+        l = -1.0 - 0.1 * rng.random(n)
+        u = 1.0 + 0.1 * rng.random(n)
+        for lo, uo in ((-1.05, 1.05), (l, u)):
+            ldv = _dev(lo)[0] if not np.isscalar(lo) else lo
+            udv = _dev(uo)[0] if not np.isscalar(uo) else uo
+            for selected in (None, range(0, n, 2)):
+                psi = s.shifted(s.shifted(H(lam), xd, ldv, udv, selected) if selected is not None else s.shifted(H(lam), xd, ldv, udv), sd)
+                y = s.iprox(psi, gd, dd).cpu().numpy()
+                mask = orc.mask_from_selected([i + 1 for i in selected], n) if selected is not None else None
+                ref = getattr(orc, "iprox_" + op)(g, d, x, sj, lam, lo, uo, mask=mask)
+                assert _bits_equal(y, ref), (op, n)
+    else:
+        psi = s.shifted(s.shifted(H(lam), xd), sd)
+        y = s.iprox(psi, gd, dd).cpu().numpy()
+        assert _bits_equal(y, getattr(orc, "iprox_" + op)(g, d, x, sj, lam))
+        dbad = d.copy()
+        dbad[n // 2] = 0.0
+        with pytest.raises(AssertionError):  # partial_prox.jl:59 @test_throws AssertionError
+            s.iprox(psi, gd, _dev(dbad)[0])
+        with pytest.raises(TypeError):
+            s.iprox(s.shifted(s.RootNormLhalf(1.0), xd), gd, dd)  # no iprox! method in the reference either

@@ -210,3 +210,57 @@ def test_l1_aliased_call_matches_reference_two_pass_semantics(orc):
     dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
     L.orc_prox_l1(dp(q), dp(q), dp(x), dp(s), 3, 1.0, 1.0)
     np.testing.assert_array_equal(q, (-x) - s)
+
+
+# ---- iprox! ----------------------------------------------------------------
+@pytest.mark.parametrize("op", ["ShiftedNormL0Box", "ShiftedNormL1Box"])
+def test_iprox_testsbox_cases_exact(orc, kats, op):
+    # test/testsbox.jl:101-304: 14 enumerated cases per operator, exact ==
+    t = kats["iprox_testsbox"]
+    c = t[op]
+    fn = orc.iprox_l0_box if op == "ShiftedNormL0Box" else orc.iprox_l1_box
+    for k, (d, g, x, lam, sol) in enumerate(zip(c["d"], c["g"], c["x"], c["lambda"], c["sol"])):
+        y = fn([g], [d], [x], [t["s"]], lam, [t["l"]], [t["u"]])
+        assert y[0] == sol, (op, k + 1, y[0], sol)
+        assert fn([g], [d], [x], [t["s"]], lam, t["l"], t["u"])[0] == sol  # scalar-bounds form
+
+
+@pytest.mark.parametrize("op", ["l0", "l1"])
+def test_iprox_partial_and_unboxed(orc, op):
+    # test/partial_prox.jl:41-72
+    rng = np.random.default_rng(4)
+    n = 5
+    x, s, q = rng.random(n), rng.random(n), rng.random(n) - 0.5
+    l, u = np.zeros(n), np.ones(n)
+    box = getattr(orc, "iprox_%s_box" % op)
+    mask = orc.mask_from_selected(range(1, n + 1, 2), n)
+    for d in (np.ones(n), -np.ones(n), np.zeros(n)):
+        y = box(q, d, x, s, 3.14, l, u)
+        z = box(q, d, x, s, 3.14, l, u, mask=mask)
+        p = np.array([orc.iprox_zero(d[i], q[i], (l - s)[i], (u - s)[i]) for i in range(n)])
+        for i in range(n):
+            assert z[i] == (y[i] if mask[i] else p[i])
+    unb = getattr(orc, "iprox_" + op)
+    with pytest.raises(AssertionError):  # @test_throws AssertionError iprox(psi, q, zeros(n))
+        unb(q, np.zeros(n), x, np.zeros(n), 3.14)
+    y = unb(q, 2 * np.ones(n), x, s, 3.14)
+    assert np.all(np.isfinite(y))
+
+
+def test_iprox_box_is_objective_minimiser(orc):
+    # independent check: brute-force minimisation of 1/2 d y^2 + g y + lambda h(x + s + y) over the box
+    rng = np.random.default_rng(8)
+    for name, h in (("iprox_l1_box", np.abs), ("iprox_l0_box", lambda v: (v != 0).astype(float))):
+        for trial in range(300):
+            x, g = rng.normal(), rng.normal()
+            d = rng.choice([rng.uniform(0.2, 2.0), -rng.uniform(0.2, 2.0), 0.0])
+            lam = rng.uniform(0.1, 2.0)
+            l, u = -rng.uniform(0.2, 1.5), rng.uniform(0.2, 1.5)
+            s = rng.uniform(l, u) * 0.5
+            t = getattr(orc, name)([g], [d], [x], [s], lam, l, u)[0]
+            obj = lambda yy: 0.5 * d * yy ** 2 + g * yy + lam * h(x + s + yy)
+            lo, hi = l - s, u - s
+            assert lo - 1e-12 <= t <= hi + 1e-12
+            grid = np.concatenate([np.linspace(lo, hi, 200001), [c for c in (-(x + s),) if lo <= c <= hi]])
+            best = np.min(obj(grid))
+            assert obj(np.array([t]))[0] <= best + 1e-9 * max(1.0, abs(best)), (name, trial, t, d)
