@@ -469,27 +469,36 @@ __global__ __launch_bounds__(256) void k_s2_main(const double* q_, const double*
       if (slot < kLdsCand) { lk[slot] = key; li[slot] = i; }
     }
   };
+  // each wave streams its quarter of the chunk through LDS: 4 KiB per vector per step (global_load_lds nt), wait,
+  // read back its own 16-byte slots -- same staging as the separable skeleton (spx_separable.hip)
   constexpr int UNROLL = 4;
+  __shared__ __attribute__((aligned(16))) char dma[4 * 3 * UNROLL * 1024];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  char* wl = dma + wave * (3 * UNROLL * 1024);
+  typedef __attribute__((address_space(3))) void lds_void;
   for (int64_t base = p0; base < p0 + kMainChunkPairs && base < n2; base += 256 * UNROLL) {
-    f64x2 a[UNROLL], b[UNROLL], c[UNROLL];
-    bool live[UNROLL];
+    const int64_t wbase = base + wave * (64 * UNROLL) + lane;
 #pragma unroll
     for (int k = 0; k < UNROLL; ++k) {
-      const int64_t i = base + k * 256 + threadIdx.x;
-      live[k] = i < n2;
-      const int64_t ii = live[k] ? i : (n2 - 1);
-      a[k] = __builtin_nontemporal_load(q + ii);
-      b[k] = __builtin_nontemporal_load(xk + ii);
-      c[k] = __builtin_nontemporal_load(sj + ii);
+      int64_t i = wbase + k * 64;
+      if (i >= n2) i = n2 - 1;
+      __builtin_amdgcn_global_load_lds((const void*)(q + i), (lds_void*)(wl + (0 * UNROLL + k) * 1024), 16, 0, 2);
+      __builtin_amdgcn_global_load_lds((const void*)(xk + i), (lds_void*)(wl + (1 * UNROLL + k) * 1024), 16, 0, 2);
+      __builtin_amdgcn_global_load_lds((const void*)(sj + i), (lds_void*)(wl + (2 * UNROLL + k) * 1024), 16, 0, 2);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int k = 0; k < UNROLL; ++k) {
-      if (live[k]) {
-        const int64_t i = base + k * 256 + threadIdx.x;
-        visit((b[k].x + c[k].x) + a[k].x, 2 * i);      // shiftedIndBallL0.jl:66  xk .+ sj .+ q
-        visit((b[k].y + c[k].y) + a[k].y, 2 * i + 1);
+      const int64_t i = wbase + k * 64;
+      const f64x2 a = *reinterpret_cast<const f64x2*>(wl + (0 * UNROLL + k) * 1024 + lane * 16);
+      const f64x2 b = *reinterpret_cast<const f64x2*>(wl + (1 * UNROLL + k) * 1024 + lane * 16);
+      const f64x2 c = *reinterpret_cast<const f64x2*>(wl + (2 * UNROLL + k) * 1024 + lane * 16);
+      if (i < n2) {
+        visit((b.x + c.x) + a.x, 2 * i);      // shiftedIndBallL0.jl:66  xk .+ sj .+ q
+        visit((b.y + c.y) + a.y, 2 * i + 1);
       }
     }
+    // the next step overwrites this wave's slots: its own ds_reads above have completed (values consumed)
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) visit((xk_[n - 1] + sj_[n - 1]) + q_[n - 1], n - 1);
   // workgroup totals
@@ -644,30 +653,36 @@ __global__ __launch_bounds__(256) void k_sel_final_q(double* y_, const double* q
                                                       int64_t n, const SelWs* ws, double delta) {
   if (!ws->fs.ok) return;  // prediction not verified: the host runs the full-vector path afterwards
   const SelState st = ws->st;
-  constexpr int UNROLL = 4;
-  constexpr int64_t TILE = 256 * UNROLL;
+  constexpr int UNROLL = 6;  // KiB per wave and vector, as k_sep_lds
+  __shared__ __attribute__((aligned(16))) char dma[4 * 3 * UNROLL * 1024];
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  char* wl = dma + wave * (3 * UNROLL * 1024);
   f64x2* y = reinterpret_cast<f64x2*>(y_);
   const f64x2* q = reinterpret_cast<const f64x2*>(q_);
   const f64x2* xk = reinterpret_cast<const f64x2*>(xk_);
   const f64x2* sj = reinterpret_cast<const f64x2*>(sj_);
   const int64_t n2 = n >> 1;
-  const int64_t base = (int64_t)blockIdx.x * TILE + threadIdx.x;
-  f64x2 a[UNROLL], b[UNROLL], c[UNROLL];
+  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * (64 * UNROLL) + lane;
 #pragma unroll
   for (int k = 0; k < UNROLL; ++k) {
-    const int64_t i = base + k * 256;
-    const int64_t ii = i < n2 ? i : (n2 - 1);
-    a[k] = __builtin_nontemporal_load(q + ii);
-    b[k] = __builtin_nontemporal_load(xk + ii);
-    c[k] = __builtin_nontemporal_load(sj + ii);
+    int64_t i = base + k * 64;
+    if (i >= n2) i = n2 - 1;
+    __builtin_amdgcn_global_load_lds((const void*)(q + i), (lds_void*)(wl + (0 * UNROLL + k) * 1024), 16, 0, 2);
+    __builtin_amdgcn_global_load_lds((const void*)(xk + i), (lds_void*)(wl + (1 * UNROLL + k) * 1024), 16, 0, 2);
+    __builtin_amdgcn_global_load_lds((const void*)(sj + i), (lds_void*)(wl + (2 * UNROLL + k) * 1024), 16, 0, 2);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int k = 0; k < UNROLL; ++k) {
-    const int64_t i = base + k * 256;
+    const int64_t i = base + k * 64;
+    const f64x2 a = *reinterpret_cast<const f64x2*>(wl + (0 * UNROLL + k) * 1024 + lane * 16);
+    const f64x2 b = *reinterpret_cast<const f64x2*>(wl + (1 * UNROLL + k) * 1024 + lane * 16);
+    const f64x2 c = *reinterpret_cast<const f64x2*>(wl + (2 * UNROLL + k) * 1024 + lane * 16);
     if (i < n2) {
       f64x2 r;
-      r.x = sel_out<BINF>((b[k].x + c[k].x) + a[k].x, 2 * i, b[k].x, c[k].x, st, delta);
-      r.y = sel_out<BINF>((b[k].y + c[k].y) + a[k].y, 2 * i + 1, b[k].y, c[k].y, st, delta);
+      r.x = sel_out<BINF>((b.x + c.x) + a.x, 2 * i, b.x, c.x, st, delta);
+      r.y = sel_out<BINF>((b.y + c.y) + a.y, 2 * i + 1, b.y, c.y, st, delta);
       __builtin_nontemporal_store(r, y + i);
     }
   }
@@ -718,7 +733,7 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     hipLaunchKernelGGL(k_s2_compact, dim3(512), dim3(256), 0, ctx->stream, (const uint64_t*)ckey, (const int64_t*)cidx,
                        ws, lkey, lidx);
     hipLaunchKernelGGL(k_s2_finish, dim3(1), dim3(1024), 0, ctx->stream, ws, (const uint64_t*)lkey, (const int64_t*)lidx);
-    hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1023) / 1024)), dim3(256), 0, ctx->stream, y, q, xk,
+    hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1535) / 1536)), dim3(256), 0, ctx->stream, y, q, xk,
                        sj, n, (const SelWs*)ws, delta);
     SPX_LAUNCH_CHECK();
     // the verdict is read back AFTER the speculative final pass has been queued: the GPU never idles on the host
