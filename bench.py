@@ -211,6 +211,16 @@ def _extra(s, L, ctx, dev, n, torch):
         res[name] = {"ms": round(ms, 4), "gelem_s": round(n / ms / 1e6, 2), "gbs_algorithmic": round(40 * n / ms / 1e6, 1),
                      "frac_of_peak": round(40 * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
 
+    # psi(y): reduction over y, xk, sj: 24 B/element, returns a host double (synchronous)
+    psi_l1b = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        psi_l1b(y)
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    res["objective_ShiftedNormL1Box"] = {"ms": round(ms, 4), "gelem_s": round(n / ms / 1e6, 2),
+                                         "gbs_algorithmic": round(24 * n / ms / 1e6, 1),
+                                         "frac_of_peak": round(24 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                         "note": "host wall time per call incl. the read-back of the value"}
     iline("iprox_ShiftedNormL1Box", s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj))
     iline("iprox_ShiftedNormL0Box", s.shifted(s.shifted(s.NormL0(1.0), xk, 1.0, chi), sj))
     del d

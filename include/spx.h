@@ -16,7 +16,9 @@
  *     (the reference borrows xk/sj/l/u by reference too: src/shiftedNormL1Box.jl:22-47).
  *   - `y` may alias `q` exactly (test/test_allocs.jl:108-113) and may be the operator's own `sol`
  *     (prox(), src/ShiftedProximalOperators.jl:189-190).  Partial overlap is undefined.
- *   - Calls are asynchronous on the context's HIP stream and ordered on it; spx_sync() waits.
+ *   - Calls are asynchronous on the context's HIP stream and ordered on it; spx_sync() waits.  Exceptions
+ *     (they return a value or a verdict to the host and therefore synchronise): spx_check_bounds, spx_obj_*,
+ *     the unboxed spx_iprox_* with check_d != 0, and the top-r operators (one 4-byte read-back per call).
  *     A context is not re-entrant (neither is a reference psi: shared scratch sol/xsy/p).
  *   - Return value: 0 = SPX_OK, else an spx_status; spx_last_error() gives a thread-local message.
  *   - Indices handed over in arrays (selected sets, group offsets) are 0-BASED int64.
@@ -126,6 +128,38 @@ int spx_iprox_l1_box(spx_ctx* ctx, double* y, const double* g, const double* d, 
 int spx_iprox_l0_box(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk,
                      const double* sj, int64_t n, double lambda, const double* l_vec,
                      const double* u_vec, double l_scalar, double u_scalar, const uint8_t* sel_mask);
+
+/* ---- psi(y): objective value h(xk + sj + y) [+ indicator of the box / trust region] ------------------------ */
+/* Generic form src/ShiftedProximalOperators.jl:51-54; *value is written on the HOST; synchronous.
+ * NormL1: lambda * sum |v|, NormL0: lambda * #nonzeros, RootNormLhalf: lambda * sum sqrt|v| (src/rootNormLhalf.jl:27-29). */
+int spx_obj_l1(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double lambda, double* value);
+int spx_obj_l0(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double lambda, double* value);
+int spx_obj_lhalf(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double lambda, double* value);
+/* Box forms (src/shiftedNormL1Box.jl:70-82, shiftedNormL0Box.jl:70-82, shiftedRootNormLhalfBox.jl:67-79): h over the
+ * selected indices; +Inf unless l - sqrt(eps) <= sj[i] + y[i] <= u + sqrt(eps) for EVERY i. */
+int spx_obj_l1_box(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double lambda,
+                   const double* l_vec, const double* u_vec, double l_scalar, double u_scalar,
+                   const uint8_t* sel_mask, double* value);
+int spx_obj_l0_box(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double lambda,
+                   const double* l_vec, const double* u_vec, double l_scalar, double u_scalar,
+                   const uint8_t* sel_mask, double* value);
+int spx_obj_lhalf_box(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double lambda,
+                      const double* l_vec, const double* u_vec, double l_scalar, double u_scalar,
+                      const uint8_t* sel_mask, double* value);
+/* IndBallL0 (0 or +Inf) and its BInf form, which adds IndBallLinf(1.1 Delta)(sj + y)
+ * (src/shiftedIndBallL0BInf.jl:44-49). */
+int spx_obj_indball_l0(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, int64_t r,
+                       double* value);
+int spx_obj_indball_l0_binf(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                            int64_t r, double delta, double* value);
+/* GroupNormL2: sum_g lambda_g ||v[idx_g]||_2 (src/groupNormL2.jl:33-39); Binf form src/shiftedGroupNormL2Binf.jl:34-39.
+ * Group description as for spx_prox_group_l2. */
+int spx_obj_group_l2(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                     const int64_t* group_offsets, int64_t group_size, int64_t ngroups,
+                     const double* lambda_vec, double* value);
+int spx_obj_group_l2_binf(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                          const int64_t* group_offsets, int64_t group_size, int64_t ngroups,
+                          const double* lambda_vec, double delta, double* value);
 
 /* ---- top-r selection ------------------------------------------------------------------- */
 /* ShiftedIndBallL0.prox!     src/shiftedIndBallL0.jl:54-72 : keep the r entries of (xk+sj)+q largest in

@@ -203,6 +203,38 @@ function prox!(y::DVec, ψ::ShiftedGroupNormL2Binf{Float64, RR, I, <:DVec, <:DVe
   r === nothing ? invoke(prox!, Tuple{AbstractVector{Float64}, ShiftedGroupNormL2Binf, AbstractVector{Float64}, Float64}, y, ψ, q, σ) : r
 end
 
+# ---------------------------------------------------------------------------------------------
+# ψ(y)                        src/ShiftedProximalOperators.jl:51-54, shiftedNormL1Box.jl:70-82 (idem L0Box, L½Box),
+#                             shiftedIndBallL0BInf.jl:44-49, shiftedGroupNormL2Binf.jl:34-39
+# ---------------------------------------------------------------------------------------------
+function objective(sym::Symbol, argt, args...)
+  out = Ref{Cdouble}(0.0)
+  check(ccall((sym, libspx), Cint, (Ptr{Cvoid}, argt..., Ptr{Cdouble}), ctx(), args..., out))
+  out[]
+end
+for (T, sym) in ((:ShiftedNormL1, :spx_obj_l1), (:ShiftedNormL0, :spx_obj_l0), (:ShiftedRootNormLhalf, :spx_obj_lhalf))
+  @eval (ψ::$T{Float64, <:DVec, <:DVec, <:DVec})(y::DVec) =
+    objective($(QuoteNode(sym)), (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble),
+              dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.λ)
+end
+for (T, sym) in ((:ShiftedNormL1Box, :spx_obj_l1_box), (:ShiftedNormL0Box, :spx_obj_l0_box),
+                 (:ShiftedRootNormLhalfBox, :spx_obj_lhalf_box))
+  @eval function (ψ::$T{Float64, <:DVec, <:DVec, <:DVec})(y::DVec)
+    m = mask_for(ψ)
+    objective($(QuoteNode(sym)),
+              (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{UInt8}),
+              dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.λ, dptr(vec_or_nothing(ψ.l)), dptr(vec_or_nothing(ψ.u)),
+              scal(ψ.l), scal(ψ.u), m === nothing ? Ptr{UInt8}(C_NULL) : Ptr{UInt8}(UInt(pointer(m))))
+  end
+end
+(ψ::ShiftedIndBallL0{<:Integer, Float64, <:DVec, <:DVec, <:DVec})(y::DVec) =
+  objective(:spx_obj_indball_l0, (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Int64),
+            dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.r)
+(ψ::ShiftedIndBallL0BInf{<:Integer, Float64, <:DVec, <:DVec, <:DVec})(y::DVec) =
+  objective(:spx_obj_indball_l0_binf, (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Int64, Cdouble),
+            dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.r, ψ.Δ)
+# (group forms: spx_obj_group_l2 / spx_obj_group_l2_binf with the layout_for(ψ.h, n) arguments, as in group_call)
+
 # shift!, set_radius!, set_bounds!, prox (src/ShiftedProximalOperators.jl:72-111,189-190) need no methods:
 # they are broadcasts / field updates on the stored (device) arrays and already work on ROCArrays.
 # The Box constructors' `any(l .> u)` (src/shiftedNormL1Box.jl:33-35) is a device reduction via broadcasting.

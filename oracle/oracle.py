@@ -61,6 +61,14 @@ def lib():
         L.orc_iprox_l0_box.restype = None
         L.orc_iprox_zero.argtypes = [d, d, d, d]
         L.orc_iprox_zero.restype = d
+        L.orc_obj_plain.argtypes = [ctypes.c_int, dp, dp, dp, i64, d]
+        L.orc_obj_plain.restype = d
+        L.orc_obj_box.argtypes = [ctypes.c_int, dp, dp, dp, i64, d, dp, dp, d, d, up]
+        L.orc_obj_box.restype = d
+        L.orc_obj_indball_l0.argtypes = [dp, dp, dp, i64, i64, d]
+        L.orc_obj_indball_l0.restype = d
+        L.orc_obj_group_l2.argtypes = [dp, dp, dp, i64, ip, i64, i64, dp, d]
+        L.orc_obj_group_l2.restype = d
         L.orc_rootnormlhalf_prox.argtypes = [dp, dp, i64, d, d]
         L.orc_rootnormlhalf_prox.restype = d
         for name in ("orc_prox_l1", "orc_prox_l0", "orc_prox_lhalf", "orc_prox_l1_box", "orc_prox_l0_box",
@@ -253,3 +261,31 @@ def iprox_l0_box(g, d, xk, sj, lam, l, u, mask=None):
 
 def iprox_zero(d, g, l, u):
     return lib().orc_iprox_zero(float(d), float(g), float(l), float(u))
+
+
+# ---- psi(y): objective value -----------------------------------------------------------------
+_KIND = {"l1": 0, "l0": 1, "lhalf": 2}
+
+
+def obj_plain(kind, y, xk, sj, lam):
+    y, xk, sj, n, _ = _prep(y, xk, sj)
+    return lib().orc_obj_plain(_KIND[kind], _dp(y), _dp(xk), _dp(sj), n, lam)
+
+
+def obj_box(kind, y, xk, sj, lam, l, u, mask=None):
+    y, xk, sj, n, _ = _prep(y, xk, sj)
+    lv, uv, ls, us = _bounds(l, u, n)
+    m, mp = _mask(mask, n)
+    return lib().orc_obj_box(_KIND[kind], _dp(y), _dp(xk), _dp(sj), n, lam, _dp(lv), _dp(uv), ls, us, mp)
+
+
+def obj_indball_l0(y, xk, sj, r, delta=None):
+    y, xk, sj, n, _ = _prep(y, xk, sj)
+    return lib().orc_obj_indball_l0(_dp(y), _dp(xk), _dp(sj), n, int(r), -1.0 if delta is None else float(delta))
+
+
+def obj_group_l2(y, xk, sj, lam, offsets=None, gsize=0, delta=None):
+    y, xk, sj, n, _ = _prep(y, xk, sj)
+    off, offp, gs, ng = _groups(n, offsets, gsize)
+    lam = _f64(lam)
+    return lib().orc_obj_group_l2(_dp(y), _dp(xk), _dp(sj), n, offp, gs, ng, _dp(lam), -1.0 if delta is None else float(delta))

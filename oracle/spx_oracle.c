@@ -625,6 +625,68 @@ ORC_API void orc_iprox_l0_box(double* y, const double* g, const double* d, const
 
 ORC_API double orc_iprox_zero(double d, double g, double l, double u) { return iprox_zero(d, g, l, u); }
 
+/* ==========================================================================================
+ * psi(y)  (SURVEY.md 8f rank 2): objective value.  Sums run left to right as the reference's loops do.
+ *   kind: 0 = NormL1 (lambda * sum |v|) [ext], 1 = NormL0 (lambda * count(v != 0)) [ext],
+ *         2 = RootNormLhalf (lambda * sum sqrt|v|, src/rootNormLhalf.jl:27-29)
+ * ========================================================================================== */
+static inline double h_term(int kind, double v) {
+  return kind == 0 ? fabs(v) : (kind == 1 ? ((v != 0.0) ? 1.0 : 0.0) : sqrt(fabs(v)));
+}
+/* generic  src/ShiftedProximalOperators.jl:51-54 */
+ORC_API double orc_obj_plain(int kind, const double* y, const double* xk, const double* sj, int64_t n, double lambda) {
+  double acc = 0.0;
+  for (int64_t i = 0; i < n; ++i) acc += h_term(kind, (xk[i] + sj[i]) + y[i]);
+  return lambda * acc;
+}
+/* Box  src/shiftedNormL1Box.jl:70-82 (idem L0Box, RootNormLhalfBox) */
+ORC_API double orc_obj_box(int kind, const double* y, const double* xk, const double* sj, int64_t n, double lambda,
+                           const double* lvec, const double* uvec, double lscal, double uscal, const uint8_t* mask) {
+  double acc = 0.0;
+  for (int64_t i = 0; i < n; ++i)
+    if (is_selected(mask, i)) acc += h_term(kind, (xk[i] + sj[i]) + y[i]); /* :71-72 */
+  const double slack = sqrt(2.220446049250313e-16); /* :73 */
+  for (int64_t i = 0; i < n; ++i) {
+    double lower = lvec ? lvec[i] : lscal, upper = uvec ? uvec[i] : uscal;
+    double t = sj[i] + y[i];
+    if (!(lower - slack <= t && t <= upper + slack)) return INFINITY; /* :77-79 */
+  }
+  return lambda * acc;
+}
+/* IndBallLinf(r)(x) [ext: ProximalOperators IndBox, strict comparisons] */
+static int outside_linf_ball(const double* sj, const double* y, int64_t n, double rad) {
+  for (int64_t i = 0; i < n; ++i) { double t = sj[i] + y[i]; if (t < -rad || t > rad) return 1; }
+  return 0;
+}
+/* ShiftedIndBallL0 (generic form) and ShiftedIndBallL0BInf  src/shiftedIndBallL0BInf.jl:44-49; delta < 0: no ball */
+ORC_API double orc_obj_indball_l0(const double* y, const double* xk, const double* sj, int64_t n, int64_t r, double delta) {
+  int64_t cnt = 0;
+  if (delta >= 0) {
+    for (int64_t i = 0; i < n; ++i) cnt += (((sj[i] + y[i]) + xk[i]) != 0.0); /* :45,:47 */
+    if (outside_linf_ball(sj, y, n, 1.1 * delta)) return INFINITY;          /* :46 */
+  } else {
+    for (int64_t i = 0; i < n; ++i) cnt += (((xk[i] + sj[i]) + y[i]) != 0.0);
+  }
+  return cnt > r ? INFINITY : 0.0;
+}
+/* GroupNormL2  src/groupNormL2.jl:33-39; Binf form src/shiftedGroupNormL2Binf.jl:34-39 (delta < 0: plain form) */
+ORC_API double orc_obj_group_l2(const double* y, const double* xk, const double* sj, int64_t n, const int64_t* offsets,
+                                int64_t gsize, int64_t ngroups, const double* lambda, double delta) {
+  double sum_c = 0.0;
+  for (int64_t g = 0; g < ngroups; ++g) {
+    int64_t lo, hi;
+    group_range(offsets, gsize, g, &lo, &hi);
+    double ss = 0.0;
+    for (int64_t i = lo; i < hi; ++i) {
+      double v = (delta >= 0) ? ((sj[i] + y[i]) + xk[i]) : ((xk[i] + sj[i]) + y[i]);
+      ss += v * v;
+    }
+    sum_c += lambda[g] * sqrt(ss);
+  }
+  if (delta >= 0 && outside_linf_ball(sj, y, n, 1.1 * delta)) return INFINITY;
+  return sum_c;
+}
+
 /* Objective value 1/(2 sigma) (t-q)^2 + lambda*h(x+s+t) helpers for the brute-force second oracle
  * live in tests/ (numpy); nothing else is exported from here. */
 ORC_API int orc_abi_version(void) { return 2; }

@@ -32,6 +32,16 @@ SIGNATURES = {
     "spx_iprox_l0": [_p, _p, _p, _p, _p, _p, _i64, _d, _int],
     "spx_iprox_l1_box": [_p, _p, _p, _p, _p, _p, _i64, _d, _p, _p, _d, _d, _p],
     "spx_iprox_l0_box": [_p, _p, _p, _p, _p, _p, _i64, _d, _p, _p, _d, _d, _p],
+    "spx_obj_l1": [_p, _p, _p, _p, _i64, _d, ctypes.POINTER(_d)],
+    "spx_obj_l0": [_p, _p, _p, _p, _i64, _d, ctypes.POINTER(_d)],
+    "spx_obj_lhalf": [_p, _p, _p, _p, _i64, _d, ctypes.POINTER(_d)],
+    "spx_obj_l1_box": [_p, _p, _p, _p, _i64, _d, _p, _p, _d, _d, _p, ctypes.POINTER(_d)],
+    "spx_obj_l0_box": [_p, _p, _p, _p, _i64, _d, _p, _p, _d, _d, _p, ctypes.POINTER(_d)],
+    "spx_obj_lhalf_box": [_p, _p, _p, _p, _i64, _d, _p, _p, _d, _d, _p, ctypes.POINTER(_d)],
+    "spx_obj_indball_l0": [_p, _p, _p, _p, _i64, _i64, ctypes.POINTER(_d)],
+    "spx_obj_indball_l0_binf": [_p, _p, _p, _p, _i64, _i64, _d, ctypes.POINTER(_d)],
+    "spx_obj_group_l2": [_p, _p, _p, _p, _i64, _p, _i64, _i64, _p, ctypes.POINTER(_d)],
+    "spx_obj_group_l2_binf": [_p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _d, ctypes.POINTER(_d)],
     "spx_prox_indball_l0": [_p, _p, _p, _p, _p, _i64, _i64],
     "spx_prox_indball_l0_binf": [_p, _p, _p, _p, _p, _i64, _i64, _d],
     "spx_prox_group_l2": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _d],

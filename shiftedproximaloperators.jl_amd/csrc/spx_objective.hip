@@ -1,0 +1,254 @@
+// spx_objective.hip -- psi(y) = h(xk + sj + y) (+ trust-region / box indicator): the objective value the solvers
+// evaluate next to every prox!.  Reference: generic form src/ShiftedProximalOperators.jl:51-54;
+// Box forms (feasibility scan with sqrt(eps) slack) src/shiftedNormL1Box.jl:70-82, shiftedNormL0Box.jl:70-82,
+// shiftedRootNormLhalfBox.jl:67-79; BInf forms (IndBallLinf(1.1 Delta) on sj + y) src/shiftedIndBallL0BInf.jl:44-49,
+// shiftedGroupNormL2Binf.jl:34-39.
+//
+// A reduction: reads y, xk, sj (24 B/element; +16 with vector bounds, +1 with a mask), writes one double.
+// Per-lane partial sums -> wavefront butterfly -> workgroup (LDS) -> one partial per workgroup in the context
+// scratch -> a single workgroup adds the partials in index order: the value is reproducible run to run.  The
+// summation order differs from the reference's left-to-right loop, hence a 1e-12 relative tolerance in tests;
+// counts (NormL0, IndBallL0) and the +Inf decisions are exact.  The value is returned to the host: these entry
+// points synchronise the stream.
+#include <cmath>
+#include <limits>
+
+#include "spx_common.hpp"
+
+namespace {
+
+constexpr int kObjBlocks = 2048;
+
+struct ObjWs {
+  double partial[kObjBlocks];
+  double result;
+  int infeasible;
+  int pad;
+};
+
+// element terms of h
+struct TermL1 { __device__ __forceinline__ double operator()(double v) const { return fabs(v); } };          // NormL1 [ext]
+struct TermL0 { __device__ __forceinline__ double operator()(double v) const { return (v != 0.0) ? 1.0 : 0.0; } };  // NormL0, IndBallL0 [ext]
+struct TermLhalf { __device__ __forceinline__ double operator()(double v) const { return sqrt(fabs(v)); } };  // src/rootNormLhalf.jl:27-29
+
+__device__ __forceinline__ double block_sum(double v, double* lds4) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds4[w] = v;
+  __syncthreads();
+  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+// MODE 0: xsy = (xk + sj) + y over every index                              (generic, :52)
+// MODE 1: Box: the same over the selected indices, plus the feasibility scan of sj + y against
+//         [l - sqrt(eps), u + sqrt(eps)] over EVERY index                  (shiftedNormL1Box.jl:70-82)
+// MODE 2: BInf: xsy = (sj + y) + xk, plus |sj + y| <= 1.1 Delta (strict IndBox test) (shiftedIndBallL0BInf.jl:44-49)
+template <class Term, int MODE>
+__global__ __launch_bounds__(256) void k_obj(const double* __restrict__ y, const double* __restrict__ xk,
+                                              const double* __restrict__ sj, const double* __restrict__ lv,
+                                              const double* __restrict__ uv, const uint8_t* __restrict__ mask,
+                                              double ls, double us, double rad, int64_t n, Term term, ObjWs* ws) {
+  __shared__ double lds4[4];
+  const double slack = 1.4901161193847656e-08;  // sqrt(eps(Float64))
+  double acc = 0.0;
+  bool bad = false;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double yi = y[i], xi = xk[i], si = sj[i];
+    if constexpr (MODE == 2) {
+      const double t = si + yi;
+      bad |= (t < -rad) || (t > rad);
+      acc += term(t + xi);
+    } else {
+      if constexpr (MODE == 1) {
+        const double lo = lv ? lv[i] : ls, up = uv ? uv[i] : us;
+        const double t = si + yi;
+        bad |= !((lo - slack <= t) && (t <= up + slack));
+        if (mask && !mask[i]) continue;
+      }
+      acc += term((xi + si) + yi);
+    }
+  }
+  acc = block_sum(acc, lds4);
+  if (threadIdx.x == 0) ws->partial[blockIdx.x] = acc;
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&ws->infeasible, 1);
+}
+
+// GroupNormL2: sum_g lambda_g ||xsy[idx_g]||_2, one wavefront per group  (src/groupNormL2.jl:33-39)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_obj_group(const double* __restrict__ y, const double* __restrict__ xk,
+                                                    const double* __restrict__ sj, int64_t n,
+                                                    const int64_t* __restrict__ offsets, int64_t gsize, int64_t ngroups,
+                                                    const double* __restrict__ lambda, double rad, ObjWs* ws) {
+  __shared__ double lds4[4];
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  double acc = 0.0;  // lane 0 of each wave accumulates lambda_g * norm_g
+  bool bad = false;
+  for (int64_t g = wave; g < ngroups; g += nwaves) {
+    int64_t lo, hi;
+    if (offsets) { lo = offsets[g]; hi = offsets[g + 1]; }
+    else { lo = g * gsize; hi = lo + gsize; }
+    if (lo < 0) lo = 0;
+    if (hi > n) hi = n;
+    double ss = 0.0;
+    for (int64_t i = lo + lane; i < hi; i += 64) {
+      double v;
+      if constexpr (MODE == 2) {
+        const double t = sj[i] + y[i];
+        bad |= (t < -rad) || (t > rad);
+        v = t + xk[i];
+      } else {
+        v = (xk[i] + sj[i]) + y[i];
+      }
+      ss += v * v;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) acc += lambda[g] * sqrt(ss);
+  }
+  acc = block_sum(acc, lds4);
+  if (threadIdx.x == 0) ws->partial[blockIdx.x] = acc;
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&ws->infeasible, 1);
+}
+
+// one workgroup: partials in index order (pairwise inside the wave, fixed shape) -> ws->result
+__global__ __launch_bounds__(256) void k_obj_final(ObjWs* ws, int nblocks) {
+  __shared__ double lds4[4];
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) acc += ws->partial[b];
+  acc = block_sum(acc, lds4);
+  if (threadIdx.x == 0) ws->result = acc;
+}
+
+int obj_finish(spx_ctx* ctx, ObjWs* ws, int blocks, double* sum, int* infeasible) {
+  hipLaunchKernelGGL(k_obj_final, dim3(1), dim3(256), 0, ctx->stream, ws, blocks);
+  SPX_LAUNCH_CHECK();
+  struct { double r; int f; int p; } host;
+  SPX_HIP(hipMemcpyAsync(&host, &ws->result, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+  SPX_HIP(hipStreamSynchronize(ctx->stream));
+  *sum = host.r;
+  *infeasible = host.f;
+  return SPX_OK;
+}
+
+template <class Term, int MODE>
+int run_obj(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, const double* lv,
+            const double* uv, double ls, double us, const uint8_t* mask, double rad, double* sum, int* infeasible) {
+  SPX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  SPX_REQUIRE(n >= 0, "n < 0");
+  SPX_REQUIRE(n == 0 || (y && xk && sj), "NULL vector with n > 0");
+  *sum = 0.0;
+  *infeasible = 0;
+  if (n == 0) return SPX_OK;
+  int rc = spx_ws_reserve(ctx, sizeof(ObjWs) + 256);
+  if (rc) return rc;
+  SPX_HIP(hipSetDevice(ctx->device));
+  ObjWs* ws = reinterpret_cast<ObjWs*>(ctx->ws);
+  SPX_HIP(hipMemsetAsync(&ws->infeasible, 0, sizeof(int), ctx->stream));
+  int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+  if (blocks > kObjBlocks) blocks = kObjBlocks;
+  hipLaunchKernelGGL((k_obj<Term, MODE>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, lv, uv, mask, ls,
+                     us, rad, n, Term{}, ws);
+  SPX_LAUNCH_CHECK();
+  return obj_finish(ctx, ws, (int)blocks, sum, infeasible);
+}
+
+template <int MODE>
+int run_obj_group(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                  const int64_t* offsets, int64_t gsize, int64_t ngroups, const double* lambda, double rad, double* value) {
+  SPX_REQUIRE(ctx != nullptr && value != nullptr, "ctx or value is NULL");
+  SPX_REQUIRE(n >= 0 && ngroups >= 0, "negative size");
+  *value = 0.0;
+  if (n == 0 || ngroups == 0) return SPX_OK;
+  SPX_REQUIRE(y && xk && sj && lambda, "NULL vector");
+  if (!offsets) SPX_REQUIRE(gsize > 0 && ngroups <= n / gsize && ngroups * gsize == n, "ngroups * group_size != n");
+  int rc = spx_ws_reserve(ctx, sizeof(ObjWs) + 256);
+  if (rc) return rc;
+  SPX_HIP(hipSetDevice(ctx->device));
+  ObjWs* ws = reinterpret_cast<ObjWs*>(ctx->ws);
+  SPX_HIP(hipMemsetAsync(&ws->infeasible, 0, sizeof(int), ctx->stream));
+  int64_t blocks = (ngroups + 3) / 4;
+  if (blocks > kObjBlocks) blocks = kObjBlocks;
+  hipLaunchKernelGGL((k_obj_group<MODE>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, offsets, gsize,
+                     ngroups, lambda, rad, ws);
+  SPX_LAUNCH_CHECK();
+  double sum;
+  int bad;
+  rc = obj_finish(ctx, ws, (int)blocks, &sum, &bad);
+  if (rc) return rc;
+  *value = bad ? std::numeric_limits<double>::infinity() : sum;
+  return SPX_OK;
+}
+
+const double kInf = std::numeric_limits<double>::infinity();
+
+}  // namespace
+
+// ---- generic forms: h(xk + sj + y) ---------------------------------------------------------------
+#define SPX_OBJ_PLAIN(NAME, TERM)                                                                                  \
+  SPX_EXPORT int NAME(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double lambda, \
+                      double* value) {                                                                             \
+    SPX_REQUIRE(value != nullptr, "value is NULL");                                                                \
+    double sum;                                                                                                    \
+    int bad;                                                                                                       \
+    int rc = run_obj<TERM, 0>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 0.0, &sum, &bad);             \
+    if (rc) return rc;                                                                                             \
+    *value = lambda * sum;                                                                                         \
+    return SPX_OK;                                                                                                 \
+  }
+SPX_OBJ_PLAIN(spx_obj_l1, TermL1)
+SPX_OBJ_PLAIN(spx_obj_l0, TermL0)
+SPX_OBJ_PLAIN(spx_obj_lhalf, TermLhalf)
+
+// ---- Box forms -----------------------------------------------------------------------------------------
+#define SPX_OBJ_BOX(NAME, TERM)                                                                                    \
+  SPX_EXPORT int NAME(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double lambda, \
+                      const double* l_vec, const double* u_vec, double l_scalar, double u_scalar,                  \
+                      const uint8_t* sel_mask, double* value) {                                                    \
+    SPX_REQUIRE(value != nullptr, "value is NULL");                                                                \
+    double sum;                                                                                                    \
+    int bad;                                                                                                       \
+    int rc = run_obj<TERM, 1>(ctx, y, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask, 0.0, &sum, &bad);     \
+    if (rc) return rc;                                                                                             \
+    *value = bad ? kInf : lambda * sum;                                                                            \
+    return SPX_OK;                                                                                                 \
+  }
+SPX_OBJ_BOX(spx_obj_l1_box, TermL1)
+SPX_OBJ_BOX(spx_obj_l0_box, TermL0)
+SPX_OBJ_BOX(spx_obj_lhalf_box, TermLhalf)
+
+// ---- IndBallL0: 0 if at most r nonzeros, else +Inf  [ext: ProximalOperators.IndBallL0] ---------------------
+SPX_EXPORT int spx_obj_indball_l0(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                                  int64_t r, double* value) {
+  SPX_REQUIRE(value != nullptr, "value is NULL");
+  double cnt;
+  int bad;
+  int rc = run_obj<TermL0, 0>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 0.0, &cnt, &bad);
+  if (rc) return rc;
+  *value = (cnt > (double)r) ? kInf : 0.0;
+  return SPX_OK;
+}
+SPX_EXPORT int spx_obj_indball_l0_binf(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                                       int64_t r, double delta, double* value) {
+  SPX_REQUIRE(value != nullptr, "value is NULL");
+  double cnt;
+  int bad;
+  int rc = run_obj<TermL0, 2>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 1.1 * delta, &cnt, &bad);
+  if (rc) return rc;
+  *value = (bad || cnt > (double)r) ? kInf : 0.0;
+  return SPX_OK;
+}
+
+// ---- GroupNormL2 ---------------------------------------------------------------------------------------
+SPX_EXPORT int spx_obj_group_l2(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                                const int64_t* group_offsets, int64_t group_size, int64_t ngroups,
+                                const double* lambda_vec, double* value) {
+  return run_obj_group<0>(ctx, y, xk, sj, n, group_offsets, group_size, ngroups, lambda_vec, 0.0, value);
+}
+SPX_EXPORT int spx_obj_group_l2_binf(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                                     const int64_t* group_offsets, int64_t group_size, int64_t ngroups,
+                                     const double* lambda_vec, double delta, double* value) {
+  return run_obj_group<2>(ctx, y, xk, sj, n, group_offsets, group_size, ngroups, lambda_vec, 1.1 * delta, value);
+}

@@ -90,6 +90,17 @@ class ShiftedProximableFunction:
     def _prox(self, L, ctx, y, q, sigma):
         raise NotImplementedError
 
+    def __call__(self, y):
+        """ψ(y) = h(xk + sj + y) [+ indicator]  (src/ShiftedProximalOperators.jl:51-54 and the Box / BInf methods);
+        evaluated on the device, returned as a Python float (synchronises)."""
+        _vec(y, "y", self.xk.numel())
+        out = ctypes.c_double(0.0)
+        self._obj(_lib.load(), _ctx(y.device), y, ctypes.byref(out))
+        return out.value
+
+    def _obj(self, L, ctx, y, out):
+        raise TypeError("MethodError: objects of type %s are not callable" % type(self).__name__)
+
     def _iprox(self, L, ctx, y, g, d, check):
         raise TypeError("MethodError: no method matching iprox!(::%s, ...)" % type(self).__name__)
 
@@ -112,18 +123,28 @@ class _Unboxed(ShiftedProximableFunction):
         _lib.check(st)
 
 
+def _unboxed_obj(self, L, ctx, y, out):
+    _lib.check(getattr(L, self._ofn)(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), y.numel(), self.h.lam, out))
+
+
+_Unboxed._obj = _unboxed_obj
+
+
 class ShiftedNormL1(_Unboxed):  # src/shiftedNormL1.jl
     _fn = "spx_prox_l1"
     _ifn = "spx_iprox_l1"
+    _ofn = "spx_obj_l1"
 
 
 class ShiftedNormL0(_Unboxed):  # src/shiftedNormL0.jl
     _fn = "spx_prox_l0"
     _ifn = "spx_iprox_l0"
+    _ofn = "spx_obj_l0"
 
 
 class ShiftedRootNormLhalf(_Unboxed):  # src/shiftedRootNormLhalf.jl
     _fn = "spx_prox_lhalf"
+    _ofn = "spx_obj_lhalf"
 
 
 _UNSET = object()
@@ -165,11 +186,13 @@ class _Boxed(ShiftedProximableFunction):
 class ShiftedNormL1Box(_Boxed):  # src/shiftedNormL1Box.jl
     _fn = "spx_prox_l1_box"
     _ifn = "spx_iprox_l1_box"
+    _ofn = "spx_obj_l1_box"
 
 
 class ShiftedNormL0Box(_Boxed):  # src/shiftedNormL0Box.jl
     _fn = "spx_prox_l0_box"
     _ifn = "spx_iprox_l0_box"
+    _ofn = "spx_obj_l0_box"
 
 
 def _boxed_iprox(self, L, ctx, y, g, d, check):
@@ -184,12 +207,23 @@ def _boxed_iprox(self, L, ctx, y, g, d, check):
                                      _ptr(self._mask[0]) if self._mask is not None else ctypes.c_void_p(0)))
 
 
+def _boxed_obj(self, L, ctx, y, out):
+    n = y.numel()
+    lv = None if _is_real(self.l) else _vec(self.l, "l", n)
+    uv = None if _is_real(self.u) else _vec(self.u, "u", n)
+    _lib.check(getattr(L, self._ofn)(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), n, self.h.lam, _ptr(lv), _ptr(uv),
+                                     float(self.l) if lv is None else 0.0, float(self.u) if uv is None else 0.0,
+                                     _ptr(self._mask[0]) if self._mask is not None else ctypes.c_void_p(0), out))
+
+
 _Boxed._ifn = None
 _Boxed._iprox = _boxed_iprox
+_Boxed._obj = _boxed_obj
 
 
 class ShiftedRootNormLhalfBox(_Boxed):  # src/shiftedRootNormLhalfBox.jl (no l > u check, :22-44)
     _fn = "spx_prox_lhalf_box"
+    _ofn = "spx_obj_lhalf_box"
     _check_bounds = False
 
 
@@ -219,6 +253,9 @@ class ShiftedIndBallL0(_TopR):  # src/shiftedIndBallL0.jl
     def _prox(self, L, ctx, y, q, sigma):
         _lib.check(L.spx_prox_indball_l0(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), y.numel(), self.h.r))
 
+    def _obj(self, L, ctx, y, out):
+        _lib.check(L.spx_obj_indball_l0(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), y.numel(), self.h.r, out))
+
 
 class ShiftedIndBallL0BInf(_TopR):  # src/shiftedIndBallL0BInf.jl
     def __init__(self, h, xk, sj, Δ, χ, shifted_twice):
@@ -229,6 +266,9 @@ class ShiftedIndBallL0BInf(_TopR):  # src/shiftedIndBallL0BInf.jl
     def _prox(self, L, ctx, y, q, sigma):
         _lib.check(L.spx_prox_indball_l0_binf(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), y.numel(),
                                               self.h.r, self.Δ))
+
+    def _obj(self, L, ctx, y, out):
+        _lib.check(L.spx_obj_indball_l0_binf(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), y.numel(), self.h.r, self.Δ, out))
 
 
 class _GroupLayout:
@@ -276,6 +316,11 @@ class ShiftedGroupNormL2(ShiftedProximableFunction):  # src/shiftedGroupNormL2.j
         _lib.check(L.spx_prox_group_l2(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), y.numel(),
                                        _ptr(g.offsets), g.group_size, g.ngroups, _ptr(g.lam), sigma))
 
+    def _obj(self, L, ctx, y, out):
+        g = self._layout
+        _lib.check(L.spx_obj_group_l2(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), y.numel(), _ptr(g.offsets),
+                                      g.group_size, g.ngroups, _ptr(g.lam), out))
+
 
 class ShiftedGroupNormL2Binf(ShiftedProximableFunction):  # src/shiftedGroupNormL2Binf.jl
     def __init__(self, h, xk, sj, Δ, χ, shifted_twice, _layout=None):
@@ -288,6 +333,11 @@ class ShiftedGroupNormL2Binf(ShiftedProximableFunction):  # src/shiftedGroupNorm
         g = self._layout
         _lib.check(L.spx_prox_group_l2_binf(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), y.numel(),
                                             _ptr(g.offsets), g.group_size, g.ngroups, _ptr(g.lam), sigma, self.Δ))
+
+    def _obj(self, L, ctx, y, out):
+        g = self._layout
+        _lib.check(L.spx_obj_group_l2_binf(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), y.numel(), _ptr(g.offsets),
+                                           g.group_size, g.ngroups, _ptr(g.lam), self.Δ, out))
 
 
 # ---------------------------------------------------------------------------------------------

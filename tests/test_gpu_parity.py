@@ -451,3 +451,73 @@ def test_iprox_parity(s, orc, op, n):
             s.iprox(psi, gd, _dev(dbad)[0])
         with pytest.raises(TypeError):
             s.iprox(s.shifted(s.RootNormLhalf(1.0), xd), gd, dd)  # no iprox! method in the reference either
+
+
+# ------------------------------------------------------------------ psi(y)
+@pytest.mark.parametrize("n", [1, 5, 1000, 65_537, 2_000_003])
+def test_objective_values(s, orc, n):
+    rng = np.random.default_rng(700 + n)
+    x, sj, _ = _data(n, 701 + n)
+    y = rng.uniform(-0.3, 0.3, size=n)
+    y[rng.random(n) < 0.1] = 0.0
+    x[rng.random(n) < 0.1] = 0.0  # exact zeros for the counting operators
+    sj = np.where(x == 0.0, 0.0, sj)
+    xd, sd, yd = _dev(x, sj, y)
+    chi = s.NormLinf(1.0)
+    rel = lambda a, b: abs(a - b) <= 1e-12 * max(1.0, abs(b))
+    for kind, H in (("l1", s.NormL1), ("l0", s.NormL0), ("lhalf", s.RootNormLhalf)):
+        lam = 0.7
+        psi = s.shifted(s.shifted(H(lam), xd), sd)
+        ref = orc.obj_plain(kind, y, x, sj, lam)
+        assert (psi(yd) == ref) if kind == "l0" else rel(psi(yd), ref), (kind, n)
+        # Box: inside (value) and outside (Inf); vector bounds and a selected subset too
+        for delta in (1.0, 0.2):
+            om = s.shifted(s.shifted(H(lam), xd, delta, chi), sd)
+            ref = orc.obj_box(kind, y, x, sj, lam, -delta, delta)
+            got = om(yd)
+            assert (got == ref) if (kind == "l0" or np.isinf(ref)) else rel(got, ref), (kind, n, delta)
+        if n >= 5:
+            l = -1.0 - 0.1 * rng.random(n); u = 1.0 + 0.1 * rng.random(n)
+            ld, ud = _dev(l, u)
+            sel = range(0, n, 2)
+            om = s.shifted(s.shifted(H(lam), xd, ld, ud, sel), sd)
+            ref = orc.obj_box(kind, y, x, sj, lam, l, u, mask=orc.mask_from_selected([i + 1 for i in sel], n))
+            assert (om(yd) == ref) if kind == "l0" else rel(om(yd), ref)
+    nnz = int(np.count_nonzero((x + sj) + y))
+    for r in (max(1, nnz - 1), nnz, nnz + 1):
+        assert s.shifted(s.shifted(s.IndBallL0(r), xd), sd)(yd) == orc.obj_indball_l0(y, x, sj, r)
+        for delta in (1.0, 0.2):
+            got = s.shifted(s.shifted(s.IndBallL0(r), xd, delta, chi), sd)(yd)
+            assert got == orc.obj_indball_l0(y, x, sj, r, delta=delta)
+
+
+def test_objective_groups_and_reference_identities(s, orc):
+    rng = np.random.default_rng(71)
+    sizes = [1, 5, 64, 129, 1000, 2, 4096, 33]
+    offsets = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(offsets[-1])
+    x, sj, _ = _data(n, 72)
+    y = rng.uniform(-0.3, 0.3, size=n)
+    lam = rng.uniform(0.2, 2.0, size=len(sizes))
+    xd, sd, yd = _dev(x, sj, y)
+    groups = [range(int(a), int(b)) for a, b in zip(offsets[:-1], offsets[1:])]
+    h = s.GroupNormL2(lam.tolist(), groups)
+    ref = orc.obj_group_l2(y, x, sj, lam, offsets=offsets)
+    assert abs(s.shifted(s.shifted(h, xd), sd)(yd) - ref) <= 1e-12 * ref
+    for delta in (1.0, 0.3):
+        got = s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd)(yd)
+        want = orc.obj_group_l2(y, x, sj, lam, offsets=offsets, delta=delta)
+        assert got == want if np.isinf(want) else abs(got - want) <= 1e-12 * want
+    # uniform 128-groups and the identities of test/runtests.jl:438-447
+    m = 128 * 100
+    x, sj, _ = _data(m, 73)
+    xd = _dev(x)[0]
+    lamu = rng.uniform(0.5, 1.5, size=100)
+    hu = s.GroupNormL2(lamu.tolist(), [range(i, i + 128) for i in range(0, m, 128)])
+    psi = s.shifted(hu, xd, 0.01, s.NormLinf(1.0))
+    import torch
+    zero = torch.zeros(m, dtype=torch.float64, device="cuda:0")
+    hx = sum(lamu[g] * np.linalg.norm(x[g * 128:(g + 1) * 128]) for g in range(100))
+    assert abs(psi(zero) - hx) <= 1e-12 * hx            # psi(zeros(n)) == h(x)
+    yy = rng.random(m); yy *= 0.01 / np.max(np.abs(yy)) / 2
+    assert np.isfinite(psi(_dev(yy)[0])) and psi(_dev(3 * yy)[0]) == np.inf   # inside / outside the trust region

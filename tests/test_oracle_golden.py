@@ -264,3 +264,28 @@ def test_iprox_box_is_objective_minimiser(orc):
             grid = np.concatenate([np.linspace(lo, hi, 200001), [c for c in (-(x + s),) if lo <= c <= hi]])
             best = np.min(obj(grid))
             assert obj(np.array([t]))[0] <= best + 1e-9 * max(1.0, abs(best)), (name, trial, t, d)
+
+
+# ---- psi(y): the identities the reference's tests check ---------------------------------
+def test_objective_identities(orc):
+    # runtests.jl:172-178, 438-447: psi(0) == h(x); psi(y) == h(x + y) inside the trust region; Inf outside
+    rng = np.random.default_rng(12)
+    n = 7
+    x = rng.random(n)
+    z = np.zeros(n)
+    assert orc.obj_plain("l1", z, x, z, 1.0) == np.sum(np.abs(x))
+    assert orc.obj_plain("l0", z, x, z, 2.0) == 2.0 * np.count_nonzero(x)
+    y = rng.random(n)
+    y *= 0.01 / np.max(np.abs(y)) / 2
+    for kind, h in (("l1", lambda v: np.sum(np.abs(v))), ("l0", lambda v: float(np.count_nonzero(v))),
+                    ("lhalf", lambda v: np.sum(np.sqrt(np.abs(v))))):
+        assert abs(orc.obj_box(kind, y, x, z, 1.0, -0.01, 0.01) - h(x + y)) <= 1e-14 * max(1.0, h(x + y))
+        assert orc.obj_box(kind, 3 * y, x, z, 1.0, -0.01, 0.01) == np.inf
+    assert orc.obj_indball_l0(y, x, z, n, delta=0.01) == 0.0
+    assert orc.obj_indball_l0(y, x, z, n - 1, delta=0.01) == np.inf
+    assert orc.obj_indball_l0(3 * y, x, z, n, delta=0.01) == np.inf   # 1.5 * Delta > 1.1 * Delta
+    lam = np.array([0.4, 0.5])
+    g = orc.obj_group_l2(y[:6], x[:6], z[:6], lam, offsets=[0, 3, 6])
+    want = 0.4 * np.linalg.norm((x + y)[:3]) + 0.5 * np.linalg.norm((x + y)[3:6])
+    assert abs(g - want) <= 1e-14
+    assert orc.obj_group_l2(3 * y[:6], x[:6], z[:6], lam, offsets=[0, 3, 6], delta=0.01) == np.inf
