@@ -53,22 +53,62 @@ __global__ __launch_bounds__(256) void k_obj(const double* __restrict__ y, const
   const double slack = 1.4901161193847656e-08;  // sqrt(eps(Float64))
   double acc = 0.0;
   bool bad = false;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double yi = y[i], xi = xk[i], si = sj[i];
+  auto visit = [&](double yi, double xi, double si, double lo, double up, bool sel) {
     if constexpr (MODE == 2) {
       const double t = si + yi;
       bad |= (t < -rad) || (t > rad);
       acc += term(t + xi);
     } else {
       if constexpr (MODE == 1) {
-        const double lo = lv ? lv[i] : ls, up = uv ? uv[i] : us;
         const double t = si + yi;
         bad |= !((lo - slack <= t) && (t <= up + slack));
-        if (mask && !mask[i]) continue;
+        if (!sel) return;
       }
       acc += term((xi + si) + yi);
     }
+  };
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool vec = (((uintptr_t)y | (uintptr_t)xk | (uintptr_t)sj | (uintptr_t)lv | (uintptr_t)uv) & 15) == 0 &&
+                   (((uintptr_t)mask) & 1) == 0;
+  if (vec) {  // 16-byte non-temporal loads, two pairs in flight per vector and lane
+    const int64_t n2 = n >> 1;
+    const f64x2* y2 = reinterpret_cast<const f64x2*>(y);
+    const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
+    const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
+    const f64x2* l2 = reinterpret_cast<const f64x2*>(lv);
+    const f64x2* u2 = reinterpret_cast<const f64x2*>(uv);
+    const uint16_t* m2 = reinterpret_cast<const uint16_t*>(mask);
+    for (int64_t i = tid; i < n2; i += 2 * stride) {
+      const int64_t j = i + stride;
+      const bool two = j < n2;
+      const int64_t jj = two ? j : i;
+      const f64x2 ya = __builtin_nontemporal_load(y2 + i), xa = __builtin_nontemporal_load(x2 + i),
+                  sa = __builtin_nontemporal_load(s2 + i);
+      const f64x2 yb = __builtin_nontemporal_load(y2 + jj), xb = __builtin_nontemporal_load(x2 + jj),
+                  sb = __builtin_nontemporal_load(s2 + jj);
+      f64x2 la = f64x2{ls, ls}, ua = f64x2{us, us}, lb = la, ub = ua;
+      uint16_t ma = 0x0101, mb = 0x0101;
+      if constexpr (MODE == 1) {
+        if (lv) { la = l2[i]; lb = l2[jj]; }
+        if (uv) { ua = u2[i]; ub = u2[jj]; }
+        if (mask) { ma = m2[i]; mb = m2[jj]; }
+      }
+      visit(ya.x, xa.x, sa.x, la.x, ua.x, (ma & 0xff) != 0);
+      visit(ya.y, xa.y, sa.y, la.y, ua.y, (ma >> 8) != 0);
+      if (two) {
+        visit(yb.x, xb.x, sb.x, lb.x, ub.x, (mb & 0xff) != 0);
+        visit(yb.y, xb.y, sb.y, lb.y, ub.y, (mb >> 8) != 0);
+      }
+    }
+    if ((n & 1) && tid == 0) {
+      const int64_t i = n - 1;
+      visit(y[i], xk[i], sj[i], lv ? lv[i] : ls, uv ? uv[i] : us, mask ? mask[i] != 0 : true);
+    }
+  } else {
+    for (int64_t i = tid; i < n; i += stride)
+      visit(y[i], xk[i], sj[i], (MODE == 1 && lv) ? lv[i] : ls, (MODE == 1 && uv) ? uv[i] : us,
+            (MODE == 1 && mask) ? mask[i] != 0 : true);
   }
   acc = block_sum(acc, lds4);
   if (threadIdx.x == 0) ws->partial[blockIdx.x] = acc;
