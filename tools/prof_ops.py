@@ -6,7 +6,7 @@ import __graft_entry__ as ge
 s = ge.build()
 dev = torch.device("cuda:0")
 n = int(os.environ.get("SPX_N", "100000000"))
-which = os.environ.get("SPX_OPS", "indball,lhalfbox,group,binf").split(",")
+which = os.environ.get("SPX_OPS", "l1box,l0box,lhalf,lhalfbox,indball,iprox,objective,group,binf").split(",")
 g = torch.Generator(device=dev).manual_seed(1)
 chi = s.NormLinf(1.0)
 def vecs(m):
@@ -14,6 +14,24 @@ def vecs(m):
             torch.rand(m, dtype=torch.float64, device=dev, generator=g) - 0.5,
             torch.randn(m, dtype=torch.float64, device=dev, generator=g))
 xk, sj, q = vecs(n); y = torch.empty_like(q)
+if "l1box" in which:
+    psi = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj)
+    for _ in range(5): s.prox_bang(y, psi, q, 1.0)
+if "l0box" in which:
+    psi = s.shifted(s.shifted(s.NormL0(1.0), xk, 1.0, chi), sj)
+    for _ in range(5): s.prox_bang(y, psi, q, 1.0)
+if "lhalf" in which:
+    psi = s.shifted(s.shifted(s.RootNormLhalf(1.0), xk), sj)
+    for _ in range(5): s.prox_bang(y, psi, q, 1.0)
+if "iprox" in which:
+    d = torch.rand(n, dtype=torch.float64, device=dev, generator=g) + 0.5
+    for H in (s.NormL1, s.NormL0):
+        psi = s.shifted(s.shifted(H(1.0), xk, 1.0, chi), sj)
+        for _ in range(5): s.iprox_bang(y, psi, q, d, check=False)
+    del d
+if "objective" in which:
+    psi = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj)
+    for _ in range(5): psi(y)
 if "indball" in which:
     psi = s.shifted(s.shifted(s.IndBallL0(n // 100), xk, 1.0, chi), sj)
     for _ in range(5): s.prox_bang(y, psi, q, 1.0)
