@@ -271,31 +271,44 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
   const double lmin = sl * (1 + eps);     // :94
   // lmax, zlmax and froot(lmin) only steer the bracket (their exact rounding never reaches y): the wave-uniform
   // divisions and square roots below use the few-ulp fast forms
-  const double ansatz = lmin + 1.0;                                      // :97 (epsilon = 1)
-  const double rsig = fast_rcp(sigma);
-  const double stepa = ansatz * rsig * fast_rcp(ansatz - sl);            // :98
-  const double thra = delta * stepa;
-  // one fused pass: ||S||, ||X||, zlmax (:99) and the A/B sums of froot(lmin) (:95)
+  // one fused pass: ||S||, ||X|| and the A/B sums of froot(lmin) (:95)
   const double ul = lmin - sl;
   const double taul = ul * fast_rcp(lmin);
-  double sz = 0.0, sS = 0.0, sX = 0.0, sal = 0.0, sbl = 0.0;
+  double sS = 0.0, sX = 0.0, sal = 0.0, sbl = 0.0;
   grp.for_each([&](double S, double X) {
-    const double za = fabs(__builtin_fma(-stepa, X, S * rsig)) - thra;  // |softthres| = max(0, |.| - thr)
-    sz += (za > 0.0) ? za * za : 0.0;
     const double s2 = S * S;
     sS += s2;
     sX += X * X;
     const double z = __builtin_fma(taul, S, -X);
     const bool act = fabs(z) > delta;
     const double b = X + signed_delta(delta, z);
-    sal += act ? 0.0 : s2;
-    sbl += act ? b * b : 0.0;
+    sal += keep_if(s2, !act);
+    sbl += keep_if(b * b, act);
   });
-  team_sum2<TEAM>(sz, sS, lds);
+  team_sum2<TEAM>(sS, sX, lds);
   team_sum2<TEAM>(sal, sbl, lds);
-  sX = team_sum<TEAM>(sX, lds);
   const double nS = sqrt_pos(sS), nX = sqrt_pos(sX);
-  const double lmax = nS + sigma * (sqrt_pos(sz) + 1.0 * lam * nX);  // :100 (|(eps-1)/eps + 1| = 1)
+  const double ub = sqrt_pos(sS + sX) * (1.0 + 8 * eps);  // a-priori bound on the root in u (see below)
+  // lmax = ||S|| + sigma (zlmax + lambda ||X||) (:100) needs one more pass for zlmax (:99).  zlmax >= 0, so
+  // lmax >= lmax_lb := ||S|| + sigma lambda ||X||.  If already lmax_lb clears both lmin (bracket not degenerate) and
+  // sl + ub (the iteration starts from the bound ub, not from lmax) the exact lmax is never used: skip the pass.
+  const double lmax_lb = nS + sigma * (lam * nX);
+  double lmax;
+  if (lmax_lb > lmin * (1.0 + 8 * eps) && (lmax_lb - sl) > ub * (1.0 + 8 * eps)) {
+    lmax = sl + ub * (1.0 + 8 * eps);  // any point >= the root serves as the upper end from here on
+  } else {
+    const double ansatz = lmin + 1.0;                                      // :97 (epsilon = 1)
+    const double rsig = fast_rcp(sigma);
+    const double stepa = ansatz * rsig * fast_rcp(ansatz - sl);            // :98
+    const double thra = delta * stepa;
+    double sz = 0.0;
+    grp.for_each([&](double S, double X) {
+      const double za = fabs(__builtin_fma(-stepa, X, S * rsig)) - thra;  // |softthres| = max(0, |.| - thr)  (:99)
+      sz += (za > 0.0) ? za * za : 0.0;
+    });
+    sz = team_sum<TEAM>(sz, lds);
+    lmax = nS + sigma * (sqrt_pos(sz) + 1.0 * lam * nX);                   // :100 (|(eps-1)/eps + 1| = 1)
+  }
   double fl = lmin - (lmin * fast_rcp(ul)) * sqrt_pos(__builtin_fma(taul * taul, sal, sbl));
   if (!(lmin < lmax) || !(ul > 0.0) || !(fl == fl)) return BINF_LITERAL;  // degenerate bracket, sl == 0, NaN
   // regular bracket sl < lmin < lmax:  fm = froot(lmax) has the sign of psi(uhi)   (:101).
@@ -308,7 +321,6 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
   // the active set did not change and u is the root; otherwise continue from the new piece.  2-3 passes on
   // the BASELINE data instead of 5-6 for Newton on psi itself; bracket-safeguarded, bounded.
   double ulo = ul, uhi = lmax - sl;
-  const double ub = sqrt_pos(sS + sX) * (1.0 + 8 * eps);
   const bool from_bound = (uhi > ub && ub > ulo);
   if (from_bound) uhi = ub;
   double u = uhi;
@@ -328,17 +340,32 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
     if (psi == 0.0 || (sa == pa && sb == pb)) break;  // exact hit, or the piece just solved is confirmed
     if (psi < 0.0) ulo = u; else uhi = u;
     // root of the current piece: g(v) = v - sqrt(sb + sa (v / (sl + v))^2), scalar Newton from u
+    // (the slope only steers the step: unrefined v_rcp/v_rsq seeds, ~1e-8 relative, are enough there; the step that
+    // follows a relative move below 1e-8 lands within ~1e-16 by quadratic convergence, so it is the last one)
     double v = u;
     for (int k = 0; k < 12; ++k) {
       const double rn = fast_rcp(sl + v);
       const double t = v * rn;
-      const double ph = sqrt_pos(__builtin_fma(t * t, sa, sb));
+      const double ph2 = __builtin_fma(t * t, sa, sb);
+      const double rph = __builtin_amdgcn_rsq(ph2);
+      double ph = ph2 * rph;
+      ph = (ph2 > 0.0) ? __builtin_fma(0.5 * rph, __builtin_fma(-ph, ph, ph2), ph) : 0.0;
+      ph = (ph2 > 0.0) ? __builtin_fma(0.5 * rph, __builtin_fma(-ph, ph, ph2), ph) : 0.0;
       const double g = v - ph;
-      const double gp = 1.0 - ((ph > 0.0) ? sa * t * (sl * rn * rn) * fast_rcp(ph) : 0.0);
-      const double vn = v - g * fast_rcp(gp);
-      const bool done = fabs(vn - v) <= 2 * eps * fabs(vn);
+      const double gp = 1.0 - ((ph2 > 0.0) ? sa * t * (sl * rn * rn) * rph : 0.0);
+      const double vn = v - g * __builtin_amdgcn_rcp(gp);
+      const bool last = fabs(vn - v) <= 1e-8 * fabs(vn);
       v = vn;
-      if (done) break;
+      if (last) {
+        // one more, fully accurate step
+        const double rn2 = fast_rcp(sl + v);
+        const double t2 = v * rn2;
+        const double p2 = __builtin_fma(t2 * t2, sa, sb);
+        const double ph_ = sqrt_pos(p2);
+        const double gp2 = 1.0 - ((ph_ > 0.0) ? sa * t2 * (sl * rn2 * rn2) * fast_rcp(ph_) : 0.0);
+        v = v - (v - ph_) * fast_rcp(gp2);
+        break;
+      }
     }
     if (!(v > ulo && v < uhi)) v = sqrt_pos(ulo) * sqrt_pos(uhi);  // safeguard: geometric bisection of the bracket
     if (!(v > ulo && v < uhi)) break;
