@@ -265,7 +265,9 @@ enum { BINF_ZERO = 0, BINF_ROOT = 1, BINF_LITERAL = 2 };
 // BINF_LITERAL: degenerate bracket / exact zero at an end / NaN -> the caller must run binf_literal_root.
 template <int TEAM, class G>
 __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma, double delta, double* lds,
-                                         double& root) {
+                                         double& root, double& out_sa, double& out_sb) {
+  out_sa = -1.0;  // >= 0 on return: the A / B sums of the last pass, which belong to `root` (||w||^2 = A + c^2 B)
+  out_sb = -1.0;
   const double eps = 2.220446049250313e-16;
   const double sl = lam * sigma;          // :85
   const double lmin = sl * (1 + eps);     // :94
@@ -379,6 +381,8 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
   double n0 = fmin(fmax(sl + u, lmin), lmax);
   if (u * 1000.0 > n0) {  // well conditioned in n: a few ulp of n cannot move step by more than ~1e-13
     root = n0;
+    out_sa = sa;
+    out_sb = sb;
     return BINF_ROOT;
   }
   // polish: find adjacent doubles a < b with froot(a) < 0 < froot(b)
@@ -483,7 +487,8 @@ __global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, 
       for (int k = 0; k < EPL; ++k) out[k] = ((snorm == 0.0) ? 0.0 : alpha * grp.S[k]) - grp.XS[k];  // :74,:77
     } else {
       double root;
-      const int status = binf_root<LPG>(grp, lam, sigma, delta, nullptr, root);
+      double rsa, rsb;
+      const int status = binf_root<LPG>(grp, lam, sigma, delta, nullptr, root, rsa, rsb);
       const double sl = lam * sigma;
       if (status == BINF_LITERAL) {
         // rare (degenerate bracket / exact zero / NaN): handed to k_group_list, which evaluates the reference's
@@ -498,11 +503,15 @@ __global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, 
         const double u = root - sl, tau = u * fast_rcp(root), c = root * fast_rcp(u);  // c = sigma * step (:106)
         double w[EPL], sw = 0.0;
 #pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-          w[k] = binf_w(grp.S[k], grp.X[k], tau, c, delta);  // :111
-          sw += w[k] * w[k];
+        for (int k = 0; k < EPL; ++k) w[k] = binf_w(grp.S[k], grp.X[k], tau, c, delta);  // :111
+        double nw;
+        if (rsa >= 0.0) {  // ||w||^2 = A + c^2 B from the root finder's last pass: no further reduction
+          nw = sqrt_pos(__builtin_fma(c * c, rsb, rsa));
+        } else {
+#pragma unroll
+          for (int k = 0; k < EPL; ++k) sw += w[k] * w[k];
+          nw = sqrt_pos(lanes_sum<LPG>(sw));
         }
-        const double nw = sqrt_pos(lanes_sum<LPG>(sw));
         const double alpha = jl_max(0.0, 1 - sl * fast_rcp(nw));  // l2prox, :83
 #pragma unroll
         for (int k = 0; k < EPL; ++k) out[k] = alpha * w[k] - grp.XS[k];  // :110-116
@@ -553,7 +562,8 @@ __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, c
       }
     } else {
       double root;
-      int status = list ? BINF_LITERAL : binf_root<TEAM>(grp, lam, sigma, delta, lds, root);
+      double rsa, rsb;
+      int status = list ? BINF_LITERAL : binf_root<TEAM>(grp, lam, sigma, delta, lds, root, rsa, rsb);
       const double sl = lam * sigma;
       if (status == BINF_LITERAL) {
         // the reference, literally, including its last step (:106-113) -- the root may lie below sl here
