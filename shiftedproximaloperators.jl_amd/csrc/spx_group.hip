@@ -449,6 +449,10 @@ __global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, 
   const int slot = lane / LPG;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  // plain GroupNormL2 stages its loads through LDS (LDS-DMA, +2 %: 0.650-0.664 vs 0.666-0.677 ms at 1e6 x 128);
+  // the Binf form is VALU-bound and loses 6 % to the lower occupancy the LDS footprint allows, so it keeps register loads
+  constexpr bool kDma = !BINF;
+  __shared__ __attribute__((aligned(16))) char dma_lds[kDma ? 4 * 3 * (EPL / 2) * 1024 : 16];
   for (int64_t g0 = wave * GPW; g0 < ngroups; g0 += nwaves * GPW) {  // wave-uniform trip count
     bool valid = (g0 + slot) < ngroups;
     const int64_t g = valid ? (g0 + slot) : (ngroups - 1);  // idle slots shadow the last group, no store
@@ -459,11 +463,31 @@ __global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, 
       const f64x2* x2 = reinterpret_cast<const f64x2*>(xk_ + base);
       const f64x2* s2 = reinterpret_cast<const f64x2*>(sj_ + base);
       f64x2 vq[EPL / 2], vx[EPL / 2], vs[EPL / 2];
+      if constexpr (kDma) {
+        // LDS-DMA staging (as k_sep_lds): piece k of a wave = the k-th 16-byte pair of each lane; lane `lane` of the
+        // wave lands at byte 16*lane of the piece, whichever group slot it serves
+        typedef __attribute__((address_space(3))) void lds_void;
+        char* wl = dma_lds + (threadIdx.x >> 6) * (3 * (EPL / 2) * 1024);
 #pragma unroll
-      for (int k = 0; k < EPL / 2; ++k) {
-        vq[k] = __builtin_nontemporal_load(q2 + k * LPG + j);
-        vx[k] = __builtin_nontemporal_load(x2 + k * LPG + j);
-        vs[k] = __builtin_nontemporal_load(s2 + k * LPG + j);
+        for (int k = 0; k < EPL / 2; ++k) {
+          __builtin_amdgcn_global_load_lds((const void*)(q2 + k * LPG + j), (lds_void*)(wl + (0 * (EPL / 2) + k) * 1024), 16, 0, 2);
+          __builtin_amdgcn_global_load_lds((const void*)(x2 + k * LPG + j), (lds_void*)(wl + (1 * (EPL / 2) + k) * 1024), 16, 0, 2);
+          __builtin_amdgcn_global_load_lds((const void*)(s2 + k * LPG + j), (lds_void*)(wl + (2 * (EPL / 2) + k) * 1024), 16, 0, 2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < EPL / 2; ++k) {
+          vq[k] = *reinterpret_cast<const f64x2*>(wl + (0 * (EPL / 2) + k) * 1024 + lane * 16);
+          vx[k] = *reinterpret_cast<const f64x2*>(wl + (1 * (EPL / 2) + k) * 1024 + lane * 16);
+          vs[k] = *reinterpret_cast<const f64x2*>(wl + (2 * (EPL / 2) + k) * 1024 + lane * 16);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < EPL / 2; ++k) {
+          vq[k] = __builtin_nontemporal_load(q2 + k * LPG + j);
+          vx[k] = __builtin_nontemporal_load(x2 + k * LPG + j);
+          vs[k] = __builtin_nontemporal_load(s2 + k * LPG + j);
+        }
       }
 #pragma unroll
       for (int k = 0; k < EPL / 2; ++k) {
