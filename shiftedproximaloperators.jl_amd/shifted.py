@@ -282,8 +282,12 @@ class _GroupLayout:
             elif isinstance(g, range):
                 a, b, st = g.start, g.stop, g.step
             else:
-                raise NotImplementedError("gather-index groups (arbitrary index vectors) are not on the accelerated "
-                                          "path; pass contiguous ranges")
+                # an explicit index vector (the reference's `collect(4:6)`): accepted when it is a contiguous run
+                idx = [int(v) for v in (g.tolist() if hasattr(g, "tolist") else g)]
+                if not idx or any(j - i != 1 for i, j in zip(idx, idx[1:])):
+                    raise NotImplementedError("gather-index groups (non-contiguous index vectors) are not on the "
+                                              "accelerated path; pass contiguous ranges")
+                a, b, st = idx[0], idx[-1] + 1, 1
             if st != 1 or a < 0 or b > n or a > b:
                 raise NotImplementedError("groups must be contiguous 0-based ranges inside 0:n")
             bounds.append((a, b))

@@ -332,6 +332,12 @@ def test_group_binf_goldens_and_edge_branches(s, orc, kats):
         h = s.GroupNormL2(k["lambda"], [range(a, b) for a, b in zip(off[:-1], off[1:])])
         y = s.prox(s.shifted(h, x, k["delta"], s.NormLinf(1.0)), q, k["sigma"]).cpu().numpy()
         np.testing.assert_allclose(y, k["expected"], rtol=k["rtol"], atol=0)
+        # explicit index vectors as in the reference test (`v = [collect(1:3), collect(4:6)]`, runtests.jl:658)
+        hv = s.GroupNormL2(k["lambda"], [list(range(a, b)) for a, b in zip(off[:-1], off[1:])])
+        yv = s.prox(s.shifted(hv, x, k["delta"], s.NormLinf(1.0)), q, k["sigma"]).cpu().numpy()
+        assert _bits_equal(y, yv)
+    with pytest.raises(NotImplementedError):
+        s.shifted(s.GroupNormL2([1.0, 1.0], [[0, 2, 4], [1, 3, 5]]), _dev(np.ones(6))[0])  # true gather groups: not built
     # branches of shiftedGroupNormL2Binf.jl:102-109: zero groups, |X| <= Delta everywhere, huge lambda
     n, g = 128 * 6, 128
     rng = np.random.default_rng(5)
