@@ -170,6 +170,12 @@ int spx_prox_indball_l0(spx_ctx* ctx, double* y, const double* q, const double* 
 int spx_prox_indball_l0_binf(spx_ctx* ctx, double* y, const double* q, const double* xk,
                              const double* sj, int64_t n, int64_t r, double delta);
 
+/* ---- l1 norm + l2-ball trust region ------------------------------------------------------ */
+/* ShiftedNormL1B2.prox!  src/shiftedNormL1B2.jl:50-67 (chi = NormL2(chi_lambda)).  All elements are coupled through
+ * one scalar root (find_zero, :62): the call runs a few global reduction passes and synchronises after each. */
+int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                   int64_t n, double lambda, double sigma, double delta, double chi_lambda);
+
 /* ---- group operators -------------------------------------------------------------------- */
 /* Groups are contiguous index ranges (the reference's `idx` entries as UnitRanges / [:]):
  *   group_offsets != NULL : CSR offsets (device, int64, length ngroups+1, 0-based, non-decreasing,

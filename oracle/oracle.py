@@ -69,6 +69,8 @@ def lib():
         L.orc_obj_indball_l0.restype = d
         L.orc_obj_group_l2.argtypes = [dp, dp, dp, i64, ip, i64, i64, dp, d]
         L.orc_obj_group_l2.restype = d
+        L.orc_prox_l1_b2.argtypes = base + [d, d, d, d]
+        L.orc_prox_l1_b2.restype = None
         L.orc_rootnormlhalf_prox.argtypes = [dp, dp, i64, d, d]
         L.orc_rootnormlhalf_prox.restype = d
         for name in ("orc_prox_l1", "orc_prox_l0", "orc_prox_lhalf", "orc_prox_l1_box", "orc_prox_l0_box",
@@ -289,3 +291,9 @@ def obj_group_l2(y, xk, sj, lam, offsets=None, gsize=0, delta=None):
     off, offp, gs, ng = _groups(n, offsets, gsize)
     lam = _f64(lam)
     return lib().orc_obj_group_l2(_dp(y), _dp(xk), _dp(sj), n, offp, gs, ng, _dp(lam), -1.0 if delta is None else float(delta))
+
+
+def prox_l1_b2(q, xk, sj, lam, sigma, delta, chi_lambda=1.0):
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    lib().orc_prox_l1_b2(_dp(y), _dp(q), _dp(xk), _dp(sj), n, lam, sigma, delta, chi_lambda)
+    return y

@@ -687,6 +687,61 @@ ORC_API double orc_obj_group_l2(const double* y, const double* xk, const double*
   return sum_c;
 }
 
+/* ==========================================================================================
+ * ShiftedNormL1B2.prox!  src/shiftedNormL1B2.jl:50-67  
+ * find_zero(froot, Delta) [ext: Roots.jl, single starting point => Order0, a bracketing hybrid]: restated as
+ * "expand from Delta until froot changes sign, then bit-midpoint bisection to exhaustion" -- the sign change is
+ * unique (froot(eta)/eta is non-decreasing), so any convergent method ends within an ulp of the same point; the
+ * reference's own stopping tolerance is unknown (its test pins the result to sqrt(eps) only).
+ * ========================================================================================== */
+typedef struct { const double *q, *xk, *sj; int64_t n; double ls, delta, chil; } b2_ctx;
+static double b2_norm_projb(const b2_ctx* c, double scale) { /* chi(ProjB((-xk) .* scale)) */
+  double ss = 0.0;
+  for (int64_t i = 0; i < c->n; ++i) {
+    double sq = c->sj[i] + c->q[i];
+    double p = jl_min(jl_max((-c->xk[i]) * scale, sq - c->ls), sq + c->ls); /* :56 */
+    ss += p * p;
+  }
+  return c->chil * sqrt(ss);
+}
+static double b2_froot(const b2_ctx* c, double eta) { return eta - b2_norm_projb(c, eta / c->delta); } /* :57 */
+
+ORC_API void orc_prox_l1_b2(double* y, const double* q, const double* xk, const double* sj, int64_t n, double lambda,
+                            double sigma, double delta, double chi_lambda) {
+  b2_ctx c = {q, xk, sj, n, lambda * sigma, delta, chi_lambda};
+  double chiy = b2_norm_projb(&c, 1.0); /* y = ProjB(-xk), :59; chi(y), :61 */
+  double scale = 1.0, back = 1.0;
+  if (delta <= chiy) {
+    double a = delta, fa = b2_froot(&c, a);
+    double eta = a;
+    if (fa != 0.0) {
+      double b = 2 * a, fb = b2_froot(&c, b);
+      for (int it = 0; it < 2000 && !(fb > 0) && isfinite(b); ++it) { a = b; fa = fb; b = 2 * b; fb = b2_froot(&c, b); }
+      if (fb == 0.0) eta = b;
+      else {
+        for (int it = 0; it < 200; ++it) {
+          double m = bit_middle(a, b);
+          if (!(a < m && m < b)) break;
+          double fm = b2_froot(&c, m);
+          if (jl_sign(fa) * jl_sign(fm) < 0) { b = m; fb = fm; } else { a = m; fa = fm; }
+        }
+        eta = (fabs(fa) < fabs(fb)) ? a : b;
+      }
+    }
+    scale = eta / delta; /* :63 */
+    back = delta / eta;
+    for (int64_t i = 0; i < n; ++i) {
+      double sq = sj[i] + q[i];
+      y[i] = jl_min(jl_max((-xk[i]) * scale, sq - c.ls), sq + c.ls) * back - sj[i]; /* :63,:65 */
+    }
+    return;
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    double sq = sj[i] + q[i];
+    y[i] = jl_min(jl_max(-xk[i], sq - c.ls), sq + c.ls) - sj[i]; /* :59,:65 */
+  }
+}
+
 /* Objective value 1/(2 sigma) (t-q)^2 + lambda*h(x+s+t) helpers for the brute-force second oracle
  * live in tests/ (numpy); nothing else is exported from here. */
 ORC_API int orc_abi_version(void) { return 2; }

@@ -7,7 +7,7 @@ from .functions import (GroupNormL2, IndBallL0, NormL0, NormL1, NormL2, NormLinf
                         RootNormLhalf)
 from .sharding import shard_range
 from .shifted import (ShiftedGroupNormL2, ShiftedGroupNormL2Binf, ShiftedIndBallL0, ShiftedIndBallL0BInf,
-                      ShiftedNormL0, ShiftedNormL0Box, ShiftedNormL1, ShiftedNormL1Box,
+                      ShiftedNormL0, ShiftedNormL0Box, ShiftedNormL1, ShiftedNormL1B2, ShiftedNormL1Box,
                       ShiftedProximableFunction, ShiftedRootNormLhalf, ShiftedRootNormLhalfBox, context, iprox,
                       iprox_bang, prox,
                       prox_bang, set_bounds_bang, set_radius_bang, shift_bang, shifted, synchronize)

@@ -369,10 +369,13 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
         break;
       }
     }
-    if (!(v > ulo && v < uhi)) v = sqrt_pos(ulo) * sqrt_pos(uhi);  // safeguard: geometric bisection of the bracket
+    const bool exact_step = (v > ulo && v < uhi);  // v is the root of the piece (sa, sb)
+    if (!exact_step) v = sqrt_pos(ulo) * sqrt_pos(uhi);  // safeguard: geometric bisection of the bracket
     if (!(v > ulo && v < uhi)) break;
     const bool small = fabs(v - u) <= 4 * eps * v;
-    pa = sa; pb = sb; u = v;
+    pa = exact_step ? sa : -1.0;  // only an exact piece root may be "confirmed" by identical sums in the next pass
+    pb = exact_step ? sb : -1.0;
+    u = v;
     if (small) break;
     const double tau = u * fast_rcp(sl + u);
     binf_ab<TEAM>(grp, tau, delta, lds, sa, sb);

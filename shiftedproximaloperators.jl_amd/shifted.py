@@ -245,6 +245,17 @@ def _build_mask(selected, xk):
     return (mask, idx)  # keep idx alive until the scatter has run on the stream
 
 
+class ShiftedNormL1B2(ShiftedProximableFunction):  # src/shiftedNormL1B2.jl
+    def __init__(self, h, xk, sj, Δ, χ, shifted_twice):
+        super().__init__(h, xk, sj, shifted_twice)
+        self.Δ = float(Δ)
+        self.χ = χ
+
+    def _prox(self, L, ctx, y, q, sigma):
+        _lib.check(L.spx_prox_l1_b2(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), y.numel(), self.h.lam, sigma,
+                                    self.Δ, self.χ.lam))
+
+
 class _TopR(ShiftedProximableFunction):
     pass
 
@@ -361,6 +372,8 @@ def shifted(h, x, *args):
             return type(ψ)(ψ.h, ψ.xk, sj, ψ.l, ψ.u, True, ψ.selected, _mask=ψ._mask)
         if isinstance(ψ, ShiftedIndBallL0BInf):
             return ShiftedIndBallL0BInf(ψ.h, ψ.xk, sj, ψ.Δ, ψ.χ, True)
+        if isinstance(ψ, ShiftedNormL1B2):
+            return ShiftedNormL1B2(ψ.h, ψ.xk, sj, ψ.Δ, ψ.χ, True)
         if isinstance(ψ, ShiftedGroupNormL2Binf):
             return ShiftedGroupNormL2Binf(ψ.h, ψ.xk, sj, ψ.Δ, ψ.χ, True, _layout=ψ._layout)
         if isinstance(ψ, ShiftedGroupNormL2):
@@ -379,6 +392,8 @@ def shifted(h, x, *args):
         if isinstance(h, GroupNormL2):
             return ShiftedGroupNormL2(h, xk, zero(), False)
         raise TypeError("MethodError: no accelerated shifted() for %s" % type(h).__name__)
+    if len(args) == 2 and isinstance(args[1], NormL2) and isinstance(h, NormL1):  # shiftedNormL1B2.jl:35-36
+        return ShiftedNormL1B2(h, xk, zero(), float(args[0]), args[1], False)
     if len(args) in (2, 3) and isinstance(args[1], NormLinf):  # shifted(h, xk, Δ, χ[, selected])
         Δ, χ = float(args[0]), args[1]
         selected = args[2] if len(args) == 3 else None

@@ -24,6 +24,7 @@ kats = {
             "ShiftedNormL0Box": [-0.010000000000000, 0.005867144197216, -0.005127050164992, -0.010000000000000, 0.010000000000000],
             "ShiftedNormL1Box": [-0.010000000000000, 0.005856155186227, -0.005138039175981, -0.010000000000000, 0.010000000000000],
             "ShiftedRootNormLhalfBox": [-0.010000000000000, 0.005861665724748, -0.005132558825434, -0.010000000000000, 0.010000000000000],
+            "ShiftedNormL1B2": [-0.006367076930786, 0.001288947922799, -0.001130889587543, -0.004285677352167, 0.006176811716709],
         },
     },
     "group_l2_binf_single": {

@@ -527,3 +527,24 @@ def test_objective_groups_and_reference_identities(s, orc):
     assert abs(psi(zero) - hx) <= 1e-12 * hx            # psi(zeros(n)) == h(x)
     yy = rng.random(m); yy *= 0.01 / np.max(np.abs(yy)) / 2
     assert np.isfinite(psi(_dev(yy)[0])) and psi(_dev(3 * yy)[0]) == np.inf   # inside / outside the trust region
+
+
+# ------------------------------------------------------------------ ShiftedNormL1B2
+def test_l1b2(s, orc, kats):
+    k = kats["box_golden"]  # test/runtests.jl:467-474
+    x, q = _dev(np.array(k["x"]), np.array(k["q"]))
+    psi = s.shifted(s.NormL1(k["lambda"]), x, k["delta"], s.NormL2(1.0))
+    assert type(psi).__name__ == "ShiftedNormL1B2"
+    y = s.prox(psi, q, k["sigma"]).cpu().numpy()
+    np.testing.assert_allclose(y, k["expected"]["ShiftedNormL1B2"], rtol=k["rtol"], atol=0)
+    for n in (1, 2, 7, 1000, 300_001):
+        xh, sh, qh = _data(n, 900 + n)
+        xd, sd, qd = _dev(xh, sh, qh)
+        for lam, sigma, delta in ((1.0, 1.0, 1.0), (0.3, 2.0, 0.05 * np.sqrt(n)), (2.0, 0.5, 100.0 * np.sqrt(n))):
+            om = s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(1.0)), sd)
+            y = s.prox(om, qd, sigma).cpu().numpy()
+            ref = orc.prox_l1_b2(qh, xh, sh, lam, sigma, delta, 1.0)
+            scale = max(np.linalg.norm(ref), np.linalg.norm(xh), 1e-300)
+            assert np.max(np.abs(y - ref)) <= 1e-12 * scale, (n, lam, sigma, delta)
+        s.set_radius_bang(om, 0.5)
+        assert om.Δ == 0.5

@@ -289,3 +289,23 @@ def test_objective_identities(orc):
     want = 0.4 * np.linalg.norm((x + y)[:3]) + 0.5 * np.linalg.norm((x + y)[3:6])
     assert abs(g - want) <= 1e-14
     assert orc.obj_group_l2(3 * y[:6], x[:6], z[:6], lam, offsets=[0, 3, 6], delta=0.01) == np.inf
+
+
+# ---- ShiftedNormL1B2 --------------------------------------------------------------------
+def test_l1b2_golden_and_minimiser(orc, kats):
+    k = kats["box_golden"]  # same inputs, test/runtests.jl:467-474
+    y = orc.prox_l1_b2(k["q"], k["x"], k["s"], k["lambda"], k["sigma"], k["delta"], 1.0)
+    np.testing.assert_allclose(y, k["expected"]["ShiftedNormL1B2"], rtol=k["rtol"], atol=0)
+    assert np.linalg.norm(y) <= k["delta"] * (1 + 1e-12)  # chi(s) <= Delta, runtests.jl:494
+    # small independent check: the result minimises 1/(2 sigma)||t - q||^2 + lambda||x + s + t||_1 over ||s + t||_2 <= Delta
+    rng = np.random.default_rng(21)
+    for trial in range(20):
+        n = 3
+        x, s, q = rng.normal(size=n), rng.uniform(-0.2, 0.2, size=n), rng.normal(size=n)
+        lam, sigma, delta = rng.uniform(0.2, 1.5), rng.uniform(0.3, 1.5), rng.uniform(0.5, 1.5)
+        t = orc.prox_l1_b2(q, x, s, lam, sigma, delta, 1.0)
+        obj = lambda tt: np.sum((tt - q) ** 2, axis=-1) / (2 * sigma) + lam * np.sum(np.abs(x + s + tt), axis=-1)
+        assert np.linalg.norm(s + t) <= delta * (1 + 1e-9)
+        cand = rng.normal(size=(200000, n))
+        cand = cand / np.linalg.norm(cand, axis=1, keepdims=True) * delta * rng.random((200000, 1)) ** (1 / n) - s
+        assert obj(t) <= np.min(obj(cand)) + 1e-6
