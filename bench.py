@@ -236,7 +236,7 @@ def _extra(s, L, ctx, dev, n, torch):
     q = torch.randn(m, dtype=torch.float64, device=dev, generator=gen)
     y = torch.empty_like(q)
     lam = torch.rand(ng, dtype=torch.float64, device=dev, generator=gen) + 0.5
-    h = s.GroupNormL2(lam, [range(i, i + 128) for i in range(0, m, 128)])
+    h = s.GroupNormL2.uniform(lam, 128)
     bpe = 32 + 8 / 128
     line("ShiftedGroupNormL2_%dx128" % ng, s.shifted(s.shifted(h, xk), sj), bpe, m, y, q)
     line("ShiftedGroupNormL2Binf_%dx128" % ng, s.shifted(s.shifted(h, xk, 1.0, chi), sj), bpe, m, y, q)

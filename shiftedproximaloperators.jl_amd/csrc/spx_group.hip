@@ -440,12 +440,16 @@ __device__ __forceinline__ double binf_w(double S, double X, double tau, double 
 #ifndef SPX_GROUP_WAVES
 #define SPX_GROUP_WAVES 3  // min waves/SIMD (VGPR cap).  Binf 1e6x128: 3 (162 VGPRs, no spill) 0.84 ms; 4 (128, cold paths spill) 0.93 ms; 5: 1.49 ms
 #endif
-template <int LPG, int EPL, bool BINF>
+// PAIRS: the group size is even (every group starts 16-byte aligned): lane j owns the pairs j, j + LPG, ...; pairs past
+// the end of the group are read as zeros (zeros are neutral in every sum of both operators).  !PAIRS: odd group size,
+// lane j owns the elements j, j + LPG, ... through 8-byte loads.
+template <int LPG, int EPL, bool BINF, bool PAIRS>
 __global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, const double* q_, const double* xk_, const double* sj_,
-                                                    int64_t ngroups, const double* __restrict__ lambda, double sigma,
-                                                    double delta, long long* deferred /* [0] = count, [1..] = groups */) {
+                                                    int64_t ngroups, int gsize, const double* __restrict__ lambda,
+                                                    double sigma, double delta,
+                                                    long long* deferred /* [0] = count, [1..] = groups */) {
   static_assert((EPL % 2) == 0, "EPL must be even (16-byte pairs)");
-  constexpr int GS = LPG * EPL;
+  const int64_t GS = gsize;  // <= LPG * EPL
   constexpr int GPW = 64 / LPG;  // groups per wave
   const int lane = threadIdx.x & 63;
   const int j = lane % LPG;
@@ -454,52 +458,71 @@ __global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, 
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   // plain GroupNormL2 stages its loads through LDS (LDS-DMA, +2 %: 0.650-0.664 vs 0.666-0.677 ms at 1e6 x 128);
   // the Binf form is VALU-bound and loses 6 % to the lower occupancy the LDS footprint allows, so it keeps register loads
-  constexpr bool kDma = !BINF;
+  constexpr bool kDma = !BINF && PAIRS;
   __shared__ __attribute__((aligned(16))) char dma_lds[kDma ? 4 * 3 * (EPL / 2) * 1024 : 16];
+  const int npairs = gsize >> 1;
   for (int64_t g0 = wave * GPW; g0 < ngroups; g0 += nwaves * GPW) {  // wave-uniform trip count
     bool valid = (g0 + slot) < ngroups;
     const int64_t g = valid ? (g0 + slot) : (ngroups - 1);  // idle slots shadow the last group, no store
     const int64_t base = g * GS;
     RegGroup<EPL> grp;
     {
-      const f64x2* q2 = reinterpret_cast<const f64x2*>(q_ + base);
-      const f64x2* x2 = reinterpret_cast<const f64x2*>(xk_ + base);
-      const f64x2* s2 = reinterpret_cast<const f64x2*>(sj_ + base);
-      f64x2 vq[EPL / 2], vx[EPL / 2], vs[EPL / 2];
-      if constexpr (kDma) {
-        // LDS-DMA staging (as k_sep_lds): piece k of a wave = the k-th 16-byte pair of each lane; lane `lane` of the
-        // wave lands at byte 16*lane of the piece, whichever group slot it serves
-        typedef __attribute__((address_space(3))) void lds_void;
-        char* wl = dma_lds + (threadIdx.x >> 6) * (3 * (EPL / 2) * 1024);
+      if constexpr (PAIRS) {
+        const f64x2* q2 = reinterpret_cast<const f64x2*>(q_ + base);
+        const f64x2* x2 = reinterpret_cast<const f64x2*>(xk_ + base);
+        const f64x2* s2 = reinterpret_cast<const f64x2*>(sj_ + base);
+        f64x2 vq[EPL / 2], vx[EPL / 2], vs[EPL / 2];
+        if constexpr (kDma) {
+          // LDS-DMA staging (as k_sep_lds): piece k of a wave = the k-th 16-byte pair of each lane; lane `lane` of the
+          // wave lands at byte 16*lane of the piece, whichever group slot it serves
+          typedef __attribute__((address_space(3))) void lds_void;
+          char* wl = dma_lds + (threadIdx.x >> 6) * (3 * (EPL / 2) * 1024);
 #pragma unroll
-        for (int k = 0; k < EPL / 2; ++k) {
-          __builtin_amdgcn_global_load_lds((const void*)(q2 + k * LPG + j), (lds_void*)(wl + (0 * (EPL / 2) + k) * 1024), 16, 0, 2);
-          __builtin_amdgcn_global_load_lds((const void*)(x2 + k * LPG + j), (lds_void*)(wl + (1 * (EPL / 2) + k) * 1024), 16, 0, 2);
-          __builtin_amdgcn_global_load_lds((const void*)(s2 + k * LPG + j), (lds_void*)(wl + (2 * (EPL / 2) + k) * 1024), 16, 0, 2);
+          for (int k = 0; k < EPL / 2; ++k) {
+            const int p = (k * LPG + j < npairs) ? (k * LPG + j) : 0;  // masked pairs re-read pair 0, zeroed below
+            __builtin_amdgcn_global_load_lds((const void*)(q2 + p), (lds_void*)(wl + (0 * (EPL / 2) + k) * 1024), 16, 0, 2);
+            __builtin_amdgcn_global_load_lds((const void*)(x2 + p), (lds_void*)(wl + (1 * (EPL / 2) + k) * 1024), 16, 0, 2);
+            __builtin_amdgcn_global_load_lds((const void*)(s2 + p), (lds_void*)(wl + (2 * (EPL / 2) + k) * 1024), 16, 0, 2);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < EPL / 2; ++k) {
+            vq[k] = *reinterpret_cast<const f64x2*>(wl + (0 * (EPL / 2) + k) * 1024 + lane * 16);
+            vx[k] = *reinterpret_cast<const f64x2*>(wl + (1 * (EPL / 2) + k) * 1024 + lane * 16);
+            vs[k] = *reinterpret_cast<const f64x2*>(wl + (2 * (EPL / 2) + k) * 1024 + lane * 16);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < EPL / 2; ++k) {
+            const int p = (k * LPG + j < npairs) ? (k * LPG + j) : 0;
+            vq[k] = __builtin_nontemporal_load(q2 + p);
+            vx[k] = __builtin_nontemporal_load(x2 + p);
+            vs[k] = __builtin_nontemporal_load(s2 + p);
+          }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int k = 0; k < EPL / 2; ++k) {
-          vq[k] = *reinterpret_cast<const f64x2*>(wl + (0 * (EPL / 2) + k) * 1024 + lane * 16);
-          vx[k] = *reinterpret_cast<const f64x2*>(wl + (1 * (EPL / 2) + k) * 1024 + lane * 16);
-          vs[k] = *reinterpret_cast<const f64x2*>(wl + (2 * (EPL / 2) + k) * 1024 + lane * 16);
+          const bool in = (k * LPG + j) < npairs;
+          const f64x2 zero2 = f64x2{0.0, 0.0};
+          const f64x2 a = in ? vq[k] : zero2, b = in ? vx[k] : zero2, c = in ? vs[k] : zero2;
+          grp.S[2 * k] = (a.x + b.x) + c.x;  // shiftedGroupNormL2.jl:65 / shiftedGroupNormL2Binf.jl:80
+          grp.S[2 * k + 1] = (a.y + b.y) + c.y;
+          grp.X[2 * k] = b.x;
+          grp.X[2 * k + 1] = b.y;
+          grp.XS[2 * k] = b.x + c.x;
+          grp.XS[2 * k + 1] = b.y + c.y;
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < EPL / 2; ++k) {
-          vq[k] = __builtin_nontemporal_load(q2 + k * LPG + j);
-          vx[k] = __builtin_nontemporal_load(x2 + k * LPG + j);
-          vs[k] = __builtin_nontemporal_load(s2 + k * LPG + j);
+        for (int k = 0; k < EPL; ++k) {
+          const int e = k * LPG + j;
+          const bool in = e < gsize;
+          const int64_t i = base + (in ? e : 0);
+          const double a = in ? q_[i] : 0.0, b = in ? xk_[i] : 0.0, c = in ? sj_[i] : 0.0;
+          grp.S[k] = (a + b) + c;
+          grp.X[k] = b;
+          grp.XS[k] = b + c;
         }
-      }
-#pragma unroll
-      for (int k = 0; k < EPL / 2; ++k) {
-        grp.S[2 * k] = (vq[k].x + vx[k].x) + vs[k].x;  // shiftedGroupNormL2.jl:65 / shiftedGroupNormL2Binf.jl:80
-        grp.S[2 * k + 1] = (vq[k].y + vx[k].y) + vs[k].y;
-        grp.X[2 * k] = vx[k].x;
-        grp.X[2 * k + 1] = vx[k].y;
-        grp.XS[2 * k] = vx[k].x + vs[k].x;
-        grp.XS[2 * k + 1] = vx[k].y + vs[k].y;
       }
     }
     const double lam = lambda[g];
@@ -545,10 +568,16 @@ __global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, 
       }
     }
     if (valid) {
-      f64x2* y2 = reinterpret_cast<f64x2*>(y_ + base);
+      if constexpr (PAIRS) {
+        f64x2* y2 = reinterpret_cast<f64x2*>(y_ + base);
 #pragma unroll
-      for (int k = 0; k < EPL / 2; ++k)
-        __builtin_nontemporal_store(f64x2{out[2 * k], out[2 * k + 1]}, y2 + k * LPG + j);
+        for (int k = 0; k < EPL / 2; ++k)
+          if (k * LPG + j < npairs) __builtin_nontemporal_store(f64x2{out[2 * k], out[2 * k + 1]}, y2 + k * LPG + j);
+      } else {
+#pragma unroll
+        for (int k = 0; k < EPL; ++k)
+          if (k * LPG + j < gsize) y_[base + k * LPG + j] = out[k];
+      }
     }
   }
 }
@@ -655,47 +684,50 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   SPX_HIP(hipSetDevice(ctx->device));
   const int64_t cap_blocks = (int64_t)ctx->num_cu * 8;
   const bool aligned = spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj);
-  if (!offsets && aligned) {
-    // register path: gsize = LPG * EPL
-    int lpg = 0;
-    switch (gsize) {
-      case 32: case 64: case 128: lpg = 16; break;
-      case 256: lpg = 32; break;
-      case 384: case 512: lpg = 64; break;
-      default: break;
+  if (!offsets && gsize <= 512) {
+    // register path: the smallest (LPG, EPL) tile that holds a group; partly filled tiles are padded with zeros
+    int lpg, epl;
+    if (gsize <= 32) { lpg = 16; epl = 2; }
+    else if (gsize <= 64) { lpg = 16; epl = 4; }
+    else if (gsize <= 128) { lpg = 16; epl = 8; }
+    else if (gsize <= 256) { lpg = 32; epl = 8; }
+    else if (gsize <= 384) { lpg = 64; epl = 6; }
+    else { lpg = 64; epl = 8; }
+    const int gpw = 64 / lpg;
+    int64_t blocks = (ngroups + 4 * gpw - 1) / (4 * gpw);  // 4 waves per 256-thread block
+    if (blocks > 0x7fffffff) blocks = 0x7fffffff;
+    dim3 grid((unsigned)blocks), block(256);
+    long long* deferred = nullptr;
+    if (BINF) {  // list of the groups whose bracket needs the reference's literal evaluation
+      rc = spx_ws_reserve(ctx, (size_t)(ngroups + 1) * sizeof(long long) + 256);
+      if (rc) return rc;
+      deferred = reinterpret_cast<long long*>(ctx->ws);
+      SPX_HIP(hipMemsetAsync(deferred, 0, sizeof(long long), ctx->stream));
     }
-    if (lpg) {
-      const int gpw = 64 / lpg;
-      int64_t blocks = (ngroups + 4 * gpw - 1) / (4 * gpw);  // 4 waves per 256-thread block
-      if (blocks > 0x7fffffff) blocks = 0x7fffffff;
-      dim3 grid((unsigned)blocks), block(256);
-      long long* deferred = nullptr;
-      if (BINF) {  // list of the groups whose bracket needs the reference's literal evaluation
-        rc = spx_ws_reserve(ctx, (size_t)(ngroups + 1) * sizeof(long long) + 256);
-        if (rc) return rc;
-        deferred = reinterpret_cast<long long*>(ctx->ws);
-        SPX_HIP(hipMemsetAsync(deferred, 0, sizeof(long long), ctx->stream));
-      }
-#define SPX_LAUNCH_REG(LPG, EPL)                                                                                 \
-  hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups, lambda, \
-                     sigma, delta, deferred)
-      switch (gsize) {
-        case 32: SPX_LAUNCH_REG(16, 2); break;
-        case 64: SPX_LAUNCH_REG(16, 4); break;
-        case 128: SPX_LAUNCH_REG(16, 8); break;
-        case 256: SPX_LAUNCH_REG(32, 8); break;
-        case 384: SPX_LAUNCH_REG(64, 6); break;
-        case 512: SPX_LAUNCH_REG(64, 8); break;
-      }
+    const bool pairs = (gsize & 1) == 0 && aligned;  // otherwise 8-byte loads
+#define SPX_LAUNCH_REG(LPG, EPL)                                                                                    \
+  do {                                                                                                              \
+    if (pairs)                                                                                                      \
+      hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, true>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,   \
+                         (int)gsize, lambda, sigma, delta, deferred);                                               \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, false>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,  \
+                         (int)gsize, lambda, sigma, delta, deferred);                                               \
+  } while (0)
+    if (lpg == 16 && epl == 2) SPX_LAUNCH_REG(16, 2);
+    else if (lpg == 16 && epl == 4) SPX_LAUNCH_REG(16, 4);
+    else if (lpg == 16) SPX_LAUNCH_REG(16, 8);
+    else if (lpg == 32) SPX_LAUNCH_REG(32, 8);
+    else if (epl == 6) SPX_LAUNCH_REG(64, 6);
+    else SPX_LAUNCH_REG(64, 8);
 #undef SPX_LAUNCH_REG
-      if (BINF) {  // usually an empty list: the kernel returns at once
-        hipLaunchKernelGGL((k_group_mem<64, BINF>), dim3((unsigned)(ctx->num_cu * 2)), dim3(256), 0, ctx->stream, y, q, xk,
-                           sj, n, (const int64_t*)nullptr, gsize, ngroups, lambda, sigma, delta,
-                           (const long long*)deferred);
-      }
-      SPX_LAUNCH_CHECK();
-      return SPX_OK;
+    if (BINF) {  // usually an empty list: the kernel returns at once
+      hipLaunchKernelGGL((k_group_mem<64, BINF>), dim3((unsigned)(ctx->num_cu * 2)), dim3(256), 0, ctx->stream, y, q, xk,
+                         sj, n, (const int64_t*)nullptr, gsize, ngroups, lambda, sigma, delta,
+                         (const long long*)deferred);
     }
+    SPX_LAUNCH_CHECK();
+    return SPX_OK;
   }
   // team width: wavefront per group unless groups are large on average
   const double avg = (double)n / (double)ngroups;

@@ -95,3 +95,28 @@ class GroupNormL2(ProximableFunction):
         self.idx = idx
 
     lambda_ = property(lambda self: self.lam)
+
+    @classmethod
+    def uniform(cls, lam, group_size):
+        """Groups 0:gs, gs:2gs, ... (one weight each) without materialising a million Python ranges; equivalent to
+        GroupNormL2(lam, [range(i, i + gs) for i in range(0, n, gs)])."""
+        import torch
+        nlam = lam.numel() if isinstance(lam, torch.Tensor) else len(lam)
+        obj = cls(lam, [None] * nlam)
+        obj.idx = UniformGroups(int(group_size), nlam)
+        return obj
+
+
+class UniformGroups:
+    """idx of GroupNormL2.uniform: `count` consecutive groups of `size` indices."""
+
+    def __init__(self, size, count):
+        if size <= 0:
+            raise ValueError("group size must be positive")
+        self.size, self.count = size, count
+
+    def __len__(self):
+        return self.count
+
+    def __iter__(self):
+        return (range(g * self.size, (g + 1) * self.size) for g in range(self.count))

@@ -286,6 +286,15 @@ class _GroupLayout:
     """Device-side description of GroupNormL2.idx / .lambda for a vector of length n."""
 
     def __init__(self, h, n, device):
+        from .functions import UniformGroups
+        if isinstance(h.idx, UniformGroups):
+            if h.idx.size * h.idx.count != n:
+                raise IndexError("BoundsError: %d groups of %d do not tile a vector of length %d" % (h.idx.count, h.idx.size, n))
+            self.ngroups, self.offsets, self.group_size = h.idx.count, None, h.idx.size
+            lam = h.lam
+            self.lam = (lam.to(device=device, dtype=torch.float64).contiguous() if isinstance(lam, torch.Tensor)
+                        else torch.tensor(lam, dtype=torch.float64, device=device))
+            return
         bounds = []
         for g in h.idx:
             if isinstance(g, slice):

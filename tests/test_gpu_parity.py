@@ -274,16 +274,28 @@ def _group_check(y, ref, q, x, sj, offsets):
     assert not bad.any(), (int(bad.sum()), float(np.max(np.abs(y - ref))))
 
 
-@pytest.mark.parametrize("gsize", [64, 128, 256, 512, 1, 7, 100, 3000])
+@pytest.mark.parametrize("gsize", [64, 128, 256, 512, 1, 2, 6, 7, 33, 66, 100, 130, 250, 257, 383, 386, 510, 511, 513,
+                                   3000])
 @pytest.mark.parametrize("binf", [False, True])
-def test_group_uniform(s, orc, gsize, binf):
-    ng = 513 if gsize <= 512 else 9
+@pytest.mark.parametrize("misaligned", [False, True])
+def test_group_uniform(s, orc, gsize, binf, misaligned):
+    # every tile of the register kernel, full and partly filled, even (16-byte pairs) and odd (8-byte loads) sizes;
+    # misaligned: all four vectors start 8 bytes off a 16-byte boundary
+    if misaligned and gsize not in (2, 64, 100, 128, 386, 512):
+        pytest.skip("misaligned views are checked on a subset")
+    ng = 513 if gsize <= 513 else 9
     n = ng * gsize
     x, sj, q = _data(n, 500 + gsize)
     lam = np.random.default_rng(gsize).uniform(0.5, 1.5, size=ng)
     sigma, delta = 1.0, 1.0
-    xd, sd, qd = _dev(x, sj, q)
-    h = s.GroupNormL2(lam.tolist(), [range(i, i + gsize) for i in range(0, n, gsize)])
+    if misaligned:
+        import torch
+        xd, sd, qd = (torch.cat([torch.zeros(1, dtype=torch.float64), torch.from_numpy(a)]).cuda()[1:] for a in (x, sj, q))
+        assert xd.data_ptr() % 16 == 8
+    else:
+        xd, sd, qd = _dev(x, sj, q)
+    h = s.GroupNormL2.uniform(lam.tolist(), gsize) if gsize % 2 else \
+        s.GroupNormL2(lam.tolist(), [range(i, i + gsize) for i in range(0, n, gsize)])
     if binf:
         psi = s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd)
         ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, gsize=gsize)

@@ -14,7 +14,7 @@ def vecs(m):
 if which in ("binf", "group"):
     ng = 1_000_000; m = ng * 128; xk, sj, q = vecs(m)
     lam = torch.rand(ng, dtype=torch.float64, device=dev, generator=g) + 0.5
-    h = s.GroupNormL2(lam, [range(i, i + 128) for i in range(0, m, 128)])
+    h = s.GroupNormL2.uniform(lam, 128)
     psi = s.shifted(s.shifted(h, xk, 1.0, chi), sj) if which == "binf" else s.shifted(s.shifted(h, xk), sj)
     bytes_ = (32 + 8 / 128) * m
 else:

@@ -43,7 +43,7 @@ if "group" in which or "binf" in which:
     del xk, sj, q, y
     xk, sj, q = vecs(m); y = torch.empty_like(q)
     lam = torch.rand(ng, dtype=torch.float64, device=dev, generator=g) + 0.5
-    h = s.GroupNormL2(lam, [range(i, i + 128) for i in range(0, m, 128)])
+    h = s.GroupNormL2.uniform(lam, 128)
     if "group" in which:
         psi = s.shifted(s.shifted(h, xk), sj)
         for _ in range(5): s.prox_bang(y, psi, q, 1.0)
