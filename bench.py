@@ -224,6 +224,31 @@ def _extra(s, L, ctx, dev, n, torch):
     iline("iprox_ShiftedNormL1Box", s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj))
     iline("iprox_ShiftedNormL0Box", s.shifted(s.shifted(s.NormL0(1.0), xk, 1.0, chi), sj))
     del d
+    # ShiftedNormL1B2: a few global reduction passes + the final pass, host round trips in between
+    psi_b2 = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, s.NormL2(1.0)), sj)
+    s.prox_bang(y, psi_b2, q, 1.0)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        s.prox_bang(y, psi_b2, q, 1.0)
+    s.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    res["ShiftedNormL1B2"] = {"ms": round(ms, 4), "gelem_s": round(n / ms / 1e6, 2),
+                              "gbs_algorithmic": round(32 * n / ms / 1e6, 1),
+                              "frac_of_peak": round(32 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+                              "note": "host wall time per call (the scalar root find synchronises)"}
+    # host-pointer form of the headline operator (spx_host_prox_l1_box): PCIe-inclusive, pageable numpy vectors
+    nh = min(n, 10**7)
+    hx, hs, hq = (t[:nh].cpu().numpy() for t in (xk, sj, q))
+    psi_h = s.shifted(s.shifted(s.NormL1(1.0), hx, 1.0, chi), hs)
+    s.prox(psi_h, hq, 1.0)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        s.prox(psi_h, hq, 1.0)
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    res["host_form_ShiftedNormL1Box_pcie_inclusive"] = {
+        "n": nh, "ms": round(ms, 3), "gelem_s": round(nh / ms / 1e6, 3), "gbs_over_pcie": round(32 * nh / ms / 1e6, 1),
+        "note": "3 vectors H2D + y D2H per call from pageable host memory; never the headline value"}
+    del hx, hs, hq, psi_h
     r = max(1, n // 100)
     line("ShiftedIndBallL0BInf_r=n/100", s.shifted(s.shifted(s.IndBallL0(r), xk, 1.0, chi), sj), 32, n, y, q)
     # group config: (n // 100) groups of 128  (10^6 x 128 at n = 10^8)

@@ -192,6 +192,76 @@ int spx_prox_group_l2_binf(spx_ctx* ctx, double* y, const double* q, const doubl
                            int64_t group_size, int64_t ngroups, const double* lambda_vec,
                            double sigma, double delta);
 
+/* ---- host-pointer forms ------------------------------------------------------------------ */
+/* The reference's callers (and its whole test suite, test/runtests.jl) hold plain Vector{Float64} in HOST memory.
+ * spx_host_X takes exactly the arguments of spx_X with EVERY vector (y, q/g/d, xk, sj, l_vec, u_vec, sel_mask,
+ * group_offsets, lambda_vec) in host memory: inputs are copied to a context-owned device staging area, the same HIP
+ * kernels run on the context's stream, y is copied back and the call synchronises.  No arithmetic happens on the CPU,
+ * and like the rest of the library these fail without a GPU.  y may alias q (g).  Cost: PCIe transfers of every
+ * vector per call -- convenience for small problems (BASELINE config 1, n = 1e4) and for running the reference's
+ * tests unchanged; solvers should keep psi on the device. */
+int spx_host_prox_l1(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+    double lambda, double sigma);
+int spx_host_prox_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+    double lambda, double sigma);
+int spx_host_prox_lhalf(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t
+    n, double lambda, double sigma);
+int spx_host_prox_l1_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t
+    n, double lambda, double sigma, const double* l_vec, const double* u_vec, double l_scalar, double
+    u_scalar, const uint8_t* sel_mask);
+int spx_host_prox_l0_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t
+    n, double lambda, double sigma, const double* l_vec, const double* u_vec, double l_scalar, double
+    u_scalar, const uint8_t* sel_mask);
+int spx_host_prox_lhalf_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+    int64_t n, double lambda, double sigma, const double* l_vec, const double* u_vec, double l_scalar, double
+    u_scalar, const uint8_t* sel_mask);
+int spx_host_iprox_l1(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk, const
+    double* sj, int64_t n, double lambda, int check_d);
+int spx_host_iprox_l0(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk, const
+    double* sj, int64_t n, double lambda, int check_d);
+int spx_host_iprox_l1_box(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk, const
+    double* sj, int64_t n, double lambda, const double* l_vec, const double* u_vec, double l_scalar, double
+    u_scalar, const uint8_t* sel_mask);
+int spx_host_iprox_l0_box(spx_ctx* ctx, double* y, const double* g, const double* d, const double* xk, const
+    double* sj, int64_t n, double lambda, const double* l_vec, const double* u_vec, double l_scalar, double
+    u_scalar, const uint8_t* sel_mask);
+int spx_host_obj_l1(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double
+    lambda, double* value);
+int spx_host_obj_l0(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double
+    lambda, double* value);
+int spx_host_obj_lhalf(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double
+    lambda, double* value);
+int spx_host_obj_l1_box(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double
+    lambda, const double* l_vec, const double* u_vec, double l_scalar, double u_scalar, const uint8_t*
+    sel_mask, double* value);
+int spx_host_obj_l0_box(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double
+    lambda, const double* l_vec, const double* u_vec, double l_scalar, double u_scalar, const uint8_t*
+    sel_mask, double* value);
+int spx_host_obj_lhalf_box(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+    double lambda, const double* l_vec, const double* u_vec, double l_scalar, double u_scalar, const uint8_t*
+    sel_mask, double* value);
+int spx_host_obj_indball_l0(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+    int64_t r, double* value);
+int spx_host_obj_indball_l0_binf(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+    int64_t r, double delta, double* value);
+int spx_host_obj_group_l2(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, const
+    int64_t* group_offsets, int64_t group_size, int64_t ngroups, const double* lambda_vec, double* value);
+int spx_host_obj_group_l2_binf(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+    const int64_t* group_offsets, int64_t group_size, int64_t ngroups, const double* lambda_vec, double delta,
+    double* value);
+int spx_host_prox_indball_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+    int64_t n, int64_t r);
+int spx_host_prox_indball_l0_binf(spx_ctx* ctx, double* y, const double* q, const double* xk, const double*
+    sj, int64_t n, int64_t r, double delta);
+int spx_host_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t
+    n, double lambda, double sigma, double delta, double chi_lambda);
+int spx_host_prox_group_l2(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+    int64_t n, const int64_t* group_offsets, int64_t group_size, int64_t ngroups, const double* lambda_vec,
+    double sigma);
+int spx_host_prox_group_l2_binf(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+    int64_t n, const int64_t* group_offsets, int64_t group_size, int64_t ngroups, const double* lambda_vec,
+    double sigma, double delta);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,9 @@ SIGNATURES = {
     "spx_prox_group_l2": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _d],
     "spx_prox_group_l2_binf": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _d, _d],
 }
+# host-pointer forms: spx_host_X has the argument list of spx_X (include/spx.h, "host-pointer forms")
+SIGNATURES.update({"spx_host_" + k[4:]: list(v) for k, v in list(SIGNATURES.items())
+                   if k.startswith(("spx_prox_", "spx_iprox_", "spx_obj_"))})
 
 
 class SpxError(RuntimeError):

@@ -7,7 +7,7 @@ ROOT="$(cd "$HERE/../.." && pwd)"
 OUT="$HERE/../lib"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS=("$HERE"/spx_ctx.hip "$HERE"/spx_separable.hip "$HERE"/spx_select.hip "$HERE"/spx_group.hip "$HERE"/spx_objective.hip "$HERE"/spx_b2.hip)
+SRCS=("$HERE"/spx_ctx.hip "$HERE"/spx_separable.hip "$HERE"/spx_select.hip "$HERE"/spx_group.hip "$HERE"/spx_objective.hip "$HERE"/spx_b2.hip "$HERE"/spx_host.hip)
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fvisibility=hidden \
   -Wall -Wno-unused-variable -Wno-unused-but-set-variable \
   -I"$ROOT/include" -I"$HERE" "${SRCS[@]}" -o "$OUT/libspx.so" "$@"

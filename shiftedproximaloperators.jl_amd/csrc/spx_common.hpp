@@ -22,6 +22,9 @@ struct spx_ctx {
   // library-owned scratch (top-r selection state, flags); grown on demand, never shrunk
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  // device staging area of the host-pointer entry points (spx_host.hip); grown on demand, never shrunk
+  void* stage = nullptr;
+  size_t stage_bytes = 0;
 };
 
 void spx_set_error(const char* fmt, ...);

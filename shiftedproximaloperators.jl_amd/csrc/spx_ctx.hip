@@ -59,6 +59,7 @@ SPX_EXPORT int spx_ctx_destroy(spx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);

@@ -15,11 +15,18 @@ spelled `f_bang` here):
 Vectors are torch float64 CUDA tensors (device memory plumbing only); like the reference, `xk`, `sj`,
 `l`, `u` are borrowed BY REFERENCE (shiftedNormL1Box.jl:22-47) and shift_bang writes into the caller's
 tensor.  All arithmetic happens in libspx (HIP); nothing here computes a prox on the host, and there is
-no CPU path: host tensors raise TypeError.  Index sets (`selected`, group ranges) are 0-based here.
+no CPU path: CPU torch tensors raise TypeError.  Index sets (`selected`, group ranges) are 0-based here.
+
+Host vectors: a ψ built on numpy float64 arrays (the reference's plain `Vector{Float64}`, as in all of
+test/runtests.jl) binds the `spx_host_*` forms of the same entry points: every call stages its vectors through
+device memory, runs the same HIP kernels and copies y back (PCIe per call -- for small problems and for running
+the reference's tests as written; solvers keep ψ on the device).  All vectors of one ψ / one call must be of the
+same kind.
 """
 import ctypes
 import numbers
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -32,6 +39,8 @@ _ctxs = {}
 
 
 def _ctx(device):
+    if device is None:  # host vectors: the current device
+        device = torch.device("cuda", torch.cuda.current_device())
     stream = torch.cuda.current_stream(device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), stream.cuda_stream)
     c = _ctxs.get(key)
@@ -43,22 +52,63 @@ def _ctx(device):
     return c
 
 
-def _vec(t, name, n=None):
-    if not isinstance(t, torch.Tensor):
-        raise TypeError("%s must be a torch tensor on the GPU (got %s); libspx has no host path" % (name, type(t)))
-    if not t.is_cuda:
-        raise TypeError("%s must live in device memory (cuda); libspx has no host path" % name)
-    if t.dtype != torch.float64:
-        raise TypeError("%s must be float64 (got %s)" % (name, t.dtype))
-    if t.dim() != 1 or (t.numel() > 1 and t.stride(0) != 1):
-        raise TypeError("%s must be a contiguous vector" % name)
-    if n is not None and t.numel() != n:
-        raise IndexError("BoundsError: %s has length %d, expected %d" % (name, t.numel(), n))
+def _is_host(t):
+    return isinstance(t, np.ndarray)
+
+
+def _n(t):
+    return t.size if _is_host(t) else t.numel()
+
+
+def _dev(t):
+    """torch device of a device vector, None for a host (numpy) vector"""
+    return None if _is_host(t) else t.device
+
+
+def _vec(t, name, n=None, like=None):
+    """Validates a vector argument: a float64 contiguous torch CUDA tensor, or a float64 contiguous numpy array
+    (host-pointer forms).  `like`: a vector it must share its kind (and device) with."""
+    if _is_host(t):
+        if t.dtype != np.float64:
+            raise TypeError("%s must be float64 (got %s)" % (name, t.dtype))
+        if t.ndim != 1 or (t.size > 1 and t.strides[0] != 8):
+            raise TypeError("%s must be a contiguous vector" % name)
+    else:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("%s must be a torch tensor on the GPU or a numpy array (got %s)" % (name, type(t)))
+        if not t.is_cuda:
+            raise TypeError("%s must live in device memory (cuda); libspx computes nothing on the CPU (numpy arrays "
+                            "are staged through the GPU)" % name)
+        if t.dtype != torch.float64:
+            raise TypeError("%s must be float64 (got %s)" % (name, t.dtype))
+        if t.dim() != 1 or (t.numel() > 1 and t.stride(0) != 1):
+            raise TypeError("%s must be a contiguous vector" % name)
+    if like is not None and _dev(t) != _dev(like):
+        raise TypeError("%s must be of the same kind (host array / device tensor on the same device) as ψ.xk" % name)
+    if n is not None and _n(t) != n:
+        raise IndexError("BoundsError: %s has length %d, expected %d" % (name, _n(t), n))
     return t
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
+    if t is None or _n(t) == 0:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.ctypes.data if _is_host(t) else t.data_ptr())
+
+
+def _empty_like(t):
+    return np.empty_like(t) if _is_host(t) else torch.empty_like(t)
+
+
+def _zeros_like(t):
+    return np.zeros_like(t) if _is_host(t) else torch.zeros_like(t)
+
+
+def _copy_into(dst, src):
+    if _is_host(dst):
+        np.copyto(dst, src)
+    else:
+        dst.copy_(src)
 
 
 def _is_real(v):
@@ -72,9 +122,14 @@ class ShiftedProximableFunction:
     def __init__(self, h, xk, sj, shifted_twice):
         self.h = h
         self.xk = _vec(xk, "xk")
-        self.sj = _vec(sj, "sj", xk.numel())
-        self.sol = torch.empty_like(xk)  # `sol = similar(xk)`
+        self.sj = _vec(sj, "sj", _n(xk), like=xk)
+        self.sol = _empty_like(xk)  # `sol = similar(xk)`
         self.shifted_twice = bool(shifted_twice)
+        self.host = _is_host(xk)
+
+    def _sym(self, L, name):
+        """the entry point `name` of libspx, or its host-pointer form for a ψ on host arrays"""
+        return getattr(L, "spx_host_" + name[4:] if self.host else name)
 
     # ψ.λ / ψ.r sugar (getproperty, :113-121)
     @property
@@ -93,9 +148,9 @@ class ShiftedProximableFunction:
     def __call__(self, y):
         """ψ(y) = h(xk + sj + y) [+ indicator]  (src/ShiftedProximalOperators.jl:51-54 and the Box / BInf methods);
         evaluated on the device, returned as a Python float (synchronises)."""
-        _vec(y, "y", self.xk.numel())
+        _vec(y, "y", _n(self.xk), like=self.xk)
         out = ctypes.c_double(0.0)
-        self._obj(_lib.load(), _ctx(y.device), y, ctypes.byref(out))
+        self._obj(_lib.load(), _ctx(_dev(y)), y, ctypes.byref(out))
         return out.value
 
     def _obj(self, L, ctx, y, out):
@@ -110,13 +165,13 @@ class _Unboxed(ShiftedProximableFunction):
     _ifn = None
 
     def _prox(self, L, ctx, y, q, sigma):
-        fn = getattr(L, self._fn)
-        _lib.check(fn(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), y.numel(), self.h.lam, sigma))
+        fn = self._sym(L, self._fn)
+        _lib.check(fn(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), _n(y), self.h.lam, sigma))
 
     def _iprox(self, L, ctx, y, g, d, check):
         if self._ifn is None:
             return super()._iprox(L, ctx, y, g, d, check)
-        st = getattr(L, self._ifn)(ctx, _ptr(y), _ptr(g), _ptr(d), _ptr(self.xk), _ptr(self.sj), y.numel(),
+        st = self._sym(L, self._ifn)(ctx, _ptr(y), _ptr(g), _ptr(d), _ptr(self.xk), _ptr(self.sj), _n(y),
                                    self.h.lam, 1 if check else 0)
         if st == 6:  # SPX_ERR_ASSERT: the reference's `@assert d[i] > 0`
             raise AssertionError("d[i] > 0")
@@ -124,7 +179,7 @@ class _Unboxed(ShiftedProximableFunction):
 
 
 def _unboxed_obj(self, L, ctx, y, out):
-    _lib.check(getattr(L, self._ofn)(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), y.numel(), self.h.lam, out))
+    _lib.check(self._sym(L, self._ofn)(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), _n(y), self.h.lam, out))
 
 
 _Unboxed._obj = _unboxed_obj
@@ -156,27 +211,31 @@ class _Boxed(ShiftedProximableFunction):
 
     def __init__(self, h, xk, sj, l, u, shifted_twice, selected, _mask=_UNSET):
         super().__init__(h, xk, sj, shifted_twice)
-        n = xk.numel()
-        self.l = l if _is_real(l) else _vec(l, "l", n)
-        self.u = u if _is_real(u) else _vec(u, "u", n)
+        n = _n(xk)
+        self.l = l if _is_real(l) else _vec(l, "l", n, like=xk)
+        self.u = u if _is_real(u) else _vec(u, "u", n, like=xk)
         self.selected = selected
         self._mask = _build_mask(selected, xk) if _mask is _UNSET else _mask  # shared by a second shift
         if self._check_bounds:
             lv = None if _is_real(self.l) else self.l
             uv = None if _is_real(self.u) else self.u
-            flag = ctypes.c_int(0)
-            L = _lib.load()
-            _lib.check(L.spx_check_bounds(_ctx(xk.device), _ptr(lv), _ptr(uv),
-                                          float(self.l) if lv is None else 0.0,
-                                          float(self.u) if uv is None else 0.0, n, ctypes.byref(flag)))
-            if flag.value:
+            if self.host:  # constructor validation on the caller's host arrays: `any(l .> u)`
+                bad = bool(np.any(np.asarray(self.l) > np.asarray(self.u)))
+            else:
+                flag = ctypes.c_int(0)
+                L = _lib.load()
+                _lib.check(L.spx_check_bounds(_ctx(xk.device), _ptr(lv), _ptr(uv),
+                                              float(self.l) if lv is None else 0.0,
+                                              float(self.u) if uv is None else 0.0, n, ctypes.byref(flag)))
+                bad = bool(flag.value)
+            if bad:
                 raise ValueError("Error: at least one lower bound is greater than the upper bound.")
 
     def _prox(self, L, ctx, y, q, sigma):
-        n = y.numel()
-        lv = None if _is_real(self.l) else _vec(self.l, "l", n)
-        uv = None if _is_real(self.u) else _vec(self.u, "u", n)
-        fn = getattr(L, self._fn)
+        n = _n(y)
+        lv = None if _is_real(self.l) else _vec(self.l, "l", n, like=y)
+        uv = None if _is_real(self.u) else _vec(self.u, "u", n, like=y)
+        fn = self._sym(L, self._fn)
         _lib.check(fn(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), n, self.h.lam, sigma,
                       _ptr(lv), _ptr(uv), float(self.l) if lv is None else 0.0,
                       float(self.u) if uv is None else 0.0,
@@ -198,20 +257,20 @@ class ShiftedNormL0Box(_Boxed):  # src/shiftedNormL0Box.jl
 def _boxed_iprox(self, L, ctx, y, g, d, check):
     if self._ifn is None:
         return ShiftedProximableFunction._iprox(self, L, ctx, y, g, d, check)
-    n = y.numel()
-    lv = None if _is_real(self.l) else _vec(self.l, "l", n)
-    uv = None if _is_real(self.u) else _vec(self.u, "u", n)
-    _lib.check(getattr(L, self._ifn)(ctx, _ptr(y), _ptr(g), _ptr(d), _ptr(self.xk), _ptr(self.sj), n, self.h.lam,
+    n = _n(y)
+    lv = None if _is_real(self.l) else _vec(self.l, "l", n, like=y)
+    uv = None if _is_real(self.u) else _vec(self.u, "u", n, like=y)
+    _lib.check(self._sym(L, self._ifn)(ctx, _ptr(y), _ptr(g), _ptr(d), _ptr(self.xk), _ptr(self.sj), n, self.h.lam,
                                      _ptr(lv), _ptr(uv), float(self.l) if lv is None else 0.0,
                                      float(self.u) if uv is None else 0.0,
                                      _ptr(self._mask[0]) if self._mask is not None else ctypes.c_void_p(0)))
 
 
 def _boxed_obj(self, L, ctx, y, out):
-    n = y.numel()
-    lv = None if _is_real(self.l) else _vec(self.l, "l", n)
-    uv = None if _is_real(self.u) else _vec(self.u, "u", n)
-    _lib.check(getattr(L, self._ofn)(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), n, self.h.lam, _ptr(lv), _ptr(uv),
+    n = _n(y)
+    lv = None if _is_real(self.l) else _vec(self.l, "l", n, like=y)
+    uv = None if _is_real(self.u) else _vec(self.u, "u", n, like=y)
+    _lib.check(self._sym(L, self._ofn)(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), n, self.h.lam, _ptr(lv), _ptr(uv),
                                      float(self.l) if lv is None else 0.0, float(self.u) if uv is None else 0.0,
                                      _ptr(self._mask[0]) if self._mask is not None else ctypes.c_void_p(0), out))
 
@@ -230,11 +289,16 @@ class ShiftedRootNormLhalfBox(_Boxed):  # src/shiftedRootNormLhalfBox.jl (no l >
 def _build_mask(selected, xk):
     """`selected` (0-based indices: range / list / tensor; any order, duplicates allowed) -> device byte
     mask, built once by libspx.  None or a full range(0, n) -> no mask (every index selected)."""
-    n = xk.numel()
+    n = _n(xk)
     if selected is None:
         return None
     if isinstance(selected, range) and selected.step == 1 and selected.start <= 0 and selected.stop >= n:
         return None
+    if _is_host(xk):  # host ψ: the byte mask is host data too (index bookkeeping, no prox arithmetic)
+        idx = np.asarray(selected.cpu() if isinstance(selected, torch.Tensor) else list(selected), dtype=np.int64)
+        mask = np.zeros(n, dtype=np.uint8)
+        mask[idx[(idx >= 0) & (idx < n)]] = 1
+        return (mask, None)
     if isinstance(selected, torch.Tensor):
         idx = selected.to(device=xk.device, dtype=torch.int64).contiguous()
     else:
@@ -252,7 +316,7 @@ class ShiftedNormL1B2(ShiftedProximableFunction):  # src/shiftedNormL1B2.jl
         self.χ = χ
 
     def _prox(self, L, ctx, y, q, sigma):
-        _lib.check(L.spx_prox_l1_b2(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), y.numel(), self.h.lam, sigma,
+        _lib.check(self._sym(L, "spx_prox_l1_b2")(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), _n(y), self.h.lam, sigma,
                                     self.Δ, self.χ.lam))
 
 
@@ -262,10 +326,10 @@ class _TopR(ShiftedProximableFunction):
 
 class ShiftedIndBallL0(_TopR):  # src/shiftedIndBallL0.jl
     def _prox(self, L, ctx, y, q, sigma):
-        _lib.check(L.spx_prox_indball_l0(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), y.numel(), self.h.r))
+        _lib.check(self._sym(L, "spx_prox_indball_l0")(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), _n(y), self.h.r))
 
     def _obj(self, L, ctx, y, out):
-        _lib.check(L.spx_obj_indball_l0(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), y.numel(), self.h.r, out))
+        _lib.check(self._sym(L, "spx_obj_indball_l0")(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), _n(y), self.h.r, out))
 
 
 class ShiftedIndBallL0BInf(_TopR):  # src/shiftedIndBallL0BInf.jl
@@ -275,11 +339,11 @@ class ShiftedIndBallL0BInf(_TopR):  # src/shiftedIndBallL0BInf.jl
         self.χ = χ
 
     def _prox(self, L, ctx, y, q, sigma):
-        _lib.check(L.spx_prox_indball_l0_binf(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), y.numel(),
+        _lib.check(self._sym(L, "spx_prox_indball_l0_binf")(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), _n(y),
                                               self.h.r, self.Δ))
 
     def _obj(self, L, ctx, y, out):
-        _lib.check(L.spx_obj_indball_l0_binf(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), y.numel(), self.h.r, self.Δ, out))
+        _lib.check(self._sym(L, "spx_obj_indball_l0_binf")(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), _n(y), self.h.r, self.Δ, out))
 
 
 class _GroupLayout:
@@ -291,9 +355,7 @@ class _GroupLayout:
             if h.idx.size * h.idx.count != n:
                 raise IndexError("BoundsError: %d groups of %d do not tile a vector of length %d" % (h.idx.count, h.idx.size, n))
             self.ngroups, self.offsets, self.group_size = h.idx.count, None, h.idx.size
-            lam = h.lam
-            self.lam = (lam.to(device=device, dtype=torch.float64).contiguous() if isinstance(lam, torch.Tensor)
-                        else torch.tensor(lam, dtype=torch.float64, device=device))
+            self.lam = self._lam(h.lam, device)
             return
         bounds = []
         for g in h.idx:
@@ -321,28 +383,33 @@ class _GroupLayout:
             self.group_size = sizes.pop()
         else:
             off = [bounds[0][0]] + [b for _, b in bounds] if bounds else [0]
-            self.offsets = torch.tensor(off, dtype=torch.int64, device=device)
+            self.offsets = (np.asarray(off, dtype=np.int64) if device is None
+                            else torch.tensor(off, dtype=torch.int64, device=device))
             self.group_size = 0
-        lam = h.lam
+        self.lam = self._lam(h.lam, device)
+
+    @staticmethod
+    def _lam(lam, device):
+        if device is None:  # host ψ
+            return np.ascontiguousarray(lam.cpu().numpy() if isinstance(lam, torch.Tensor) else lam, dtype=np.float64)
         if isinstance(lam, torch.Tensor):
-            self.lam = lam.to(device=device, dtype=torch.float64).contiguous()
-        else:
-            self.lam = torch.tensor(lam, dtype=torch.float64, device=device)
+            return lam.to(device=device, dtype=torch.float64).contiguous()
+        return torch.tensor(lam, dtype=torch.float64, device=device)
 
 
 class ShiftedGroupNormL2(ShiftedProximableFunction):  # src/shiftedGroupNormL2.jl
     def __init__(self, h, xk, sj, shifted_twice, _layout=None):
         super().__init__(h, xk, sj, shifted_twice)
-        self._layout = _layout or _GroupLayout(h, xk.numel(), xk.device)
+        self._layout = _layout or _GroupLayout(h, _n(xk), _dev(xk))
 
     def _prox(self, L, ctx, y, q, sigma):
         g = self._layout
-        _lib.check(L.spx_prox_group_l2(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), y.numel(),
+        _lib.check(self._sym(L, "spx_prox_group_l2")(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), _n(y),
                                        _ptr(g.offsets), g.group_size, g.ngroups, _ptr(g.lam), sigma))
 
     def _obj(self, L, ctx, y, out):
         g = self._layout
-        _lib.check(L.spx_obj_group_l2(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), y.numel(), _ptr(g.offsets),
+        _lib.check(self._sym(L, "spx_obj_group_l2")(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), _n(y), _ptr(g.offsets),
                                       g.group_size, g.ngroups, _ptr(g.lam), out))
 
 
@@ -351,16 +418,16 @@ class ShiftedGroupNormL2Binf(ShiftedProximableFunction):  # src/shiftedGroupNorm
         super().__init__(h, xk, sj, shifted_twice)
         self.Δ = float(Δ)
         self.χ = χ
-        self._layout = _layout or _GroupLayout(h, xk.numel(), xk.device)
+        self._layout = _layout or _GroupLayout(h, _n(xk), _dev(xk))
 
     def _prox(self, L, ctx, y, q, sigma):
         g = self._layout
-        _lib.check(L.spx_prox_group_l2_binf(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), y.numel(),
+        _lib.check(self._sym(L, "spx_prox_group_l2_binf")(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), _n(y),
                                             _ptr(g.offsets), g.group_size, g.ngroups, _ptr(g.lam), sigma, self.Δ))
 
     def _obj(self, L, ctx, y, out):
         g = self._layout
-        _lib.check(L.spx_obj_group_l2_binf(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), y.numel(), _ptr(g.offsets),
+        _lib.check(self._sym(L, "spx_obj_group_l2_binf")(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), _n(y), _ptr(g.offsets),
                                            g.group_size, g.ngroups, _ptr(g.lam), self.Δ, out))
 
 
@@ -376,7 +443,7 @@ def shifted(h, x, *args):
     if isinstance(h, ShiftedProximableFunction):
         if args:
             raise TypeError("MethodError: shifted(ψ, sj) takes no trust-region arguments")
-        ψ, sj = h, _vec(x, "sj", h.xk.numel())
+        ψ, sj = h, _vec(x, "sj", _n(h.xk), like=h.xk)
         if isinstance(ψ, _Boxed):
             return type(ψ)(ψ.h, ψ.xk, sj, ψ.l, ψ.u, True, ψ.selected, _mask=ψ._mask)
         if isinstance(ψ, ShiftedIndBallL0BInf):
@@ -390,7 +457,7 @@ def shifted(h, x, *args):
         return type(ψ)(ψ.h, ψ.xk, sj, True)
 
     xk = _vec(x, "xk")
-    zero = lambda: torch.zeros_like(xk)  # `zero(xk)`
+    zero = lambda: _zeros_like(xk)  # `zero(xk)`
     if isinstance(h, NormL2):  # shiftedGroupNormL2.jl:34-35, shiftedGroupNormL2Binf.jl:48-49
         h = GroupNormL2([h.lam])
     if len(args) == 0:
@@ -431,12 +498,10 @@ def prox_bang(y, ψ, q, σ):
     torch stream.  y may be q itself or ψ.sol."""
     if not isinstance(ψ, ShiftedProximableFunction):
         raise TypeError("ψ must be a ShiftedProximableFunction")
-    n = ψ.xk.numel()
-    _vec(q, "q", n)
-    _vec(y, "y", n)
-    if q.device != ψ.xk.device or y.device != ψ.xk.device:
-        raise TypeError("y, q and ψ.xk must live on the same device")
-    ψ._prox(_lib.load(), _ctx(y.device), y, q, float(σ))
+    n = _n(ψ.xk)
+    _vec(q, "q", n, like=ψ.xk)
+    _vec(y, "y", n, like=ψ.xk)
+    ψ._prox(_lib.load(), _ctx(_dev(y)), y, q, float(σ))
     return y
 
 
@@ -451,11 +516,11 @@ def iprox_bang(y, ψ, g, d, check=True):
     synchronises to raise AssertionError; pass check=False to stay asynchronous)."""
     if not isinstance(ψ, ShiftedProximableFunction):
         raise TypeError("ψ must be a ShiftedProximableFunction")
-    n = ψ.xk.numel()
-    _vec(g, "g", n)
-    _vec(d, "d", n)
-    _vec(y, "y", n)
-    ψ._iprox(_lib.load(), _ctx(y.device), y, g, d, check)
+    n = _n(ψ.xk)
+    _vec(g, "g", n, like=ψ.xk)
+    _vec(d, "d", n, like=ψ.xk)
+    _vec(y, "y", n, like=ψ.xk)
+    ψ._iprox(_lib.load(), _ctx(_dev(y)), y, g, d, check)
     return y
 
 
@@ -467,8 +532,8 @@ def iprox(ψ, g, d):
 def shift_bang(ψ, shift):
     """shift!(ψ, v): in-place copy into ψ.sj (twice shifted) or ψ.xk -- i.e. into the caller's tensor
     (src/ShiftedProximalOperators.jl:72-79)."""
-    _vec(shift, "shift", ψ.xk.numel())
-    (ψ.sj if ψ.shifted_twice else ψ.xk).copy_(shift)
+    _vec(shift, "shift", _n(ψ.xk), like=ψ.xk)
+    _copy_into(ψ.sj if ψ.shifted_twice else ψ.xk, shift)
     return ψ
 
 
@@ -477,15 +542,15 @@ def set_bounds_bang(ψ, l, u):
     replaces a stored scalar, otherwise it is copied into the stored vector."""
     if not isinstance(ψ, _Boxed):
         raise AttributeError("type %s has no field l" % type(ψ).__name__)
-    n = ψ.xk.numel()
+    n = _n(ψ.xk)
     for name, new in (("l", l), ("u", u)):
         cur = getattr(ψ, name)
         if _is_real(new):
             setattr(ψ, name, new)
         elif _is_real(cur):
-            setattr(ψ, name, _vec(new, name, n))
+            setattr(ψ, name, _vec(new, name, n, like=ψ.xk))
         else:
-            cur.copy_(_vec(new, name, n))
+            _copy_into(cur, _vec(new, name, n, like=ψ.xk))
     return ψ
 
 

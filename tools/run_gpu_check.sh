@@ -10,5 +10,5 @@ python - <<PY
 import json
 d=json.loads([l for l in open("gpurun_out/bench_$TAG.log") if l.startswith("{")][-1])
 print("L1Box: %.1f GB/s  %.4f ms/step (wall)" % (d["roofline"]["achieved"], d["ms_per_step"]))
-for k,v in d["other_operators"].items(): print("%-40s %8.4f ms %7.1f GB/s %.3f"%(k,v["ms"],v["gbs_algorithmic"],v["frac_of_peak"]))
+for k,v in d["other_operators"].items(): print("%-44s %9.4f ms %7.1f GB/s %.3f"%(k,v["ms"],v.get("gbs_algorithmic",v.get("gbs_over_pcie",0)),v.get("frac_of_peak",0)))
 PY
