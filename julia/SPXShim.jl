@@ -154,6 +154,18 @@ function prox!(y::DVec, ψ::ShiftedIndBallL0BInf{<:Integer, Float64, <:DVec, <:D
 end
 
 # ---------------------------------------------------------------------------------------------
+# l1 norm + l2-ball trust region      src/shiftedNormL1B2.jl:50-67   (χ = NormL2(χ.lambda))
+# ---------------------------------------------------------------------------------------------
+function prox!(y::DVec, ψ::ShiftedProximalOperators.ShiftedNormL1B2{Float64, <:DVec, <:DVec, <:DVec}, q::DVec, σ::Float64)
+  n = length(ψ.xk)
+  (length(y) == n && length(q) == n) || throw(BoundsError())
+  check(ccall((:spx_prox_l1_b2, libspx), Cint,
+              (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cdouble, Cdouble, Cdouble),
+              ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, ψ.λ, σ, ψ.Δ, ψ.χ.lambda))
+  return y
+end
+
+# ---------------------------------------------------------------------------------------------
 # groups                      src/shiftedGroupNormL2.jl:52-79, shiftedGroupNormL2Binf.jl:67-119
 # ψ.h.idx must be consecutive contiguous ranges (UnitRanges or [:]); anything else falls back to the
 # reference method.  Offsets / weights are uploaded once per h and cached.
