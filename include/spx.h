@@ -192,6 +192,26 @@ int spx_prox_group_l2_binf(spx_ctx* ctx, double* y, const double* q, const doubl
                            int64_t group_size, int64_t ngroups, const double* lambda_vec,
                            double sigma, double delta);
 
+/* Groups as ARBITRARY index sets -- the reference's `idx::Vector{Vector{Int}}` (src/groupNormL2.jl:30-31,
+ * test/runtests.jl:290): group g = group_index[group_ptr[g] .. group_ptr[g+1]) (device int64, 0-based; group_ptr has
+ * ngroups+1 entries, group_index nnz).  Literal reference semantics: an index listed by several groups keeps the value
+ * of the LAST of them; an index inside no group keeps y on entry, minus xk+sj for ShiftedGroupNormL2
+ * (src/shiftedGroupNormL2.jl:77) and unchanged for the Binf form (src/shiftedGroupNormL2Binf.jl:116).  An index outside
+ * [0, n) returns SPX_ERR_INVALID_ARG before y is written (the reference: BoundsError).  Uses n doubles + n ints of
+ * library scratch (the reference's psi.sol) and synchronises once. */
+int spx_prox_group_l2_gather(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                             int64_t n, const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups,
+                             int64_t nnz, const double* lambda_vec, double sigma);
+int spx_prox_group_l2_binf_gather(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                                  int64_t n, const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups,
+                                  int64_t nnz, const double* lambda_vec, double sigma, double delta);
+int spx_obj_group_l2_gather(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                            const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups, int64_t nnz,
+                            const double* lambda_vec, double* value);
+int spx_obj_group_l2_binf_gather(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                                 const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups, int64_t nnz,
+                                 const double* lambda_vec, double delta, double* value);
+
 /* ---- host-pointer forms ------------------------------------------------------------------ */
 /* The reference's callers (and its whole test suite, test/runtests.jl) hold plain Vector{Float64} in HOST memory.
  * spx_host_X takes exactly the arguments of spx_X with EVERY vector (y, q/g/d, xk, sj, l_vec, u_vec, sel_mask,
@@ -261,6 +281,18 @@ int spx_host_prox_group_l2(spx_ctx* ctx, double* y, const double* q, const doubl
 int spx_host_prox_group_l2_binf(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
     int64_t n, const int64_t* group_offsets, int64_t group_size, int64_t ngroups, const double* lambda_vec,
     double sigma, double delta);
+int spx_host_prox_group_l2_gather(spx_ctx* ctx, double* y, const double* q, const double* xk, const double*
+    sj, int64_t n, const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups, int64_t nnz, const
+    double* lambda_vec, double sigma);
+int spx_host_prox_group_l2_binf_gather(spx_ctx* ctx, double* y, const double* q, const double* xk, const
+    double* sj, int64_t n, const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups, int64_t nnz,
+    const double* lambda_vec, double sigma, double delta);
+int spx_host_obj_group_l2_gather(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+    const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups, int64_t nnz, const double*
+    lambda_vec, double* value);
+int spx_host_obj_group_l2_binf_gather(spx_ctx* ctx, const double* y, const double* xk, const double* sj,
+    int64_t n, const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups, int64_t nnz, const
+    double* lambda_vec, double delta, double* value);
 
 #ifdef __cplusplus
 }

@@ -167,21 +167,29 @@ end
 
 # ---------------------------------------------------------------------------------------------
 # groups                      src/shiftedGroupNormL2.jl:52-79, shiftedGroupNormL2Binf.jl:67-119
-# ψ.h.idx must be consecutive contiguous ranges (UnitRanges or [:]); anything else falls back to the
-# reference method.  Offsets / weights are uploaded once per h and cached.
+# ψ.h.idx as consecutive contiguous ranges (UnitRanges or [:]) takes the CSR / uniform entry points; any other
+# index sets (Vector{Int}s, gaps, overlaps, any order) take the gather entry points, which reproduce the reference's
+# sequential loop literally.  Offsets / indices / weights are uploaded once per h and cached.
 # ---------------------------------------------------------------------------------------------
 const LAYOUTS = IdDict{Any, Any}()
 
 function layout_for(h, n)
   get!(LAYOUTS, h) do
     rngs = map(g -> g isa Colon ? (1:n) : g, h.idx)
-    all(g -> g isa AbstractUnitRange, rngs) || return nothing
-    all(i -> first(rngs[i + 1]) == last(rngs[i]) + 1, 1:(length(rngs) - 1)) || return nothing
+    lam = ROCVector{Float64}(collect(Float64, h.lambda))
+    if !(all(g -> g isa AbstractUnitRange, rngs) &&
+         all(i -> first(rngs[i + 1]) == last(rngs[i]) + 1, 1:(length(rngs) - 1)))
+      ptr = Int64[0; cumsum(Int64[length(g) for g in rngs])]       # gather form: 0-based ptr / index
+      index = Int64[i - 1 for g in rngs for i in g]
+      all(i -> 0 <= i < n, index) || throw(BoundsError())
+      return (gather = true, ptr = ROCVector{Int64}(ptr), index = ROCVector{Int64}(index), nnz = length(index),
+              ngroups = length(rngs), lambda = lam)
+    end
     off = Int64[first(rngs[1]) - 1; [last(g) for g in rngs]]      # 0-based CSR offsets
     sizes = diff(off)
     uniform = off[1] == 0 && off[end] == n && all(==(sizes[1]), sizes)
-    (offsets = uniform ? nothing : ROCVector{Int64}(off), gsize = uniform ? sizes[1] : 0,
-     ngroups = length(rngs), lambda = ROCVector{Float64}(collect(Float64, h.lambda)))
+    (gather = false, offsets = uniform ? nothing : ROCVector{Int64}(off), gsize = uniform ? sizes[1] : 0,
+     ngroups = length(rngs), lambda = lam)
   end
 end
 
@@ -189,6 +197,23 @@ function group_call(sym, y, ψ, q, σ, extra...)
   n = length(ψ.xk)
   L = layout_for(ψ.h, n)
   L === nothing && return nothing
+  if L.gather
+    ip(v) = Ptr{Int64}(UInt(pointer(v)))
+    if isempty(extra)
+      check(ccall((:spx_prox_group_l2_gather, libspx), Cint,
+                  (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Ptr{Int64}, Ptr{Int64}, Int64,
+                   Int64, Ptr{Cdouble}, Cdouble),
+                  ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, ip(L.ptr), ip(L.index), L.ngroups, L.nnz,
+                  dptr(L.lambda), σ))
+    else
+      check(ccall((:spx_prox_group_l2_binf_gather, libspx), Cint,
+                  (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Ptr{Int64}, Ptr{Int64}, Int64,
+                   Int64, Ptr{Cdouble}, Cdouble, Cdouble),
+                  ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, ip(L.ptr), ip(L.index), L.ngroups, L.nnz,
+                  dptr(L.lambda), σ, extra[1]))
+    end
+    return y
+  end
   offp = L.offsets === nothing ? Ptr{Int64}(C_NULL) : Ptr{Int64}(UInt(pointer(L.offsets)))
   if isempty(extra)
     check(ccall((:spx_prox_group_l2, libspx), Cint,

@@ -69,6 +69,12 @@ def lib():
         L.orc_obj_indball_l0.restype = d
         L.orc_obj_group_l2.argtypes = [dp, dp, dp, i64, ip, i64, i64, dp, d]
         L.orc_obj_group_l2.restype = d
+        L.orc_prox_group_l2_idx.argtypes = base + [ip, ip, i64, dp, d]
+        L.orc_prox_group_l2_idx.restype = None
+        L.orc_prox_group_l2_binf_idx.argtypes = base + [ip, ip, i64, dp, d, d]
+        L.orc_prox_group_l2_binf_idx.restype = None
+        L.orc_obj_group_l2_idx.argtypes = [dp, dp, dp, i64, ip, ip, i64, dp, d]
+        L.orc_obj_group_l2_idx.restype = d
         L.orc_prox_l1_b2.argtypes = base + [d, d, d, d]
         L.orc_prox_l1_b2.restype = None
         L.orc_rootnormlhalf_prox.argtypes = [dp, dp, i64, d, d]
@@ -207,6 +213,42 @@ def prox_group_l2_binf(q, xk, sj, lam, sigma, delta, offsets=None, gsize=0):
     assert lam.shape[0] == ng
     lib().orc_prox_group_l2_binf(_dp(y), _dp(q), _dp(xk), _dp(sj), n, offp, gs, ng, _dp(lam), sigma, delta)
     return y
+
+
+def _index_sets(groups):
+    """list of 0-based index lists -> (ptr, index) int64 arrays"""
+    ptr = np.zeros(len(groups) + 1, dtype=np.int64)
+    for k, g in enumerate(groups):
+        ptr[k + 1] = ptr[k] + len(g)
+    index = np.ascontiguousarray(np.concatenate([np.asarray(list(g), dtype=np.int64) for g in groups])
+                                 if len(groups) else np.zeros(0, dtype=np.int64))
+    return ptr, index
+
+
+def prox_group_l2_idx(q, xk, sj, lam, sigma, groups, delta=None, y0=None):
+    """Groups = arbitrary 0-based index sets (the reference's idx::Vector{Vector{Int}}); delta = None: ShiftedGroupNormL2,
+    else the Binf form.  y0 = y on entry (indices in no group keep it; default zeros)."""
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    y[:] = 0.0 if y0 is None else _f64(y0)
+    ptr, index = _index_sets(groups)
+    lam = _f64(lam)
+    assert lam.shape[0] == len(groups)
+    ip = lambda a: a.ctypes.data_as(_c_int64_p)
+    if delta is None:
+        lib().orc_prox_group_l2_idx(_dp(y), _dp(q), _dp(xk), _dp(sj), n, ip(ptr), ip(index), len(groups), _dp(lam), sigma)
+    else:
+        lib().orc_prox_group_l2_binf_idx(_dp(y), _dp(q), _dp(xk), _dp(sj), n, ip(ptr), ip(index), len(groups), _dp(lam),
+                                         sigma, delta)
+    return y
+
+
+def obj_group_l2_idx(y, xk, sj, lam, groups, delta=None):
+    y, xk, sj = _f64(y), _f64(xk), _f64(sj)
+    ptr, index = _index_sets(groups)
+    lam = _f64(lam)
+    ip = lambda a: a.ctypes.data_as(_c_int64_p)
+    return lib().orc_obj_group_l2_idx(_dp(y), _dp(xk), _dp(sj), y.shape[0], ip(ptr), ip(index), len(groups), _dp(lam),
+                                      -1.0 if delta is None else delta)
 
 
 def rootnormlhalf_prox(x, lam, gamma):

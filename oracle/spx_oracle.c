@@ -438,6 +438,79 @@ ORC_API void orc_prox_group_l2_binf(double* y, const double* q, const double* xk
   free(w);
 }
 
+/* ---- the same two operators on arbitrary index sets (idx::Vector{Vector{Int}}, src/groupNormL2.jl:30-31,
+ * test/runtests.jl:290): group g = index[ptr[g] .. ptr[g+1]) (0-based).  Literal: groups are processed in order, so an
+ * index listed by several groups keeps the LAST group's value; an index in no group keeps y on entry, minus the
+ * shift for ShiftedGroupNormL2 (:77 runs over every index) and untouched for the Binf form (:116 is per group). */
+ORC_API void orc_prox_group_l2_idx(double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                   const int64_t* ptr, const int64_t* index, int64_t ngroups, const double* lambda,
+                                   double sigma) {
+  double* sol = (double*)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+  for (int64_t i = 0; i < n; ++i) sol[i] = (q[i] + xk[i]) + sj[i]; /* :65 */
+  for (int64_t g = 0; g < ngroups; ++g) {
+    double ss = 0.0;
+    for (int64_t p = ptr[g]; p < ptr[g + 1]; ++p) ss += sol[index[p]] * sol[index[p]];
+    double snorm = sqrt(ss); /* :69 */
+    if (snorm == 0) {
+      for (int64_t p = ptr[g]; p < ptr[g + 1]; ++p) y[index[p]] = 0.0;
+    } else {
+      double alpha = jl_max(1 - sigma * lambda[g] / snorm, 0.0); /* :73 */
+      for (int64_t p = ptr[g]; p < ptr[g + 1]; ++p) y[index[p]] = alpha * sol[index[p]];
+    }
+  }
+  for (int64_t i = 0; i < n; ++i) y[i] = y[i] - (xk[i] + sj[i]); /* :77 */
+  free(sol);
+}
+
+ORC_API void orc_prox_group_l2_binf_idx(double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                        const int64_t* ptr, const int64_t* index, int64_t ngroups,
+                                        const double* lambda, double sigma, double delta) {
+  int64_t mmax = 1;
+  for (int64_t g = 0; g < ngroups; ++g)
+    if (ptr[g + 1] - ptr[g] > mmax) mmax = ptr[g + 1] - ptr[g];
+  double* sol = (double*)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+  double* S = (double*)malloc((size_t)mmax * sizeof(double));
+  double* X = (double*)malloc((size_t)mmax * sizeof(double));
+  double* w = (double*)malloc((size_t)mmax * sizeof(double));
+  for (int64_t i = 0; i < n; ++i) sol[i] = (q[i] + xk[i]) + sj[i]; /* :80 */
+  const double eps = 2.220446049250313e-16;
+  const double epsilon = 1.0; /* :81 */
+  for (int64_t g = 0; g < ngroups; ++g) {
+    const int64_t* idx = index + ptr[g];
+    int64_t m = ptr[g + 1] - ptr[g];
+    for (int64_t i = 0; i < m; ++i) { S[i] = sol[idx[i]]; X[i] = xk[idx[i]]; }
+    double lam = lambda[g];
+    double sl = lam * sigma; /* :85 */
+    froot_ctx c = {S, X, m, sigma, sl, delta, w};
+    double lmin = sl * (1 + eps); /* :94 */
+    double fl = froot(&c, lmin);
+    double ansatz = lmin + epsilon; /* :97 */
+    double step = ansatz / (sigma * (ansatz - sl));
+    for (int64_t i = 0; i < m; ++i) w[i] = softthres(S[i] / sigma - step * X[i], delta * step);
+    double zlmax = norm2(w, m); /* :99 */
+    double lmax = norm2(S, m) + sigma * (zlmax + fabs((epsilon - 1) / epsilon + 1) * lam * norm2(X, m)); /* :100 */
+    double fm = froot(&c, lmax);
+    if (fl * fm > 0) { /* :102 */
+      for (int64_t i = 0; i < m; ++i) y[idx[i]] = 0.0;
+    } else {
+      double nn = orc_bisect(&c, lmin, fl, lmax, fm); /* :105 */
+      step = nn / (sigma * (nn - sl));
+      if (fabs(nn - sl) == 0.0) { /* :107 */
+        for (int64_t i = 0; i < m; ++i) y[idx[i]] = 0.0;
+      } else {
+        for (int64_t i = 0; i < m; ++i) w[i] = S[i] - sigma * softthres(S[i] / sigma - step * X[i], delta * step); /* :111 */
+        double nw = norm2(w, m);
+        double alpha = jl_max(0.0, 1 - sl / nw); /* :83 */
+        for (int64_t i = 0; i < m; ++i) y[idx[i]] = alpha * w[i];
+      }
+    }
+    /* :116  y[idx] .-= (xk[idx] + sj[idx]): gather, subtract, scatter (a repeated index is subtracted once) */
+    for (int64_t i = 0; i < m; ++i) w[i] = y[idx[i]] - (xk[idx[i]] + sj[idx[i]]);
+    for (int64_t i = 0; i < m; ++i) y[idx[i]] = w[i];
+  }
+  free(sol); free(S); free(X); free(w);
+}
+
 /* ==========================================================================================
  * iprox!  (SURVEY.md 8f rank 1): indefinite prox  argmin 1/2 y'Dy + g'y + psi(y), D = diag(d)
  * ========================================================================================== */
@@ -687,6 +760,23 @@ ORC_API double orc_obj_group_l2(const double* y, const double* xk, const double*
   return sum_c;
 }
 
+/* psi(y) for groups given as arbitrary index sets (same value rules as orc_obj_group_l2) */
+ORC_API double orc_obj_group_l2_idx(const double* y, const double* xk, const double* sj, int64_t n, const int64_t* ptr,
+                                    const int64_t* index, int64_t ngroups, const double* lambda, double delta) {
+  double sum_c = 0.0;
+  for (int64_t g = 0; g < ngroups; ++g) {
+    double ss = 0.0;
+    for (int64_t p = ptr[g]; p < ptr[g + 1]; ++p) {
+      int64_t i = index[p];
+      double v = (delta >= 0) ? ((sj[i] + y[i]) + xk[i]) : ((xk[i] + sj[i]) + y[i]);
+      ss += v * v;
+    }
+    sum_c += lambda[g] * sqrt(ss);
+  }
+  if (delta >= 0 && outside_linf_ball(sj, y, n, 1.1 * delta)) return INFINITY;
+  return sum_c;
+}
+
 /* ==========================================================================================
  * ShiftedNormL1B2.prox!  src/shiftedNormL1B2.jl:50-67  
  * find_zero(froot, Delta) [ext: Roots.jl, single starting point => Order0, a bracketing hybrid]: restated as
@@ -744,4 +834,4 @@ ORC_API void orc_prox_l1_b2(double* y, const double* q, const double* xk, const 
 
 /* Objective value 1/(2 sigma) (t-q)^2 + lambda*h(x+s+t) helpers for the brute-force second oracle
  * live in tests/ (numpy); nothing else is exported from here. */
-ORC_API int orc_abi_version(void) { return 2; }
+ORC_API int orc_abi_version(void) { return 3; }

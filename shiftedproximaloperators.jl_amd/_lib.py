@@ -47,6 +47,10 @@ SIGNATURES = {
     "spx_prox_l1_b2": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d],
     "spx_prox_group_l2": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _d],
     "spx_prox_group_l2_binf": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _d, _d],
+    "spx_prox_group_l2_gather": [_p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _d],
+    "spx_prox_group_l2_binf_gather": [_p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _d, _d],
+    "spx_obj_group_l2_gather": [_p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _p, ctypes.POINTER(_d)],
+    "spx_obj_group_l2_binf_gather": [_p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _d, ctypes.POINTER(_d)],
 }
 # host-pointer forms: spx_host_X has the argument list of spx_X (include/spx.h, "host-pointer forms")
 SIGNATURES.update({"spx_host_" + k[4:]: list(v) for k, v in list(SIGNATURES.items())

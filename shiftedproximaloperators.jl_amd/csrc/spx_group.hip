@@ -109,6 +109,15 @@ struct MemGroup {
       f((q[i] + x) + sj[i], x);
     }
   }
+  // y[i] = f(S, X) - (xk + sj) for every element this lane owns (q[i] is read before y[i] is written: y may alias q)
+  template <class F>
+  __device__ __forceinline__ void store(double* y, F&& f) const {
+    for (int64_t i = lo + lane; i < hi; i += TEAM) {
+      const double x = xk[i], s = sj[i];
+      const double S = (q[i] + x) + s;
+      y[i] = f(S, x) - (x + s);
+    }
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -583,9 +592,91 @@ __global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// general kernel: any contiguous groups (CSR offsets or uniform size), TEAM lanes per group,
-// elements re-read from memory for every reduction.
+// general kernels: TEAM lanes per group, elements re-read from memory for every reduction.
+//   k_group_mem    : contiguous groups (CSR offsets or uniform size)
+//   k_group_gather : arbitrary index sets (the reference's idx::Vector{Vector{Int}}, src/groupNormL2.jl:30-31)
+// Both run group_body on an element provider (MemGroup / GatherGroup).
 // ---------------------------------------------------------------------------------------------
+// Gather provider.  `sol` = (q + xk) + sj was materialised by k_gather_prepare (as the reference's psi.sol, :65 -- so
+// y may alias q and groups may overlap); owner[j] = the LAST group containing j: only that group stores y[j], which is
+// what the reference's sequential loop over the groups leaves behind.
+template <int TEAM>
+struct GatherGroup {
+  const double* sol;
+  const double* xk;
+  const double* sj;
+  const int64_t* index;
+  const int* owner;
+  int64_t lo, hi;  // positions in `index`
+  int lane;
+  int g;
+  template <class F>
+  __device__ __forceinline__ void for_each(F&& f) const {
+    for (int64_t p = lo + lane; p < hi; p += TEAM) {
+      const int64_t j = index[p];
+      f(sol[j], xk[j]);
+    }
+  }
+  // y[j] = f(S, X) - (xk + sj) for every owned element
+  template <class F>
+  __device__ __forceinline__ void store(double* y, F&& f) const {
+    for (int64_t p = lo + lane; p < hi; p += TEAM) {
+      const int64_t j = index[p];
+      const double x = xk[j], s = sj[j];
+      const double v = f(sol[j], x) - (x + s);
+      if (owner[j] == g) y[j] = v;
+    }
+  }
+};
+
+template <int TEAM, bool BINF, class GRP>
+__device__ __forceinline__ void group_body(const GRP& grp, double* y, double lam, double sigma, double delta, double* lds,
+                                           bool literal_only) {
+  if constexpr (!BINF) {
+    double ss = 0.0;
+    grp.for_each([&](double S, double) { ss += S * S; });
+    const double snorm = sqrt(team_sum<TEAM>(ss, lds));
+    const double alpha = (snorm == 0.0) ? 0.0 : jl_max(1 - sigma * lam / snorm, 0.0);
+    grp.store(y, [&](double S, double) { return (snorm == 0.0) ? 0.0 : alpha * S; });
+  } else {
+    double root;
+    double rsa, rsb;
+    int status = literal_only ? BINF_LITERAL : binf_root<TEAM>(grp, lam, sigma, delta, lds, root, rsa, rsb);
+    const double sl = lam * sigma;
+    if (status == BINF_LITERAL) {
+      // the reference, literally, including its last step (:106-113) -- the root may lie below sl here
+      const bool ok = binf_literal_root<TEAM>(grp, lam, sigma, delta, lds, root);
+      if (!ok || (root - sl) == 0.0) {
+        grp.store(y, [&](double, double) { return 0.0; });
+      } else {
+        const double step = root / (sigma * (root - sl));
+        double sw = 0.0;
+        grp.for_each([&](double S, double X) {
+          double w = S - sigma * softthres(S / sigma - step * X, delta * step);
+          sw += w * w;
+        });
+        const double nw = sqrt(team_sum<TEAM>(sw, lds));
+        const double alpha = jl_max(0.0, 1 - sl / nw);
+        grp.store(y, [&](double S, double X) {
+          return alpha * (S - sigma * softthres(S / sigma - step * X, delta * step));
+        });
+      }
+    } else if (status == BINF_ZERO || (root - sl) == 0.0) {
+      grp.store(y, [&](double, double) { return 0.0; });
+    } else {
+      const double u = root - sl, tau = u / root, c = root / u;
+      double sw = 0.0;
+      grp.for_each([&](double S, double X) {
+        double w = binf_w(S, X, tau, c, delta);
+        sw += w * w;
+      });
+      const double nw = sqrt(team_sum<TEAM>(sw, lds));
+      const double alpha = jl_max(0.0, 1 - sl / nw);
+      grp.store(y, [&](double S, double X) { return alpha * binf_w(S, X, tau, c, delta); });
+    }
+  }
+}
+
 template <int TEAM, bool BINF>
 __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, const double* xk, const double* sj,
                                                     int64_t n, const int64_t* __restrict__ offsets, int64_t gsize,
@@ -605,62 +696,79 @@ __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, c
     if (lo < 0) lo = 0;
     if (hi > n) hi = n;
     MemGroup<TEAM> grp{q, xk, sj, lo, hi, lane};
-    const double lam = lambda[g];
-    if constexpr (!BINF) {
-      double ss = 0.0;
-      grp.for_each([&](double S, double) { ss += S * S; });
-      const double snorm = sqrt(team_sum<TEAM>(ss, lds));
-      const double alpha = (snorm == 0.0) ? 0.0 : jl_max(1 - sigma * lam / snorm, 0.0);
-      for (int64_t i = lo + lane; i < hi; i += TEAM) {
-        double x = xk[i], s = sj[i];
-        double S = (q[i] + x) + s;
-        y[i] = ((snorm == 0.0) ? 0.0 : alpha * S) - (x + s);
-      }
-    } else {
-      double root;
-      double rsa, rsb;
-      int status = list ? BINF_LITERAL : binf_root<TEAM>(grp, lam, sigma, delta, lds, root, rsa, rsb);
-      const double sl = lam * sigma;
-      if (status == BINF_LITERAL) {
-        // the reference, literally, including its last step (:106-113) -- the root may lie below sl here
-        const bool ok = binf_literal_root<TEAM>(grp, lam, sigma, delta, lds, root);
-        if (!ok || (root - sl) == 0.0) {
-          for (int64_t i = lo + lane; i < hi; i += TEAM) y[i] = 0.0 - (xk[i] + sj[i]);
-        } else {
-          const double step = root / (sigma * (root - sl));
-          double sw = 0.0;
-          grp.for_each([&](double S, double X) {
-            double w = S - sigma * softthres(S / sigma - step * X, delta * step);
-            sw += w * w;
-          });
-          const double nw = sqrt(team_sum<TEAM>(sw, lds));
-          const double alpha = jl_max(0.0, 1 - sl / nw);
-          for (int64_t i = lo + lane; i < hi; i += TEAM) {
-            double x = xk[i], s = sj[i];
-            double S = (q[i] + x) + s;
-            y[i] = alpha * (S - sigma * softthres(S / sigma - step * x, delta * step)) - (x + s);
-          }
-        }
-      } else if (status == BINF_ZERO || (root - sl) == 0.0) {
-        for (int64_t i = lo + lane; i < hi; i += TEAM) y[i] = 0.0 - (xk[i] + sj[i]);
-      } else {
-        const double u = root - sl, tau = u / root, c = root / u;
-        double sw = 0.0;
-        grp.for_each([&](double S, double X) {
-          double w = binf_w(S, X, tau, c, delta);
-          sw += w * w;
-        });
-        const double nw = sqrt(team_sum<TEAM>(sw, lds));
-        const double alpha = jl_max(0.0, 1 - sl / nw);
-        for (int64_t i = lo + lane; i < hi; i += TEAM) {
-          double x = xk[i], s = sj[i];
-          double S = (q[i] + x) + s;
-          y[i] = alpha * binf_w(S, x, tau, c, delta) - (x + s);
-        }
-      }
-    }
+    group_body<TEAM, BINF>(grp, y, lambda[g], sigma, delta, lds, list != nullptr);
     if constexpr (TEAM == 256) __syncthreads();
   }
+}
+
+// ShiftedGroupNormL2 with CSR offsets that do not span 0:n: indices before offsets[0] / from offsets[ngroups] on keep
+// the caller's y minus the shift (src/shiftedGroupNormL2.jl:77 runs over every index)
+__global__ __launch_bounds__(256) void k_csr_uncovered(double* y, const double* xk, const double* sj,
+                                                        const int64_t* __restrict__ offsets, int64_t ngroups, int64_t n) {
+  int64_t head = offsets[0], tail0 = offsets[ngroups];
+  if (head < 0) head = 0;
+  if (head > n) head = n;
+  if (tail0 < head) tail0 = head;
+  if (tail0 > n) tail0 = n;
+  const int64_t total = head + (n - tail0);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t i = (t < head) ? t : tail0 + (t - head);
+    y[i] = y[i] - (xk[i] + sj[i]);
+  }
+}
+
+// sol = (q + xk) + sj (:65 / :80), owner = -1
+__global__ __launch_bounds__(256) void k_gather_prepare(double* __restrict__ sol, int* __restrict__ owner,
+                                                         const double* q, const double* xk, const double* sj, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    sol[i] = (q[i] + xk[i]) + sj[i];
+    owner[i] = -1;
+  }
+}
+
+// owner[j] = max{g : j in idx_g}; flags an index outside [0, n) (the reference: BoundsError)
+__global__ __launch_bounds__(256) void k_gather_owner(int* owner, const int64_t* __restrict__ ptr,
+                                                       const int64_t* __restrict__ index, int64_t ngroups, int64_t n,
+                                                       int64_t nnz, int* flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t g = wave; g < ngroups; g += nwaves) {
+    int64_t lo = ptr[g], hi = ptr[g + 1];
+    if (lo < 0 || hi > nnz || lo > hi) { if (lane == 0) atomicOr(flag, 2); continue; }
+    for (int64_t p = lo + lane; p < hi; p += 64) {
+      const int64_t j = index[p];
+      if (j < 0 || j >= n) atomicOr(flag, 1);
+      else atomicMax(owner + j, (int)g);
+    }
+  }
+}
+
+template <int TEAM, bool BINF>
+__global__ __launch_bounds__(256) void k_group_gather(double* y, const double* sol, const double* xk, const double* sj,
+                                                       const int* owner, const int64_t* __restrict__ ptr,
+                                                       const int64_t* __restrict__ index, int64_t ngroups,
+                                                       const double* __restrict__ lambda, double sigma, double delta) {
+  __shared__ double lds[8];
+  constexpr int TPB = 256 / TEAM;
+  const int lane = threadIdx.x % TEAM;
+  const int64_t team = (int64_t)blockIdx.x * TPB + threadIdx.x / TEAM;
+  const int64_t nteams = (int64_t)gridDim.x * TPB;
+  for (int64_t g = team; g < ngroups; g += nteams) {
+    GatherGroup<TEAM> grp{sol, xk, sj, index, owner, ptr[g], ptr[g + 1], lane, (int)g};
+    group_body<TEAM, BINF>(grp, y, lambda[g], sigma, delta, lds, false);
+    if constexpr (TEAM == 256) __syncthreads();
+  }
+}
+
+// indices no group contains keep the caller's y (the reference never assigns them) minus the shift (:77 / :116)
+__global__ __launch_bounds__(256) void k_gather_rest(double* y, const double* xk, const double* sj, const int* owner,
+                                                      int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if (owner[i] < 0) y[i] = y[i] - (xk[i] + sj[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -673,7 +781,15 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   int rc = spx_check_common(ctx, y, q, xk, sj, n);
   if (rc) return rc;
   SPX_REQUIRE(ngroups >= 0, "ngroups < 0");
-  if (ngroups == 0 || n == 0) return SPX_OK;
+  if (n == 0) return SPX_OK;
+  if (ngroups == 0) {  // no group at all: ShiftedGroupNormL2 still subtracts the shift everywhere (:77)
+    if (!BINF && offsets) {
+      SPX_HIP(hipSetDevice(ctx->device));
+      hipLaunchKernelGGL(k_csr_uncovered, dim3(256), dim3(256), 0, ctx->stream, y, xk, sj, offsets, ngroups, n);
+      SPX_LAUNCH_CHECK();
+    }
+    return SPX_OK;
+  }
   SPX_REQUIRE(lambda != nullptr, "lambda_vec is NULL");
   if (!offsets) {
     SPX_REQUIRE(gsize > 0, "group_size <= 0 with NULL group_offsets");
@@ -730,6 +846,8 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     return SPX_OK;
   }
   // team width: wavefront per group unless groups are large on average
+  if (!BINF && offsets)
+    hipLaunchKernelGGL(k_csr_uncovered, dim3(256), dim3(256), 0, ctx->stream, y, xk, sj, offsets, ngroups, n);
   const double avg = (double)n / (double)ngroups;
   if (avg <= 2048.0) {
     int64_t blocks = (ngroups + 3) / 4;
@@ -755,4 +873,72 @@ SPX_EXPORT int spx_prox_group_l2_binf(spx_ctx* ctx, double* y, const double* q, 
                                       int64_t n, const int64_t* group_offsets, int64_t group_size, int64_t ngroups,
                                       const double* lambda_vec, double sigma, double delta) {
   return run_group<true>(ctx, y, q, xk, sj, n, group_offsets, group_size, ngroups, lambda_vec, sigma, delta);
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather-index groups: idx_g = group_index[group_ptr[g] .. group_ptr[g+1])
+// ---------------------------------------------------------------------------------------------
+template <bool BINF>
+static int run_group_gather(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                            const int64_t* ptr, const int64_t* index, int64_t ngroups, int64_t nnz,
+                            const double* lambda, double sigma, double delta) {
+  int rc = spx_check_common(ctx, y, q, xk, sj, n);
+  if (rc) return rc;
+  SPX_REQUIRE(ngroups >= 0 && ngroups < 0x7fffffff, "ngroups out of range");
+  SPX_REQUIRE(nnz >= 0, "nnz < 0");
+  if (n == 0) return SPX_OK;
+  if (ngroups > 0) SPX_REQUIRE(ptr != nullptr && lambda != nullptr, "group_ptr or lambda_vec is NULL");
+  if (nnz > 0) SPX_REQUIRE(index != nullptr, "group_index is NULL");
+  SPX_HIP(hipSetDevice(ctx->device));
+  // workspace: flag (256 B) | sol (n doubles) | owner (n ints)
+  const size_t sol_off = 256, own_off = sol_off + (size_t)n * sizeof(double);
+  rc = spx_ws_reserve(ctx, own_off + (size_t)n * sizeof(int) + 256);
+  if (rc) return rc;
+  char* ws = static_cast<char*>(ctx->ws);
+  int* flag = reinterpret_cast<int*>(ws);
+  double* sol = reinterpret_cast<double*>(ws + sol_off);
+  int* owner = reinterpret_cast<int*>(ws + own_off);
+  const int64_t cap_blocks = (int64_t)ctx->num_cu * 8;
+  int64_t eb = (n + 255) / 256;
+  if (eb > cap_blocks) eb = cap_blocks;
+  SPX_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(k_gather_prepare, dim3((unsigned)eb), dim3(256), 0, ctx->stream, sol, owner, q, xk, sj, n);
+  if (ngroups > 0) {
+    int64_t gb = (ngroups + 3) / 4;
+    if (gb > cap_blocks) gb = cap_blocks;
+    hipLaunchKernelGGL(k_gather_owner, dim3((unsigned)gb), dim3(256), 0, ctx->stream, owner, ptr, index, ngroups, n, nnz,
+                       flag);
+    SPX_LAUNCH_CHECK();
+    int hflag = 0;  // the reference throws BoundsError before touching y: check before the stores
+    SPX_HIP(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SPX_HIP(hipStreamSynchronize(ctx->stream));
+    if (hflag & 2) { spx_set_error("invalid argument: group_ptr is not a non-decreasing sequence inside [0, nnz]"); return SPX_ERR_INVALID_ARG; }
+    if (hflag & 1) { spx_set_error("invalid argument: group index outside [0, n) (BoundsError)"); return SPX_ERR_INVALID_ARG; }
+    const double avg = (double)nnz / (double)ngroups;
+    if (avg <= 2048.0) {
+      hipLaunchKernelGGL((k_group_gather<64, BINF>), dim3((unsigned)gb), dim3(256), 0, ctx->stream, y, sol, xk, sj, owner,
+                         ptr, index, ngroups, lambda, sigma, delta);
+    } else {
+      int64_t blocks = ngroups < cap_blocks ? ngroups : cap_blocks;
+      hipLaunchKernelGGL((k_group_gather<256, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, sol, xk, sj,
+                         owner, ptr, index, ngroups, lambda, sigma, delta);
+    }
+  }
+  // :77 subtracts the shift at EVERY index; the Binf form does so per group (:116) and leaves the rest of y alone
+  if (!BINF) hipLaunchKernelGGL(k_gather_rest, dim3((unsigned)eb), dim3(256), 0, ctx->stream, y, xk, sj, owner, n);
+  SPX_LAUNCH_CHECK();
+  return SPX_OK;
+}
+
+SPX_EXPORT int spx_prox_group_l2_gather(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                                        int64_t n, const int64_t* group_ptr, const int64_t* group_index,
+                                        int64_t ngroups, int64_t nnz, const double* lambda_vec, double sigma) {
+  return run_group_gather<false>(ctx, y, q, xk, sj, n, group_ptr, group_index, ngroups, nnz, lambda_vec, sigma, 0.0);
+}
+
+SPX_EXPORT int spx_prox_group_l2_binf_gather(spx_ctx* ctx, double* y, const double* q, const double* xk,
+                                             const double* sj, int64_t n, const int64_t* group_ptr,
+                                             const int64_t* group_index, int64_t ngroups, int64_t nnz,
+                                             const double* lambda_vec, double sigma, double delta) {
+  return run_group_gather<true>(ctx, y, q, xk, sj, n, group_ptr, group_index, ngroups, nnz, lambda_vec, sigma, delta);
 }

@@ -143,6 +143,26 @@ int host_group(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   return stage_out(ctx, y, dy, vbytes(n));
 }
 
+// gather-index groups: + group_ptr, group_index and lambda_vec
+template <class F>
+int host_gather(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                const int64_t* ptr, const int64_t* index, int64_t ngroups, int64_t nnz, const double* lambda_vec,
+                F&& f) {
+  int rc = check_host(ctx, y, q, xk, sj, n);
+  if (rc) return rc;
+  SPX_REQUIRE(ngroups >= 0 && nnz >= 0, "negative size");
+  // y is an input as well: indices no group contains keep the caller's value
+  const In in[7] = {{q, vbytes(n)}, {xk, vbytes(n)}, {sj, vbytes(n)}, {ptr, ptr ? (size_t)(ngroups + 1) * sizeof(int64_t) : 0},
+                    {index, (size_t)nnz * sizeof(int64_t)}, {lambda_vec, vbytes(ngroups)}, {y, vbytes(n)}};
+  const void* d[7];
+  rc = stage_in(ctx, in, d, 0, nullptr);
+  if (rc) return rc;
+  double* dy = const_cast<double*>(D(d[6]));
+  rc = f(dy, D(d[0]), D(d[1]), D(d[2]), static_cast<const int64_t*>(d[3]), static_cast<const int64_t*>(d[4]), D(d[5]));
+  if (rc) return rc;
+  return stage_out(ctx, y, dy, vbytes(n));
+}
+
 // psi(y): y, xk, sj (+ extras), value returned by the device twin (which synchronises)
 template <class F>
 int host_obj(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, const double* a,
@@ -223,6 +243,28 @@ SPX_EXPORT int spx_host_prox_group_l2_binf(spx_ctx* ctx, double* y, const double
                       return spx_prox_group_l2_binf(ctx, dy, dq, dx, ds, n, doff, group_size, ngroups, dlam, sigma,
                                                     delta);
                     });
+}
+
+SPX_EXPORT int spx_host_prox_group_l2_gather(spx_ctx* ctx, double* y, const double* q, const double* xk,
+                                             const double* sj, int64_t n, const int64_t* group_ptr,
+                                             const int64_t* group_index, int64_t ngroups, int64_t nnz,
+                                             const double* lambda_vec, double sigma) {
+  return host_gather(ctx, y, q, xk, sj, n, group_ptr, group_index, ngroups, nnz, lambda_vec,
+                     [&](double* dy, const double* dq, const double* dx, const double* ds, const int64_t* dp,
+                         const int64_t* di, const double* dlam) {
+                       return spx_prox_group_l2_gather(ctx, dy, dq, dx, ds, n, dp, di, ngroups, nnz, dlam, sigma);
+                     });
+}
+SPX_EXPORT int spx_host_prox_group_l2_binf_gather(spx_ctx* ctx, double* y, const double* q, const double* xk,
+                                                  const double* sj, int64_t n, const int64_t* group_ptr,
+                                                  const int64_t* group_index, int64_t ngroups, int64_t nnz,
+                                                  const double* lambda_vec, double sigma, double delta) {
+  return host_gather(ctx, y, q, xk, sj, n, group_ptr, group_index, ngroups, nnz, lambda_vec,
+                     [&](double* dy, const double* dq, const double* dx, const double* ds, const int64_t* dp,
+                         const int64_t* di, const double* dlam) {
+                       return spx_prox_group_l2_binf_gather(ctx, dy, dq, dx, ds, n, dp, di, ngroups, nnz, dlam, sigma,
+                                                            delta);
+                     });
 }
 
 // ---- iprox! -----------------------------------------------------------------------------------
@@ -320,4 +362,40 @@ SPX_EXPORT int spx_host_obj_group_l2_binf(spx_ctx* ctx, const double* y, const d
                     return spx_obj_group_l2_binf(ctx, dy, dx, ds, n, static_cast<const int64_t*>(doff), group_size,
                                                  ngroups, D(dlam), delta, value);
                   });
+}
+
+// gather objective: y, xk, sj, lambda_vec, group_ptr, group_index
+template <class F>
+static int host_obj_gather(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                           const int64_t* ptr, const int64_t* index, int64_t ngroups, int64_t nnz,
+                           const double* lambda_vec, F&& f) {
+  int rc = check_host(ctx, y, y, xk, sj, n);
+  if (rc) return rc;
+  SPX_REQUIRE(ngroups >= 0 && nnz >= 0, "negative size");
+  const In in[6] = {{y, vbytes(n)}, {xk, vbytes(n)}, {sj, vbytes(n)}, {lambda_vec, vbytes(ngroups)},
+                    {ptr, ptr ? (size_t)(ngroups + 1) * sizeof(int64_t) : 0}, {index, (size_t)nnz * sizeof(int64_t)}};
+  const void* d[6];
+  rc = stage_in(ctx, in, d, 0, nullptr);
+  if (rc) return rc;
+  return f(D(d[0]), D(d[1]), D(d[2]), D(d[3]), static_cast<const int64_t*>(d[4]), static_cast<const int64_t*>(d[5]));
+}
+SPX_EXPORT int spx_host_obj_group_l2_gather(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                                            const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups,
+                                            int64_t nnz, const double* lambda_vec, double* value) {
+  return host_obj_gather(ctx, y, xk, sj, n, group_ptr, group_index, ngroups, nnz, lambda_vec,
+                         [&](const double* dy, const double* dx, const double* ds, const double* dlam, const int64_t* dp,
+                             const int64_t* di) {
+                           return spx_obj_group_l2_gather(ctx, dy, dx, ds, n, dp, di, ngroups, nnz, dlam, value);
+                         });
+}
+SPX_EXPORT int spx_host_obj_group_l2_binf_gather(spx_ctx* ctx, const double* y, const double* xk, const double* sj,
+                                                 int64_t n, const int64_t* group_ptr, const int64_t* group_index,
+                                                 int64_t ngroups, int64_t nnz, const double* lambda_vec, double delta,
+                                                 double* value) {
+  return host_obj_gather(ctx, y, xk, sj, n, group_ptr, group_index, ngroups, nnz, lambda_vec,
+                         [&](const double* dy, const double* dx, const double* ds, const double* dlam, const int64_t* dp,
+                             const int64_t* di) {
+                           return spx_obj_group_l2_binf_gather(ctx, dy, dx, ds, n, dp, di, ngroups, nnz, dlam, delta,
+                                                               value);
+                         });
 }

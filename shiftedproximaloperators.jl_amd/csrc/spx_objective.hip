@@ -120,21 +120,28 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_obj_group(const double* __restrict__ y, const double* __restrict__ xk,
                                                     const double* __restrict__ sj, int64_t n,
                                                     const int64_t* __restrict__ offsets, int64_t gsize, int64_t ngroups,
-                                                    const double* __restrict__ lambda, double rad, ObjWs* ws) {
+                                                    const int64_t* __restrict__ index /* NULL: contiguous groups */,
+                                                    int64_t nnz, const double* __restrict__ lambda, double rad,
+                                                    ObjWs* ws) {
   __shared__ double lds4[4];
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   double acc = 0.0;  // lane 0 of each wave accumulates lambda_g * norm_g
-  bool bad = false;
+  bool bad = false, bad_index = false;
   for (int64_t g = wave; g < ngroups; g += nwaves) {
     int64_t lo, hi;
     if (offsets) { lo = offsets[g]; hi = offsets[g + 1]; }
     else { lo = g * gsize; hi = lo + gsize; }
     if (lo < 0) lo = 0;
-    if (hi > n) hi = n;
+    if (hi > (index ? nnz : n)) hi = index ? nnz : n;
     double ss = 0.0;
-    for (int64_t i = lo + lane; i < hi; i += 64) {
+    for (int64_t p = lo + lane; p < hi; p += 64) {
+      int64_t i = p;
+      if (index) {
+        i = index[p];
+        if (i < 0 || i >= n) { bad_index = true; continue; }
+      }
       double v;
       if constexpr (MODE == 2) {
         const double t = sj[i] + y[i];
@@ -150,6 +157,19 @@ __global__ __launch_bounds__(256) void k_obj_group(const double* __restrict__ y,
   }
   acc = block_sum(acc, lds4);
   if (threadIdx.x == 0) ws->partial[blockIdx.x] = acc;
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&ws->infeasible, 1);
+  if (__any(bad_index) && (threadIdx.x & 63) == 0) atomicOr(&ws->infeasible, 2);
+}
+
+// IndBallLinf(1.1 Delta)(sj + y) over EVERY index (src/shiftedGroupNormL2Binf.jl:35-36), for groups that need not tile 1:n
+__global__ __launch_bounds__(256) void k_obj_linf_scan(const double* __restrict__ y, const double* __restrict__ sj,
+                                                        int64_t n, double rad, ObjWs* ws) {
+  bool bad = false;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double t = sj[i] + y[i];
+    bad |= (t < -rad) || (t > rad);
+  }
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&ws->infeasible, 1);
 }
 
@@ -197,13 +217,17 @@ int run_obj(spx_ctx* ctx, const double* y, const double* xk, const double* sj, i
 
 template <int MODE>
 int run_obj_group(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
-                  const int64_t* offsets, int64_t gsize, int64_t ngroups, const double* lambda, double rad, double* value) {
+                  const int64_t* offsets, int64_t gsize, int64_t ngroups, const int64_t* index, int64_t nnz,
+                  const double* lambda, double rad, double* value) {
   SPX_REQUIRE(ctx != nullptr && value != nullptr, "ctx or value is NULL");
-  SPX_REQUIRE(n >= 0 && ngroups >= 0, "negative size");
+  SPX_REQUIRE(n >= 0 && ngroups >= 0 && nnz >= 0, "negative size");
   *value = 0.0;
-  if (n == 0 || ngroups == 0) return SPX_OK;
-  SPX_REQUIRE(y && xk && sj && lambda, "NULL vector");
-  if (!offsets) SPX_REQUIRE(gsize > 0 && ngroups <= n / gsize && ngroups * gsize == n, "ngroups * group_size != n");
+  if (n == 0) return SPX_OK;
+  SPX_REQUIRE(y && xk && sj, "NULL vector");
+  if (ngroups > 0) SPX_REQUIRE(lambda != nullptr, "lambda_vec is NULL");
+  if (index || nnz > 0) SPX_REQUIRE(offsets != nullptr && index != nullptr, "group_ptr or group_index is NULL");
+  if (!offsets && ngroups > 0)
+    SPX_REQUIRE(gsize > 0 && ngroups <= n / gsize && ngroups * gsize == n, "ngroups * group_size != n");
   int rc = spx_ws_reserve(ctx, sizeof(ObjWs) + 256);
   if (rc) return rc;
   SPX_HIP(hipSetDevice(ctx->device));
@@ -211,13 +235,23 @@ int run_obj_group(spx_ctx* ctx, const double* y, const double* xk, const double*
   SPX_HIP(hipMemsetAsync(&ws->infeasible, 0, sizeof(int), ctx->stream));
   int64_t blocks = (ngroups + 3) / 4;
   if (blocks > kObjBlocks) blocks = kObjBlocks;
+  if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((k_obj_group<MODE>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, offsets, gsize,
-                     ngroups, lambda, rad, ws);
+                     ngroups, index, nnz, lambda, rad, ws);
+  if (MODE == 2 && offsets) {  // the groups need not tile 0:n: the trust-region indicator covers every index
+    int64_t sb = (n + 256 * 8 - 1) / (256 * 8);
+    if (sb > kObjBlocks) sb = kObjBlocks;
+    hipLaunchKernelGGL(k_obj_linf_scan, dim3((unsigned)sb), dim3(256), 0, ctx->stream, y, sj, n, rad, ws);
+  }
   SPX_LAUNCH_CHECK();
   double sum;
   int bad;
   rc = obj_finish(ctx, ws, (int)blocks, &sum, &bad);
   if (rc) return rc;
+  if (bad & 2) {
+    spx_set_error("invalid argument: group index outside [0, n) (BoundsError)");
+    return SPX_ERR_INVALID_ARG;
+  }
   *value = bad ? std::numeric_limits<double>::infinity() : sum;
   return SPX_OK;
 }
@@ -285,10 +319,25 @@ SPX_EXPORT int spx_obj_indball_l0_binf(spx_ctx* ctx, const double* y, const doub
 SPX_EXPORT int spx_obj_group_l2(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
                                 const int64_t* group_offsets, int64_t group_size, int64_t ngroups,
                                 const double* lambda_vec, double* value) {
-  return run_obj_group<0>(ctx, y, xk, sj, n, group_offsets, group_size, ngroups, lambda_vec, 0.0, value);
+  return run_obj_group<0>(ctx, y, xk, sj, n, group_offsets, group_size, ngroups, nullptr, 0, lambda_vec, 0.0, value);
 }
 SPX_EXPORT int spx_obj_group_l2_binf(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
                                      const int64_t* group_offsets, int64_t group_size, int64_t ngroups,
                                      const double* lambda_vec, double delta, double* value) {
-  return run_obj_group<2>(ctx, y, xk, sj, n, group_offsets, group_size, ngroups, lambda_vec, 1.1 * delta, value);
+  return run_obj_group<2>(ctx, y, xk, sj, n, group_offsets, group_size, ngroups, nullptr, 0, lambda_vec, 1.1 * delta,
+                          value);
+}
+
+// groups as arbitrary index sets (group_ptr / group_index as for spx_prox_group_l2_gather)
+SPX_EXPORT int spx_obj_group_l2_gather(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                                       const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups,
+                                       int64_t nnz, const double* lambda_vec, double* value) {
+  SPX_REQUIRE(group_ptr != nullptr || ngroups == 0, "group_ptr is NULL");
+  return run_obj_group<0>(ctx, y, xk, sj, n, group_ptr, 0, ngroups, group_index, nnz, lambda_vec, 0.0, value);
+}
+SPX_EXPORT int spx_obj_group_l2_binf_gather(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                                            const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups,
+                                            int64_t nnz, const double* lambda_vec, double delta, double* value) {
+  SPX_REQUIRE(group_ptr != nullptr || ngroups == 0, "group_ptr is NULL");
+  return run_obj_group<2>(ctx, y, xk, sj, n, group_ptr, 0, ngroups, group_index, nnz, lambda_vec, 1.1 * delta, value);
 }

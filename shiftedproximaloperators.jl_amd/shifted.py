@@ -96,6 +96,13 @@ def _ptr(t):
     return ctypes.c_void_p(t.ctypes.data if _is_host(t) else t.data_ptr())
 
 
+def _iptr(t):
+    """address of an index array even when it is empty-but-present (ptr of zero groups has one entry)"""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.ctypes.data if _is_host(t) else t.data_ptr())
+
+
 def _empty_like(t):
     return np.empty_like(t) if _is_host(t) else torch.empty_like(t)
 
@@ -354,29 +361,52 @@ class _GroupLayout:
         if isinstance(h.idx, UniformGroups):
             if h.idx.size * h.idx.count != n:
                 raise IndexError("BoundsError: %d groups of %d do not tile a vector of length %d" % (h.idx.count, h.idx.size, n))
-            self.ngroups, self.offsets, self.group_size = h.idx.count, None, h.idx.size
+            self.ngroups, self.offsets, self.group_size, self.index = h.idx.count, None, h.idx.size, None
             self.lam = self._lam(h.lam, device)
             return
-        bounds = []
+        self.index = None  # gather mode: (ptr, index) instead of offsets
+        bounds, sets, contiguous = [], [], True
         for g in h.idx:
             if isinstance(g, slice):
                 a, b, st = g.indices(n)
-            elif isinstance(g, range):
+                g = range(a, b, st)
+            if isinstance(g, range):
                 a, b, st = g.start, g.stop, g.step
+                if st == 1 and a <= b:
+                    if a < 0 or b > n:
+                        raise IndexError("BoundsError: group %s outside 0:%d" % (g, n))
+                    bounds.append((a, b))
+                    sets.append(g)
+                    continue
+                idx = list(g)
             else:
-                # an explicit index vector (the reference's `collect(4:6)`): accepted when it is a contiguous run
                 idx = [int(v) for v in (g.tolist() if hasattr(g, "tolist") else g)]
-                if not idx or any(j - i != 1 for i, j in zip(idx, idx[1:])):
-                    raise NotImplementedError("gather-index groups (non-contiguous index vectors) are not on the "
-                                              "accelerated path; pass contiguous ranges")
-                a, b, st = idx[0], idx[-1] + 1, 1
-            if st != 1 or a < 0 or b > n or a > b:
-                raise NotImplementedError("groups must be contiguous 0-based ranges inside 0:n")
-            bounds.append((a, b))
-        for (a0, b0), (a1, b1) in zip(bounds, bounds[1:]):
-            if a1 != b0:
-                raise NotImplementedError("groups must be consecutive ranges (CSR offsets); got a gap/overlap")
-        self.ngroups = len(bounds)
+            # an explicit index vector (the reference's `collect(4:6)`, runtests.jl:290): a contiguous run is a range
+            if idx and all(j - i == 1 for i, j in zip(idx, idx[1:])):
+                if idx[0] < 0 or idx[-1] >= n:
+                    raise IndexError("BoundsError: group index outside 0:%d" % n)
+                bounds.append((idx[0], idx[-1] + 1))
+            else:
+                contiguous = False
+            sets.append(idx)
+        if contiguous and any(a1 != b0 for (a0, b0), (a1, b1) in zip(bounds, bounds[1:])):
+            contiguous = False  # gaps / overlaps / out of order: general index sets
+        self.ngroups = len(sets)
+        if not contiguous:
+            # gather form: literal reference semantics for arbitrary (overlapping, partial) index sets
+            ptr = np.zeros(self.ngroups + 1, dtype=np.int64)
+            for k, g in enumerate(sets):
+                ptr[k + 1] = ptr[k] + len(g)
+            index = (np.concatenate([np.asarray(g, dtype=np.int64) for g in sets]) if self.ngroups
+                     else np.zeros(0, dtype=np.int64))
+            if index.size and (index.min() < 0 or index.max() >= n):
+                raise IndexError("BoundsError: group index outside 0:%d" % n)
+            self.nnz = int(index.size)
+            self.offsets = ptr if device is None else torch.from_numpy(ptr).to(device)
+            self.index = index if device is None else torch.from_numpy(index).to(device)
+            self.group_size = 0
+            self.lam = self._lam(h.lam, device)
+            return
         sizes = {b - a for a, b in bounds}
         if self.ngroups and len(sizes) == 1 and bounds[0][0] == 0 and bounds[-1][1] == n and n > 0:
             self.offsets = None
@@ -404,11 +434,21 @@ class ShiftedGroupNormL2(ShiftedProximableFunction):  # src/shiftedGroupNormL2.j
 
     def _prox(self, L, ctx, y, q, sigma):
         g = self._layout
+        if g.index is not None:
+            _lib.check(self._sym(L, "spx_prox_group_l2_gather")(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), _n(y),
+                                                                _iptr(g.offsets), _iptr(g.index), g.ngroups, g.nnz,
+                                                                _ptr(g.lam), sigma))
+            return
         _lib.check(self._sym(L, "spx_prox_group_l2")(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), _n(y),
                                        _ptr(g.offsets), g.group_size, g.ngroups, _ptr(g.lam), sigma))
 
     def _obj(self, L, ctx, y, out):
         g = self._layout
+        if g.index is not None:
+            _lib.check(self._sym(L, "spx_obj_group_l2_gather")(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), _n(y),
+                                                               _iptr(g.offsets), _iptr(g.index), g.ngroups, g.nnz,
+                                                               _ptr(g.lam), out))
+            return
         _lib.check(self._sym(L, "spx_obj_group_l2")(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), _n(y), _ptr(g.offsets),
                                       g.group_size, g.ngroups, _ptr(g.lam), out))
 
@@ -422,11 +462,21 @@ class ShiftedGroupNormL2Binf(ShiftedProximableFunction):  # src/shiftedGroupNorm
 
     def _prox(self, L, ctx, y, q, sigma):
         g = self._layout
+        if g.index is not None:
+            _lib.check(self._sym(L, "spx_prox_group_l2_binf_gather")(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj),
+                                                                     _n(y), _iptr(g.offsets), _iptr(g.index), g.ngroups,
+                                                                     g.nnz, _ptr(g.lam), sigma, self.Δ))
+            return
         _lib.check(self._sym(L, "spx_prox_group_l2_binf")(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), _n(y),
                                             _ptr(g.offsets), g.group_size, g.ngroups, _ptr(g.lam), sigma, self.Δ))
 
     def _obj(self, L, ctx, y, out):
         g = self._layout
+        if g.index is not None:
+            _lib.check(self._sym(L, "spx_obj_group_l2_binf_gather")(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), _n(y),
+                                                                    _iptr(g.offsets), _iptr(g.index), g.ngroups, g.nnz,
+                                                                    _ptr(g.lam), self.Δ, out))
+            return
         _lib.check(self._sym(L, "spx_obj_group_l2_binf")(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), _n(y), _ptr(g.offsets),
                                            g.group_size, g.ngroups, _ptr(g.lam), self.Δ, out))
 

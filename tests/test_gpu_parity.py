@@ -336,6 +336,99 @@ def test_group_ragged_and_single(s, orc, binf):
     _group_check(y, ref, q, x, np.zeros(n), [0, n])
 
 
+@pytest.mark.parametrize("binf", [False, True])
+@pytest.mark.parametrize("layout", ["interleaved", "permuted_big", "overlap_partial", "one_huge", "with_empty"])
+def test_group_gather_index_sets(s, orc, binf, layout):
+    """Groups as arbitrary index vectors (idx::Vector{Vector{Int}}, src/groupNormL2.jl:30-31): literal reference
+    semantics incl. overlapping groups (last group wins) and indices in no group (y on entry survives)."""
+    rng = np.random.default_rng({"interleaved": 1, "permuted_big": 2, "overlap_partial": 3, "one_huge": 4,
+                                 "with_empty": 5}[layout])
+    if layout == "interleaved":          # v = [[0, 2, 4, ...], [1, 3, 5, ...]]
+        n = 2000
+        groups = [list(range(0, n, 2)), list(range(1, n, 2))]
+    elif layout == "permuted_big":       # a random partition into 3000 groups of mixed sizes
+        n = 200_000
+        perm = rng.permutation(n)
+        cuts = np.sort(rng.choice(np.arange(1, n), size=2999, replace=False))
+        groups = [g.tolist() for g in np.split(perm, cuts)]
+    elif layout == "overlap_partial":    # overlapping groups, a repeated index, indices in no group
+        n = 5000
+        groups = [rng.choice(n // 2, size=300, replace=False).tolist() for _ in range(40)]
+        groups[3] = groups[3] + groups[3][:5]
+    elif layout == "one_huge":           # workgroup-per-group kernel
+        n = 30_000
+        groups = [rng.permutation(n)[:25_000].tolist(), [7, 3]]
+    else:                                # an empty group among others
+        n = 300
+        groups = [list(range(0, 100)), [], list(range(299, 99, -1))]
+    x, sj, q = _data(n, 600 + len(groups))
+    lam = rng.uniform(0.3, 1.5, size=len(groups))
+    y0 = rng.normal(size=n)
+    sigma, delta = 0.9, 0.8
+    xd, sd, qd, yd = _dev(x, sj, q, y0)
+    h = s.GroupNormL2(lam.tolist(), groups)
+    if binf:
+        psi = s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd)
+        ref = orc.prox_group_l2_idx(q, x, sj, lam, sigma, groups, delta=delta, y0=y0)
+    else:
+        psi = s.shifted(s.shifted(h, xd), sd)
+        ref = orc.prox_group_l2_idx(q, x, sj, lam, sigma, groups, y0=y0)
+    assert psi._layout.index is not None
+    y = s.prox_bang(yd, psi, qd, sigma).cpu().numpy()
+    S = (q + x) + sj
+    scale = np.abs(ref).copy()
+    for g in groups:
+        if len(g):
+            scale[g] = np.maximum(scale[g], np.linalg.norm(S[g]))
+    covered = np.zeros(n, dtype=bool)
+    for g in groups:
+        covered[g] = True
+    bad = np.abs(y - ref) > GROUP_TOL * np.maximum(scale, 1e-300)
+    assert not bad.any(), (int(bad.sum()), float(np.max(np.abs(y - ref))))
+    assert _bits_equal(y[~covered], ref[~covered])            # untouched / shift-only entries are exact
+    # y === q
+    q2 = qd.clone()
+    s.prox_bang(q2, psi, q2, sigma)
+    ref2 = orc.prox_group_l2_idx(q, x, sj, lam, sigma, groups, delta=delta if binf else None, y0=q)
+    bad = np.abs(q2.cpu().numpy() - ref2) > GROUP_TOL * np.maximum(scale, 1e-300)
+    assert not bad.any()
+    # psi(y) on the same index sets
+    val = psi(_dev(ref * 0.5)[0])
+    exp = orc.obj_group_l2_idx(ref * 0.5, x, sj, lam, groups, delta=delta if binf else None)
+    assert (val == exp) or abs(val - exp) <= 1e-12 * abs(exp)
+    # host-pointer form: same kernels
+    hy = y0.copy()
+    psi_h = s.shifted(s.shifted(h, x, delta, s.NormLinf(1.0)), sj) if binf else s.shifted(s.shifted(h, x), sj)
+    s.prox_bang(hy, psi_h, q, sigma)
+    assert _bits_equal(hy, y)
+
+
+def test_group_l2_csr_partial_cover(s, orc):
+    """Consecutive ranges that do not span 0:n: ShiftedGroupNormL2 subtracts the shift at every index
+    (src/shiftedGroupNormL2.jl:77), the Binf form only inside the groups (src/shiftedGroupNormL2Binf.jl:116)."""
+    n = 1000
+    x, sj, q = _data(n, 5)
+    y0 = np.random.default_rng(6).normal(size=n)
+    groups = [range(100, 300), range(300, 650), range(650, 900)]
+    lam = [0.5, 1.0, 0.7]
+    xd, sd, qd = _dev(x, sj, q)
+    h = s.GroupNormL2(lam, groups)
+    for binf in (False, True):
+        psi = s.shifted(s.shifted(h, xd, 0.8, s.NormLinf(1.0)), sd) if binf else s.shifted(s.shifted(h, xd), sd)
+        assert psi._layout.index is None and psi._layout.offsets is not None
+        y = s.prox_bang(_dev(y0)[0], psi, qd, 0.9).cpu().numpy()
+        ref = orc.prox_group_l2_idx(q, x, sj, lam, 0.9, [list(g) for g in groups], delta=0.8 if binf else None, y0=y0)
+        np.testing.assert_allclose(y, ref, rtol=0, atol=1e-12)
+        out = np.r_[0:100, 900:n]
+        assert _bits_equal(y[out], ref[out])
+        # objective: an infeasible entry OUTSIDE every group still makes the Binf value +Inf
+        yy = np.zeros(n)
+        yy[5] = 10.0
+        val = psi(_dev(yy)[0])
+        exp = orc.obj_group_l2_idx(yy, x, sj, lam, [list(g) for g in groups], delta=0.8 if binf else None)
+        assert (val == exp) or abs(val - exp) <= 1e-12 * abs(exp)
+
+
 def test_group_binf_goldens_and_edge_branches(s, orc, kats):
     for name in ("group_l2_binf_single", "group_l2_binf_two"):  # test/runtests.jl:587-606, 658-705
         k = kats[name]
@@ -348,8 +441,8 @@ def test_group_binf_goldens_and_edge_branches(s, orc, kats):
         hv = s.GroupNormL2(k["lambda"], [list(range(a, b)) for a, b in zip(off[:-1], off[1:])])
         yv = s.prox(s.shifted(hv, x, k["delta"], s.NormLinf(1.0)), q, k["sigma"]).cpu().numpy()
         assert _bits_equal(y, yv)
-    with pytest.raises(NotImplementedError):
-        s.shifted(s.GroupNormL2([1.0, 1.0], [[0, 2, 4], [1, 3, 5]]), _dev(np.ones(6))[0])  # true gather groups: not built
+    with pytest.raises(IndexError):
+        s.shifted(s.GroupNormL2([1.0, 1.0], [[0, 2, 4], [1, 3, 6]]), _dev(np.ones(6))[0])  # BoundsError
     # branches of shiftedGroupNormL2Binf.jl:102-109: zero groups, |X| <= Delta everywhere, huge lambda
     n, g = 128 * 6, 128
     rng = np.random.default_rng(5)
