@@ -56,6 +56,41 @@ def test_group_l2_binf_golden(orc, kats, name):
     assert np.max(np.abs(y)) <= k["delta"] * (1 + 1e-8)
 
 
+@pytest.mark.parametrize("name", ["group_l2_binf_single", "group_l2_binf_two"])
+def test_group_index_set_form_matches_ranges_and_golden(orc, kats, name):
+    # the reference test builds its groups as index VECTORS (`v = [collect(1:3), collect(4:6)]`, runtests.jl:658):
+    # the index-set restatement must give the golden too, and equal the range restatement bit for bit
+    k = kats[name]
+    off = k["offsets"]
+    groups = [list(range(a, b)) for a, b in zip(off[:-1], off[1:])]
+    y = orc.prox_group_l2_idx(k["q"], k["x"], k["s"], k["lambda"], k["sigma"], groups, delta=k["delta"])
+    np.testing.assert_allclose(y, k["expected"], rtol=k["rtol"], atol=0)
+    assert np.array_equal(y, orc.prox_group_l2_binf(k["q"], k["x"], k["s"], k["lambda"], k["sigma"], k["delta"],
+                                                    offsets=off))
+    y2 = orc.prox_group_l2_idx(k["q"], k["x"], k["s"], k["lambda"], k["sigma"], groups)
+    assert np.array_equal(y2, orc.prox_group_l2(k["q"], k["x"], k["s"], k["lambda"], k["sigma"], offsets=off))
+
+
+def test_group_index_sets_sequential_semantics(orc):
+    # overlapping groups: the later group's value stays; an index in no group keeps y on entry (minus the shift for
+    # ShiftedGroupNormL2, src/shiftedGroupNormL2.jl:77; untouched for Binf, src/shiftedGroupNormL2Binf.jl:116)
+    rng = np.random.default_rng(3)
+    n = 9
+    q, x, s = rng.normal(size=n), rng.normal(size=n), rng.uniform(-0.5, 0.5, size=n)
+    y0 = rng.normal(size=n)
+    groups = [[0, 1, 2, 3], [3, 4, 5]]
+    lam = [0.3, 0.4]
+    y = orc.prox_group_l2_idx(q, x, s, lam, 0.5, groups, y0=y0)
+    S = (q + x) + s
+    second = _norml2_prox(S[[3, 4, 5]], 0.4, 0.5)
+    first = _norml2_prox(S[[0, 1, 2, 3]], 0.3, 0.5)
+    np.testing.assert_allclose(y[[3, 4, 5]], second - (x + s)[[3, 4, 5]], rtol=1e-14)
+    np.testing.assert_allclose(y[[0, 1, 2]], first[:3] - (x + s)[[0, 1, 2]], rtol=1e-14)
+    assert np.array_equal(y[6:], y0[6:] - (x[6:] + s[6:]))
+    yb = orc.prox_group_l2_idx(q, x, s, lam, 0.5, groups, delta=0.7, y0=y0)
+    assert np.array_equal(yb[6:], y0[6:])
+
+
 def _norml2_prox(x, lam, gamma):
     # ProximalOperators.NormL2 prox [ext]: max(1 - gamma*lam/||x||, 0) * x
     nx = np.linalg.norm(x)
