@@ -60,9 +60,18 @@ struct SelWs {
   unsigned long long hist[kBins];
 };
 
+// Candidates of the main pass: every WAVEFRONT of its grid owns a fixed region of kWaveSlots entries and one count
+// word {candidates, elements above the band}: no atomics, no barrier, nothing a wave has to wait for before it exits,
+// and a candidate order that is the same run to run.
+constexpr int kWaveSlots = 64;
+struct WaveCount {
+  unsigned int cand, above;
+};
+
 constexpr int kSample = 65536;        // sample size (256 chunks of 256 consecutive elements)
-constexpr int kMainChunkPairs = 8192; // 16-byte pairs per workgroup of the main pass
-constexpr int kLdsCand = 1024;        // per-workgroup candidate staging
+constexpr int kMainUnroll = 6;        // KiB per wave and vector in the main pass (as k_sep_lds)
+constexpr int kMainTilePairs = 256 * kMainUnroll;  // 16-byte pairs per workgroup of the main pass
+constexpr int kMainWaveElems = 2 * 64 * kMainUnroll;  // elements per wavefront of the main pass (768; ~0.5 % are candidates)
 constexpr int kShortList = 4096;      // candidates left after the first digit that k_s2_finish resolves in LDS
 
 __device__ __forceinline__ uint64_t key_of(double v) { return (uint64_t)__double_as_longlong(v) & kAbsMask; }
@@ -328,17 +337,22 @@ __global__ __launch_bounds__(256) void k_sel_final(double* y, const double* xk, 
 //   2. k_s2_pick     one workgroup: exact order statistics of the sample at ranks p*M -/+ (6 sigma + 16),
 //                    p = r/n, sigma = sqrt(M p (1-p))  ->  key band [t_lo, t_hi] that contains the r-th
 //                    largest |v| of the whole vector except with probability ~1e-9 per side
-//   3. k_s2_main     ONE streaming pass over q, xk, sj (24 B/element, nothing written): counts the
-//                    elements above the band and appends the (key, index) of the ~1% inside it to a
-//                    candidate buffer (LDS staging per workgroup, one global atomic per workgroup)
-//   4. k_s2_verify   cnt_above < r <= cnt_above + candidates ?  -> the selection continues on the
-//                    candidates only (same digit machinery, a few microseconds per pass)
-//   5. k_sel_final_q y[i] from q, xk, sj and the thresholds (24 B read + 8 B written per element)
-// Total 56 B/element instead of >= 80.  The prediction is only a performance device: if the verification
-// fails (or a buffer overflows) the full-vector radix select above runs instead, so the result is exact
-// for any input.  The host reads the 4-byte verdict back once, after the final pass has been queued
-// speculatively (the final pass returns at once if the verdict is negative).
-// y is not touched before step 5 and step 5 reads q[i] before writing y[i]: y may alias q.
+//   3. k_s2_main     ONE streaming pass over q, xk, sj: counts the elements above the band and writes the (key, index
+//                    [, kept value]) of the ~0.5 % inside it into the candidate region of the WAVEFRONT that saw them
+//                    (fixed regions + one count word per wave: no atomics, no barrier, deterministic order).
+//                    If y overlaps none of the inputs the pass also stores y speculatively (above the band: kept,
+//                    otherwise dropped) -- 32 B/element, the algorithmic minimum; else it writes nothing (24 B/element).
+//   4. k_sel_hist_cand / k_s2_scan_verify   totals of step 3, the verdict  cnt_above < r <= cnt_above + candidates,
+//                    and the first digit of the selection among the candidates; k_s2_compact + k_s2_finish resolve the
+//                    rest on a short list in one workgroup (regions are walked transposed: 64 regions per wavefront)
+//   5a. k_s2_fixup   (y disjoint) stores the kept value of the candidates that made the cut: ~0.25 % of y, scattered
+//   5b. k_sel_final_q (y aliases an input) y[i] from q, xk, sj and the thresholds (24 B read + 8 B written per element)
+// Total 32 B/element (+ ~1 % for the candidates) in the disjoint case, 56 B/element when y aliases an input, instead
+// of >= 80.  The prediction is only a performance device: if the verification fails (or a region overflows) the
+// full-vector radix select above runs instead -- it recomputes everything from q, xk, sj, which the speculative stores
+// cannot have touched -- so the result is exact for any input.  The host reads the 4-byte verdict back once, after
+// the last kernel has been queued (steps 5a/5b return at once if the verdict is negative).
+// In the aliased case y is not touched before step 5b and step 5b reads q[i] before writing y[i].
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_s2_sample(const double* q, const double* xk, const double* sj, int64_t n,
                                                     double* samp, SelWs* ws) {
@@ -442,167 +456,251 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
     f.key_passes = 0;
     f.overflow = 0;
     f.list_count = 0;
+    // digit machinery of the candidate selection: everything that depends on the band only (the counts -- verdict,
+    // quota -- are filled in by k_s2_scan_verify).  First digit = the first one in which the band's ends differ.
+    SelState& s = ws->st;
+    s.t_floor = f.t_lo;
+    s.t_eq = ~0ull;
+    s.icut = -1;
+    s.t_ge = ~0ull;
+    s.quota = 0;
+    const uint64_t d = f.t_lo ^ f.t_hi;
+    if (d == 0) {  // one key value in the band: straight to the index tie-break
+      s.t_ge = f.t_lo + 1;
+      s.t_eq = f.t_lo;
+      s.phase = 1;
+      s.prefix = 0;
+      const int idx_bits = s.idx_bits;
+      const int w = idx_bits % kDigitBits ? idx_bits % kDigitBits : kDigitBits;
+      s.shift = idx_bits - w;
+      s.width = w;
+    } else {
+      const int hb = 63 - __clzll((long long)d);  // highest differing bit
+      f.key_passes = (hb + 1 + kDigitBits - 1) / kDigitBits;
+      const int width = hb + 1 < kDigitBits ? hb + 1 : kDigitBits;
+      const int shift = hb + 1 - width;
+      s.phase = 0;
+      s.shift = shift;
+      s.width = width;
+      s.prefix = (shift + width >= 64) ? 0ull : (f.t_hi >> (shift + width));
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void k_s2_main(const double* q_, const double* xk_, const double* sj_, int64_t n,
-                                                  SelWs* ws, uint64_t* cand_key, int64_t* cand_idx, int64_t cap) {
-  __shared__ uint64_t lk[kLdsCand];
-  __shared__ int64_t li[kLdsCand];
-  __shared__ unsigned int lcnt, labove;
-  __shared__ unsigned long long gbase;
-  if (threadIdx.x == 0) { lcnt = 0; labove = 0; }
-  __syncthreads();
+// Main pass: one tile per workgroup, waves fully independent (no barrier, no atomics).  Counts the elements above the
+// band and appends the band's elements to the wave's own candidate region.
+// WRITE (y overlaps none of the inputs): the pass also stores y, speculatively -- entries above the band as kept,
+// entries below it and inside it as dropped; the kept value of a band entry travels with the candidate and
+// k_s2_fixup stores it once the cut is known.  The call then moves the algorithmic 32 B/element plus the ~0.5 % of
+// candidates, instead of 56 B/element with the separate final pass (k_sel_final_q, used when y aliases an input).
+template <bool BINF, bool WRITE>
+__global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, const double* xk_, const double* sj_,
+                                                  int64_t n, const SelWs* ws, uint64_t* cand_key, int64_t* cand_idx,
+                                                  double* cand_val, WaveCount* counts, double delta) {
   const uint64_t t_hi = ws->fs.t_hi, t_lo = ws->fs.t_lo;
   const f64x2* q = reinterpret_cast<const f64x2*>(q_);
   const f64x2* xk = reinterpret_cast<const f64x2*>(xk_);
   const f64x2* sj = reinterpret_cast<const f64x2*>(sj_);
+  f64x2* y2 = reinterpret_cast<f64x2*>(y_);
   const int64_t n2 = n >> 1;
-  const int64_t p0 = (int64_t)blockIdx.x * kMainChunkPairs;
-  unsigned int above = 0;
-  auto visit = [&](double v, int64_t i) {
-    const uint64_t key = key_of(v);
-    if (key > t_hi) {
-      ++above;
-    } else if (key >= t_lo) {
-      const unsigned int slot = atomicAdd(&lcnt, 1u);
-      if (slot < kLdsCand) { lk[slot] = key; li[slot] = i; }
-    }
-  };
-  // each wave streams its quarter of the chunk through LDS: 4 KiB per vector per step (global_load_lds nt), wait,
-  // read back its own 16-byte slots -- same staging as the separable skeleton (spx_separable.hip)
-  constexpr int UNROLL = 4;
+  constexpr int UNROLL = kMainUnroll;
   __shared__ __attribute__((aligned(16))) char dma[4 * 3 * UNROLL * 1024];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  char* wl = dma + wave * (3 * UNROLL * 1024);
-  typedef __attribute__((address_space(3))) void lds_void;
-  for (int64_t base = p0; base < p0 + kMainChunkPairs && base < n2; base += 256 * UNROLL) {
-    const int64_t wbase = base + wave * (64 * UNROLL) + lane;
-#pragma unroll
-    for (int k = 0; k < UNROLL; ++k) {
-      int64_t i = wbase + k * 64;
-      if (i >= n2) i = n2 - 1;
-      __builtin_amdgcn_global_load_lds((const void*)(q + i), (lds_void*)(wl + (0 * UNROLL + k) * 1024), 16, 0, 2);
-      __builtin_amdgcn_global_load_lds((const void*)(xk + i), (lds_void*)(wl + (1 * UNROLL + k) * 1024), 16, 0, 2);
-      __builtin_amdgcn_global_load_lds((const void*)(sj + i), (lds_void*)(wl + (2 * UNROLL + k) * 1024), 16, 0, 2);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < UNROLL; ++k) {
-      const int64_t i = wbase + k * 64;
-      const f64x2 a = *reinterpret_cast<const f64x2*>(wl + (0 * UNROLL + k) * 1024 + lane * 16);
-      const f64x2 b = *reinterpret_cast<const f64x2*>(wl + (1 * UNROLL + k) * 1024 + lane * 16);
-      const f64x2 c = *reinterpret_cast<const f64x2*>(wl + (2 * UNROLL + k) * 1024 + lane * 16);
-      if (i < n2) {
-        visit((b.x + c.x) + a.x, 2 * i);      // shiftedIndBallL0.jl:66  xk .+ sj .+ q
-        visit((b.y + c.y) + a.y, 2 * i + 1);
+  const int64_t gwave = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t rbase = gwave * kWaveSlots;  // this wave's candidate region
+  const unsigned long long lt_mask = (1ull << lane) - 1;
+  unsigned int above = 0;   // per lane
+  unsigned int ncand = 0;   // wave-uniform
+  // Called by all 64 lanes together (the ballot needs them); returns the value stored speculatively (WRITE).
+  auto visit = [&](bool valid, double v, int64_t i, double x, double s) -> double {
+    const uint64_t key = key_of(v);
+    double kept = 0.0, dropped = 0.0;
+    if constexpr (WRITE) {
+      const double xs = x + s;
+      kept = v - xs;            // shiftedIndBallL0.jl:70 on a kept entry
+      dropped = 0.0 - xs;       // :69-70 on a zeroed entry
+      if constexpr (BINF) {     // shiftedIndBallL0BInf.jl:91
+        kept = jl_min(jl_max(kept, -delta), delta);
+        dropped = jl_min(jl_max(dropped, -delta), delta);
       }
     }
-    // the next step overwrites this wave's slots: its own ds_reads above have completed (values consumed)
+    const bool is_above = valid && key > t_hi;
+    const bool in_band = valid && !is_above && key >= t_lo;
+    above += is_above ? 1u : 0u;
+    const unsigned long long m = __ballot(in_band);
+    if (m) {
+      const unsigned int pos = ncand + (unsigned int)__popcll(m & lt_mask);
+      if (in_band && pos < (unsigned)kWaveSlots) {
+        cand_key[rbase + pos] = key;
+        cand_idx[rbase + pos] = i;
+        if constexpr (WRITE) cand_val[rbase + pos] = kept;
+      }
+      ncand += (unsigned int)__popcll(m);
+    }
+    return is_above ? kept : dropped;
+  };
+  // each wave moves kMainUnroll KiB per vector through LDS (global_load_lds nt), waits once and reads back its own
+  // 16-byte slots -- the staging of the separable skeleton (spx_separable.hip)
+  char* wl = dma + wave * (3 * UNROLL * 1024);
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int64_t wbase = gwave * (64 * UNROLL) + lane;
+#pragma unroll
+  for (int k = 0; k < UNROLL; ++k) {
+    int64_t i = wbase + k * 64;
+    if (i >= n2) i = n2 - 1;
+    __builtin_amdgcn_global_load_lds((const void*)(q + i), (lds_void*)(wl + (0 * UNROLL + k) * 1024), 16, 0, 2);
+    __builtin_amdgcn_global_load_lds((const void*)(xk + i), (lds_void*)(wl + (1 * UNROLL + k) * 1024), 16, 0, 2);
+    __builtin_amdgcn_global_load_lds((const void*)(sj + i), (lds_void*)(wl + (2 * UNROLL + k) * 1024), 16, 0, 2);
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) visit((xk_[n - 1] + sj_[n - 1]) + q_[n - 1], n - 1);
-  // workgroup totals
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < UNROLL; ++k) {
+    const int64_t i = wbase + k * 64;
+    const f64x2 a = *reinterpret_cast<const f64x2*>(wl + (0 * UNROLL + k) * 1024 + lane * 16);
+    const f64x2 b = *reinterpret_cast<const f64x2*>(wl + (1 * UNROLL + k) * 1024 + lane * 16);
+    const f64x2 c = *reinterpret_cast<const f64x2*>(wl + (2 * UNROLL + k) * 1024 + lane * 16);
+    const bool valid = i < n2;
+    f64x2 o;
+    o.x = visit(valid, (b.x + c.x) + a.x, 2 * i, b.x, c.x);      // shiftedIndBallL0.jl:66  xk .+ sj .+ q
+    o.y = visit(valid, (b.y + c.y) + a.y, 2 * i + 1, b.y, c.y);
+    if constexpr (WRITE) {
+      if (valid) __builtin_nontemporal_store(o, y2 + i);
+    }
+  }
+  if ((n & 1) && gwave == 0) {  // the odd last element rides with wave 0 (all of its lanes call visit)
+    const int64_t i = n - 1;
+    const double o = visit(lane == 0, (xk_[i] + sj_[i]) + q_[i], i, xk_[i], sj_[i]);
+    if constexpr (WRITE) {
+      if (lane == 0) y_[i] = o;
+    }
+  }
   for (int off = 32; off >= 1; off >>= 1) above += __shfl_xor(above, off, 64);
-  if ((threadIdx.x & 63) == 0 && above) atomicAdd(&labove, above);
-  __syncthreads();
-  unsigned int cnt = lcnt;
-  if (threadIdx.x == 0) {
-    if (labove) atomicAdd(&ws->fs.cnt_above, (unsigned long long)labove);
-    if (cnt > kLdsCand) { atomicExch(&ws->fs.overflow, 1); cnt = kLdsCand; }
-    gbase = cnt ? atomicAdd(&ws->fs.cand_count, (unsigned long long)cnt) : 0ull;
-  }
-  __syncthreads();
-  if (cnt > kLdsCand) cnt = kLdsCand;
-  const unsigned long long g0 = gbase;
-  for (unsigned int e = threadIdx.x; e < cnt; e += 256) {
-    if ((int64_t)(g0 + e) < cap) { cand_key[g0 + e] = lk[e]; cand_idx[g0 + e] = li[e]; }
-  }
+  if (lane == 0) counts[gwave] = WaveCount{ncand, above};  // ncand > kWaveSlots = overflow, seen by the consumers
 }
 
-// verdict + set up the digit machinery on the candidates (first digit = the first one in which the band's
-// ends differ; everything above it is the common prefix)
-__global__ void k_s2_verify(SelWs* ws, int64_t n, int64_t r, int64_t cap) {
-  if (threadIdx.x != 0) return;
-  FastState& f = ws->fs;
-  SelState& s = ws->st;
-  const unsigned long long above = f.cnt_above, cand = f.cand_count;
-  const bool ok = !f.overflow && (int64_t)cand <= cap && above < (unsigned long long)r &&
-                  (unsigned long long)r <= above + cand;
-  f.ok = ok ? 1 : 0;
-  f.key_passes = 0;
-  if (!ok) return;
-  s.quota = (int64_t)((unsigned long long)r - above);
-  s.t_floor = f.t_lo;
-  s.t_eq = ~0ull;
-  s.icut = -1;
-  s.t_ge = ~0ull;
-  const uint64_t d = f.t_lo ^ f.t_hi;
-  int idx_bits = s.idx_bits;
-  if (d == 0) {  // one key value in the band: straight to the index tie-break (or everything kept)
-    if ((unsigned long long)s.quota == cand) { s.phase = 2; s.t_ge = f.t_lo; return; }
-    s.t_ge = f.t_lo + 1;
-    s.t_eq = f.t_lo;
-    s.phase = 1;
-    s.prefix = 0;
-    int w = idx_bits % kDigitBits ? idx_bits % kDigitBits : kDigitBits;
-    s.shift = idx_bits - w;
-    s.width = w;
-    return;
+// Candidate kernels walk the regions TRANSPOSED: a wavefront takes 64 regions at a time, lane l owns region w0 + l and
+// steps through its few entries (4 loads in flight per lane), so the count words are read coalesced and no lane waits
+// on a chain of dependent loads.  f(position, key, index) is called for every valid entry; the return value holds this
+// LANE's totals over the regions it owned.
+struct RegionTotals {
+  unsigned long long cand, above;
+  bool overflow;
+};
+template <class F>
+__device__ __forceinline__ RegionTotals for_each_candidate(const WaveCount* counts, int64_t nregions,
+                                                           const uint64_t* cand_key, const int64_t* cand_idx, F&& f) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  RegionTotals t{0ull, 0ull, false};
+  for (int64_t w0 = wave * 64; w0 < nregions; w0 += nwaves * 64) {
+    const int64_t w = w0 + lane;
+    WaveCount c{0u, 0u};
+    if (w < nregions) c = counts[w];
+    t.cand += c.cand;
+    t.above += c.above;
+    t.overflow |= c.cand > (unsigned)kWaveSlots;
+    const int cnt = c.cand < (unsigned)kWaveSlots ? (int)c.cand : kWaveSlots;
+    const int64_t e0 = w * kWaveSlots;
+    for (int s0 = 0; __any(s0 < cnt); s0 += 4) {
+      uint64_t k[4];
+      int64_t ix[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u < cnt) { k[u] = cand_key[e0 + s0 + u]; ix[u] = cand_idx[e0 + s0 + u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u < cnt) f(e0 + s0 + u, k[u], ix[u]);
+    }
   }
-  const int hb = 63 - __clzll((long long)d);  // highest differing bit
-  f.key_passes = (hb + 1 + kDigitBits - 1) / kDigitBits;
-  int width = hb + 1 < kDigitBits ? hb + 1 : kDigitBits;
-  int shift = hb + 1 - width;
-  s.phase = 0;
-  s.shift = shift;
-  s.width = width;
-  s.prefix = (shift + width >= 64) ? 0ull : (f.t_hi >> (shift + width));
+  return t;
 }
 
-// histogram of the current digit over the candidates
-__global__ __launch_bounds__(256) void k_sel_hist_cand(const uint64_t* cand_key, const int64_t* cand_idx, SelWs* ws) {
+// the kept band entries get their value (everything else was stored by k_s2_main<.., true>)
+__global__ __launch_bounds__(256) void k_s2_fixup(double* y, const uint64_t* cand_key, const int64_t* cand_idx,
+                                                   const double* cand_val, const SelWs* ws, const WaveCount* counts,
+                                                   int64_t nregions) {
+  if (!ws->fs.ok) return;
   const SelState st = ws->st;
-  if (!ws->fs.ok || st.phase == 2) return;
+  for_each_candidate(counts, nregions, cand_key, cand_idx, [&](int64_t e, uint64_t key, int64_t i) {
+    if ((key >= st.t_ge) || (key == st.t_eq && i <= st.icut)) y[i] = cand_val[e];
+  });
+}
+
+// histogram of the first candidate digit (set up by k_s2_pick) + the totals of the main pass
+__global__ __launch_bounds__(256) void k_sel_hist_cand(const uint64_t* cand_key, const int64_t* cand_idx, SelWs* ws,
+                                                        const WaveCount* counts, int64_t nregions) {
+  const SelState st = ws->st;
   __shared__ unsigned int lh[kBins];
   for (int b = threadIdx.x; b < kBins; b += blockDim.x) lh[b] = 0u;
   __syncthreads();
-  const int64_t m = (int64_t)ws->fs.cand_count;
   const int shift = st.shift;
   const int hs = st.shift + st.width;
   const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = tid; e < m; e += stride) {
-    const uint64_t key = cand_key[e];
+  RegionTotals t = for_each_candidate(counts, nregions, cand_key, cand_idx, [&](int64_t, uint64_t key, int64_t idx) {
     if (st.phase == 0) {
       if ((hs >= 64 ? 0ull : (key >> hs)) == st.prefix) atomicAdd(&lh[(key >> shift) & dmask], 1u);
     } else if (key == st.t_eq) {
-      const uint64_t i = (uint64_t)cand_idx[e];
+      const uint64_t i = (uint64_t)idx;
       if ((i >> hs) == st.prefix) atomicAdd(&lh[(i >> shift) & dmask], 1u);
     }
+  });
+  for (int off = 32; off >= 1; off >>= 1) {  // per-lane totals -> wave totals
+    t.cand += __shfl_xor(t.cand, off, 64);
+    t.above += __shfl_xor(t.above, off, 64);
+  }
+  const bool any_overflow = __any(t.overflow);
+  if ((threadIdx.x & 63) == 0) {
+    if (t.cand) atomicAdd(&ws->fs.cand_count, t.cand);
+    if (t.above) atomicAdd(&ws->fs.cnt_above, t.above);
+    if (any_overflow) atomicExch(&ws->fs.overflow, 1);
   }
   flush_hist(lh, ws->hist);
 }
 
+// One workgroup: the verdict (is the r-th largest provably inside the band?), then the first scan step.
+__global__ __launch_bounds__(256) void k_s2_scan_verify(SelWs* ws, int64_t r) {
+  __shared__ unsigned long long scratch[8];
+  __shared__ int sok;
+  __shared__ SelState sst;
+  if (threadIdx.x == 0) {
+    FastState& f = ws->fs;
+    SelState& s = ws->st;
+    const unsigned long long above = f.cnt_above, cand = f.cand_count;
+    const bool ok = !f.overflow && above < (unsigned long long)r && (unsigned long long)r <= above + cand;
+    f.ok = ok ? 1 : 0;
+    if (ok) {
+      s.quota = (int64_t)((unsigned long long)r - above);
+      if (f.t_lo == f.t_hi && (unsigned long long)s.quota == cand) {  // a one-key band, all of it kept
+        s.phase = 2;
+        s.t_ge = f.t_lo;
+        s.t_eq = ~0ull;
+      }
+    }
+    sok = ok ? 1 : 0;
+    sst = s;
+  }
+  __syncthreads();
+  if (sok && sst.phase != 2) sel_scan_step(ws->hist, sst, &ws->st, scratch);
+  __syncthreads();
+  for (int b = threadIdx.x; b < kBins; b += blockDim.x) ws->hist[b] = 0ull;
+}
+
 // after the first candidate digit: the candidates still in play (same decided prefix, or tied key) -> short list
 __global__ __launch_bounds__(256) void k_s2_compact(const uint64_t* cand_key, const int64_t* cand_idx, SelWs* ws,
-                                                     uint64_t* list_key, int64_t* list_idx) {
+                                                     uint64_t* list_key, int64_t* list_idx, const WaveCount* counts,
+                                                     int64_t nregions) {
   const SelState st = ws->st;
   if (!ws->fs.ok || st.phase == 2) return;
-  const int64_t m = (int64_t)ws->fs.cand_count;
   const int hs = st.shift + st.width;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = tid; e < m; e += stride) {
-    const uint64_t key = cand_key[e];
-    const int64_t i = cand_idx[e];
+  for_each_candidate(counts, nregions, cand_key, cand_idx, [&](int64_t, uint64_t key, int64_t i) {
     const bool in = (st.phase == 0) ? ((hs >= 64 ? 0ull : (key >> hs)) == st.prefix)
                                     : (key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix);
     if (in) {
       const unsigned int slot = atomicAdd(&ws->fs.list_count, 1u);
       if (slot < (unsigned)kShortList) { list_key[slot] = key; list_idx[slot] = i; }
     }
-  }
+  });
 }
 
 // one workgroup: finishes the selection on the short list, entirely in LDS
@@ -693,6 +791,7 @@ __global__ __launch_bounds__(256) void k_sel_final_q(double* y_, const double* q
 }
 
 static int g_sel_fast = 1;  // spx_set_tuning key 2: 0 disables the sample-predicted path
+static int g_sel_spec = 1;  // spx_set_tuning key 4: 0 disables the single-pass (speculative store) form of it
 
 template <bool BINF>
 int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n, int64_t r,
@@ -703,11 +802,17 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   SPX_HIP(hipSetDevice(ctx->device));
   const int vec = (spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj)) ? 1 : 0;
   const bool try_fast = g_sel_fast && vec && n >= ((int64_t)1 << 22) && r > 0 && r < n;
-  const int64_t ccap = try_fast ? (n / 16 > (1 << 20) ? n / 16 : (1 << 20)) : 0;  // candidate capacity
+  // fast path scratch: one candidate region + count word per wavefront of the main pass
+  const int64_t n2 = n >> 1;
+  const int64_t mblocks = (n2 + kMainTilePairs - 1) / kMainTilePairs;
+  const int64_t nregions = try_fast ? mblocks * 4 : 0;
+  const int64_t ccap = nregions * kWaveSlots;
   const size_t off_samp = (sizeof(SelWs) + 255) & ~(size_t)255;
-  const size_t off_ckey = off_samp + (size_t)kSample * sizeof(double);
+  const size_t off_cnt = off_samp + (size_t)kSample * sizeof(double);
+  const size_t off_ckey = (off_cnt + (size_t)nregions * sizeof(WaveCount) + 255) & ~(size_t)255;
   const size_t off_cidx = off_ckey + (size_t)ccap * sizeof(uint64_t);
-  const size_t off_lkey = off_cidx + (size_t)ccap * sizeof(int64_t);
+  const size_t off_cval = off_cidx + (size_t)ccap * sizeof(int64_t);
+  const size_t off_lkey = off_cval + (size_t)ccap * sizeof(double);
   const size_t off_lidx = off_lkey + (size_t)kShortList * sizeof(uint64_t);
   rc = spx_ws_reserve(ctx, off_lidx + (size_t)kShortList * sizeof(int64_t) + 256);
   if (rc) return rc;
@@ -715,26 +820,39 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   if (try_fast) {
     char* wsb = reinterpret_cast<char*>(ctx->ws);
     double* samp = reinterpret_cast<double*>(wsb + off_samp);
+    WaveCount* counts = reinterpret_cast<WaveCount*>(wsb + off_cnt);
     uint64_t* ckey = reinterpret_cast<uint64_t*>(wsb + off_ckey);
     int64_t* cidx = reinterpret_cast<int64_t*>(wsb + off_cidx);
+    double* cval = reinterpret_cast<double*>(wsb + off_cval);
+    // single-pass form when y overlaps none of the inputs (a failed prediction recomputes everything from them)
+    auto disjoint = [&](const double* a) { return (y + n <= a) || (a + n <= y); };
+    const bool write = g_sel_spec && disjoint(q) && disjoint(xk) && disjoint(sj);
     uint64_t* lkey = reinterpret_cast<uint64_t*>(wsb + off_lkey);
     int64_t* lidx = reinterpret_cast<int64_t*>(wsb + off_lidx);
-    const int64_t n2 = n >> 1;
     hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, ctx->stream, ws, n, r);
     hipLaunchKernelGGL(k_s2_sample, dim3(256), dim3(256), 0, ctx->stream, q, xk, sj, n, samp, ws);
     hipLaunchKernelGGL(k_s2_pick, dim3(1), dim3(1024), 0, ctx->stream, (const double*)samp, n, r, ws);
-    hipLaunchKernelGGL(k_s2_main, dim3((unsigned)((n2 + kMainChunkPairs - 1) / kMainChunkPairs)), dim3(256), 0,
-                       ctx->stream, q, xk, sj, n, ws, ckey, cidx, ccap);
-    hipLaunchKernelGGL(k_s2_verify, dim3(1), dim3(64), 0, ctx->stream, ws, n, r, ccap);
-    // first candidate digit with all CUs, survivors -> short list, rest of the selection in one workgroup
-    hipLaunchKernelGGL(k_sel_hist_cand, dim3(512), dim3(256), 0, ctx->stream, (const uint64_t*)ckey, (const int64_t*)cidx,
-                       ws);
-    hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(256), 0, ctx->stream, ws);
-    hipLaunchKernelGGL(k_s2_compact, dim3(512), dim3(256), 0, ctx->stream, (const uint64_t*)ckey, (const int64_t*)cidx,
-                       ws, lkey, lidx);
+    const dim3 mgrid((unsigned)mblocks);
+    if (write)
+      hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y, q, xk, sj, n, (const SelWs*)ws,
+                         ckey, cidx, cval, counts, delta);
+    else
+      hipLaunchKernelGGL((k_s2_main<BINF, false>), mgrid, dim3(256), 0, ctx->stream, y, q, xk, sj, n, (const SelWs*)ws,
+                         ckey, cidx, cval, counts, delta);
+    // first candidate digit with many CUs (+ the totals and the verdict), survivors -> short list, the rest of the
+    // selection in one workgroup
+    hipLaunchKernelGGL(k_sel_hist_cand, dim3(128), dim3(256), 0, ctx->stream, (const uint64_t*)ckey, (const int64_t*)cidx,
+                       ws, (const WaveCount*)counts, nregions);
+    hipLaunchKernelGGL(k_s2_scan_verify, dim3(1), dim3(256), 0, ctx->stream, ws, r);
+    hipLaunchKernelGGL(k_s2_compact, dim3(256), dim3(256), 0, ctx->stream, (const uint64_t*)ckey, (const int64_t*)cidx, ws,
+                       lkey, lidx, (const WaveCount*)counts, nregions);
     hipLaunchKernelGGL(k_s2_finish, dim3(1), dim3(1024), 0, ctx->stream, ws, (const uint64_t*)lkey, (const int64_t*)lidx);
-    hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1535) / 1536)), dim3(256), 0, ctx->stream, y, q, xk,
-                       sj, n, (const SelWs*)ws, delta);
+    if (write)
+      hipLaunchKernelGGL(k_s2_fixup, dim3(512), dim3(256), 0, ctx->stream, y, (const uint64_t*)ckey, (const int64_t*)cidx,
+                         (const double*)cval, (const SelWs*)ws, (const WaveCount*)counts, nregions);
+    else
+      hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1535) / 1536)), dim3(256), 0, ctx->stream, y, q,
+                         xk, sj, n, (const SelWs*)ws, delta);
     SPX_LAUNCH_CHECK();
     // the verdict is read back AFTER the speculative final pass has been queued: the GPU never idles on the host
     int ok = 0;
@@ -770,6 +888,7 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
 }  // namespace
 
 void spx_select_set_fast(int on) { g_sel_fast = on ? 1 : 0; }
+void spx_select_set_spec(int on) { g_sel_spec = on ? 1 : 0; }
 
 SPX_EXPORT int spx_prox_indball_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
                                    int64_t n, int64_t r) {

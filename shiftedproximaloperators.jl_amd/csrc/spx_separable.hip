@@ -538,7 +538,8 @@ __global__ __launch_bounds__(256) void k_sep_scalar(double* y, const double* q, 
 
 // Tuning knobs (spx_set_tuning).  Defaults from tools/sweep_sep.py on MI355X, n = 1e8 (profiles/r01_sweep_sep.txt):
 // one tile per workgroup (no cap) + non-temporal loads/stores: 6.15 TB/s vs 5.66 TB/s for 16 WG/CU, plain.
-void spx_select_set_fast(int on);  // spx_select.hip
+void spx_select_set_fast(int on);
+void spx_select_set_spec(int on);  // spx_select.hip
 static int g_sep_blocks_per_cu = 0;  // 0 = no cap: grid = number of tiles
 static int g_sep_nt = 1;
 
@@ -616,6 +617,7 @@ SPX_EXPORT int spx_set_tuning(int key, int value) {
   if (key == 1) { g_sep_nt = value ? 1 : 0; return SPX_OK; }
   if (key == 2) { spx_select_set_fast(value); return SPX_OK; }
   if (key == 3) { g_sep_lds = value ? 1 : 0; return SPX_OK; }
+  if (key == 4) { spx_select_set_spec(value); return SPX_OK; }
   spx_set_error("invalid argument: unknown tuning key/value");
   return SPX_ERR_INVALID_ARG;
 }

@@ -188,16 +188,22 @@ def test_indball_fast_path_and_fallback(s, orc, case):
     L = s._lib.load()
     for r in (1, 7, n // 1000, n // 3, n - 5):
         ref = orc.prox_indball_l0_binf(q, x, sj, r, 1.0)
-        for fast in (1, 0):
+        # (fast, spec): single-pass speculative form (default), two-pass form, full-vector radix select
+        for fast, spec in ((1, 1), (1, 0), (0, 1)):
             s._lib.check(L.spx_set_tuning(2, fast))
+            s._lib.check(L.spx_set_tuning(4, spec))
             try:
                 psi = s.shifted(s.shifted(s.IndBallL0(r), xd, 1.0, s.NormLinf(1.0)), sd)
+                psi.sol.fill_(float("nan"))  # every entry must be written
                 y = s.prox(psi, qd, 1.0).cpu().numpy()
             finally:
                 s._lib.check(L.spx_set_tuning(2, 1))
-            assert _bits_equal(y, ref), (case, r, fast)
-    # y === q on the fast path
+                s._lib.check(L.spx_set_tuning(4, 1))
+            assert _bits_equal(y, ref), (case, r, fast, spec)
+    # plain IndBallL0 (no clamp) through the single-pass form
     ref = orc.prox_indball_l0(q, x, sj, n // 50)
+    assert _bits_equal(s.prox(s.shifted(s.shifted(s.IndBallL0(n // 50), xd), sd), qd, 1.0).cpu().numpy(), ref)
+    # y === q on the fast path (two-pass form: y may not be written before the cut is known)
     s.prox_bang(qd, s.shifted(s.shifted(s.IndBallL0(n // 50), xd), sd), qd, 1.0)
     assert _bits_equal(qd.cpu().numpy(), ref)
 
