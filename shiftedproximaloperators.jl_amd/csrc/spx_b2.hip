@@ -10,7 +10,8 @@
 // ||ProjB||^2 = (eta/Delta)^2 P + C with P = sum_{unclamped} xk_i^2, C = sum_{clamped} bound_i^2, whose root is closed
 // form: eta = chi_lambda sqrt(C / (1 - chi_lambda^2 P / Delta^2)).  Iteration: one reduction pass gives (P, C) at the
 // current eta, the piece's root is taken, the next pass verifies it (identical sums = same piece = done); a bracket
-// [froot < 0, froot > 0] safeguards every step.  Typically 2-3 passes of 24 B/element + the final 32 B/element pass.
+// [froot < 0, froot > 0] safeguards every step.  The iteration starts from the a-priori upper bound chi sqrt(F)
+// (F = sum of the far bounds squared, from the first pass): typically 4-5 passes of 24 B/element + the final 32 B/element pass.
 // The host drives the loop (one 16-byte read-back per pass).
 #include <cmath>
 
@@ -23,7 +24,8 @@ constexpr int kB2Blocks = 2048;
 struct B2Ws {
   double partP[kB2Blocks];
   double partC[kB2Blocks];
-  double P, C;  // reduced sums of the last pass
+  double partF[kB2Blocks];
+  double P, C, F;  // reduced sums of the last pass
 };
 
 __device__ __forceinline__ double b2_block_sum(double v, double* lds4) {
@@ -35,60 +37,137 @@ __device__ __forceinline__ double b2_block_sum(double v, double* lds4) {
   return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
-// sums at scale r = eta / Delta: P over the components ProjB leaves at z_i = -xk_i r, C over the clamped ones
+// sums at scale r = eta / Delta: P over the components ProjB leaves at z_i = -xk_i r, C over the clamped ones.
+// FIRST (the r = 1 pass) also returns F = sum of bound_i^2 with bound_i the end of [lo_i, hi_i] that z_i runs into as
+// eta -> inf: |ProjB(z)_i| <= |bound_i| for every eta >= 0, so chi_lambda sqrt(F) bounds the root from above.
+// VEC: 16-byte non-temporal loads, 4 pairs of each vector in flight per lane; else 8-byte loads (unaligned views).
+template <bool FIRST, bool VEC>
 __global__ __launch_bounds__(256) void k_b2_pass(const double* __restrict__ q, const double* __restrict__ xk,
                                                   const double* __restrict__ sj, int64_t n, double ls, double r,
                                                   B2Ws* ws) {
   __shared__ double lds4[4];
-  double p = 0.0, c = 0.0;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double x = xk[i];
-    const double sq = sj[i] + q[i];
+  double p = 0.0, c = 0.0, f = 0.0;
+  auto visit = [&](double qi, double x, double s) {
+    const double sq = s + qi;
     const double lo = sq - ls, hi = sq + ls;
     const double z = (-x) * r;
     const double pz = jl_min(jl_max(z, lo), hi);
     if (pz == z) p += x * x; else c += pz * pz;
+    if constexpr (FIRST) {
+      const double far = (x < 0.0) ? hi : (x > 0.0) ? lo : pz;  // -x > 0: z -> +inf -> hi
+      f += far * far;
+    }
+  };
+  if constexpr (VEC) {
+    const f64x2* q2 = reinterpret_cast<const f64x2*>(q);
+    const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
+    const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
+    const int64_t n2 = n >> 1;
+    const int64_t ntiles = (n2 + 1023) / 1024;  // 256 lanes x 4 pairs
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int64_t base = tile * 1024 + threadIdx.x;
+      f64x2 a[4], b[4], d[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t i = (base + k * 256 < n2) ? base + k * 256 : n2 - 1;
+        a[k] = __builtin_nontemporal_load(q2 + i);
+        b[k] = __builtin_nontemporal_load(x2 + i);
+        d[k] = __builtin_nontemporal_load(s2 + i);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (base + k * 256 < n2) {
+          visit(a[k].x, b[k].x, d[k].x);
+          visit(a[k].y, b[k].y, d[k].y);
+        }
+      }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) visit(q[n - 1], xk[n - 1], sj[n - 1]);
+  } else {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) visit(q[i], xk[i], sj[i]);
   }
   p = b2_block_sum(p, lds4);
   c = b2_block_sum(c, lds4);
-  if (threadIdx.x == 0) { ws->partP[blockIdx.x] = p; ws->partC[blockIdx.x] = c; }
+  if constexpr (FIRST) f = b2_block_sum(f, lds4);
+  if (threadIdx.x == 0) {
+    ws->partP[blockIdx.x] = p;
+    ws->partC[blockIdx.x] = c;
+    if constexpr (FIRST) ws->partF[blockIdx.x] = f;
+  }
 }
 
-__global__ __launch_bounds__(256) void k_b2_reduce(B2Ws* ws, int nblocks) {
+__global__ __launch_bounds__(256) void k_b2_reduce(B2Ws* ws, int nblocks, int first) {
   __shared__ double lds4[4];
-  double p = 0.0, c = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += 256) { p += ws->partP[b]; c += ws->partC[b]; }
+  double p = 0.0, c = 0.0, f = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+    p += ws->partP[b];
+    c += ws->partC[b];
+    if (first) f += ws->partF[b];
+  }
   p = b2_block_sum(p, lds4);
   c = b2_block_sum(c, lds4);
-  if (threadIdx.x == 0) { ws->P = p; ws->C = c; }
+  f = b2_block_sum(f, lds4);
+  if (threadIdx.x == 0) { ws->P = p; ws->C = c; ws->F = f; }
 }
 
 // y = ProjB((-xk) r) * rinv - sj     (r = eta/Delta, rinv = Delta/eta; r = rinv = 1 with scaled == 0: y = ProjB(-xk) - sj)
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_b2_final(double* y, const double* q, const double* xk, const double* sj,
                                                    int64_t n, double ls, double r, double rinv, int scaled) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double x = xk[i], s = sj[i];
-    const double sq = s + q[i];
+  auto out = [&](double qi, double x, double s) -> double {
+    const double sq = s + qi;
     const double lo = sq - ls, hi = sq + ls;
     double t;
     if (scaled) t = jl_min(jl_max((-x) * r, lo), hi) * rinv;  // :63
     else t = jl_min(jl_max(-x, lo), hi);                      // :59
-    y[i] = t - s;                                             // :65
+    return t - s;                                             // :65
+  };
+  if constexpr (VEC) {
+    f64x2* y2 = reinterpret_cast<f64x2*>(y);
+    const f64x2* q2 = reinterpret_cast<const f64x2*>(q);
+    const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
+    const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
+    const int64_t n2 = n >> 1;
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;  // one tile of 256 lanes x 4 pairs per workgroup
+    f64x2 a[4], b[4], d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = (base + k * 256 < n2) ? base + k * 256 : n2 - 1;
+      a[k] = __builtin_nontemporal_load(q2 + i);
+      b[k] = __builtin_nontemporal_load(x2 + i);
+      d[k] = __builtin_nontemporal_load(s2 + i);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (base + k * 256 < n2)
+        __builtin_nontemporal_store(f64x2{out(a[k].x, b[k].x, d[k].x), out(a[k].y, b[k].y, d[k].y)}, y2 + base + k * 256);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = out(q[n - 1], xk[n - 1], sj[n - 1]);
+  } else {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = out(q[i], xk[i], sj[i]);
   }
 }
 
 int b2_sums(spx_ctx* ctx, const double* q, const double* xk, const double* sj, int64_t n, double ls, double r, B2Ws* ws,
-            int blocks, double* P, double* C) {
-  hipLaunchKernelGGL(k_b2_pass, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, q, xk, sj, n, ls, r, ws);
-  hipLaunchKernelGGL(k_b2_reduce, dim3(1), dim3(256), 0, ctx->stream, ws, blocks);
+            int blocks, bool vec, bool first, double* P, double* C, double* F) {
+  const dim3 grid((unsigned)blocks), block(256);
+  if (first) {
+    if (vec) hipLaunchKernelGGL((k_b2_pass<true, true>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws);
+    else hipLaunchKernelGGL((k_b2_pass<true, false>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws);
+  } else {
+    if (vec) hipLaunchKernelGGL((k_b2_pass<false, true>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws);
+    else hipLaunchKernelGGL((k_b2_pass<false, false>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws);
+  }
+  hipLaunchKernelGGL(k_b2_reduce, dim3(1), dim3(256), 0, ctx->stream, ws, blocks, first ? 1 : 0);
   SPX_LAUNCH_CHECK();
-  double pc[2];
-  SPX_HIP(hipMemcpyAsync(pc, &ws->P, sizeof(pc), hipMemcpyDeviceToHost, ctx->stream));
+  double pcf[3];
+  SPX_HIP(hipMemcpyAsync(pcf, &ws->P, sizeof(pcf), hipMemcpyDeviceToHost, ctx->stream));
   SPX_HIP(hipStreamSynchronize(ctx->stream));
-  *P = pc[0];
-  *C = pc[1];
+  *P = pcf[0];
+  *C = pcf[1];
+  if (F) *F = pcf[2];
   return SPX_OK;
 }
 
@@ -104,13 +183,13 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   SPX_HIP(hipSetDevice(ctx->device));
   B2Ws* ws = reinterpret_cast<B2Ws*>(ctx->ws);
   const double ls = lambda * sigma;  // `psi.lambda * sigma`, :56
-  int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+  const bool vec = n >= 2 && spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj);
+  int64_t blocks = vec ? ((n >> 1) + 1023) / 1024 : (n + 256 * 8 - 1) / (256 * 8);
   if (blocks > kB2Blocks) blocks = kB2Blocks;
-  int64_t fblocks = (n + 255) / 256;
-  if (fblocks > (int64_t)ctx->num_cu * 16) fblocks = (int64_t)ctx->num_cu * 16;
+  if (blocks < 1) blocks = 1;
   // y = ProjB(-xk); chi(y) = chi_lambda * ||y||: at r = 1,  ||y||^2 = P + C
-  double P, C;
-  rc = b2_sums(ctx, q, xk, sj, n, ls, 1.0, ws, (int)blocks, &P, &C);
+  double P, C, F;
+  rc = b2_sums(ctx, q, xk, sj, n, ls, 1.0, ws, (int)blocks, vec, true, &P, &C, &F);
   if (rc) return rc;
   const double chiy = chi_lambda * std::sqrt(P + C);
   int scaled = 0;
@@ -121,6 +200,15 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
     double lo = delta, hi = INFINITY;
     double pP = -1.0, pC = -1.0;
     bool exact_step = false;  // eta was set to the exact root of the piece (pP, pC)
+    // a-priori upper bound of the root: froot(chi_lambda sqrt(F)) >= 0.  The iteration starts THERE: from above the
+    // piece roots decrease monotonically to the root (2-3 passes), whereas from eta = Delta the first pieces have no
+    // root at all (1 - chi^2 P / Delta^2 <= 0) and the bracket would have to be grown by doubling.
+    const double eta_ub = chi_lambda * std::sqrt(F);
+    if (eta_ub > delta && std::isfinite(eta_ub)) {
+      eta = eta_ub;
+      rc = b2_sums(ctx, q, xk, sj, n, ls, eta / delta, ws, (int)blocks, vec, false, &P, &C, nullptr);
+      if (rc) return rc;
+    }
     for (int it = 0; it < 200; ++it) {
       const double r = eta / delta;
       const double f = eta - chi_lambda * std::sqrt(r * r * P + C);
@@ -135,12 +223,20 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
       const bool small = std::fabs(next - eta) <= 4e-16 * next;
       pP = P; pC = C; eta = next;
       if (small) break;
-      rc = b2_sums(ctx, q, xk, sj, n, ls, eta / delta, ws, (int)blocks, &P, &C);
+      rc = b2_sums(ctx, q, xk, sj, n, ls, eta / delta, ws, (int)blocks, vec, false, &P, &C, nullptr);
       if (rc) return rc;
     }
   }
-  hipLaunchKernelGGL(k_b2_final, dim3((unsigned)fblocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n, ls, eta / delta,
-                     delta / eta, scaled);
+  if (vec) {
+    const int64_t fblocks = ((n >> 1) + 1023) / 1024;
+    hipLaunchKernelGGL((k_b2_final<true>), dim3((unsigned)(fblocks < 1 ? 1 : fblocks)), dim3(256), 0, ctx->stream, y, q,
+                       xk, sj, n, ls, eta / delta, delta / eta, scaled);
+  } else {
+    int64_t fblocks = (n + 255) / 256;
+    if (fblocks > (int64_t)ctx->num_cu * 16) fblocks = (int64_t)ctx->num_cu * 16;
+    hipLaunchKernelGGL((k_b2_final<false>), dim3((unsigned)fblocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n, ls,
+                       eta / delta, delta / eta, scaled);
+  }
   SPX_LAUNCH_CHECK();
   return SPX_OK;
 }

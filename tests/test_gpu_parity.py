@@ -653,3 +653,29 @@ def test_l1b2(s, orc, kats):
             assert np.max(np.abs(y - ref)) <= 1e-12 * scale, (n, lam, sigma, delta)
         s.set_radius_bang(om, 0.5)
         assert om.Δ == 0.5
+    # 8-byte-aligned views (scalar kernels), chi = NormL2(0.7), y === q
+    import torch
+    n = 50_001
+    xh, sh, qh = _data(n, 4242)
+    xd, sd, qd = (torch.cat([torch.zeros(1, dtype=torch.float64), torch.from_numpy(a)]).cuda()[1:] for a in (xh, sh, qh))
+    om = s.shifted(s.shifted(s.NormL1(0.8), xd, 3.0, s.NormL2(0.7)), sd)
+    ref = orc.prox_l1_b2(qh, xh, sh, 0.8, 1.3, 3.0, 0.7)
+    scale = max(np.linalg.norm(ref), np.linalg.norm(xh))
+    assert np.max(np.abs(s.prox(om, qd, 1.3).cpu().numpy() - ref)) <= 1e-12 * scale
+    xa, sa, qa = _dev(xh, sh, qh)
+    oma = s.shifted(s.shifted(s.NormL1(0.8), xa, 3.0, s.NormL2(0.7)), sa)
+    s.prox_bang(qa, oma, qa, 1.3)
+    assert np.max(np.abs(qa.cpu().numpy() - ref)) <= 1e-12 * scale
+
+
+def test_l1b2_large(s, orc):
+    # n = 4e6: vectorised reduction passes, iteration started from the a-priori upper bound of the root
+    n = 4_000_000
+    xh, sh, qh = _data(n, 77)
+    xd, sd, qd = _dev(xh, sh, qh)
+    for lam, sigma, delta in ((1.0, 1.0, 1.0), (0.2, 1.0, 300.0), (1.0, 1.0, 1e6)):
+        om = s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(1.0)), sd)
+        y = s.prox(om, qd, sigma).cpu().numpy()
+        ref = orc.prox_l1_b2(qh, xh, sh, lam, sigma, delta, 1.0)
+        scale = max(np.linalg.norm(ref), np.linalg.norm(xh))
+        assert np.max(np.abs(y - ref)) <= 1e-12 * scale, (lam, sigma, delta)
