@@ -87,6 +87,8 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // ---------------------------------------------------------------------------------------------
 template <int EPL>
 struct RegGroup {
+  static constexpr bool kReg = true;
+  static constexpr int kEpl = EPL;
   double S[EPL], X[EPL], XS[EPL];  // XS = xk + sj (subtracted at the end)
   template <class F>
   __device__ __forceinline__ void for_each(F&& f) const {
@@ -97,6 +99,8 @@ struct RegGroup {
 
 template <int TEAM>
 struct MemGroup {
+  static constexpr bool kReg = false;
+  static constexpr int kEpl = 1;
   const double* q;
   const double* xk;
   const double* sj;
@@ -180,6 +184,23 @@ __device__ __forceinline__ void binf_ab(const G& grp, double tau, double delta, 
     sb += keep_if(b * b, act);
   });
   team_sum2<TEAM>(sa, sb, lds);
+}
+
+// Register-resident groups: true in the lanes of a team whose active set {i : |tau S_i - X_i| > Delta} is the same at
+// tau_a and tau_b (2 fma + 2 compares per element; nothing is stored between passes -- keeping the previous pass's lane
+// masks alive costs more registers than the kernel has, measured: 0.83 -> 1.01 ms).
+template <int TEAM, class G>
+__device__ __forceinline__ bool binf_same_active_set(const G& grp, double tau_a, double tau_b, double delta) {
+  unsigned long long diff = 0ull;
+#pragma unroll
+  for (int k = 0; k < G::kEpl; ++k) {
+    const double za = __builtin_fma(tau_a, grp.S[k], -grp.X[k]);
+    const double zb = __builtin_fma(tau_b, grp.S[k], -grp.X[k]);
+    diff |= __ballot((fabs(za) > delta) != (fabs(zb) > delta));
+  }
+  const int lane = threadIdx.x & 63;
+  const unsigned long long mine = (TEAM >= 64) ? ~0ull : (((1ull << (TEAM & 63)) - 1ull) << ((lane / TEAM) * TEAM));
+  return (diff & mine) == 0ull;
 }
 
 __device__ __forceinline__ double sqrt_pos(double v) {  // sqrt for v >= 0: rsq seed + two corrections
@@ -336,10 +357,12 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
   if (from_bound) uhi = ub;
   double u = uhi;
   double sa, sb, psi;
+  double tau_full;  // tau of the last full pass (the one sa, sb belong to)
   {
     const double tau = u * fast_rcp(sl + u);
     binf_ab<TEAM>(grp, tau, delta, lds, sa, sb);
     psi = u - sqrt_pos(__builtin_fma(tau * tau, sa, sb));
+    tau_full = tau;
   }
   {
     const double fm = from_bound ? ((psi > 0.0) ? psi : 1.0) : (lmax * fast_rcp(u)) * psi;
@@ -387,8 +410,18 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
     u = v;
     if (small) break;
     const double tau = u * fast_rcp(sl + u);
+    if constexpr (G::kReg) {
+      // Cheap confirmation instead of a pass whose sums would only come back bit-identical: the active set at the piece's
+      // root is the one the piece was built from (and no active z can have changed sign: |d tau| ||S|| <= 2 Delta) -> u
+      // is the root.  Not tried after the first pass (it == 0): the start from the bound is far from the root and a
+      // wavefront of several groups almost never confirms there.
+      if (exact_step && it >= 1 && fabs(tau - tau_full) * nS <= 2.0 * delta &&
+          binf_same_active_set<TEAM>(grp, tau, tau_full, delta))
+        break;
+    }
     binf_ab<TEAM>(grp, tau, delta, lds, sa, sb);
     psi = u - sqrt_pos(__builtin_fma(tau * tau, sa, sb));
+    tau_full = tau;
   }
   double n0 = fmin(fmax(sl + u, lmin), lmax);
   if (u * 1000.0 > n0) {  // well conditioned in n: a few ulp of n cannot move step by more than ~1e-13
@@ -602,6 +635,8 @@ __global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, 
 // what the reference's sequential loop over the groups leaves behind.
 template <int TEAM>
 struct GatherGroup {
+  static constexpr bool kReg = false;
+  static constexpr int kEpl = 1;
   const double* sol;
   const double* xk;
   const double* sj;
