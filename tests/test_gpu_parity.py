@@ -275,15 +275,15 @@ def _group_check(y, ref, q, x, sj, offsets):
 
 
 @pytest.mark.parametrize("gsize", [64, 128, 256, 512, 1, 2, 6, 7, 33, 66, 100, 130, 250, 257, 383, 386, 510, 511, 513,
-                                   3000])
+                                   1024, 2048, 2049, 3000, 4096, 4097, 8200])
 @pytest.mark.parametrize("binf", [False, True])
 @pytest.mark.parametrize("misaligned", [False, True])
 def test_group_uniform(s, orc, gsize, binf, misaligned):
     # every tile of the register kernel, full and partly filled, even (16-byte pairs) and odd (8-byte loads) sizes;
     # misaligned: all four vectors start 8 bytes off a 16-byte boundary
-    if misaligned and gsize not in (2, 64, 100, 128, 386, 512):
+    if misaligned and gsize not in (2, 64, 100, 128, 386, 512, 3000):
         pytest.skip("misaligned views are checked on a subset")
-    ng = 513 if gsize <= 513 else 9
+    ng = 513 if gsize <= 513 else 19  # > 512: LDS-resident group per workgroup (<= 8192), general kernel above
     n = ng * gsize
     x, sj, q = _data(n, 500 + gsize)
     lam = np.random.default_rng(gsize).uniform(0.5, 1.5, size=ng)
