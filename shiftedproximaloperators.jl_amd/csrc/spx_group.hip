@@ -891,7 +891,11 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   if (!offsets && gsize <= 512) {
     // register path: the smallest (LPG, EPL) tile that holds a group; partly filled tiles are padded with zeros
     int lpg, epl;
-    if (gsize <= 32) { lpg = 16; epl = 2; }
+    // Binf: small groups on 8 lanes (8 groups per wave) -- the wave-uniform scalar work of the root find, which every
+    // lane executes, is then shared by twice as many groups
+    if (BINF && gsize <= 32) { lpg = 8; epl = 4; }
+    else if (BINF && gsize <= 64) { lpg = 8; epl = 8; }
+    else if (gsize <= 32) { lpg = 16; epl = 2; }
     else if (gsize <= 64) { lpg = 16; epl = 4; }
     else if (gsize <= 128) { lpg = 16; epl = 8; }
     else if (gsize <= 256) { lpg = 32; epl = 8; }
@@ -918,7 +922,9 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, false>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,  \
                          (int)gsize, lambda, sigma, delta, deferred);                                               \
   } while (0)
-    if (lpg == 16 && epl == 2) SPX_LAUNCH_REG(16, 2);
+    if (lpg == 8 && epl == 4) { if constexpr (BINF) SPX_LAUNCH_REG(8, 4); }
+    else if (lpg == 8) { if constexpr (BINF) SPX_LAUNCH_REG(8, 8); }
+    else if (lpg == 16 && epl == 2) SPX_LAUNCH_REG(16, 2);
     else if (lpg == 16 && epl == 4) SPX_LAUNCH_REG(16, 4);
     else if (lpg == 16) SPX_LAUNCH_REG(16, 8);
     else if (lpg == 32) SPX_LAUNCH_REG(32, 8);
