@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspx.so")
+LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("SPX_LIB_NAME", "libspx.so"))  # SPX_LIB_NAME: A/B builds (tools/)
 
 c_double_p = ctypes.c_void_p  # device pointers are passed as plain addresses
 _i64, _d, _p, _int = ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_int
