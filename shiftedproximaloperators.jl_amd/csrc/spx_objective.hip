@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_obj(const double* __restrict__ y, const
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const bool vec = (((uintptr_t)y | (uintptr_t)xk | (uintptr_t)sj | (uintptr_t)lv | (uintptr_t)uv) & 15) == 0 &&
                    (((uintptr_t)mask) & 1) == 0;
-  if (vec) {  // 16-byte non-temporal loads, two pairs in flight per vector and lane
+  if (vec && n >= 2) {  // 16-byte non-temporal loads, four pairs in flight per vector and lane
     const int64_t n2 = n >> 1;
     const f64x2* y2 = reinterpret_cast<const f64x2*>(y);
     const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
@@ -79,26 +79,31 @@ __global__ __launch_bounds__(256) void k_obj(const double* __restrict__ y, const
     const f64x2* l2 = reinterpret_cast<const f64x2*>(lv);
     const f64x2* u2 = reinterpret_cast<const f64x2*>(uv);
     const uint16_t* m2 = reinterpret_cast<const uint16_t*>(mask);
-    for (int64_t i = tid; i < n2; i += 2 * stride) {
-      const int64_t j = i + stride;
-      const bool two = j < n2;
-      const int64_t jj = two ? j : i;
-      const f64x2 ya = __builtin_nontemporal_load(y2 + i), xa = __builtin_nontemporal_load(x2 + i),
-                  sa = __builtin_nontemporal_load(s2 + i);
-      const f64x2 yb = __builtin_nontemporal_load(y2 + jj), xb = __builtin_nontemporal_load(x2 + jj),
-                  sb = __builtin_nontemporal_load(s2 + jj);
-      f64x2 la = f64x2{ls, ls}, ua = f64x2{us, us}, lb = la, ub = ua;
-      uint16_t ma = 0x0101, mb = 0x0101;
-      if constexpr (MODE == 1) {
-        if (lv) { la = l2[i]; lb = l2[jj]; }
-        if (uv) { ua = u2[i]; ub = u2[jj]; }
-        if (mask) { ma = m2[i]; mb = m2[jj]; }
+    const int64_t ntiles = (n2 + 1023) / 1024;  // a tile = 256 lanes x 4 pairs; 12 16-byte loads in flight per lane
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int64_t base = tile * 1024 + threadIdx.x;
+      f64x2 yv[4], xv[4], sv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t i = (base + k * 256 < n2) ? base + k * 256 : n2 - 1;
+        yv[k] = __builtin_nontemporal_load(y2 + i);
+        xv[k] = __builtin_nontemporal_load(x2 + i);
+        sv[k] = __builtin_nontemporal_load(s2 + i);
       }
-      visit(ya.x, xa.x, sa.x, la.x, ua.x, (ma & 0xff) != 0);
-      visit(ya.y, xa.y, sa.y, la.y, ua.y, (ma >> 8) != 0);
-      if (two) {
-        visit(yb.x, xb.x, sb.x, lb.x, ub.x, (mb & 0xff) != 0);
-        visit(yb.y, xb.y, sb.y, lb.y, ub.y, (mb >> 8) != 0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + k * 256;
+        if (i < n2) {
+          f64x2 la = f64x2{ls, ls}, ua = f64x2{us, us};
+          uint16_t ma = 0x0101;
+          if constexpr (MODE == 1) {
+            if (lv) la = l2[i];
+            if (uv) ua = u2[i];
+            if (mask) ma = m2[i];
+          }
+          visit(yv[k].x, xv[k].x, sv[k].x, la.x, ua.x, (ma & 0xff) != 0);
+          visit(yv[k].y, xv[k].y, sv[k].y, la.y, ua.y, (ma >> 8) != 0);
+        }
       }
     }
     if ((n & 1) && tid == 0) {

@@ -23,6 +23,16 @@ else:
            "lhalfbox": lambda: s.shifted(s.shifted(s.RootNormLhalf(1.0), xk, 1.0, chi), sj),
            "l1box": lambda: s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj)}[which]()
 y = torch.empty_like(q)
+if len(sys.argv) > 3 and sys.argv[3] == "obj":  # psi(y): synchronous, host wall time per call
+    import time
+    y.copy_(q * 0.01); psi(y)
+    ts = []
+    for rnd in range(5):
+        t0 = time.perf_counter()
+        for _ in range(iters): psi(y)
+        ts.append((time.perf_counter() - t0) / iters * 1e3)
+    ts.sort(); print("%s objective: median %.4f ms (wall, incl. read-back) -> %.0f GB/s on 24 B/element" % (which, ts[2], 24 * y.numel() / ts[2] / 1e6))
+    sys.exit(0)
 ts = []
 for rnd in range(5):
     ms = ctypes.c_float(); L.spx_timer_start(ctx)
