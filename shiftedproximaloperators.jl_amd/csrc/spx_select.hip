@@ -54,10 +54,17 @@ struct FastState {
   unsigned int list_count;        // entries appended to the short list by k_s2_compact
 };
 
+// totals of the main pass: fire-and-forget atomics of its wavefronts, spread over kShards lines (wave w -> shard
+// w % kShards) so that no single address serialises them; k_s2_scan_verify adds the shards up
+constexpr int kShards = 64;
+constexpr int kShardStride = 16;  // unsigned long longs between two shards (128 bytes)
+
 struct SelWs {
   SelState st;
   FastState fs;
   unsigned long long hist[kBins];
+  unsigned long long shard_above[kShards * kShardStride];
+  unsigned long long shard_cand[kShards * kShardStride];
 };
 
 // Candidates of the main pass: every WAVEFRONT of its grid owns a fixed region of kWaveSlots entries and one count
@@ -342,8 +349,10 @@ __global__ __launch_bounds__(256) void k_sel_final(double* y, const double* xk, 
 //                    (fixed regions + one count word per wave: no atomics, no barrier, deterministic order).
 //                    If y overlaps none of the inputs the pass also stores y speculatively (above the band: kept,
 //                    otherwise dropped) -- 32 B/element, the algorithmic minimum; else it writes nothing (24 B/element).
-//   4. k_sel_hist_cand / k_s2_scan_verify   totals of step 3, the verdict  cnt_above < r <= cnt_above + candidates,
-//                    and the first digit of the selection among the candidates; k_s2_compact + k_s2_finish resolve the
+//                    The pass also histograms the first digit of the candidates (one global atomic per candidate) and
+//                    adds its totals into sharded counters (fire-and-forget).
+//   4. k_s2_scan_verify   the verdict  cnt_above < r <= cnt_above + candidates  and the first scan step of the
+//                    selection among the candidates; k_s2_compact + k_s2_finish resolve the
 //                    rest on a short list in one workgroup (regions are walked transposed: 64 regions per wavefront)
 //   5a. k_s2_fixup   (y disjoint) stores the kept value of the candidates that made the cut: ~0.25 % of y, scattered
 //   5b. k_sel_final_q (y aliases an input) y[i] from q, xk, sj and the thresholds (24 B read + 8 B written per element)
@@ -456,6 +465,7 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
     f.key_passes = 0;
     f.overflow = 0;
     f.list_count = 0;
+    // (the shard counters are zeroed below by lanes 0..kShards-1)
     // digit machinery of the candidate selection: everything that depends on the band only (the counts -- verdict,
     // quota -- are filled in by k_s2_scan_verify).  First digit = the first one in which the band's ends differ.
     SelState& s = ws->st;
@@ -485,6 +495,7 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
       s.prefix = (shift + width >= 64) ? 0ull : (f.t_hi >> (shift + width));
     }
   }
+  if (t < kShards) { ws->shard_above[t * kShardStride] = 0ull; ws->shard_cand[t * kShardStride] = 0ull; }
 }
 
 // Main pass: one tile per workgroup, waves fully independent (no barrier, no atomics).  Counts the elements above the
@@ -495,9 +506,13 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
 // candidates, instead of 56 B/element with the separate final pass (k_sel_final_q, used when y aliases an input).
 template <bool BINF, bool WRITE>
 __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, const double* xk_, const double* sj_,
-                                                  int64_t n, const SelWs* ws, uint64_t* cand_key, int64_t* cand_idx,
+                                                  int64_t n, SelWs* ws, uint64_t* cand_key, int64_t* cand_idx,
                                                   double* cand_val, WaveCount* counts, double delta) {
   const uint64_t t_hi = ws->fs.t_hi, t_lo = ws->fs.t_lo;
+  // first digit of the selection among the candidates (set up by k_s2_pick): histogrammed right here, one
+  // fire-and-forget global atomic per candidate (~0.5 % of the elements, spread over the band's bins)
+  const int d_phase = ws->st.phase, d_shift = ws->st.shift, d_hs = ws->st.shift + ws->st.width;
+  const uint64_t d_mask = ((uint64_t)1 << ws->st.width) - 1, d_prefix = ws->st.prefix, d_teq = ws->st.t_eq;
   const f64x2* q = reinterpret_cast<const f64x2*>(q_);
   const f64x2* xk = reinterpret_cast<const f64x2*>(xk_);
   const f64x2* sj = reinterpret_cast<const f64x2*>(sj_);
@@ -534,6 +549,13 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
         cand_key[rbase + pos] = key;
         cand_idx[rbase + pos] = i;
         if constexpr (WRITE) cand_val[rbase + pos] = kept;
+      }
+      if (in_band) {
+        if (d_phase == 0) {
+          if ((d_hs >= 64 ? 0ull : (key >> d_hs)) == d_prefix) atomicAdd(&ws->hist[(key >> d_shift) & d_mask], 1ull);
+        } else if (key == d_teq && (((uint64_t)i) >> d_hs) == d_prefix) {
+          atomicAdd(&ws->hist[(((uint64_t)i) >> d_shift) & d_mask], 1ull);
+        }
       }
       ncand += (unsigned int)__popcll(m);
     }
@@ -575,7 +597,13 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
     }
   }
   for (int off = 32; off >= 1; off >>= 1) above += __shfl_xor(above, off, 64);
-  if (lane == 0) counts[gwave] = WaveCount{ncand, above};  // ncand > kWaveSlots = overflow, seen by the consumers
+  if (lane == 0) {
+    counts[gwave] = WaveCount{ncand, above};
+    const int shard = (int)(gwave % kShards) * kShardStride;
+    if (above) atomicAdd(&ws->shard_above[shard], (unsigned long long)above);
+    if (ncand) atomicAdd(&ws->shard_cand[shard], (unsigned long long)ncand);
+    if (ncand > (unsigned)kWaveSlots) atomicExch(&ws->fs.overflow, 1);
+  }
 }
 
 // Candidate kernels walk the regions TRANSPOSED: a wavefront takes 64 regions at a time, lane l owns region w0 + l and
@@ -627,46 +655,27 @@ __global__ __launch_bounds__(256) void k_s2_fixup(double* y, const uint64_t* can
   });
 }
 
-// histogram of the first candidate digit (set up by k_s2_pick) + the totals of the main pass
-__global__ __launch_bounds__(256) void k_sel_hist_cand(const uint64_t* cand_key, const int64_t* cand_idx, SelWs* ws,
-                                                        const WaveCount* counts, int64_t nregions) {
-  const SelState st = ws->st;
-  __shared__ unsigned int lh[kBins];
-  for (int b = threadIdx.x; b < kBins; b += blockDim.x) lh[b] = 0u;
-  __syncthreads();
-  const int shift = st.shift;
-  const int hs = st.shift + st.width;
-  const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
-  RegionTotals t = for_each_candidate(counts, nregions, cand_key, cand_idx, [&](int64_t, uint64_t key, int64_t idx) {
-    if (st.phase == 0) {
-      if ((hs >= 64 ? 0ull : (key >> hs)) == st.prefix) atomicAdd(&lh[(key >> shift) & dmask], 1u);
-    } else if (key == st.t_eq) {
-      const uint64_t i = (uint64_t)idx;
-      if ((i >> hs) == st.prefix) atomicAdd(&lh[(i >> shift) & dmask], 1u);
-    }
-  });
-  for (int off = 32; off >= 1; off >>= 1) {  // per-lane totals -> wave totals
-    t.cand += __shfl_xor(t.cand, off, 64);
-    t.above += __shfl_xor(t.above, off, 64);
-  }
-  const bool any_overflow = __any(t.overflow);
-  if ((threadIdx.x & 63) == 0) {
-    if (t.cand) atomicAdd(&ws->fs.cand_count, t.cand);
-    if (t.above) atomicAdd(&ws->fs.cnt_above, t.above);
-    if (any_overflow) atomicExch(&ws->fs.overflow, 1);
-  }
-  flush_hist(lh, ws->hist);
-}
-
 // One workgroup: the verdict (is the r-th largest provably inside the band?), then the first scan step.
 __global__ __launch_bounds__(256) void k_s2_scan_verify(SelWs* ws, int64_t r) {
   __shared__ unsigned long long scratch[8];
   __shared__ int sok;
   __shared__ SelState sst;
+  unsigned long long above = 0, cand = 0;
+  if (threadIdx.x < 64) {  // wave 0 adds up the shards of the main pass
+    for (int k = threadIdx.x; k < kShards; k += 64) {
+      above += ws->shard_above[k * kShardStride];
+      cand += ws->shard_cand[k * kShardStride];
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+      above += __shfl_xor(above, off, 64);
+      cand += __shfl_xor(cand, off, 64);
+    }
+  }
   if (threadIdx.x == 0) {
     FastState& f = ws->fs;
     SelState& s = ws->st;
-    const unsigned long long above = f.cnt_above, cand = f.cand_count;
+    f.cnt_above = above;
+    f.cand_count = cand;
     const bool ok = !f.overflow && above < (unsigned long long)r && (unsigned long long)r <= above + cand;
     f.ok = ok ? 1 : 0;
     if (ok) {
@@ -834,15 +843,13 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     hipLaunchKernelGGL(k_s2_pick, dim3(1), dim3(1024), 0, ctx->stream, (const double*)samp, n, r, ws);
     const dim3 mgrid((unsigned)mblocks);
     if (write)
-      hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y, q, xk, sj, n, (const SelWs*)ws,
-                         ckey, cidx, cval, counts, delta);
+      hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y, q, xk, sj, n, ws, ckey, cidx, cval,
+                         counts, delta);
     else
-      hipLaunchKernelGGL((k_s2_main<BINF, false>), mgrid, dim3(256), 0, ctx->stream, y, q, xk, sj, n, (const SelWs*)ws,
-                         ckey, cidx, cval, counts, delta);
-    // first candidate digit with many CUs (+ the totals and the verdict), survivors -> short list, the rest of the
-    // selection in one workgroup
-    hipLaunchKernelGGL(k_sel_hist_cand, dim3(128), dim3(256), 0, ctx->stream, (const uint64_t*)ckey, (const int64_t*)cidx,
-                       ws, (const WaveCount*)counts, nregions);
+      hipLaunchKernelGGL((k_s2_main<BINF, false>), mgrid, dim3(256), 0, ctx->stream, y, q, xk, sj, n, ws, ckey, cidx,
+                         cval, counts, delta);
+    // the main pass has already histogrammed the first candidate digit: verdict + first scan step, survivors ->
+    // short list, the rest of the selection in one workgroup
     hipLaunchKernelGGL(k_s2_scan_verify, dim3(1), dim3(256), 0, ctx->stream, ws, r);
     hipLaunchKernelGGL(k_s2_compact, dim3(256), dim3(256), 0, ctx->stream, (const uint64_t*)ckey, (const int64_t*)cidx, ws,
                        lkey, lidx, (const WaveCount*)counts, nregions);
