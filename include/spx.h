@@ -176,6 +176,10 @@ int spx_prox_indball_l0_binf(spx_ctx* ctx, double* y, const double* q, const dou
  * one scalar root (find_zero, :62): the call runs a few global reduction passes and synchronises after each. */
 int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
                    int64_t n, double lambda, double sigma, double delta, double chi_lambda);
+/* psi(y) of ShiftedNormL1B2, src/shiftedNormL1B2.jl:32: lambda ||xk + sj + y||_1 + IndBallL2(Delta)(sj + y); the value is
+ * written on the host (synchronous). */
+int spx_obj_l1_b2(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double lambda,
+                  double delta, double* value);
 
 /* ---- group operators -------------------------------------------------------------------- */
 /* Groups are contiguous index ranges (the reference's `idx` entries as UnitRanges / [:]):
@@ -294,6 +298,8 @@ int spx_host_obj_group_l2_gather(spx_ctx* ctx, const double* y, const double* xk
 int spx_host_obj_group_l2_binf_gather(spx_ctx* ctx, const double* y, const double* xk, const double* sj,
     int64_t n, const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups, int64_t nnz, const
     double* lambda_vec, double delta, double* value);
+int spx_host_obj_l1_b2(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double lambda,
+    double delta, double* value);
 
 #ifdef __cplusplus
 }

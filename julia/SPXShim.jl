@@ -267,6 +267,9 @@ end
 (ψ::ShiftedIndBallL0{<:Integer, Float64, <:DVec, <:DVec, <:DVec})(y::DVec) =
   objective(:spx_obj_indball_l0, (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Int64),
             dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.r)
+(ψ::ShiftedProximalOperators.ShiftedNormL1B2{Float64, <:DVec, <:DVec, <:DVec})(y::DVec) =   # src/shiftedNormL1B2.jl:32
+  objective(:spx_obj_l1_b2, (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cdouble),
+            dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.λ, ψ.Δ)
 (ψ::ShiftedIndBallL0BInf{<:Integer, Float64, <:DVec, <:DVec, <:DVec})(y::DVec) =
   objective(:spx_obj_indball_l0_binf, (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Int64, Cdouble),
             dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.r, ψ.Δ)

@@ -75,6 +75,8 @@ def lib():
         L.orc_prox_group_l2_binf_idx.restype = None
         L.orc_obj_group_l2_idx.argtypes = [dp, dp, dp, i64, ip, ip, i64, dp, d]
         L.orc_obj_group_l2_idx.restype = d
+        L.orc_obj_l1_b2.argtypes = [dp, dp, dp, i64, d, d]
+        L.orc_obj_l1_b2.restype = d
         L.orc_prox_l1_b2.argtypes = base + [d, d, d, d]
         L.orc_prox_l1_b2.restype = None
         L.orc_rootnormlhalf_prox.argtypes = [dp, dp, i64, d, d]
@@ -333,6 +335,11 @@ def obj_group_l2(y, xk, sj, lam, offsets=None, gsize=0, delta=None):
     off, offp, gs, ng = _groups(n, offsets, gsize)
     lam = _f64(lam)
     return lib().orc_obj_group_l2(_dp(y), _dp(xk), _dp(sj), n, offp, gs, ng, _dp(lam), -1.0 if delta is None else float(delta))
+
+
+def obj_l1_b2(y, xk, sj, lam, delta):
+    y, xk, sj = _f64(y), _f64(xk), _f64(sj)
+    return lib().orc_obj_l1_b2(_dp(y), _dp(xk), _dp(sj), y.shape[0], lam, delta)
 
 
 def prox_l1_b2(q, xk, sj, lam, sigma, delta, chi_lambda=1.0):

@@ -834,4 +834,21 @@ ORC_API void orc_prox_l1_b2(double* y, const double* q, const double* xk, const 
 
 /* Objective value 1/(2 sigma) (t-q)^2 + lambda*h(x+s+t) helpers for the brute-force second oracle
  * live in tests/ (numpy); nothing else is exported from here. */
-ORC_API int orc_abi_version(void) { return 3; }
+/* (psi::ShiftedNormL1B2)(y) = h(xk + sj + y) + IndBallL2(Delta)(sj + y)   src/shiftedNormL1B2.jl:32
+ * IndBallL2 [ext, ProximalOperators.jl]: 0 iff isapprox_le(norm(v), r, atol = eps, rtol = sqrt(eps)), i.e.
+ * norm(v) <= r or |norm(v) - r| <= max(eps, sqrt(eps) max(norm(v), r)); +Inf otherwise. */
+ORC_API double orc_obj_l1_b2(const double* y, const double* xk, const double* sj, int64_t n, double lambda, double delta) {
+  double l1 = 0.0, ss = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    l1 += fabs((xk[i] + sj[i]) + y[i]);
+    double t = sj[i] + y[i];
+    ss += t * t;
+  }
+  const double eps = 2.220446049250313e-16;
+  double nrm = sqrt(ss);
+  double tol = fmax(eps, sqrt(eps) * fmax(nrm, fabs(delta)));
+  int inside = (nrm <= delta) || (fabs(nrm - delta) <= tol);
+  return inside ? lambda * l1 : INFINITY;
+}
+
+ORC_API int orc_abi_version(void) { return 4; }

@@ -171,7 +171,88 @@ int b2_sums(spx_ctx* ctx, const double* q, const double* xk, const double* sj, i
   return SPX_OK;
 }
 
+// psi(y) = lambda ||xk + sj + y||_1 + IndBallL2(Delta)(sj + y)   (:32): P = sum |(xk + sj) + y|, C = sum (sj + y)^2
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_b2_obj(const double* __restrict__ y, const double* __restrict__ xk,
+                                                 const double* __restrict__ sj, int64_t n, B2Ws* ws) {
+  __shared__ double lds4[4];
+  double p = 0.0, c = 0.0;
+  auto visit = [&](double yi, double x, double s) {
+    p += fabs((x + s) + yi);
+    const double t = s + yi;
+    c += t * t;
+  };
+  if constexpr (VEC) {
+    const f64x2* y2 = reinterpret_cast<const f64x2*>(y);
+    const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
+    const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
+    const int64_t n2 = n >> 1;
+    const int64_t ntiles = (n2 + 1023) / 1024;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int64_t base = tile * 1024 + threadIdx.x;
+      f64x2 a[4], b[4], d[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t i = (base + k * 256 < n2) ? base + k * 256 : n2 - 1;
+        a[k] = __builtin_nontemporal_load(y2 + i);
+        b[k] = __builtin_nontemporal_load(x2 + i);
+        d[k] = __builtin_nontemporal_load(s2 + i);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (base + k * 256 < n2) {
+          visit(a[k].x, b[k].x, d[k].x);
+          visit(a[k].y, b[k].y, d[k].y);
+        }
+      }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) visit(y[n - 1], xk[n - 1], sj[n - 1]);
+  } else {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) visit(y[i], xk[i], sj[i]);
+  }
+  p = b2_block_sum(p, lds4);
+  c = b2_block_sum(c, lds4);
+  if (threadIdx.x == 0) { ws->partP[blockIdx.x] = p; ws->partC[blockIdx.x] = c; }
+}
+
 }  // namespace
+
+// ShiftedNormL1B2 as a function (src/shiftedNormL1B2.jl:32).  IndBallL2(Delta)(v) [ext: ProximalOperators.jl] is 0 iff
+// ||v|| <= Delta or ||v|| ~ Delta (isapprox, atol = eps, rtol = sqrt(eps)), +Inf otherwise.
+SPX_EXPORT int spx_obj_l1_b2(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                             double lambda, double delta, double* value) {
+  SPX_REQUIRE(ctx != nullptr && value != nullptr, "ctx or value is NULL");
+  SPX_REQUIRE(n >= 0, "n < 0");
+  *value = 0.0;
+  double P = 0.0, C = 0.0;
+  if (n > 0) {
+    SPX_REQUIRE(y && xk && sj, "NULL vector with n > 0");
+    int rc = spx_ws_reserve(ctx, sizeof(B2Ws) + 256);
+    if (rc) return rc;
+    SPX_HIP(hipSetDevice(ctx->device));
+    B2Ws* ws = reinterpret_cast<B2Ws*>(ctx->ws);
+    const bool vec = n >= 2 && spx_aligned16(y) && spx_aligned16(xk) && spx_aligned16(sj);
+    int64_t blocks = vec ? ((n >> 1) + 1023) / 1024 : (n + 256 * 8 - 1) / (256 * 8);
+    if (blocks > kB2Blocks) blocks = kB2Blocks;
+    if (blocks < 1) blocks = 1;
+    if (vec) hipLaunchKernelGGL((k_b2_obj<true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, ws);
+    else hipLaunchKernelGGL((k_b2_obj<false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, ws);
+    hipLaunchKernelGGL(k_b2_reduce, dim3(1), dim3(256), 0, ctx->stream, ws, (int)blocks, 0);
+    SPX_LAUNCH_CHECK();
+    double pc[2];
+    SPX_HIP(hipMemcpyAsync(pc, &ws->P, sizeof(pc), hipMemcpyDeviceToHost, ctx->stream));
+    SPX_HIP(hipStreamSynchronize(ctx->stream));
+    P = pc[0];
+    C = pc[1];
+  }
+  const double nrm = std::sqrt(C);
+  const double eps = 2.220446049250313e-16;
+  const double tol = std::fmax(eps, std::sqrt(eps) * std::fmax(nrm, std::fabs(delta)));
+  const bool inside = (nrm <= delta) || (std::fabs(nrm - delta) <= tol);
+  *value = inside ? lambda * P : INFINITY;
+  return SPX_OK;
+}
 
 SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
                               double lambda, double sigma, double delta, double chi_lambda) {

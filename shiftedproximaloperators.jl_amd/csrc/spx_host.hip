@@ -399,3 +399,10 @@ SPX_EXPORT int spx_host_obj_group_l2_binf_gather(spx_ctx* ctx, const double* y, 
                                                                value);
                          });
 }
+SPX_EXPORT int spx_host_obj_l1_b2(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+                                  double lambda, double delta, double* value) {
+  return host_obj(ctx, y, xk, sj, n, nullptr, 0, nullptr, 0, nullptr, 0,
+                  [&](const double* dy, const double* dx, const double* ds, const void*, const void*, const void*) {
+                    return spx_obj_l1_b2(ctx, dy, dx, ds, n, lambda, delta, value);
+                  });
+}

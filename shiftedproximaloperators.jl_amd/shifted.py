@@ -326,6 +326,9 @@ class ShiftedNormL1B2(ShiftedProximableFunction):  # src/shiftedNormL1B2.jl
         _lib.check(self._sym(L, "spx_prox_l1_b2")(ctx, _ptr(y), _ptr(q), _ptr(self.xk), _ptr(self.sj), _n(y), self.h.lam, sigma,
                                     self.Δ, self.χ.lam))
 
+    def _obj(self, L, ctx, y, out):  # :32  h(xk + sj + y) + IndBallL2(Δ)(sj + y)
+        _lib.check(self._sym(L, "spx_obj_l1_b2")(ctx, _ptr(y), _ptr(self.xk), _ptr(self.sj), _n(y), self.h.lam, self.Δ, out))
+
 
 class _TopR(ShiftedProximableFunction):
     pass

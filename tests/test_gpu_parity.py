@@ -666,6 +666,13 @@ def test_l1b2(s, orc, kats):
     oma = s.shifted(s.shifted(s.NormL1(0.8), xa, 3.0, s.NormL2(0.7)), sa)
     s.prox_bang(qa, oma, qa, 1.3)
     assert np.max(np.abs(qa.cpu().numpy() - ref)) <= 1e-12 * scale
+    # psi(y) = lambda ||xk + sj + y||_1 + IndBallL2(Delta)(sj + y)   (src/shiftedNormL1B2.jl:32)
+    yin = ref                                             # the prox lies inside the ball (up to rounding)
+    for yy in (yin, 0.5 * yin, 3.0 * yin, np.zeros(n)):
+        val, exp = oma(_dev(yy)[0]), orc.obj_l1_b2(yy, xh, sh, 0.8, 3.0)
+        assert (val == exp) or abs(val - exp) <= 1e-12 * abs(exp), (val, exp)
+    assert om(torch.cat([torch.zeros(1, dtype=torch.float64), torch.from_numpy(3.0 * yin)]).cuda()[1:]) == \
+        orc.obj_l1_b2(3.0 * yin, xh, sh, 0.8, 3.0)
 
 
 def test_l1b2_large(s, orc):

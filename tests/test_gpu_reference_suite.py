@@ -1,0 +1,207 @@
+"""The reference's own test flow for the operators of the prox! path (test/runtests.jl, v0.2.2), re-expressed against
+the host mirror on plain HOST vectors (numpy float64 = the reference's Vector{Float64}): construction, field
+aliasing, psi(y) identities, golden prox values, shift!, set_radius!, second shifts.  Everything numeric runs on the
+GPU through the spx_host_* forms of the C ABI.
+
+Differences from the reference that these tests state instead of hide:
+  * `ψ(y) == h(x + y)` is exact (==) in the reference because both sides sum sequentially on the CPU; here psi(y) is a
+    GPU reduction, so sums compare to VALUE_RTOL; counts (NormL0) and +-Inf are exact.
+  * Float32 / strided views ("test different types") are outside the accelerated path: TypeError.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+VALUE_RTOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def s():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as ge
+    return ge.build()
+
+
+def _h(orc, kind, x, lam):  # h(x) of NormL1 / NormL0 / RootNormLhalf  [ext: ProximalOperators.jl, src/rootNormLhalf.jl:27-29]
+    return orc.obj_plain(kind, np.zeros_like(x), x, np.zeros_like(x), lam)
+
+
+def _close(a, b):
+    return a == b or abs(a - b) <= VALUE_RTOL * max(abs(a), abs(b))
+
+
+UNBOXED = [("NormL0", "ShiftedNormL0", "l0"), ("NormL1", "ShiftedNormL1", "l1"),
+           ("RootNormLhalf", "ShiftedRootNormLhalf", "lhalf")]
+
+
+@pytest.mark.parametrize("op,shifted_op,kind", UNBOXED)
+def test_operators_without_trust_region(s, orc, op, shifted_op, kind):  # runtests.jl:157-214
+    rng = np.random.default_rng(0)
+    h = getattr(s, op)(1.2)
+    x = np.ones(3)
+    psi = s.shifted(h, x)
+    assert type(psi).__name__ == shifted_op
+    assert np.all(psi.sj == 0) and psi.xk is x          # xk is borrowed, not copied
+    assert psi.λ == 1.2
+    assert _close(psi(np.zeros(3)), _h(orc, kind, x, 1.2))
+    y = rng.random(3)
+    assert _close(psi(y), _h(orc, kind, x + y, 1.2))
+    # shift update
+    x0 = x.copy()
+    s.shift_bang(psi, y)
+    assert np.all(psi.sj == 0) and np.all(psi.xk == y)
+    # shift a shifted operator (the reference builds it from a ψ whose xk now equals y)
+    sv = np.ones(3) / 2
+    phi = s.shifted(psi, sv)
+    assert phi.sj is sv and phi.xk is psi.xk and phi.shifted_twice
+    assert _close(phi(np.zeros(3)), _h(orc, kind, psi.xk + sv, 1.2))
+    t = rng.random(3)
+    assert _close(phi(t), _h(orc, kind, psi.xk + sv + t, 1.2))
+    # "different types": Float32 and strided views are not on the accelerated path
+    with pytest.raises(TypeError):
+        s.shifted(getattr(s, op)(1.2), np.ones(3, dtype=np.float32))
+    with pytest.raises(TypeError):
+        s.shifted(getattr(s, op)(1.2), rng.random(10)[::2])
+    del x0
+
+
+def test_norml2_as_one_group(s, orc):  # runtests.jl:216-277
+    rng = np.random.default_rng(1)
+    lam = rng.random()
+    x = np.ones(6)
+    nu = rng.random()
+    q = rng.normal(size=6)
+    psi = s.shifted(s.NormL2(lam), x)
+    assert type(psi).__name__ == "ShiftedGroupNormL2"
+    assert np.all(psi.sj == 0) and psi.xk is x and list(psi.λ) == [lam]
+    assert _close(psi(np.zeros(6)), lam * np.linalg.norm(x))
+    y = rng.random(6)
+    assert _close(psi(y), lam * np.linalg.norm(x + y))
+    ypsi = np.empty(6)
+    s.prox_bang(ypsi, psi, q, nu)
+    v = q + x                                            # NormL2 prox [ext]: max(1 - nu lam / ||v||, 0) v
+    yp = max(1 - nu * lam / np.linalg.norm(v), 0.0) * v
+    assert np.sqrt(np.sum((ypsi - (yp - x)) ** 2)) <= 1e-11
+    s.shift_bang(psi, y)
+    assert np.all(psi.sj == 0) and np.all(psi.xk == y)
+    sv = np.ones(6) / 2
+    phi = s.shifted(psi, sv)
+    assert phi.sj is sv and phi.xk is psi.xk
+    assert _close(phi(np.zeros(6)), lam * np.linalg.norm(psi.xk + sv))
+
+
+def test_groupnorml2_index_vectors(s, orc):  # runtests.jl:286-330: v = [collect(1:3), collect(4:6)]
+    rng = np.random.default_rng(2)
+    v = [[0, 1, 2], [3, 4, 5]]
+    lam = rng.random(2)
+    h = s.GroupNormL2(lam.tolist(), v)
+    x = np.ones(6)
+    nu = rng.random()
+    q = rng.normal(size=6)
+    psi = s.shifted(h, x)
+    assert type(psi).__name__ == "ShiftedGroupNormL2" and np.all(psi.sj == 0) and psi.xk is x
+    hval = lambda z: sum(l * np.linalg.norm(z[g]) for l, g in zip(lam, v))
+    assert _close(psi(np.zeros(6)), hval(x))
+    y = rng.random(6)
+    assert _close(psi(y), hval(x + y))
+    ypsi = np.empty(6)
+    s.prox_bang(ypsi, psi, q, nu)
+    yp = np.empty(6)
+    for l, g in zip(lam, v):                             # per-group NormL2 prox of q + x
+        z = (q + x)[g]
+        yp[g] = max(1 - nu * l / np.linalg.norm(z), 0.0) * z
+    assert np.sqrt(np.sum((ypsi - (yp - x)) ** 2)) <= 1e-11
+
+
+def test_indballl0(s, orc):  # runtests.jl:362-414
+    rng = np.random.default_rng(3)
+    h = s.IndBallL0(1)
+    x = np.ones(3)
+    psi = s.shifted(h, x)
+    assert type(psi).__name__ == "ShiftedIndBallL0" and psi.xk is x and psi.r == 1
+    assert psi(np.zeros(3)) == np.inf                    # h(x): three nonzeros > r
+    assert s.shifted(s.IndBallL0(3), x)(np.zeros(3)) == 0.0
+    y = rng.random(3)
+    assert psi(y) == orc.obj_indball_l0(y, x, np.zeros(3), 1)
+    s.shift_bang(psi, y)
+    assert np.all(psi.xk == y)
+    sv = np.ones(3) / 2
+    phi = s.shifted(psi, sv)
+    assert phi.sj is sv and phi.xk is psi.xk
+    assert phi(-(psi.xk + sv)) == 0.0                    # xk + sj + t = 0: inside every l0 ball
+
+
+TR = [("NormL0", "NormLinf", "ShiftedNormL0Box", "l0"), ("NormL1", "NormLinf", "ShiftedNormL1Box", "l1"),
+      ("NormL1", "NormL2", "ShiftedNormL1B2", "l1"), ("RootNormLhalf", "NormLinf", "ShiftedRootNormLhalfBox", "lhalf")]
+
+
+@pytest.mark.parametrize("op,tr,shifted_op,kind", TR)
+def test_operators_with_trust_region(s, orc, kats, op, tr, shifted_op, kind):  # runtests.jl:417-556
+    rng = np.random.default_rng(4)
+    chi_norm = (lambda z: np.max(np.abs(z))) if tr == "NormLinf" else (lambda z: np.linalg.norm(z))
+    chi = getattr(s, tr)(1.0)
+    n = 5
+    h = getattr(s, op)(1.0)
+    x = np.ones(n)
+    delta = 0.01
+    psi = s.shifted(h, x, delta, chi)
+    assert type(psi).__name__ == shifted_op
+    if shifted_op == "ShiftedNormL1B2":
+        assert psi.Δ == delta
+    assert np.all(psi.sj == 0) and psi.xk is x and psi.λ == 1.0
+    assert _close(psi(np.zeros(n)), _h(orc, kind, x, 1.0))
+    y = rng.random(n)
+    y *= delta / chi_norm(y) / 2
+    assert _close(psi(y), _h(orc, kind, x + y, 1.0))     # y inside the trust region
+    assert psi(3 * y) == np.inf                          # y outside the trust region
+    # prox golden (runtests.jl:449-494)
+    k = kats["box_golden"]
+    q = np.array(k["q"])
+    sol = s.prox(psi, q, k["sigma"])
+    assert sol is psi.sol
+    np.testing.assert_allclose(sol, k["expected"][shifted_op], rtol=k["rtol"], atol=0)
+    assert chi_norm(sol) <= delta * (1 + 1e-12)
+    # shift update
+    s.shift_bang(psi, y)
+    assert np.all(psi.sj == 0) and np.all(psi.xk == y)
+    # radius / bounds update
+    d2 = 1.1
+    s.set_radius_bang(psi, d2)
+    if shifted_op == "ShiftedNormL1B2":
+        assert psi.Δ == d2
+    else:
+        assert psi.l == -d2 and psi.u == d2
+    # shift a shifted operator
+    sv = np.ones(n)
+    sv /= 2 * chi_norm(sv)
+    phi = s.shifted(psi, sv)
+    assert phi.sj is sv and phi.xk is psi.xk
+    assert _close(phi(np.zeros(n)), _h(orc, kind, psi.xk + sv, 1.0))
+    t = rng.random(n)
+    t *= d2 / chi_norm(t) / 2
+    assert _close(phi(t), _h(orc, kind, psi.xk + sv + t, 1.0))   # inside
+    assert phi(3 * t) == np.inf                                   # outside
+
+
+def test_groupnorml2_binf_flow(s, orc, kats):  # runtests.jl:558-650
+    rng = np.random.default_rng(5)
+    k = kats["group_l2_binf_single"]
+    x = np.array(k["x"])
+    n = x.size
+    lam = k["lambda"][0]
+    delta = k["delta"]
+    psi = s.shifted(s.NormL2(lam), x, delta, s.NormLinf(1.0))
+    assert type(psi).__name__ == "ShiftedGroupNormL2Binf" and psi.Δ == delta
+    assert np.all(psi.sj == 0) and psi.xk is x and list(psi.λ) == [lam]
+    assert _close(psi(np.zeros(n)), lam * np.linalg.norm(x))
+    y = rng.random(n)
+    y *= delta / np.max(np.abs(y)) / 2
+    assert _close(psi(y), lam * np.linalg.norm(x + y))
+    assert psi(3 * y) == np.inf
+    sol = s.prox(psi, np.array(k["q"]), k["sigma"])
+    np.testing.assert_allclose(sol, k["expected"], rtol=k["rtol"], atol=0)
+    assert np.max(np.abs(sol)) <= delta * (1 + 1e-8)
+    s.set_radius_bang(psi, 1.1)
+    assert psi.Δ == 1.1

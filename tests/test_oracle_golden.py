@@ -344,3 +344,20 @@ def test_l1b2_golden_and_minimiser(orc, kats):
         cand = rng.normal(size=(200000, n))
         cand = cand / np.linalg.norm(cand, axis=1, keepdims=True) * delta * rng.random((200000, 1)) ** (1 / n) - s
         assert obj(t) <= np.min(obj(cand)) + 1e-6
+
+
+def test_l1b2_objective(orc):
+    # (psi::ShiftedNormL1B2)(y) = h(xk + sj + y) + IndBallL2(Delta)(sj + y)   src/shiftedNormL1B2.jl:32; the reference
+    # test checks inside -> h(x + y), outside -> Inf (test/runtests.jl:443-447)
+    rng = np.random.default_rng(8)
+    n = 5
+    x, s0 = np.ones(n), np.zeros(n)
+    y = rng.random(n)
+    y *= 0.01 / np.linalg.norm(y) / 2
+    assert orc.obj_l1_b2(np.zeros(n), x, s0, 1.0, 0.01) == 5.0
+    assert abs(orc.obj_l1_b2(y, x, s0, 1.0, 0.01) - np.sum(np.abs(x + y))) <= 1e-15
+    assert orc.obj_l1_b2(3 * y, x, s0, 1.0, 0.01) == np.inf
+    # on the sphere (||sj + y|| = Delta up to rounding): inside, by IndBallL2's isapprox slack
+    yb = y / np.linalg.norm(y) * 0.01
+    assert np.isfinite(orc.obj_l1_b2(yb, x, s0, 1.0, 0.01))
+    assert orc.obj_l1_b2(yb * (1 + 1e-6), x, s0, 1.0, 0.01) == np.inf
