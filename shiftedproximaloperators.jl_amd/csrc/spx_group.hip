@@ -68,6 +68,25 @@ __device__ __forceinline__ void team_sum2(double& a, double& b, double* lds) {
   }
 }
 
+// max over the team of a non-negative, NaN-free value
+template <int TEAM>
+__device__ __forceinline__ double team_max(double v, double* lds) {
+  v = fmax(v, dpp_f64<0xB1>(v));
+  v = fmax(v, dpp_f64<0x4E>(v));
+  v = fmax(v, dpp_f64<0x141>(v));
+  if constexpr (TEAM >= 16) v = fmax(v, dpp_f64<0x140>(v));
+  if constexpr (TEAM >= 32) v = fmax(v, __shfl_xor(v, 16, 64));
+  if constexpr (TEAM >= 64) v = fmax(v, __shfl_xor(v, 32, 64));
+  if constexpr (TEAM == 256) {
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[w] = v;
+    __syncthreads();
+    v = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
+  }
+  return v;
+}
+
 // softthres(x, a) = sign(x) * max(0, |x| - a)          src/shiftedGroupNormL2Binf.jl:82
 __device__ __forceinline__ double softthres(double x, double a) { return jl_sign(x) * jl_max(0.0, fabs(x) - a); }
 
@@ -308,22 +327,17 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
   const double lmin = sl * (1 + eps);     // :94
   // lmax, zlmax and froot(lmin) only steer the bracket (their exact rounding never reaches y): the wave-uniform
   // divisions and square roots below use the few-ulp fast forms
-  // one fused pass: ||S||, ||X|| and the A/B sums of froot(lmin) (:95)
+  // first pass: ||S||, ||X|| and max |X_i|
   const double ul = lmin - sl;
   const double taul = ul * fast_rcp(lmin);
-  double sS = 0.0, sX = 0.0, sal = 0.0, sbl = 0.0;
+  double sS = 0.0, sX = 0.0, mX = 0.0;
   grp.for_each([&](double S, double X) {
-    const double s2 = S * S;
-    sS += s2;
+    sS += S * S;
     sX += X * X;
-    const double z = __builtin_fma(taul, S, -X);
-    const bool act = fabs(z) > delta;
-    const double b = X + signed_delta(delta, z);
-    sal += keep_if(s2, !act);
-    sbl += keep_if(b * b, act);
+    mX = fmax(mX, fabs(X));
   });
   team_sum2<TEAM>(sS, sX, lds);
-  team_sum2<TEAM>(sal, sbl, lds);
+  mX = team_max<TEAM>(mX, lds);
   const double nS = sqrt_pos(sS), nX = sqrt_pos(sX);
   const double ub = sqrt_pos(sS + sX) * (1.0 + 8 * eps);  // a-priori bound on the root in u (see below)
   // lmax = ||S|| + sigma (zlmax + lambda ||X||) (:100) needs one more pass for zlmax (:99).  zlmax >= 0, so
@@ -346,7 +360,19 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
     sz = team_sum<TEAM>(sz, lds);
     lmax = nS + sigma * (sqrt_pos(sz) + 1.0 * lam * nX);                   // :100 (|(eps-1)/eps + 1| = 1)
   }
-  double fl = lmin - (lmin * fast_rcp(ul)) * sqrt_pos(__builtin_fma(taul * taul, sal, sbl));
+  // fl = froot(lmin) (:95): only its sign is used.  lmin sits eps above the pole of step(n): tau(lmin) ~ eps, the element
+  // with the largest |X_i| has |tau S_i - X_i| >= max|X| - tau ||S||; if that exceeds Delta by a relative 1e-9 the
+  // element is active with |b_i| >= 1e-9 Delta, so froot(lmin) <= lmin - (lmin/ul) 1e-9 Delta < 0 as soon as
+  // ul = eps sl < 1e-9 Delta -- decided without the A/B sums at lmin.  Otherwise (all |X_i| <= Delta, huge lambda) they
+  // are formed as in every other evaluation.
+  double fl;
+  if ((sS + sX < INFINITY) && (mX - taul * nS > delta * (1.0 + 1e-9)) && (ul < 1e-9 * delta)) {
+    fl = -1.0;
+  } else {
+    double sal, sbl;
+    binf_ab<TEAM>(grp, taul, delta, lds, sal, sbl);
+    fl = lmin - (lmin * fast_rcp(ul)) * sqrt_pos(__builtin_fma(taul * taul, sal, sbl));
+  }
   if (!(lmin < lmax) || !(ul > 0.0) || !(fl == fl)) return BINF_LITERAL;  // degenerate bracket, sl == 0, NaN
   // regular bracket sl < lmin < lmax:  fm = froot(lmax) has the sign of psi(uhi)   (:101).
   // |b_i| <= max(|S_i|, |X_i|) gives phi(u) <= ub := sqrt(||S||^2 + ||X||^2) for every u, so the root is <= ub:
