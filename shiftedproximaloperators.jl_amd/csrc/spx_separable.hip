@@ -466,7 +466,8 @@ __device__ __forceinline__ void dma16_nt(const f64x2* g, char* wave_lds_piece) {
 template <class Op, int UNROLL, bool VECB, bool MASK>
 __global__ __launch_bounds__(256) void k_sep_lds(double* y_, const double* q_, const double* d_, const double* xk_,
                                                   const double* sj_, const double* l_, const double* u_,
-                                                  const uint8_t* mask_, double ls, double us, int64_t n2, Op op) {
+                                                  const uint8_t* mask_, double ls, double us, int64_t n2, Op op,
+                                                  int64_t xcd_chunk) {
   constexpr int NARR = Op::kNIn + ((VECB && Op::kBox) ? 2 : 0);
   const f64x2* dv = reinterpret_cast<const f64x2*>(d_);
   __shared__ __attribute__((aligned(16))) char lds[4 * NARR * UNROLL * 1024];
@@ -479,7 +480,15 @@ __global__ __launch_bounds__(256) void k_sep_lds(double* y_, const double* q_, c
   const f64x2* lv = reinterpret_cast<const f64x2*>(l_);
   const f64x2* uv = reinterpret_cast<const f64x2*>(u_);
   const uint16_t* mk = reinterpret_cast<const uint16_t*>(mask_);
-  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * (64 * UNROLL) + lane;  // this lane's first pair
+  // Workgroups are dealt to the 8 XCDs round-robin.  xcd_chunk == 0 (default): tile = workgroup id, so neighbouring tiles
+  // land on different XCDs; xcd_chunk > 0 (spx_set_tuning key 5, experiment): XCD x works through the contiguous range
+  // [x * xcd_chunk, (x + 1) * xcd_chunk) of tiles.  No tile is ever re-read, so neither L2 has anything to win -- measured.
+  int64_t bid = blockIdx.x;
+  if (xcd_chunk > 0) {
+    bid = (int64_t)(blockIdx.x & 7) * xcd_chunk + (blockIdx.x >> 3);
+    if (bid * (256 * UNROLL) >= n2) return;
+  }
+  const int64_t base = (bid * 4 + wave) * (64 * UNROLL) + lane;  // this lane's first pair
   uint16_t vm[UNROLL];
 #pragma unroll
   for (int k = 0; k < UNROLL; ++k) {
@@ -544,6 +553,7 @@ static int g_sep_blocks_per_cu = 0;  // 0 = no cap: grid = number of tiles
 static int g_sep_nt = 1;
 
 static int g_sep_lds = 1;  // 1 = LDS-staged skeleton (default), 0 = register-staged
+static int g_sep_xcd = 0;  // 1 = XCD-contiguous tile ranges (experiment, see k_sep_lds)
 
 template <class Op, bool VECB, bool MASK>
 static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d, const double* xk, const double* sj,
@@ -551,9 +561,14 @@ static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d,
   if constexpr (Op::kLdsKiB > 0) if (g_sep_lds) {
     // 3 input vectors: 6 KiB per wave and vector -> 72 KiB per workgroup; 5 vectors (vector bounds): 3 KiB -> 60 KiB
     constexpr int U = (VECB && Op::kBox) ? (Op::kLdsKiB > 3 ? 3 : Op::kLdsKiB) : Op::kLdsKiB;  // <= 72 KiB per workgroup
-    const int64_t blocks = (n2 + 256 * U - 1) / (256 * U);
+    int64_t blocks = (n2 + 256 * U - 1) / (256 * U);
+    int64_t xcd_chunk = 0;
+    if (g_sep_xcd) {
+      xcd_chunk = (blocks + 7) / 8;
+      blocks = xcd_chunk * 8;
+    }
     hipLaunchKernelGGL((k_sep_lds<Op, U, VECB, MASK>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, d, xk,
-                       sj, l, u, mask, ls, us, n2, op);
+                       sj, l, u, mask, ls, us, n2, op, xcd_chunk);
     SPX_LAUNCH_CHECK();
     return SPX_OK;
   }
@@ -618,6 +633,7 @@ SPX_EXPORT int spx_set_tuning(int key, int value) {
   if (key == 2) { spx_select_set_fast(value); return SPX_OK; }
   if (key == 3) { g_sep_lds = value ? 1 : 0; return SPX_OK; }
   if (key == 4) { spx_select_set_spec(value); return SPX_OK; }
+  if (key == 5) { g_sep_xcd = value ? 1 : 0; return SPX_OK; }
   spx_set_error("invalid argument: unknown tuning key/value");
   return SPX_ERR_INVALID_ARG;
 }
