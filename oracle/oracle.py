@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libspx_oracle.so")
+_SO = os.environ.get("SPX_ORACLE_SO") or os.path.join(_HERE, "libspx_oracle.so")  # override: sanitizer build (make asan)
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_int64_p = ctypes.POINTER(ctypes.c_int64)
@@ -23,6 +23,8 @@ _c_uint8_p = ctypes.POINTER(ctypes.c_uint8)
 def build(force=False):
     """Compile oracle/spx_oracle.c with gcc (no FMA contraction, no fast-math)."""
     src = os.path.join(_HERE, "spx_oracle.c")
+    if os.environ.get("SPX_ORACLE_SO"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"] if force else ["make", "-C", _HERE, "-s"])
     return _SO
