@@ -1,0 +1,88 @@
+"""Host-side logic of the mirror that needs no GPU: argument validation, group layouts (uniform / CSR / gather),
+selection masks and constructor errors on host (numpy) vectors.  Nothing here computes a prox."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def s():
+    import __graft_entry__ as ge
+    return ge.build()
+
+
+def test_vector_validation(s):
+    import torch
+    with pytest.raises(TypeError):
+        s.shifted(s.NormL1(1.0), np.ones(4, dtype=np.float32))          # Float32: not on the accelerated path
+    with pytest.raises(TypeError):
+        s.shifted(s.NormL1(1.0), np.ones(8)[::2])                        # strided view
+    with pytest.raises(TypeError):
+        s.shifted(s.NormL1(1.0), torch.ones(4, dtype=torch.float64))     # CPU torch tensor: never staged silently
+    with pytest.raises(TypeError):
+        s.shifted(s.NormL1(1.0), [1.0, 2.0])
+    psi = s.shifted(s.NormL1(1.0), np.ones(4))
+    assert psi.host and psi.sol.shape == (4,) and not psi.shifted_twice
+    with pytest.raises(IndexError):
+        s.shifted(psi, np.ones(5))                                       # BoundsError
+    with pytest.raises(TypeError):
+        s.shifted(s.IndBallL0(1), np.ones(4), 1.0, s.NormLinf(1.0), [0, 1])   # `selected` only for the Box operators
+
+
+def test_box_constructor_checks_on_host(s):
+    x = np.zeros(3)
+    lo, up = np.array([0.0, 1.0, 0.0]), np.array([1.0, 0.5, 1.0])
+    for H in (s.NormL1, s.NormL0):                                       # src/shiftedNormL1Box.jl:33-35, L0Box :33-35
+        with pytest.raises(ValueError, match="lower bound is greater"):
+            s.shifted(H(1.0), x, lo, up)
+        with pytest.raises(ValueError):
+            s.shifted(H(1.0), x, 2.0, 1.0)
+    s.shifted(s.RootNormLhalf(1.0), x, lo, up)                           # no such check (src/shiftedRootNormLhalfBox.jl:22-44)
+    psi = s.shifted(s.NormL1(1.0), x, -1.0, 1.0, [2, 0, 2])
+    assert psi._mask[0].tolist() == [1, 0, 1]
+    assert s.shifted(s.NormL1(1.0), x, -1.0, 1.0, range(0, 3))._mask is None   # selected == 1:n
+    om = s.shifted(psi, np.ones(3))
+    assert om._mask is psi._mask and om.l == -1.0 and om.shifted_twice
+    s.set_bounds_bang(om, lo, 2.0)
+    assert om.l is lo and om.u == 2.0
+    s.set_radius_bang(om, 0.25)
+    assert om.l == -0.25 and om.u == 0.25
+
+
+def test_group_layouts(s):
+    x = np.zeros(12)
+    lay = lambda idx, lam=None: s.shifted(s.GroupNormL2(lam or [1.0] * len(idx), idx), x)._layout
+    g = lay([range(0, 4), range(4, 8), range(8, 12)])                    # uniform: no index array at all
+    assert g.offsets is None and g.group_size == 4 and g.ngroups == 3 and g.index is None
+    g = lay([range(0, 3), [3, 4, 5, 6], slice(7, 12)])                   # consecutive ragged ranges: CSR offsets
+    assert g.index is None and g.offsets.tolist() == [0, 3, 7, 12] and g.group_size == 0
+    g = lay([range(2, 5), range(5, 9)])                                  # consecutive but not spanning 0:n: still CSR
+    assert g.index is None and g.offsets.tolist() == [2, 5, 9]
+    g = lay([[0, 2, 4], [1, 3, 5]])                                      # true index sets: gather form
+    assert g.index.tolist() == [0, 2, 4, 1, 3, 5] and g.offsets.tolist() == [0, 3, 6] and g.nnz == 6
+    g = lay([range(4, 8), range(0, 4)])                                  # out of order: gather (sequential semantics)
+    assert g.index is not None
+    g = lay([range(0, 5), range(3, 8)])                                  # overlapping: gather
+    assert g.index is not None and g.nnz == 10
+    g = lay([range(0, 12, 2)])                                           # strided range: gather
+    assert g.index.tolist() == [0, 2, 4, 6, 8, 10]
+    with pytest.raises(IndexError):
+        lay([[0, 12]])
+    with pytest.raises(IndexError):
+        lay([range(8, 13)])
+    with pytest.raises(ValueError):
+        s.GroupNormL2([1.0, -1.0], [range(0, 6), range(6, 12)])          # src/groupNormL2.jl:20-21
+    u = s.shifted(s.GroupNormL2.uniform([0.5, 0.6, 0.7], 4), x)._layout
+    assert u.group_size == 4 and u.ngroups == 3 and u.lam.tolist() == [0.5, 0.6, 0.7]
+    with pytest.raises(IndexError):
+        s.shifted(s.GroupNormL2.uniform([0.5, 0.6], 4), x)
+    one = s.shifted(s.NormL2(0.3), x)                                    # NormL2 -> one group [:]
+    assert type(one).__name__ == "ShiftedGroupNormL2" and one._layout.ngroups == 1 and one._layout.group_size == 12
+
+
+def test_no_gpu_means_loud_failure(s):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    psi = s.shifted(s.NormL1(1.0), np.ones(4))
+    with pytest.raises(Exception):
+        s.prox(psi, np.ones(4), 1.0)                                     # host vectors are staged through a GPU: none here
