@@ -78,7 +78,6 @@ struct WaveCount {
 constexpr int kSample = 65536;        // sample size (256 chunks of 256 consecutive elements)
 constexpr int kMainUnroll = 6;        // KiB per wave and vector in the main pass (as k_sep_lds)
 constexpr int kMainTilePairs = 256 * kMainUnroll;  // 16-byte pairs per workgroup of the main pass
-constexpr int kMainWaveElems = 2 * 64 * kMainUnroll;  // elements per wavefront of the main pass (768; ~0.5 % are candidates)
 constexpr int kShortList = 4096;      // candidates left after the first digit that k_s2_finish resolves in LDS
 
 __device__ __forceinline__ uint64_t key_of(double v) { return (uint64_t)__double_as_longlong(v) & kAbsMask; }
@@ -608,27 +607,18 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
 
 // Candidate kernels walk the regions TRANSPOSED: a wavefront takes 64 regions at a time, lane l owns region w0 + l and
 // steps through its few entries (4 loads in flight per lane), so the count words are read coalesced and no lane waits
-// on a chain of dependent loads.  f(position, key, index) is called for every valid entry; the return value holds this
-// LANE's totals over the regions it owned.
-struct RegionTotals {
-  unsigned long long cand, above;
-  bool overflow;
-};
+// on a chain of dependent loads.  f(position, key, index) is called for every valid entry.
 template <class F>
-__device__ __forceinline__ RegionTotals for_each_candidate(const WaveCount* counts, int64_t nregions,
-                                                           const uint64_t* cand_key, const int64_t* cand_idx, F&& f) {
+__device__ __forceinline__ void for_each_candidate(const WaveCount* counts, int64_t nregions, const uint64_t* cand_key,
+                                                   const int64_t* cand_idx, F&& f) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  RegionTotals t{0ull, 0ull, false};
   for (int64_t w0 = wave * 64; w0 < nregions; w0 += nwaves * 64) {
     const int64_t w = w0 + lane;
-    WaveCount c{0u, 0u};
-    if (w < nregions) c = counts[w];
-    t.cand += c.cand;
-    t.above += c.above;
-    t.overflow |= c.cand > (unsigned)kWaveSlots;
-    const int cnt = c.cand < (unsigned)kWaveSlots ? (int)c.cand : kWaveSlots;
+    unsigned int c = 0;
+    if (w < nregions) c = counts[w].cand;
+    const int cnt = c < (unsigned)kWaveSlots ? (int)c : kWaveSlots;
     const int64_t e0 = w * kWaveSlots;
     for (int s0 = 0; __any(s0 < cnt); s0 += 4) {
       uint64_t k[4];
@@ -641,7 +631,6 @@ __device__ __forceinline__ RegionTotals for_each_candidate(const WaveCount* coun
         if (s0 + u < cnt) f(e0 + s0 + u, k[u], ix[u]);
     }
   }
-  return t;
 }
 
 // the kept band entries get their value (everything else was stored by k_s2_main<.., true>)
