@@ -29,10 +29,10 @@ __device__ __forceinline__ double dpp_f64(double v) {
 }
 template <int TEAM>
 __device__ __forceinline__ double lanes_sum(double v) {
-  static_assert(TEAM == 8 || TEAM == 16 || TEAM == 32 || TEAM == 64, "TEAM");
+  static_assert(TEAM == 4 || TEAM == 8 || TEAM == 16 || TEAM == 32 || TEAM == 64, "TEAM");
   v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
   v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_f64<0x141>(v);  // row_half_mirror: the other quad of each 8
+  if constexpr (TEAM >= 8) v += dpp_f64<0x141>(v);  // row_half_mirror: the other quad of each 8
   if constexpr (TEAM >= 16) v += dpp_f64<0x140>(v);  // row_mirror: the other half of each 16-lane row
   if constexpr (TEAM >= 32) v += __shfl_xor(v, 16, 64);
   if constexpr (TEAM >= 64) v += __shfl_xor(v, 32, 64);
@@ -73,7 +73,7 @@ template <int TEAM>
 __device__ __forceinline__ double team_max(double v, double* lds) {
   v = fmax(v, dpp_f64<0xB1>(v));
   v = fmax(v, dpp_f64<0x4E>(v));
-  v = fmax(v, dpp_f64<0x141>(v));
+  if constexpr (TEAM >= 8) v = fmax(v, dpp_f64<0x141>(v));
   if constexpr (TEAM >= 16) v = fmax(v, dpp_f64<0x140>(v));
   if constexpr (TEAM >= 32) v = fmax(v, __shfl_xor(v, 16, 64));
   if constexpr (TEAM >= 64) v = fmax(v, __shfl_xor(v, 32, 64));
@@ -511,13 +511,16 @@ __device__ __forceinline__ double binf_w(double S, double X, double tau, double 
 // the group is resident in registers.  Lane j of a group owns the 16-byte pairs j, j + LPG, j + 2 LPG, ...
 // ---------------------------------------------------------------------------------------------
 #ifndef SPX_GROUP_WAVES
-#define SPX_GROUP_WAVES 3  // min waves/SIMD (VGPR cap).  Binf 1e6x128: 3 (162 VGPRs, no spill) 0.84 ms; 4 (128, cold paths spill) 0.93 ms; 5: 1.49 ms
+#define SPX_GROUP_WAVES 3  // min waves/SIMD (VGPR cap) of the 8-element tiles.  Binf 1e6x128 on 16 lanes x 8: 3 (162 VGPRs, no spill) 0.84 ms; 4 (128, cold paths spill) 0.93 ms; 5: 1.49 ms
+// Binf tiles with 16 elements per lane (8 x 16 for 128-element groups: 8 groups per wave) run at 2 waves/SIMD (253 VGPRs):
+// the kernel is VALU-bound and the wave-uniform scalar work of the root find is shared by twice as many elements --
+// 0.79 -> 0.70 ms at 1e6 x 128 in spite of the lower occupancy.
 #endif
 // PAIRS: the group size is even (every group starts 16-byte aligned): lane j owns the pairs j, j + LPG, ...; pairs past
 // the end of the group are read as zeros (zeros are neutral in every sum of both operators).  !PAIRS: odd group size,
 // lane j owns the elements j, j + LPG, ... through 8-byte loads.
 template <int LPG, int EPL, bool BINF, bool PAIRS>
-__global__ __launch_bounds__(256, SPX_GROUP_WAVES) void k_group_reg(double* y_, const double* q_, const double* xk_, const double* sj_,
+__global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) void k_group_reg(double* y_, const double* q_, const double* xk_, const double* sj_,
                                                     int64_t ngroups, int gsize, const double* __restrict__ lambda,
                                                     double sigma, double delta,
                                                     long long* deferred /* [0] = count, [1..] = groups */) {
@@ -922,10 +925,14 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   if (!offsets && gsize <= 512) {
     // register path: the smallest (LPG, EPL) tile that holds a group; partly filled tiles are padded with zeros
     int lpg, epl;
-    // Binf: small groups on 8 lanes (8 groups per wave) -- the wave-uniform scalar work of the root find, which every
-    // lane executes, is then shared by twice as many groups
-    if (BINF && gsize <= 32) { lpg = 8; epl = 4; }
-    else if (BINF && gsize <= 64) { lpg = 8; epl = 8; }
+    // Binf: as few lanes per group as the registers allow (4 x 4/8, 8 x 8/16, 16 x 16, 32 x 16 elements) -- the wave-uniform
+    // scalar work of the root find, which every lane executes, is then shared by more groups per wave
+    if (BINF && gsize <= 16) { lpg = 4; epl = 4; }
+    else if (BINF && gsize <= 32) { lpg = 4; epl = 8; }
+    else if (BINF && gsize <= 64) { lpg = 8; epl = 8; }  // (4 x 16 is slower here: 64-byte runs per group and load)
+    else if (BINF && gsize <= 128) { lpg = 8; epl = 16; }
+    else if (BINF && gsize <= 256) { lpg = 16; epl = 16; }
+    else if (BINF && gsize <= 512) { lpg = 32; epl = 16; }
     else if (gsize <= 32) { lpg = 16; epl = 2; }
     else if (gsize <= 64) { lpg = 16; epl = 4; }
     else if (gsize <= 128) { lpg = 16; epl = 8; }
@@ -953,8 +960,12 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, false>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,  \
                          (int)gsize, lambda, sigma, delta, deferred);                                               \
   } while (0)
-    if (lpg == 8 && epl == 4) { if constexpr (BINF) SPX_LAUNCH_REG(8, 4); }
-    else if (lpg == 8) { if constexpr (BINF) SPX_LAUNCH_REG(8, 8); }
+    if (lpg == 4 && epl == 4) { if constexpr (BINF) SPX_LAUNCH_REG(4, 4); }
+    else if (lpg == 4 && epl == 8) { if constexpr (BINF) SPX_LAUNCH_REG(4, 8); }
+    else if (lpg == 8 && epl == 8) { if constexpr (BINF) SPX_LAUNCH_REG(8, 8); }
+    else if (lpg == 8) { if constexpr (BINF) SPX_LAUNCH_REG(8, 16); }
+    else if (lpg == 16 && epl == 16) { if constexpr (BINF) SPX_LAUNCH_REG(16, 16); }
+    else if (lpg == 32 && epl == 16) { if constexpr (BINF) SPX_LAUNCH_REG(32, 16); }
     else if (lpg == 16 && epl == 2) SPX_LAUNCH_REG(16, 2);
     else if (lpg == 16 && epl == 4) SPX_LAUNCH_REG(16, 4);
     else if (lpg == 16) SPX_LAUNCH_REG(16, 8);
