@@ -12,13 +12,16 @@
  *
  * Conventions
  *   - Every data pointer is a DEVICE pointer to contiguous float64 (or as typed) memory on the
- *     context's device.  Nothing is retained past a call; the caller owns all vectors
+ *     context's device (the spx_host_* twins at the end of this file take HOST pointers and stage them).
+ *     Nothing is retained past a call; the caller owns all vectors
  *     (the reference borrows xk/sj/l/u by reference too: src/shiftedNormL1Box.jl:22-47).
  *   - `y` may alias `q` exactly (test/test_allocs.jl:108-113) and may be the operator's own `sol`
  *     (prox(), src/ShiftedProximalOperators.jl:189-190).  Partial overlap is undefined.
  *   - Calls are asynchronous on the context's HIP stream and ordered on it; spx_sync() waits.  Exceptions
  *     (they return a value or a verdict to the host and therefore synchronise): spx_check_bounds, spx_obj_*,
- *     the unboxed spx_iprox_* with check_d != 0, and the top-r operators (one 4-byte read-back per call).
+ *     the unboxed spx_iprox_* with check_d != 0, the top-r operators (one 4-byte read-back per call),
+ *     spx_prox_l1_b2 (one read-back per reduction pass), the gather-index group forms (index validation) and
+ *     every spx_host_* form.
  *     A context is not re-entrant (neither is a reference psi: shared scratch sol/xsy/p).
  *   - Return value: 0 = SPX_OK, else an spx_status; spx_last_error() gives a thread-local message.
  *   - Indices handed over in arrays (selected sets, group offsets) are 0-BASED int64.
