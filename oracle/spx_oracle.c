@@ -258,6 +258,11 @@ ORC_API void orc_prox_lhalf_box(double* y, const double* q, const double* xk, co
  * sortperm!(p, y, rev=true, by=abs): stable permutation, descending |y|, ties ascending index.
  * Stable bottom-up merge sort of indices.
  * ------------------------------------------------------------------------------------------ */
+static inline int jl_isless(double x, double y) { /* Base.isless on Float64 (non-negative arguments here) */
+  if (x != x) return 0;
+  if (y != y) return 1;
+  return x < y;
+}
 static void stable_sortperm_desc_abs(int64_t* p, const double* y, int64_t n) {
   int64_t* tmp = (int64_t*)malloc((size_t)n * sizeof(int64_t));
   for (int64_t i = 0; i < n; ++i) p[i] = i;
@@ -269,8 +274,9 @@ static void stable_sortperm_desc_abs(int64_t* p, const double* y, int64_t n) {
       int64_t hi = lo + 2 * w < n ? lo + 2 * w : n;
       int64_t a = lo, b = mid, k = lo;
       while (a < mid && b < hi) {
-        /* take from the right run only if strictly larger in |.| (keeps stability) */
-        if (fabs(y[src[b]]) > fabs(y[src[a]])) dst[k++] = src[b++];
+        /* take from the right run only if strictly larger in |.| (keeps stability); "larger" in Julia's total order
+         * isless (the `lt` of sort): a NaN is greater than everything, NaNs are equal among themselves */
+        if (jl_isless(fabs(y[src[a]]), fabs(y[src[b]]))) dst[k++] = src[b++];
         else dst[k++] = src[a++];
       }
       while (a < mid) dst[k++] = src[a++];

@@ -80,7 +80,14 @@ constexpr int kMainUnroll = 6;        // KiB per wave and vector in the main pas
 constexpr int kMainTilePairs = 256 * kMainUnroll;  // 16-byte pairs per workgroup of the main pass
 constexpr int kShortList = 4096;      // candidates left after the first digit that k_s2_finish resolves in LDS
 
-__device__ __forceinline__ uint64_t key_of(double v) { return (uint64_t)__double_as_longlong(v) & kAbsMask; }
+// bits(|v|): ordered like |v| for finite values and Inf.  Every NaN maps to ONE key above Inf: the reference's sort
+// compares with isless, where NaN is the largest value and all NaNs are equal (ties -> ascending index).
+constexpr uint64_t kInfKey = 0x7ff0000000000000ull;
+constexpr uint64_t kNanKey = 0x7ff8000000000000ull;
+__device__ __forceinline__ uint64_t key_of(double v) {
+  const uint64_t k = (uint64_t)__double_as_longlong(v) & kAbsMask;
+  return k > kInfKey ? kNanKey : k;
+}
 
 // exclusive prefix sum over 256 consecutive lanes (4 wavefronts: tt = 0..255); wtot = 4 shared slots of that group
 __device__ __forceinline__ unsigned long long scan256_exclusive(unsigned long long v, int tt, unsigned long long* wtot) {

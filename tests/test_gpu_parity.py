@@ -42,6 +42,12 @@ def _bits_equal(a, b):
     return np.array_equal(np.asarray(a).view(np.int64), np.asarray(b).view(np.int64))
 
 
+def _same_or_both_nan(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    nan = np.isnan(a) & np.isnan(b)
+    return bool(np.all(nan | (a.view(np.int64) == b.view(np.int64))))
+
+
 SIZES = [0, 1, 2, 3, 63, 255, 1024, 2049, 10_000, 1_000_003]
 
 
@@ -262,6 +268,30 @@ def test_indball_l0_ties_and_kats(s, orc, kats):
     xd, sd, qd = _dev(x, sj, q)
     s.prox_bang(qd, s.shifted(s.shifted(s.IndBallL0(123), xd), sd), qd, 1.0)
     assert _bits_equal(qd.cpu().numpy(), orc.prox_indball_l0(q, x, sj, 123))
+
+
+def test_indball_l0_nan_inf(s, orc):
+    """Non-finite entries: the reference's sortperm compares with isless, so a NaN is the largest magnitude, all NaNs
+    tie (ascending index decides) and +-Inf come next.  Kept-index set and values (NaN-aware) must match the oracle."""
+    rng = np.random.default_rng(12)
+    for n in (1000, (1 << 22) + 77):           # full-vector radix select / sample-predicted path
+        x, sj, q = _data(n, 13)
+        nan_at = rng.choice(n, size=9, replace=False)
+        q[nan_at[:5]] = np.nan
+        q[nan_at[5:7]] = -np.nan                # sign / payload must not matter
+        x[nan_at[7:]] = np.nan
+        inf_at = rng.choice(np.setdiff1d(np.arange(n), nan_at), size=6, replace=False)
+        q[inf_at[:3]] = np.inf
+        q[inf_at[3:]] = -np.inf
+        xd, sd, qd = _dev(x, sj, q)
+        for r in (1, 4, 9, 12, 15, 16, n // 7):
+            with np.errstate(all="ignore"):
+                ref = orc.prox_indball_l0_binf(q, x, sj, r, 0.6)
+                ref0 = orc.prox_indball_l0(q, x, sj, r)
+            y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.6, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
+            assert _same_or_both_nan(y, ref), (n, r)
+            y0 = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qd, 1.0).cpu().numpy()
+            assert _same_or_both_nan(y0, ref0), (n, r)
 
 
 # ------------------------------------------------------------------ groups
@@ -686,3 +716,31 @@ def test_l1b2_large(s, orc):
         ref = orc.prox_l1_b2(qh, xh, sh, lam, sigma, delta, 1.0)
         scale = max(np.linalg.norm(ref), np.linalg.norm(xh))
         assert np.max(np.abs(y - ref)) <= 1e-12 * scale, (lam, sigma, delta)
+
+
+# ------------------------------------------------------------------ special values
+def test_special_values_separable(s, orc):
+    """+-0, +-Inf, NaN, subnormals, huge values and points exactly on the thresholds, in every combination of
+    (q, xk, sj): the L1 / L0 families must reproduce the reference formulas bit for bit (signed zeros included; a NaN
+    must be a NaN, its payload is not compared), also through iprox!."""
+    lam, sigma = 1.0, 1.0
+    vals = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 2.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1e308, -1e308,
+                     np.sqrt(2.0), -np.sqrt(2.0), np.nextafter(1.0, 2.0), np.nextafter(1.0, 0.0)])
+    Q, X, S = (g.ravel().copy() for g in np.meshgrid(vals, vals, vals, indexing="ij"))
+    n = Q.size
+    qd, xd, sd = _dev(Q, X, S)
+    with np.errstate(all="ignore"):
+        for op, H in (("l1", s.NormL1), ("l0", s.NormL0)):
+            y = s.prox(s.shifted(s.shifted(H(lam), xd), sd), qd, sigma).cpu().numpy()
+            assert _same_or_both_nan(y, getattr(orc, "prox_" + op)(Q, X, S, lam, sigma)), op
+        for op, H in (("l1_box", s.NormL1), ("l0_box", s.NormL0)):
+            for lo, up in ((-1.0, 1.0), (0.0, 0.0), (-np.inf, np.inf), (-0.0, 2.0)):
+                y = s.prox(s.shifted(s.shifted(H(lam), xd, lo, up), sd), qd, sigma).cpu().numpy()
+                ref = getattr(orc, "prox_" + op)(Q, X, S, lam, sigma, lo, up)
+                assert _same_or_both_nan(y, ref), (op, lo, up, int(np.sum(~(np.isnan(y) & np.isnan(ref)) & (y.view(np.int64) != ref.view(np.int64)))))
+        # iprox!: d runs over the same special values (Box forms accept any sign of d)
+        D = np.resize(np.array([1.0, -1.0, 0.0, -0.0, 2.0, 1e-17, -1e-17, np.inf, 5e-324, 0.5]), n)
+        dd = _dev(D)[0]
+        for name, H in (("iprox_l1_box", s.NormL1), ("iprox_l0_box", s.NormL0)):
+            y = s.iprox(s.shifted(s.shifted(H(lam), xd, -1.0, 1.0), sd), qd, dd).cpu().numpy()
+            assert _same_or_both_nan(y, getattr(orc, name)(Q, D, X, S, lam, -1.0, 1.0)), name
