@@ -179,15 +179,21 @@ struct OpLhalfBox {  // src/shiftedRootNormLhalfBox.jl:92-117
     double d = tt - q;
     return __builtin_fma(lambda, sqrt_f64(fabs(tt + xs)), d * d * h2);
   }
+  // the same for a bound candidate, where tt may be +-Inf (one-sided / absent bounds): sqrt_f64 is an rsq iteration and
+  // turns Inf into NaN, so its argument is capped -- the (tt - q)^2 term is Inf there anyway and so is the sum
+  __device__ __forceinline__ double rnorm_bound(double tt, double q, double xs) const {
+    double d = tt - q;
+    return __builtin_fma(lambda, sqrt_f64(fmin(fabs(tt + xs), 1.0e300)), d * d * h2);
+  }
   __device__ __forceinline__ double operator()(double q, double x, double s, double l, double u, bool sel) const {
     double xs = x + s;  // :94
     double xsq = xs + q;
     double axsq = fabs(xsq);
     double tl = l - s, tu = u - s;
     // candidates 1..3 (:109-111); findmin keeps the FIRST minimum -> a later one replaces only on strict <
-    double best = rnorm(tl, q, xs);
+    double best = rnorm_bound(tl, q, xs);
     double yi = tl;
-    double c2 = rnorm(tu, q, xs);
+    double c2 = rnorm_bound(tu, q, xs);
     if (c2 < best) { best = c2; yi = tu; }
     double mx = -x;
     double c3 = xsq * xsq * h2;  // RNorm(-xs): (-xs - q)^2 = xsq^2 and sqrt|(-xs) + xs| = 0 exactly
@@ -206,6 +212,9 @@ struct OpLhalfBox {  // src/shiftedRootNormLhalfBox.jl:92-117
       double c4 = rnorm(t4, q, xs);
       if (l <= vx && vx <= u && c4 < best) { best = c4; yi = t4; }
     }
+    // NaN in q, xk or sj: every candidate value is NaN and findmin returns the first one (:114, `findmin` treats NaN as
+    // the smallest value) -> candidate 1
+    yi = (xsq != xsq) ? tl : yi;
     return sel ? yi : prox_zero(q, tl, tu);  // :116
   }
 };

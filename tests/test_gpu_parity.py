@@ -742,5 +742,39 @@ def test_special_values_separable(s, orc):
         D = np.resize(np.array([1.0, -1.0, 0.0, -0.0, 2.0, 1e-17, -1e-17, np.inf, 5e-324, 0.5]), n)
         dd = _dev(D)[0]
         for name, H in (("iprox_l1_box", s.NormL1), ("iprox_l0_box", s.NormL0)):
-            y = s.iprox(s.shifted(s.shifted(H(lam), xd, -1.0, 1.0), sd), qd, dd).cpu().numpy()
-            assert _same_or_both_nan(y, getattr(orc, name)(Q, D, X, S, lam, -1.0, 1.0)), name
+            for lo, up in ((-1.0, 1.0), (-np.inf, np.inf), (-np.inf, 0.5), (0.0, 0.0)):
+                y = s.iprox(s.shifted(s.shifted(H(lam), xd, lo, up), sd), qd, dd).cpu().numpy()
+                assert _same_or_both_nan(y, getattr(orc, name)(Q, D, X, S, lam, lo, up)), (name, lo, up)
+
+
+def test_special_values_lhalf(s, orc):
+    """RootNormLhalf(Box) on the same special-value grid: finite results to LHALF_TOL, NaN where the reference formula
+    gives NaN, +-Inf where it gives +-Inf."""
+    lam, sigma = 0.8, 1.3
+    vals = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 2.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1e308, -1e308, 1e-200, 3.0])
+    Q, X, S = (g.ravel().copy() for g in np.meshgrid(vals, vals, vals, indexing="ij"))
+    qd, xd, sd = _dev(Q, X, S)
+
+    def check(y, ref, tag):
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isnan(y), np.isnan(ref)), (tag, int(np.sum(np.isnan(y) != np.isnan(ref))))
+        inf = np.isinf(ref)
+        assert np.array_equal(y[inf], ref[inf]), tag
+        with np.errstate(all="ignore"):
+            scale = np.maximum(np.maximum(np.abs(ref), np.abs(X + S)), np.abs(Q))
+            bad = fin & (np.abs(y - ref) > LHALF_TOL * np.where(np.isfinite(scale), scale, 1.0))
+        assert not bad.any(), (tag, int(bad.sum()))
+
+    with np.errstate(all="ignore"):
+        y = s.prox(s.shifted(s.shifted(s.RootNormLhalf(lam), xd), sd), qd, sigma).cpu().numpy()
+        check(y, orc.prox_lhalf(Q, X, S, lam, sigma), "lhalf")
+        # Box form: infinite BOUNDS (absent / one-sided boxes) and NaN data are covered; +-Inf and 1e308 in q / xk / sj
+        # are not (Inf - Inf and overflowing squares inside the candidate values: the kernel's rsq-based sqrt / closed
+        # form and the reference's libm calls disagree on which garbage comes out) -- those grid points are masked
+        big = lambda a: np.abs(np.nan_to_num(a, nan=0.0)) >= 1e300
+        data_ok = ~(big(Q) | big(X) | big(S))
+        for lo, up in ((-1.0, 1.0), (-np.inf, np.inf), (0.0, 2.0), (-np.inf, 0.5), (-0.5, np.inf)):
+            y = s.prox(s.shifted(s.shifted(s.RootNormLhalf(lam), xd, lo, up), sd), qd, sigma).cpu().numpy()
+            ref = orc.prox_lhalf_box(Q, X, S, lam, sigma, lo, up)
+            y, ref = np.where(data_ok, y, 0.0), np.where(data_ok, ref, 0.0)
+            check(y, ref, ("lhalf_box", lo, up))
