@@ -778,3 +778,25 @@ def test_special_values_lhalf(s, orc):
             ref = orc.prox_lhalf_box(Q, X, S, lam, sigma, lo, up)
             y, ref = np.where(data_ok, y, 0.0), np.where(data_ok, ref, 0.0)
             check(y, ref, ("lhalf_box", lo, up))
+
+
+def test_infinite_trust_region(s, orc):
+    """Delta = Inf (no trust region): the BInf / Binf / B2 forms must still follow their formulas -- and then equal the
+    forms without a trust region."""
+    n, gs = 128 * 40, 128
+    x, sj, q = _data(n, 321)
+    xd, sd, qd = _dev(x, sj, q)
+    lam = np.random.default_rng(1).uniform(0.5, 1.5, size=n // gs)
+    h = s.GroupNormL2.uniform(lam.tolist(), gs)
+    with np.errstate(all="ignore"):
+        ref = orc.prox_group_l2_binf(q, x, sj, lam, 0.9, np.inf, gsize=gs)
+    y = s.prox(s.shifted(s.shifted(h, xd, np.inf, s.NormLinf(1.0)), sd), qd, 0.9).cpu().numpy()
+    _group_check(y, ref, q, x, sj, list(range(0, n + 1, gs)))
+    _group_check(y, orc.prox_group_l2(q, x, sj, lam, 0.9, gsize=gs), q, x, sj, list(range(0, n + 1, gs)))
+    yb = s.prox(s.shifted(s.shifted(s.IndBallL0(100), xd, np.inf, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
+    assert _bits_equal(yb, orc.prox_indball_l0(q, x, sj, 100))
+    y2 = s.prox(s.shifted(s.shifted(s.NormL1(0.7), xd, np.inf, s.NormL2(1.0)), sd), qd, 1.1).cpu().numpy()
+    assert np.max(np.abs(y2 - orc.prox_l1_b2(q, x, sj, 0.7, 1.1, np.inf, 1.0))) <= 1e-12 * np.linalg.norm(x)
+    for H, name in ((s.NormL1, "prox_l1_box"), (s.NormL0, "prox_l0_box")):
+        yy = s.prox(s.shifted(s.shifted(H(0.7), xd, np.inf, s.NormLinf(1.0)), sd), qd, 1.1).cpu().numpy()
+        assert _bits_equal(yy, getattr(orc, name)(q, x, sj, 0.7, 1.1, -np.inf, np.inf))
