@@ -800,3 +800,37 @@ def test_infinite_trust_region(s, orc):
     for H, name in ((s.NormL1, "prox_l1_box"), (s.NormL0, "prox_l0_box")):
         yy = s.prox(s.shifted(s.shifted(H(0.7), xd, np.inf, s.NormLinf(1.0)), sd), qd, 1.1).cpu().numpy()
         assert _bits_equal(yy, getattr(orc, name)(q, x, sj, 0.7, 1.1, -np.inf, np.inf))
+
+
+@pytest.mark.parametrize("gs", [16, 128, 300, 1024])
+def test_group_parameter_edges(s, orc, gs):
+    """lambda = 0 groups, Delta = 0, tiny / huge sigma, all-zero and constant groups, for every group kernel family
+    (4- / 8-lane tiles, partly filled tile, LDS-resident group)."""
+    ng = 24
+    n = ng * gs
+    rng = np.random.default_rng(gs)
+    x, sj, q = _data(n, 7000 + gs)
+    x[:gs] = 0.0; sj[:gs] = 0.0; q[:gs] = 0.0                      # an all-zero group
+    x[gs:2 * gs] = 0.25; sj[gs:2 * gs] = 0.0; q[gs:2 * gs] = 1.0   # a constant group
+    x[2 * gs:3 * gs] = 0.0                                          # X = 0: nothing active at lmin
+    lam = rng.uniform(0.2, 2.0, size=ng)
+    lam[3] = 0.0                                                    # weight zero: sl = 0
+    lam[4] = 1e-300
+    xd, sd, qd = _dev(x, sj, q)
+    h = s.GroupNormL2.uniform(lam.tolist(), gs)
+    offs = list(range(0, n + 1, gs))
+    for sigma, delta in ((1.0, 1.0), (1e-8, 1.0), (1e6, 1.0), (1.0, 0.0), (1.0, 1e-300), (0.7, 1e9)):
+        with np.errstate(all="ignore"):
+            ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, gsize=gs)
+            ref_plain = orc.prox_group_l2(q, x, sj, lam, sigma, gsize=gs)
+        y = s.prox(s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd), qd, sigma).cpu().numpy()
+        S = (q + x) + sj
+        scale = np.abs(ref).copy()
+        for lo, hi in zip(offs[:-1], offs[1:]):
+            scale[lo:hi] = np.maximum(scale[lo:hi], np.linalg.norm(S[lo:hi]))
+        err = np.abs(y - ref) / np.maximum(scale, 1e-300)
+        # sigma*lambda >> ||S|| makes the reference's own last step cancel (see test_group_binf_goldens_and_edge_branches)
+        tol = 1e-9 if sigma >= 1e6 else GROUP_TOL
+        assert np.array_equal(np.isnan(y), np.isnan(ref)) and float(np.nanmax(err)) <= tol, (sigma, delta, float(np.nanmax(err)))
+        yp = s.prox(s.shifted(s.shifted(h, xd), sd), qd, sigma).cpu().numpy()
+        _group_check(yp, ref_plain, q, x, sj, offs)
