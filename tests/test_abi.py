@@ -74,3 +74,14 @@ def test_shard_range_tiles(built):
             assert lo == prev and lo <= hi and (lo % align == 0 or lo == n)
             prev = hi
         assert prev == n
+
+
+def test_header_is_plain_c_and_cxx():
+    # the drop-in boundary is a C ABI: include/spx.h must compile as C99 and as C++11 on its own
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "spx.h")
+    if shutil.which("gcc"):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    if shutil.which("g++"):
+        subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
