@@ -142,6 +142,8 @@ def main():
         out["other_operators"] = _extra(s, L, ctx, dev, n, torch)
     if rank == 0 and not args.no_cpu:
         out["cpu_baseline"] = _cpu_baseline(s, psi, q, xk, sj, y, n, torch)
+        if not args.no_extra:
+            out["cpu_port_other_configs"] = _cpu_other_configs()
     barrier()
     if rank == 0:
         print(json.dumps(out))
@@ -292,6 +294,41 @@ def _cpu_baseline(s, psi, q, xk, sj, y, n, torch):
             "sample": "first %d elements of the same workload, best of %d runs (%.2f s each)" % (m, reps, best),
             "note": "reference (Julia) cannot run in this image; port = oracle/spx_oracle.c, gcc -O2 -ffp-contract=off",
             "gpu_bit_exact_on_sample": same}
+
+
+def _cpu_other_configs():
+    """The single-thread CPU port (oracle) on bounded samples of the other BASELINE configs, for the GPU/CPU picture of
+    each operator -- reported, never a target (the Julia reference itself cannot run here)."""
+    from oracle import oracle
+    import numpy as np
+    rng = np.random.default_rng(20250613)
+
+    def data(m):
+        return rng.normal(size=m), rng.uniform(-0.5, 0.5, size=m), rng.normal(size=m)
+
+    res = {}
+
+    def timed(name, m, fn):
+        dt = None
+        for _ in range(2):  # best of two: the first run also pays the page faults of the result vector
+            t0 = time.perf_counter()
+            fn()
+            d1 = time.perf_counter() - t0
+            dt = d1 if dt is None else min(dt, d1)
+        res[name] = {"gelem_s": round(m / dt / 1e9, 5), "sample_elements": m, "seconds": round(dt, 2), "cores": 1}
+
+    m = 20_000_000
+    x, sj, q = data(m)
+    timed("ShiftedNormL0Box", m, lambda: oracle.prox_l0_box(q, x, sj, 1.0, 1.0, -1.0, 1.0))
+    m = 5_000_000
+    x, sj, q = x[:m], sj[:m], q[:m]
+    timed("ShiftedRootNormLhalfBox", m, lambda: oracle.prox_lhalf_box(q, x, sj, 1.0, 1.0, -1.0, 1.0))
+    timed("ShiftedIndBallL0BInf_r=n/100", m, lambda: oracle.prox_indball_l0_binf(q, x, sj, m // 100, 1.0))
+    ng = 20_000
+    m = ng * 128
+    lam = rng.uniform(0.5, 1.5, size=ng)
+    timed("ShiftedGroupNormL2Binf_%dx128" % ng, m, lambda: oracle.prox_group_l2_binf(q[:m], x[:m], sj[:m], lam, 1.0, 1.0, gsize=128))
+    return res
 
 
 if __name__ == "__main__":
