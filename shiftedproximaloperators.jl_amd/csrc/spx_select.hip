@@ -74,6 +74,14 @@ constexpr int kWaveSlots = 64;
 struct WaveCount {
   unsigned int cand, above;
 };
+// One candidate: key, index and (single-pass form) the value y[index] gets if the entry makes the cut.  An array of
+// structs: the handful of entries a region holds then shares one or two cache lines, instead of one line in each of
+// three arrays, when the candidate kernels walk the regions.
+struct Cand {
+  uint64_t key;
+  int64_t idx;
+  double val;
+};
 
 constexpr int kSample = 65536;        // sample size (256 chunks of 256 consecutive elements)
 constexpr int kMainUnroll = 6;        // KiB per wave and vector in the main pass (as k_sep_lds)
@@ -512,8 +520,7 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
 // candidates, instead of 56 B/element with the separate final pass (k_sel_final_q, used when y aliases an input).
 template <bool BINF, bool WRITE>
 __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, const double* xk_, const double* sj_,
-                                                  int64_t n, SelWs* ws, uint64_t* cand_key, int64_t* cand_idx,
-                                                  double* cand_val, WaveCount* counts, double delta) {
+                                                  int64_t n, SelWs* ws, Cand* cand, WaveCount* counts, double delta) {
   const uint64_t t_hi = ws->fs.t_hi, t_lo = ws->fs.t_lo;
   // first digit of the selection among the candidates (set up by k_s2_pick): histogrammed right here, one
   // fire-and-forget global atomic per candidate (~0.5 % of the elements, spread over the band's bins)
@@ -552,9 +559,9 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
     if (m) {
       const unsigned int pos = ncand + (unsigned int)__popcll(m & lt_mask);
       if (in_band && pos < (unsigned)kWaveSlots) {
-        cand_key[rbase + pos] = key;
-        cand_idx[rbase + pos] = i;
-        if constexpr (WRITE) cand_val[rbase + pos] = kept;
+        cand[rbase + pos].key = key;
+        cand[rbase + pos].idx = i;
+        if constexpr (WRITE) cand[rbase + pos].val = kept;
       }
       if (in_band) {
         if (d_phase == 0) {
@@ -614,10 +621,9 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
 
 // Candidate kernels walk the regions TRANSPOSED: a wavefront takes 64 regions at a time, lane l owns region w0 + l and
 // steps through its few entries (4 loads in flight per lane), so the count words are read coalesced and no lane waits
-// on a chain of dependent loads.  f(position, key, index) is called for every valid entry.
+// on a chain of dependent loads.  f(key, index, value) is called for every valid entry.
 template <class F>
-__device__ __forceinline__ void for_each_candidate(const WaveCount* counts, int64_t nregions, const uint64_t* cand_key,
-                                                   const int64_t* cand_idx, F&& f) {
+__device__ __forceinline__ void for_each_candidate(const WaveCount* counts, int64_t nregions, const Cand* cand, F&& f) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -627,27 +633,26 @@ __device__ __forceinline__ void for_each_candidate(const WaveCount* counts, int6
     if (w < nregions) c = counts[w].cand;
     const int cnt = c < (unsigned)kWaveSlots ? (int)c : kWaveSlots;
     const int64_t e0 = w * kWaveSlots;
-    for (int s0 = 0; __any(s0 < cnt); s0 += 4) {
-      uint64_t k[4];
-      int64_t ix[4];
+    constexpr int U = 8;  // entries in flight per lane (a region holds ~4 on average)
+    for (int s0 = 0; __any(s0 < cnt); s0 += U) {
+      Cand c[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (s0 + u < cnt) { k[u] = cand_key[e0 + s0 + u]; ix[u] = cand_idx[e0 + s0 + u]; }
+      for (int u = 0; u < U; ++u)
+        if (s0 + u < cnt) c[u] = cand[e0 + s0 + u];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (s0 + u < cnt) f(e0 + s0 + u, k[u], ix[u]);
+      for (int u = 0; u < U; ++u)
+        if (s0 + u < cnt) f(c[u].key, c[u].idx, c[u].val);
     }
   }
 }
 
 // the kept band entries get their value (everything else was stored by k_s2_main<.., true>)
-__global__ __launch_bounds__(256) void k_s2_fixup(double* y, const uint64_t* cand_key, const int64_t* cand_idx,
-                                                   const double* cand_val, const SelWs* ws, const WaveCount* counts,
+__global__ __launch_bounds__(256) void k_s2_fixup(double* y, const Cand* cand, const SelWs* ws, const WaveCount* counts,
                                                    int64_t nregions) {
   if (!ws->fs.ok) return;
   const SelState st = ws->st;
-  for_each_candidate(counts, nregions, cand_key, cand_idx, [&](int64_t e, uint64_t key, int64_t i) {
-    if ((key >= st.t_ge) || (key == st.t_eq && i <= st.icut)) y[i] = cand_val[e];
+  for_each_candidate(counts, nregions, cand, [&](uint64_t key, int64_t i, double v) {
+    if ((key >= st.t_ge) || (key == st.t_eq && i <= st.icut)) y[i] = v;
   });
 }
 
@@ -692,13 +697,13 @@ __global__ __launch_bounds__(256) void k_s2_scan_verify(SelWs* ws, int64_t r) {
 }
 
 // after the first candidate digit: the candidates still in play (same decided prefix, or tied key) -> short list
-__global__ __launch_bounds__(256) void k_s2_compact(const uint64_t* cand_key, const int64_t* cand_idx, SelWs* ws,
+__global__ __launch_bounds__(256) void k_s2_compact(const Cand* cand, SelWs* ws,
                                                      uint64_t* list_key, int64_t* list_idx, const WaveCount* counts,
                                                      int64_t nregions) {
   const SelState st = ws->st;
   if (!ws->fs.ok || st.phase == 2) return;
   const int hs = st.shift + st.width;
-  for_each_candidate(counts, nregions, cand_key, cand_idx, [&](int64_t, uint64_t key, int64_t i) {
+  for_each_candidate(counts, nregions, cand, [&](uint64_t key, int64_t i, double) {
     const bool in = (st.phase == 0) ? ((hs >= 64 ? 0ull : (key >> hs)) == st.prefix)
                                     : (key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix);
     if (in) {
@@ -815,9 +820,7 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   const size_t off_samp = (sizeof(SelWs) + 255) & ~(size_t)255;
   const size_t off_cnt = off_samp + (size_t)kSample * sizeof(double);
   const size_t off_ckey = (off_cnt + (size_t)nregions * sizeof(WaveCount) + 255) & ~(size_t)255;
-  const size_t off_cidx = off_ckey + (size_t)ccap * sizeof(uint64_t);
-  const size_t off_cval = off_cidx + (size_t)ccap * sizeof(int64_t);
-  const size_t off_lkey = off_cval + (size_t)ccap * sizeof(double);
+  const size_t off_lkey = off_ckey + (size_t)ccap * sizeof(Cand);
   const size_t off_lidx = off_lkey + (size_t)kShortList * sizeof(uint64_t);
   rc = spx_ws_reserve(ctx, off_lidx + (size_t)kShortList * sizeof(int64_t) + 256);
   if (rc) return rc;
@@ -826,9 +829,7 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     char* wsb = reinterpret_cast<char*>(ctx->ws);
     double* samp = reinterpret_cast<double*>(wsb + off_samp);
     WaveCount* counts = reinterpret_cast<WaveCount*>(wsb + off_cnt);
-    uint64_t* ckey = reinterpret_cast<uint64_t*>(wsb + off_ckey);
-    int64_t* cidx = reinterpret_cast<int64_t*>(wsb + off_cidx);
-    double* cval = reinterpret_cast<double*>(wsb + off_cval);
+    Cand* cand = reinterpret_cast<Cand*>(wsb + off_ckey);
     // single-pass form when y overlaps none of the inputs (a failed prediction recomputes everything from them)
     auto disjoint = [&](const double* a) { return (y + n <= a) || (a + n <= y); };
     const bool write = g_sel_spec && disjoint(q) && disjoint(xk) && disjoint(sj);
@@ -839,20 +840,20 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     hipLaunchKernelGGL(k_s2_pick, dim3(1), dim3(1024), 0, ctx->stream, (const double*)samp, n, r, ws);
     const dim3 mgrid((unsigned)mblocks);
     if (write)
-      hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y, q, xk, sj, n, ws, ckey, cidx, cval,
-                         counts, delta);
+      hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y, q, xk, sj, n, ws, cand, counts,
+                         delta);
     else
-      hipLaunchKernelGGL((k_s2_main<BINF, false>), mgrid, dim3(256), 0, ctx->stream, y, q, xk, sj, n, ws, ckey, cidx,
-                         cval, counts, delta);
+      hipLaunchKernelGGL((k_s2_main<BINF, false>), mgrid, dim3(256), 0, ctx->stream, y, q, xk, sj, n, ws, cand, counts,
+                         delta);
     // the main pass has already histogrammed the first candidate digit: verdict + first scan step, survivors ->
     // short list, the rest of the selection in one workgroup
     hipLaunchKernelGGL(k_s2_scan_verify, dim3(1), dim3(256), 0, ctx->stream, ws, r);
-    hipLaunchKernelGGL(k_s2_compact, dim3(256), dim3(256), 0, ctx->stream, (const uint64_t*)ckey, (const int64_t*)cidx, ws,
-                       lkey, lidx, (const WaveCount*)counts, nregions);
+    hipLaunchKernelGGL(k_s2_compact, dim3(512), dim3(256), 0, ctx->stream, (const Cand*)cand, ws, lkey, lidx,
+                       (const WaveCount*)counts, nregions);
     hipLaunchKernelGGL(k_s2_finish, dim3(1), dim3(1024), 0, ctx->stream, ws, (const uint64_t*)lkey, (const int64_t*)lidx);
     if (write)
-      hipLaunchKernelGGL(k_s2_fixup, dim3(512), dim3(256), 0, ctx->stream, y, (const uint64_t*)ckey, (const int64_t*)cidx,
-                         (const double*)cval, (const SelWs*)ws, (const WaveCount*)counts, nregions);
+      hipLaunchKernelGGL(k_s2_fixup, dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, (const SelWs*)ws,
+                         (const WaveCount*)counts, nregions);
     else
       hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1535) / 1536)), dim3(256), 0, ctx->stream, y, q,
                          xk, sj, n, (const SelWs*)ws, delta);
