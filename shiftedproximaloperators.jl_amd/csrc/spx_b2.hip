@@ -41,13 +41,15 @@ __device__ __forceinline__ double b2_block_sum(double v, double* lds4) {
 // FIRST (the r = 1 pass) also returns F = sum of bound_i^2 with bound_i the end of [lo_i, hi_i] that z_i runs into as
 // eta -> inf: |ProjB(z)_i| <= |bound_i| for every eta >= 0, so chi_lambda sqrt(F) bounds the root from above.
 // VEC: 16-byte non-temporal loads, 4 pairs of each vector in flight per lane; else 8-byte loads (unaligned views).
+// ywrite != NULL (vector path, y disjoint from the inputs): the pass also stores y = ProjB(z) rinv - sj for ITS scale
+// (:63, :65) -- if the iteration then stops at this very eta the separate final pass is not needed.
 template <bool FIRST, bool VEC>
 __global__ __launch_bounds__(256) void k_b2_pass(const double* __restrict__ q, const double* __restrict__ xk,
                                                   const double* __restrict__ sj, int64_t n, double ls, double r,
-                                                  B2Ws* ws) {
+                                                  B2Ws* ws, double* ywrite, double rinv) {
   __shared__ double lds4[4];
   double p = 0.0, c = 0.0, f = 0.0;
-  auto visit = [&](double qi, double x, double s) {
+  auto visit = [&](double qi, double x, double s) -> double {
     const double sq = s + qi;
     const double lo = sq - ls, hi = sq + ls;
     const double z = (-x) * r;
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(256) void k_b2_pass(const double* __restrict__ q, c
       const double far = (x < 0.0) ? hi : (x > 0.0) ? lo : pz;  // -x > 0: z -> +inf -> hi
       f += far * far;
     }
+    return pz * rinv - s;
   };
   if constexpr (VEC) {
     const f64x2* q2 = reinterpret_cast<const f64x2*>(q);
@@ -77,12 +80,17 @@ __global__ __launch_bounds__(256) void k_b2_pass(const double* __restrict__ q, c
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (base + k * 256 < n2) {
-          visit(a[k].x, b[k].x, d[k].x);
-          visit(a[k].y, b[k].y, d[k].y);
+          f64x2 o;
+          o.x = visit(a[k].x, b[k].x, d[k].x);
+          o.y = visit(a[k].y, b[k].y, d[k].y);
+          if (ywrite) __builtin_nontemporal_store(o, reinterpret_cast<f64x2*>(ywrite) + base + k * 256);
         }
       }
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) visit(q[n - 1], xk[n - 1], sj[n - 1]);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+      const double o = visit(q[n - 1], xk[n - 1], sj[n - 1]);
+      if (ywrite) ywrite[n - 1] = o;
+    }
   } else {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) visit(q[i], xk[i], sj[i]);
@@ -151,14 +159,16 @@ __global__ __launch_bounds__(256) void k_b2_final(double* y, const double* q, co
 }
 
 int b2_sums(spx_ctx* ctx, const double* q, const double* xk, const double* sj, int64_t n, double ls, double r, B2Ws* ws,
-            int blocks, bool vec, bool first, double* P, double* C, double* F) {
+            int blocks, bool vec, bool first, double* P, double* C, double* F, double* ywrite = nullptr,
+            double rinv = 1.0) {
   const dim3 grid((unsigned)blocks), block(256);
+  double* yw = vec ? ywrite : nullptr;
   if (first) {
-    if (vec) hipLaunchKernelGGL((k_b2_pass<true, true>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws);
-    else hipLaunchKernelGGL((k_b2_pass<true, false>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws);
+    if (vec) hipLaunchKernelGGL((k_b2_pass<true, true>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws, yw, rinv);
+    else hipLaunchKernelGGL((k_b2_pass<true, false>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws, yw, rinv);
   } else {
-    if (vec) hipLaunchKernelGGL((k_b2_pass<false, true>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws);
-    else hipLaunchKernelGGL((k_b2_pass<false, false>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws);
+    if (vec) hipLaunchKernelGGL((k_b2_pass<false, true>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws, yw, rinv);
+    else hipLaunchKernelGGL((k_b2_pass<false, false>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws, yw, rinv);
   }
   hipLaunchKernelGGL(k_b2_reduce, dim3(1), dim3(256), 0, ctx->stream, ws, blocks, first ? 1 : 0);
   SPX_LAUNCH_CHECK();
@@ -275,6 +285,7 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   const double chiy = chi_lambda * std::sqrt(P + C);
   int scaled = 0;
   double eta = delta;
+  double y_eta = -1.0;  // eta for which a reduction pass has stored y (speculatively), or -1
   if (delta <= chiy) {  // :61
     scaled = 1;
     // froot(eta) = eta - chi_lambda sqrt((eta/Delta)^2 P + C); froot(Delta) <= 0 here.  Bracket lo: froot <= 0, hi: froot > 0.
@@ -290,6 +301,11 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
       rc = b2_sums(ctx, q, xk, sj, n, ls, eta / delta, ws, (int)blocks, vec, false, &P, &C, nullptr);
       if (rc) return rc;
     }
+    // y overlaps none of the inputs: a pass that is likely to be the last one (the step has become small) also stores y
+    // for its eta; the iteration always ends on an eta that a pass has evaluated, so if that pass stored y the final
+    // pass below is skipped (the call then costs the reduction passes only)
+    auto disjoint = [&](const double* a) { return (y + n <= a) || (a + n <= y); };
+    const bool can_spec = vec && disjoint(q) && disjoint(xk) && disjoint(sj);
     for (int it = 0; it < 200; ++it) {
       const double r = eta / delta;
       const double f = eta - chi_lambda * std::sqrt(r * r * P + C);
@@ -301,13 +317,16 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
       exact_step = (next > lo && next < hi);
       if (!exact_step) next = std::isinf(hi) ? 2.0 * lo : 0.5 * (lo + hi);
       if (!(next > lo && next < hi)) break;  // bracket exhausted
-      const bool small = std::fabs(next - eta) <= 4e-16 * next;
+      if (std::fabs(next - eta) <= 4e-16 * next) break;  // converged: eta (evaluated) and next agree to the last bits
+      const bool spec = can_spec && std::fabs(next - eta) <= 1e-3 * next;
       pP = P; pC = C; eta = next;
-      if (small) break;
-      rc = b2_sums(ctx, q, xk, sj, n, ls, eta / delta, ws, (int)blocks, vec, false, &P, &C, nullptr);
+      rc = b2_sums(ctx, q, xk, sj, n, ls, eta / delta, ws, (int)blocks, vec, false, &P, &C, nullptr, spec ? y : nullptr,
+                   delta / eta);
       if (rc) return rc;
+      y_eta = spec ? eta : -1.0;
     }
   }
+  if (scaled && y_eta == eta) return SPX_OK;  // y already holds ProjB((-xk) eta/Delta) Delta/eta - sj
   if (vec) {
     const int64_t fblocks = ((n >> 1) + 1023) / 1024;
     hipLaunchKernelGGL((k_b2_final<true>), dim3((unsigned)(fblocks < 1 ? 1 : fblocks)), dim3(256), 0, ctx->stream, y, q,
