@@ -224,6 +224,17 @@ def _extra(s, L, ctx, dev, n, torch):
                                          "gbs_algorithmic": round(24 * n / ms / 1e6, 1),
                                          "frac_of_peak": round(24 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
                                          "note": "host wall time per call incl. the read-back of the value"}
+    # prox! fused with h at the result (one pass instead of prox! + psi(y)); host wall time, the value is read back
+    s.prox_value_bang(y, psi_l1b, q, 1.0)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        s.prox_value_bang(y, psi_l1b, q, 1.0)
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    res["prox_value_ShiftedNormL1Box"] = {"ms": round(ms, 4), "gelem_s": round(n / ms / 1e6, 2),
+                                          "gbs_algorithmic": round(32 * n / ms / 1e6, 1),
+                                          "frac_of_peak": round(32 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                          "note": "prox! and h(xk + sj + y) in one pass (separately: the two lines above); "
+                                                  "host wall time incl. the read-back of the value"}
     iline("iprox_ShiftedNormL1Box", s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj))
     iline("iprox_ShiftedNormL0Box", s.shifted(s.shifted(s.NormL0(1.0), xk, 1.0, chi), sj))
     del d

@@ -154,6 +154,25 @@ function prox!(y::DVec, ψ::ShiftedIndBallL0BInf{<:Integer, Float64, <:DVec, <:D
 end
 
 # ---------------------------------------------------------------------------------------------
+# prox! fused with h at the result (no counterpart in the reference; what R2 does in two steps:
+# `prox!(s, ψ, mν∇fk, ν)` then `hkn = ψ(s)`): one pass over the vectors instead of two.  Headline operator shown;
+# spx_proxval_l1 / l0 / lhalf / l0_box / lhalf_box follow the same pattern.
+# ---------------------------------------------------------------------------------------------
+function prox_value!(y::DVec, ψ::ShiftedNormL1Box{Float64, <:DVec, <:DVec, <:DVec}, q::DVec, σ::Float64)
+  n = length(ψ.xk)
+  (length(y) == n && length(q) == n) || throw(BoundsError())
+  m = mask_for(ψ)
+  out = Ref{Cdouble}(0.0)
+  check(ccall((:spx_proxval_l1_box, libspx), Cint,
+              (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cdouble,
+               Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{UInt8}, Ptr{Cdouble}),
+              ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, ψ.λ, σ,
+              dptr(vec_or_nothing(ψ.l)), dptr(vec_or_nothing(ψ.u)), scal(ψ.l), scal(ψ.u),
+              m === nothing ? Ptr{UInt8}(C_NULL) : Ptr{UInt8}(UInt(pointer(m))), out))
+  return y, out[]
+end
+
+# ---------------------------------------------------------------------------------------------
 # l1 norm + l2-ball trust region      src/shiftedNormL1B2.jl:50-67   (χ = NormL2(χ.lambda))
 # ---------------------------------------------------------------------------------------------
 function prox!(y::DVec, ψ::ShiftedProximalOperators.ShiftedNormL1B2{Float64, <:DVec, <:DVec, <:DVec}, q::DVec, σ::Float64)

@@ -23,7 +23,8 @@ struct OpL1 {  // src/shiftedNormL1.jl:46-51
   double ls;   // lambda * sigma
   static constexpr bool kBox = false;
   static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
-  static constexpr int kNIn = 3;     // input vectors besides bounds: q, xk, sj
+  static constexpr int kNIn = 3;
+  static constexpr bool kObj = false;     // input vectors besides bounds: q, xk, sj
   __device__ __forceinline__ double operator()(double q, double x, double s, double, double, bool) const {
     double t = (-x) - s;                          // :47  @. y = -xk - sj
     return jl_min(jl_max(t, q - ls), q + ls);     // :50
@@ -32,7 +33,8 @@ struct OpL1 {  // src/shiftedNormL1.jl:46-51
 struct OpL1Aliased {  // y === q in the reference: the broadcast at :47 overwrites q before :50 reads it
   static constexpr bool kBox = false;
   static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
-  static constexpr int kNIn = 3;     // input vectors besides bounds: q, xk, sj
+  static constexpr int kNIn = 3;
+  static constexpr bool kObj = false;     // input vectors besides bounds: q, xk, sj
   __device__ __forceinline__ double operator()(double, double x, double s, double, double, bool) const {
     return (-x) - s;  // min(max(t, t - ls), t + ls) == t bit for bit whenever ls >= 0
   }
@@ -41,7 +43,8 @@ struct OpL0 {  // src/shiftedNormL0.jl:45-52
   double c;    // sqrt(2 * lambda * sigma)
   static constexpr bool kBox = false;
   static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
-  static constexpr int kNIn = 3;     // input vectors besides bounds: q, xk, sj
+  static constexpr int kNIn = 3;
+  static constexpr bool kObj = false;     // input vectors besides bounds: q, xk, sj
   __device__ __forceinline__ double operator()(double q, double x, double s, double, double, bool) const {
     double xps = x + s;
     return (fabs(xps + q) <= c) ? -xps : q;
@@ -51,7 +54,8 @@ struct OpL1Box {  // src/shiftedNormL1Box.jl:96-122
   double sl;      // sigma * lambda
   static constexpr bool kBox = true;
   static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
-  static constexpr int kNIn = 3;     // input vectors besides bounds: q, xk, sj
+  static constexpr int kNIn = 3;
+  static constexpr bool kObj = false;     // input vectors besides bounds: q, xk, sj
   __device__ __forceinline__ double operator()(double q, double x, double s, double l, double u, bool sel) const {
     double xs = x + s;
     double xsq = xs + q;
@@ -64,7 +68,8 @@ struct OpL0Box {  // src/shiftedNormL0Box.jl:96-128
   double c;       // 2 * lambda * sigma
   static constexpr bool kBox = true;
   static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
-  static constexpr int kNIn = 3;     // input vectors besides bounds: q, xk, sj
+  static constexpr int kNIn = 3;
+  static constexpr bool kObj = false;     // input vectors besides bounds: q, xk, sj
   __device__ __forceinline__ double operator()(double q, double x, double s, double l, double u, bool sel) const {
     double sq = s + q;
     double xs = x + s;
@@ -155,7 +160,8 @@ struct OpLhalf {  // src/shiftedRootNormLhalf.jl:47-60
   double p;       // 54^(1/3) * (2 sigma lambda)^(2/3) / 4
   static constexpr bool kBox = false;
   static constexpr int kLdsKiB = 6;  // KiB per wave and input vector in the LDS-staged skeleton
-  static constexpr int kNIn = 3;     // input vectors besides bounds: q, xk, sj
+  static constexpr int kNIn = 3;
+  static constexpr bool kObj = false;     // input vectors besides bounds: q, xk, sj
   __device__ __forceinline__ double operator()(double q, double x, double s, double, double, bool) const {
     double xs = x + s;
     double sol = q + xs;  // :50
@@ -174,6 +180,7 @@ struct OpLhalfBox {  // src/shiftedRootNormLhalfBox.jl:92-117
   static constexpr bool kBox = true;
   static constexpr int kLdsKiB = 0;  // 0: register-staged skeleton (VALU-heavy: needs the occupancy; 5.97 vs 5.68 TB/s)
   static constexpr int kNIn = 3;
+  static constexpr bool kObj = false;
   // RNorm(tt) = (tt - q)^2 / 2 / sigma + lambda sqrt|tt + xs|   (:95); used only to pick the argmin
   __device__ __forceinline__ double rnorm(double tt, double q, double xs) const {
     double d = tt - q;
@@ -238,6 +245,7 @@ struct OpIproxL1 {  // src/shiftedNormL1.jl:60-75
   static constexpr bool kBox = false;
   static constexpr int kLdsKiB = 4;
   static constexpr int kNIn = 4;
+  static constexpr bool kObj = false;
   __device__ __forceinline__ double call4(double g, double d, double x, double s, double, double, bool) const {
     if (!(d > 0.0)) atomicOr(flag, 1);
     const double t = (-x) - s;                                                       // :67
@@ -250,6 +258,7 @@ struct OpIproxL0 {  // src/shiftedNormL0.jl:61-80
   static constexpr bool kBox = false;
   static constexpr int kLdsKiB = 4;
   static constexpr int kNIn = 4;
+  static constexpr bool kObj = false;
   __device__ __forceinline__ double call4(double g, double d, double x, double s, double, double, bool) const {
     if (!(d > 0.0)) atomicOr(flag, 1);
     const double ci = sqrt(2 * lambda * d);                                          // :71
@@ -262,6 +271,7 @@ struct OpIproxL1Box {  // src/shiftedNormL1Box.jl:131-225
   static constexpr bool kBox = true;
   static constexpr int kLdsKiB = 0;  // register-staged: five fp64 divisions per element want the occupancy (6.10 vs 5.70 TB/s)
   static constexpr int kNIn = 4;
+  static constexpr bool kObj = false;
   __device__ __forceinline__ double call4(double g, double d, double x, double s, double l, double u, bool sel) const {
     const double eps = 2.220446049250313e-16;
     const double xs = x + s;
@@ -316,6 +326,7 @@ struct OpIproxL0Box {  // src/shiftedNormL0Box.jl:137-231
   static constexpr bool kBox = true;
   static constexpr int kLdsKiB = 4;
   static constexpr int kNIn = 4;
+  static constexpr bool kObj = false;
   __device__ __forceinline__ double call4(double g, double d, double x, double s, double l, double u, bool sel) const {
     const double eps = 2.220446049250313e-16;
     const double xs = x + s;
@@ -363,6 +374,44 @@ struct OpIproxL0Box {  // src/shiftedNormL0Box.jl:137-231
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// prox! fused with the value of h at the result ("fused with prox where possible"): the kernels
+// below add Term((xk + sj) + y) over the selected indices into one partial per wavefront / workgroup
+// (src/ShiftedProximalOperators.jl:51-54 for the association), a second small kernel adds the partials in index order.
+// ---------------------------------------------------------------------------------------------
+struct HTermL1 { __device__ __forceinline__ double operator()(double v) const { return fabs(v); } };               // NormL1 [ext]
+struct HTermL0 { __device__ __forceinline__ double operator()(double v) const { return (v != 0.0) ? 1.0 : 0.0; } };  // NormL0 [ext]
+struct HTermLhalf { __device__ __forceinline__ double operator()(double v) const { return sqrt(fabs(v)); } };      // src/rootNormLhalf.jl:27-29
+template <class Base, class Term>
+struct WithValue : Base {
+  static constexpr bool kObj = true;
+  double* partials;  // one slot per wavefront (LDS skeleton) / workgroup (register skeleton, scalar kernel)
+  __device__ __forceinline__ double hterm(double x, double s, double y, bool sel) const {
+    return sel ? Term{}((x + s) + y) : 0.0;
+  }
+};
+__device__ __forceinline__ double block_sum4(double v, double* lds4) {  // 256-lane workgroup
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+// partials[0..count) -> *out, fixed order: reproducible run to run
+__global__ __launch_bounds__(1024) void k_value_reduce(const double* partials, int64_t count, double* out) {
+  __shared__ double lds[16];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < count; i += 1024) acc += partials[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += lds[w];
+    *out = t;
+  }
+}
+
 // uniform call: 3-input operators ignore d
 template <class Op>
 __device__ __forceinline__ double apply_op(const Op& op, double q, double d, double x, double s, double l, double u,
@@ -400,6 +449,7 @@ __global__ __launch_bounds__(256) void k_sep_vec(double* y_, const double* q_, c
   const f64x2* uv = reinterpret_cast<const f64x2*>(u_);
   const uint16_t* mk = reinterpret_cast<const uint16_t*>(mask_);
   const int64_t ntiles = (n2 + TILE - 1) / TILE;
+  double hacc = 0.0;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t base = tile * TILE + threadIdx.x;
     f64x2 vq[UNROLL], vx[UNROLL], vs[UNROLL], vl[UNROLL], vu[UNROLL], vd[UNROLL];
@@ -428,6 +478,7 @@ __global__ __launch_bounds__(256) void k_sep_vec(double* y_, const double* q_, c
         f64x2 r;
         r.x = apply_op(op, vq[k].x, vd[k].x, vx[k].x, vs[k].x, l0, u0, s0);
         r.y = apply_op(op, vq[k].y, vd[k].y, vx[k].y, vs[k].y, l1, u1, s1);
+        if constexpr (Op::kObj) hacc += op.hterm(vx[k].x, vs[k].x, r.x, s0) + op.hterm(vx[k].y, vs[k].y, r.y, s1);
         st2<NT>(y + i, r);
       }
     } else {  // last, partial tile
@@ -448,10 +499,16 @@ __global__ __launch_bounds__(256) void k_sep_vec(double* y_, const double* q_, c
           f64x2 r;
           r.x = apply_op(op, a.x, dd.x, b.x, c.x, l0, u0, s0);
           r.y = apply_op(op, a.y, dd.y, b.y, c.y, l1, u1, s1);
+          if constexpr (Op::kObj) hacc += op.hterm(b.x, c.x, r.x, s0) + op.hterm(b.y, c.y, r.y, s1);
           y[i] = r;
         }
       }
     }
+  }
+  if constexpr (Op::kObj) {
+    __shared__ double lds4[4];
+    const double t = block_sum4(hacc, lds4);
+    if (threadIdx.x == 0) op.partials[blockIdx.x] = t;
   }
 }
 
@@ -498,6 +555,7 @@ __global__ __launch_bounds__(256) void k_sep_lds(double* y_, const double* q_, c
     if (bid * (256 * UNROLL) >= n2) return;
   }
   const int64_t base = (bid * 4 + wave) * (64 * UNROLL) + lane;  // this lane's first pair
+  double hacc = 0.0;
   uint16_t vm[UNROLL];
 #pragma unroll
   for (int k = 0; k < UNROLL; ++k) {
@@ -532,7 +590,14 @@ __global__ __launch_bounds__(256) void k_sep_lds(double* y_, const double* q_, c
     f64x2 r;
     r.x = apply_op(op, a.x, dd.x, b.x, c.x, l0, u0, s0);
     r.y = apply_op(op, a.y, dd.y, b.y, c.y, l1, u1, s1);
+    if constexpr (Op::kObj) {
+      if (i < n2) hacc += op.hterm(b.x, c.x, r.x, s0) + op.hterm(b.y, c.y, r.y, s1);
+    }
     if (i < n2) __builtin_nontemporal_store(r, y + i);
+  }
+  if constexpr (Op::kObj) {
+    const double t = wave_sum(hacc);
+    if (lane == 0) op.partials[bid * 4 + wave] = t;  // every wave of the grid writes its slot (0 for an idle tail wave)
   }
 }
 
@@ -544,13 +609,22 @@ __global__ __launch_bounds__(256) void k_sep_scalar(double* y, const double* q, 
                                                      int64_t n, Op op) {
   int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double hacc = 0.0;
   for (; i < n; i += stride) {
     double li = l_ ? l_[i] : ls;
     double ui = u_ ? u_[i] : us;
     bool sel = mask ? (mask[i] != 0) : true;
     double di = 0.0;
     if constexpr (Op::kNIn == 4) di = d_[i];
-    y[i] = apply_op(op, q[i], di, xk[i], sj[i], li, ui, sel);
+    const double xi = xk[i], si = sj[i];
+    const double yi = apply_op(op, q[i], di, xi, si, li, ui, sel);
+    if constexpr (Op::kObj) hacc += op.hterm(xi, si, yi, sel);
+    y[i] = yi;
+  }
+  if constexpr (Op::kObj) {
+    __shared__ double lds4[4];
+    const double t = block_sum4(hacc, lds4);
+    if (threadIdx.x == 0) op.partials[blockIdx.x] = t;
   }
 }
 
@@ -566,11 +640,13 @@ static int g_sep_xcd = 0;  // 1 = XCD-contiguous tile ranges (experiment, see k_
 
 template <class Op, bool VECB, bool MASK>
 static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d, const double* xk, const double* sj,
-                      const double* l, const double* u, const uint8_t* mask, double ls, double us, int64_t n2, Op op) {
+                      const double* l, const double* u, const uint8_t* mask, double ls, double us, int64_t n2, Op op,
+                      int64_t* value_slots /* out: partial slots written (Op::kObj) */) {
   if constexpr (Op::kLdsKiB > 0) if (g_sep_lds) {
     // 3 input vectors: 6 KiB per wave and vector -> 72 KiB per workgroup; 5 vectors (vector bounds): 3 KiB -> 60 KiB
     constexpr int U = (VECB && Op::kBox) ? (Op::kLdsKiB > 3 ? 3 : Op::kLdsKiB) : Op::kLdsKiB;  // <= 72 KiB per workgroup
     int64_t blocks = (n2 + 256 * U - 1) / (256 * U);
+    *value_slots = blocks * 4;  // one per wavefront
     int64_t xcd_chunk = 0;
     if (g_sep_xcd) {
       xcd_chunk = (blocks + 7) / 8;
@@ -586,6 +662,7 @@ static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d,
   int64_t blocks = ntiles;
   const int64_t cap = g_sep_blocks_per_cu > 0 ? (int64_t)ctx->num_cu * g_sep_blocks_per_cu : (int64_t)0x7fffffff;
   if (blocks > cap) blocks = cap;
+  *value_slots = blocks;  // one per workgroup
   if (g_sep_nt)
     hipLaunchKernelGGL((k_sep_vec<Op, UNROLL, VECB, MASK, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y,
                        q, d, xk, sj, l, u, mask, ls, us, n2, op);
@@ -599,9 +676,18 @@ static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d,
 template <class Op>
 static int run_separable(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
                          const double* l, const double* u, double ls, double us, const uint8_t* mask, Op op,
-                         const double* d = nullptr) {
+                         const double* d = nullptr, double* value = nullptr /* Op::kObj: sum of the h terms */) {
+  if constexpr (Op::kObj) *value = 0.0;
   if (n == 0) return SPX_OK;
   SPX_HIP(hipSetDevice(ctx->device));
+  double* partials = nullptr;  // ws: [result | pad to 256 B | partial slots]
+  int64_t used = 0;
+  if constexpr (Op::kObj) {
+    const int64_t maxslots = ((n / 2) / (256 * 3) + 2) * 4 + (int64_t)ctx->num_cu * 8 + 16;
+    int rcw = spx_ws_reserve(ctx, 256 + (size_t)maxslots * sizeof(double));
+    if (rcw) return rcw;
+    partials = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + 256);
+  }
   bool vec_ok = spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj) && (!d || spx_aligned16(d)) &&
                 (!l || spx_aligned16(l)) && (!u || spx_aligned16(u)) &&
                 (!mask || (reinterpret_cast<uintptr_t>(mask) & 1u) == 0);
@@ -609,17 +695,20 @@ static int run_separable(spx_ctx* ctx, double* y, const double* q, const double*
   if (vec_ok && n >= 2) {
     const int64_t n2 = n / 2;
     int rc;
+    int64_t slots = 0;
+    if constexpr (Op::kObj) op.partials = partials;
     if constexpr (Op::kBox) {
       const bool vecb = (l || u);
       const bool msk = (mask != nullptr);
-      if (vecb && msk) rc = launch_vec<Op, true, true>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op);
-      else if (vecb) rc = launch_vec<Op, true, false>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op);
-      else if (msk) rc = launch_vec<Op, false, true>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op);
-      else rc = launch_vec<Op, false, false>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op);
+      if (vecb && msk) rc = launch_vec<Op, true, true>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op, &slots);
+      else if (vecb) rc = launch_vec<Op, true, false>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op, &slots);
+      else if (msk) rc = launch_vec<Op, false, true>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op, &slots);
+      else rc = launch_vec<Op, false, false>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op, &slots);
     } else {
-      rc = launch_vec<Op, false, false>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op);
+      rc = launch_vec<Op, false, false>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op, &slots);
     }
     if (rc) return rc;
+    used += slots;
     done = 2 * n2;
   }
   if (done < n) {
@@ -627,9 +716,18 @@ static int run_separable(spx_ctx* ctx, double* y, const double* q, const double*
     int64_t blocks = (rem + 255) / 256;
     const int64_t cap = (int64_t)ctx->num_cu * 8;
     if (blocks > cap) blocks = cap;
+    if constexpr (Op::kObj) op.partials = partials + used;
     hipLaunchKernelGGL((k_sep_scalar<Op>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, d, xk, sj, l, u,
                        mask, ls, us, done, n, op);
     SPX_LAUNCH_CHECK();
+    used += blocks;
+  }
+  if constexpr (Op::kObj) {
+    double* result = reinterpret_cast<double*>(ctx->ws);
+    hipLaunchKernelGGL(k_value_reduce, dim3(1), dim3(1024), 0, ctx->stream, (const double*)partials, used, result);
+    SPX_LAUNCH_CHECK();
+    SPX_HIP(hipMemcpyAsync(value, result, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SPX_HIP(hipStreamSynchronize(ctx->stream));
   }
   return SPX_OK;
 }
@@ -698,6 +796,62 @@ SPX_EXPORT int spx_prox_lhalf_box(spx_ctx* ctx, double* y, const double* q, cons
   if (rc) return rc;
   return run_separable(ctx, y, q, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask,
                        OpLhalfBox{sigma * lambda / 4, lambda, 0.5 / sigma});
+}
+
+// ---------------------------------------------------------------------------------------------
+// prox! + value of h at the result, in one pass (synchronous: *value is written on the host)
+// ---------------------------------------------------------------------------------------------
+template <class Base, class Term>
+static int run_proxval(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                       const double* l, const double* u, double ls, double us, const uint8_t* mask, Base base,
+                       double lambda, double* value) {
+  int rc = spx_check_common(ctx, y, q, xk, sj, n);
+  if (rc) return rc;
+  SPX_REQUIRE(value != nullptr, "value is NULL");
+  WithValue<Base, Term> op{base, nullptr};
+  double sum = 0.0;
+  rc = run_separable(ctx, y, q, xk, sj, n, l, u, ls, us, mask, op, nullptr, &sum);
+  *value = lambda * sum;
+  return rc;
+}
+
+SPX_EXPORT int spx_proxval_l1(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                              double lambda, double sigma, double* value) {
+  if (y == q && lambda * sigma >= 0.0)  // the reference's two-pass body with y === q (see OpL1Aliased)
+    return run_proxval<OpL1Aliased, HTermL1>(ctx, y, q, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, OpL1Aliased{},
+                                             lambda, value);
+  return run_proxval<OpL1, HTermL1>(ctx, y, q, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, OpL1{lambda * sigma},
+                                    lambda, value);
+}
+SPX_EXPORT int spx_proxval_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                              double lambda, double sigma, double* value) {
+  return run_proxval<OpL0, HTermL0>(ctx, y, q, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr,
+                                    OpL0{std::sqrt(2 * lambda * sigma)}, lambda, value);
+}
+SPX_EXPORT int spx_proxval_lhalf(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                 double lambda, double sigma, double* value) {
+  const double nl = sigma * lambda;
+  const double p = std::pow(54.0, 1.0 / 3.0) * std::pow(2 * nl, 2.0 / 3.0) / 4;
+  return run_proxval<OpLhalf, HTermLhalf>(ctx, y, q, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, OpLhalf{nl / 4, p},
+                                          lambda, value);
+}
+SPX_EXPORT int spx_proxval_l1_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                  double lambda, double sigma, const double* l_vec, const double* u_vec,
+                                  double l_scalar, double u_scalar, const uint8_t* sel_mask, double* value) {
+  return run_proxval<OpL1Box, HTermL1>(ctx, y, q, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask,
+                                       OpL1Box{sigma * lambda}, lambda, value);
+}
+SPX_EXPORT int spx_proxval_l0_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                  double lambda, double sigma, const double* l_vec, const double* u_vec,
+                                  double l_scalar, double u_scalar, const uint8_t* sel_mask, double* value) {
+  return run_proxval<OpL0Box, HTermL0>(ctx, y, q, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask,
+                                       OpL0Box{2 * lambda * sigma}, lambda, value);
+}
+SPX_EXPORT int spx_proxval_lhalf_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
+                                     int64_t n, double lambda, double sigma, const double* l_vec, const double* u_vec,
+                                     double l_scalar, double u_scalar, const uint8_t* sel_mask, double* value) {
+  return run_proxval<OpLhalfBox, HTermLhalf>(ctx, y, q, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask,
+                                             OpLhalfBox{sigma * lambda / 4, lambda, 0.5 / sigma}, lambda, value);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -563,6 +563,35 @@ def prox(ψ, q, σ):
     return prox_bang(ψ.sol, ψ, q, σ)
 
 
+def prox_value_bang(y, ψ, q, σ):
+    """prox!(y, ψ, q, σ) and h(xk + sj + y) of the result in ONE pass over the vectors (the pair a solver iteration makes:
+    R2's `prox!(s, ψ, …)` followed by `ψ(s)`): returns (y, value).  Device vectors, the separable operators
+    (ShiftedNormL1 / NormL0 / RootNormLhalf and their Box forms); synchronises to return the value.  The Box forms
+    return the h part of ψ(y): the prox lies inside the box by construction."""
+    if not isinstance(ψ, (_Unboxed, _Boxed)) or ψ.host:
+        raise TypeError("prox_value is available for the separable operators on device vectors")
+    n = _n(ψ.xk)
+    _vec(q, "q", n, like=ψ.xk)
+    _vec(y, "y", n, like=ψ.xk)
+    L, ctx = _lib.load(), _ctx(_dev(y))
+    out = ctypes.c_double(0.0)
+    fn = getattr(L, ψ._fn.replace("spx_prox_", "spx_proxval_"))
+    if isinstance(ψ, _Boxed):
+        lv = None if _is_real(ψ.l) else _vec(ψ.l, "l", n, like=y)
+        uv = None if _is_real(ψ.u) else _vec(ψ.u, "u", n, like=y)
+        _lib.check(fn(ctx, _ptr(y), _ptr(q), _ptr(ψ.xk), _ptr(ψ.sj), n, ψ.h.lam, float(σ), _ptr(lv), _ptr(uv),
+                      float(ψ.l) if lv is None else 0.0, float(ψ.u) if uv is None else 0.0,
+                      _ptr(ψ._mask[0]) if ψ._mask is not None else ctypes.c_void_p(0), ctypes.byref(out)))
+    else:
+        _lib.check(fn(ctx, _ptr(y), _ptr(q), _ptr(ψ.xk), _ptr(ψ.sj), n, ψ.h.lam, float(σ), ctypes.byref(out)))
+    return y, out.value
+
+
+def prox_value(ψ, q, σ):
+    """(prox(ψ, q, σ), h(xk + sj + prox)) in one pass; see prox_value_bang"""
+    return prox_value_bang(ψ.sol, ψ, q, σ)
+
+
 def iprox_bang(y, ψ, g, d, check=True):
     """iprox!(y, ψ, g, d): y <- argmin_t ½ tᵀDt + gᵀt + ψ(t), D = diag(d); returns y.  Defined for ShiftedNormL1/L0 and
     their Box forms (as in the reference).  The unboxed forms assert d .> 0 like the reference (`check=True`

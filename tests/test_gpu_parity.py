@@ -834,3 +834,43 @@ def test_group_parameter_edges(s, orc, gs):
         assert np.array_equal(np.isnan(y), np.isnan(ref)) and float(np.nanmax(err)) <= tol, (sigma, delta, float(np.nanmax(err)))
         yp = s.prox(s.shifted(s.shifted(h, xd), sd), qd, sigma).cpu().numpy()
         _group_check(yp, ref_plain, q, x, sj, offs)
+
+
+# ------------------------------------------------------------------ prox! fused with the value of h
+@pytest.mark.parametrize("n", [1, 2, 3, 1000, 1_000_003])
+def test_prox_value_fused(s, orc, n):
+    """spx_proxval_*: y must be bit-identical to the plain prox!, the value equal to psi(y) of that y (<= 1e-12; the
+    NormL0 count exactly), for scalar / vector bounds, a selection mask, aligned and 8-byte-aligned vectors."""
+    import torch
+    x, sj, q = _data(n, 8100 + n)
+    rng = np.random.default_rng(n)
+    lo, up = -1.0 - 0.1 * rng.random(n), 1.0 + 0.1 * rng.random(n)
+    selected = sorted(rng.choice(n, size=max(1, n // 3), replace=False).tolist())
+    for misaligned in (False, True):
+        if misaligned:
+            xd, sd, qd, ld, ud = (torch.cat([torch.zeros(1, dtype=torch.float64), torch.from_numpy(a)]).cuda()[1:]
+                                  for a in (x, sj, q, lo, up))
+        else:
+            xd, sd, qd, ld, ud = _dev(x, sj, q, lo, up)
+        cases = []
+        for H, kind in ((s.NormL1, "l1"), (s.NormL0, "l0"), (s.RootNormLhalf, "lhalf")):
+            cases.append((s.shifted(s.shifted(H(0.7), xd), sd), kind))
+            cases.append((s.shifted(s.shifted(H(0.7), xd, 0.9, s.NormLinf(1.0)), sd), kind))
+            cases.append((s.shifted(s.shifted(H(0.7), xd, ld, ud, selected), sd), kind))
+        for psi, kind in cases:
+            y_plain = s.prox(psi, qd, 1.1).clone()
+            y, val = s.prox_value(psi, qd, 1.1)
+            assert torch.equal(y, y_plain), (type(psi).__name__, misaligned)
+            exp = psi(y_plain)
+            assert np.isfinite(exp)
+            if kind == "l0":
+                assert val == exp
+            else:
+                assert abs(val - exp) <= 1e-12 * max(abs(exp), 1e-300), (type(psi).__name__, val, exp)
+    # y === q (ShiftedNormL1: the reference's two-pass quirk) through the fused form too
+    xd, sd, qd = _dev(x, sj, q)
+    psi = s.shifted(s.shifted(s.NormL1(0.7), xd), sd)
+    q1, q2 = qd.clone(), qd.clone()
+    s.prox_bang(q1, psi, q1, 1.1)
+    _, val = s.prox_value_bang(q2, psi, q2, 1.1)
+    assert torch.equal(q1, q2) and abs(val - psi(q1)) <= 1e-12 * max(abs(val), 1e-300)
