@@ -133,13 +133,14 @@ __device__ __forceinline__ double sqrt_f64(double v) {
   return (v > 0.0) ? s : 0.0;
 }
 // a = sl4 * (az/3)^(-3/2) and t = az/3
-__device__ __forceinline__ double lhalf_a(double az, double sl4, double& t) {
+__device__ __forceinline__ double lhalf_a(double az, double sl4, double& t, double* r_out = nullptr) {
   t = az * 0.33333333333333331;
   const double r = rsqrt_f64(t);
+  if (r_out) *r_out = r;
   return sl4 * (r * r * r);
 }
 // sign(z) * 4 t w^2 for a in [0, 1]
-__device__ __forceinline__ double lhalf_val_from_a(double z, double t, double a) {
+__device__ __forceinline__ double lhalf_val_from_a(double z, double t, double a, double* w_out = nullptr) {
   const double m = fmax(1.0 - a, 0.0);
   const double e = (double)__builtin_amdgcn_sqrtf((float)m);
   double d = e * __builtin_fma(e, __builtin_fma(e, __builtin_fma(e, -0.003676457097091405, 0.016543212998449176),
@@ -152,6 +153,7 @@ __device__ __forceinline__ double lhalf_val_from_a(double z, double t, double a)
     d = __builtin_fma(-g, inv, d);
   }
   const double w = 0.5 + d;
+  if (w_out) *w_out = w;
   const double v = 4.0 * t * (w * w);
   return (z < 0.0) ? -v : v;
 }
@@ -210,13 +212,21 @@ struct OpLhalfBox {  // src/shiftedRootNormLhalfBox.jl:92-117
     // then V-shaped around v = 0 so that candidate can never be strictly smaller than the first three
     //  and is skipped here.  a is Inf/NaN for xsq == 0 -> skipped too, as in the
     // reference (`li <= NaN <= ui` is false).
-    double t;
-    double a = lhalf_a(axsq, sl4, t);
+    double t, r, w;
+    double a = lhalf_a(axsq, sl4, t, &r);
     if (a <= 1.0) {
-      double val = lhalf_val_from_a(xsq, t, a);
+      double val = lhalf_val_from_a(xsq, t, a, &w);
       double vx = val - x;
       double t4 = val - xs;
+#ifdef SPX_LHALFBOX_SQRT_T4
       double c4 = rnorm(t4, q, xs);
+#else
+      // RNorm(t4) = (t4 - q)^2 / 2 sigma + lambda sqrt|t4 + xs| with |t4 + xs| = |val| = 4 t w^2 up to rounding:
+      // sqrt|val| = 2 sqrt(t) w = 2 (t r) w from the reciprocal square root already at hand -- one square root less.
+      // (The value only ranks the candidates; the other three keep the faithfully rounded square root.)
+      const double d4 = t4 - q;
+      double c4 = __builtin_fma(lambda, 2.0 * (t * r) * w, d4 * d4 * h2);
+#endif
       if (l <= vx && vx <= u && c4 < best) { best = c4; yi = t4; }
     }
     // NaN in q, xk or sj: every candidate value is NaN and findmin returns the first one (:114, `findmin` treats NaN as
