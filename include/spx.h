@@ -209,7 +209,10 @@ int spx_obj_l1_b2(spx_ctx* ctx, const double* y, const double* xk, const double*
 /* ---- group operators -------------------------------------------------------------------- */
 /* Groups are contiguous index ranges (the reference's `idx` entries as UnitRanges / [:]):
  *   group_offsets != NULL : CSR offsets (device, int64, length ngroups+1, 0-based, non-decreasing,
- *                           offsets[0] >= 0, offsets[ngroups] <= n); group g = [off[g], off[g+1])
+ *                           offsets[0] >= 0, offsets[ngroups] <= n); group g = [off[g], off[g+1]).
+ *                           group_size is then a HINT: 0 = unknown, > 0 = an upper bound on the group sizes; a bound
+ *                           <= 512 selects the register-tile kernels (a group that exceeds it is still computed
+ *                           correctly, by the general kernel).
  *   group_offsets == NULL : uniform groups of group_size, ngroups * group_size == n.
  * lambda_vec: device, length ngroups (GroupNormL2.lambda, src/groupNormL2.jl:15-28). */
 /* ShiftedGroupNormL2.prox!     src/shiftedGroupNormL2.jl:52-79 */

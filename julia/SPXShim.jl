@@ -207,7 +207,8 @@ function layout_for(h, n)
     off = Int64[first(rngs[1]) - 1; [last(g) for g in rngs]]      # 0-based CSR offsets
     sizes = diff(off)
     uniform = off[1] == 0 && off[end] == n && all(==(sizes[1]), sizes)
-    (gather = false, offsets = uniform ? nothing : ROCVector{Int64}(off), gsize = uniform ? sizes[1] : 0,
+    # with offsets, gsize is the size bound that lets libspx use its register-tile / LDS-resident kernels
+    (gather = false, offsets = uniform ? nothing : ROCVector{Int64}(off), gsize = uniform ? sizes[1] : maximum(sizes),
      ngroups = length(rngs), lambda = lam)
   end
 end

@@ -523,7 +523,8 @@ template <int LPG, int EPL, bool BINF, bool PAIRS>
 __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) void k_group_reg(double* y_, const double* q_, const double* xk_, const double* sj_,
                                                     int64_t ngroups, int gsize, const double* __restrict__ lambda,
                                                     double sigma, double delta,
-                                                    long long* deferred /* [0] = count, [1..] = groups */) {
+                                                    long long* deferred /* [0] = count, [1..] = groups */,
+                                                    const int64_t* __restrict__ offsets /* !PAIRS only: ragged groups */) {
   static_assert((EPL % 2) == 0, "EPL must be even (16-byte pairs)");
   const int64_t GS = gsize;  // <= LPG * EPL
   constexpr int GPW = 64 / LPG;  // groups per wave
@@ -540,7 +541,21 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
   for (int64_t g0 = wave * GPW; g0 < ngroups; g0 += nwaves * GPW) {  // wave-uniform trip count
     bool valid = (g0 + slot) < ngroups;
     const int64_t g = valid ? (g0 + slot) : (ngroups - 1);  // idle slots shadow the last group, no store
-    const int64_t base = g * GS;
+    int64_t base = g * GS;
+    int gs = gsize;  // this group's size (row-uniform)
+    if constexpr (!PAIRS) {
+      if (offsets) {  // ragged groups whose sizes the caller bounded by the tile (group_size hint)
+        base = offsets[g];
+        const int64_t sz = offsets[g + 1] - base;
+        if (sz > LPG * EPL || sz < 0) {  // the hint was wrong for this group: the general kernel takes it
+          if (valid && j == 0) deferred[1 + atomicAdd((unsigned long long*)deferred, 1ull)] = g;
+          valid = false;
+          gs = 0;
+        } else {
+          gs = (int)sz;
+        }
+      }
+    }
     RegGroup<EPL> grp;
     {
       if constexpr (PAIRS) {
@@ -592,7 +607,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
 #pragma unroll
         for (int k = 0; k < EPL; ++k) {
           const int e = k * LPG + j;
-          const bool in = e < gsize;
+          const bool in = e < gs;
           const int64_t i = base + (in ? e : 0);
           const double a = in ? q_[i] : 0.0, b = in ? xk_[i] : 0.0, c = in ? sj_[i] : 0.0;
           grp.S[k] = (a + b) + c;
@@ -652,7 +667,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
       } else {
 #pragma unroll
         for (int k = 0; k < EPL; ++k)
-          if (k * LPG + j < gsize) y_[base + k * LPG + j] = out[k];
+          if (k * LPG + j < gs) y_[base + k * LPG + j] = out[k];
       }
     }
   }
@@ -801,16 +816,31 @@ struct LdsGroup {
 
 template <bool BINF>
 __global__ __launch_bounds__(256) void k_group_lds(double* y, const double* q, const double* xk, const double* sj,
-                                                    int64_t gsize, int64_t ngroups, const double* __restrict__ lambda,
-                                                    double sigma, double delta) {
+                                                    int64_t n, const int64_t* __restrict__ offsets /* NULL: uniform */,
+                                                    int64_t gsize /* group size, or the bound on it with offsets */,
+                                                    int64_t ngroups, const double* __restrict__ lambda, double sigma,
+                                                    double delta) {
   extern __shared__ __attribute__((aligned(16))) double dyn[];  // S[gsize] | X[gsize]
   __shared__ double lds[8];
   double* S = dyn;
   double* X = dyn + gsize;
   const int tid = threadIdx.x;
-  const int m = (int)gsize;
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    const int64_t lo = g * gsize;
+    int64_t lo = g * gsize, sz = gsize;
+    if (offsets) {
+      lo = offsets[g];
+      int64_t hi = offsets[g + 1];
+      if (lo < 0) lo = 0;
+      if (hi > n) hi = n;
+      sz = hi > lo ? hi - lo : 0;
+      if (sz > gsize) {  // the caller's bound was wrong for this group: straight from memory, as the general kernel
+        MemGroup<256> big{q, xk, sj, lo, hi, tid};
+        group_body<256, BINF>(big, y, lambda[g], sigma, delta, lds, false);
+        __syncthreads();
+        continue;
+      }
+    }
+    const int m = (int)sz;
     for (int i = tid; i < m; i += 256) {
       const double x = xk[lo + i];
       S[i] = (q[lo + i] + x) + sj[lo + i];  // shiftedGroupNormL2.jl:65 / shiftedGroupNormL2Binf.jl:80
@@ -922,8 +952,11 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   SPX_HIP(hipSetDevice(ctx->device));
   const int64_t cap_blocks = (int64_t)ctx->num_cu * 8;
   const bool aligned = spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj);
-  if (!offsets && gsize <= 512) {
-    // register path: the smallest (LPG, EPL) tile that holds a group; partly filled tiles are padded with zeros
+  const bool ragged_reg = offsets && gsize > 0 && gsize <= 512;  // ragged groups with a size bound from the caller
+  if ((!offsets && gsize <= 512) || ragged_reg) {
+    // register path: the smallest (LPG, EPL) tile that holds a group; partly filled tiles are padded with zeros.
+    // Ragged groups (CSR offsets + an upper bound on the sizes in group_size) use the same tiles through the 8-byte
+    // loads; a group that exceeds the bound after all is handed to the general kernel.
     int lpg, epl;
     // Binf: as few lanes per group as the registers allow (4 x 4/8, 8 x 8/16, 16 x 16, 32 x 16 elements) -- the wave-uniform
     // scalar work of the root find, which every lane executes, is then shared by more groups per wave
@@ -944,21 +977,23 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     if (blocks > 0x7fffffff) blocks = 0x7fffffff;
     dim3 grid((unsigned)blocks), block(256);
     long long* deferred = nullptr;
-    if (BINF) {  // list of the groups whose bracket needs the reference's literal evaluation
+    if (BINF || ragged_reg) {  // list of the groups whose bracket needs the reference's literal evaluation / oversize groups
       rc = spx_ws_reserve(ctx, (size_t)(ngroups + 1) * sizeof(long long) + 256);
       if (rc) return rc;
       deferred = reinterpret_cast<long long*>(ctx->ws);
       SPX_HIP(hipMemsetAsync(deferred, 0, sizeof(long long), ctx->stream));
     }
-    const bool pairs = (gsize & 1) == 0 && aligned;  // otherwise 8-byte loads
+    const bool pairs = !ragged_reg && (gsize & 1) == 0 && aligned;  // otherwise 8-byte loads
+    if (!BINF && ragged_reg)  // offsets need not span 0:n (src/shiftedGroupNormL2.jl:77 runs over every index)
+      hipLaunchKernelGGL(k_csr_uncovered, dim3(256), dim3(256), 0, ctx->stream, y, xk, sj, offsets, ngroups, n);
 #define SPX_LAUNCH_REG(LPG, EPL)                                                                                    \
   do {                                                                                                              \
     if (pairs)                                                                                                      \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, true>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,   \
-                         (int)gsize, lambda, sigma, delta, deferred);                                               \
+                         (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr);                      \
     else                                                                                                            \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, false>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,  \
-                         (int)gsize, lambda, sigma, delta, deferred);                                               \
+                         (int)gsize, lambda, sigma, delta, deferred, ragged_reg ? offsets : (const int64_t*)nullptr); \
   } while (0)
     if (lpg == 4 && epl == 4) { if constexpr (BINF) SPX_LAUNCH_REG(4, 4); }
     else if (lpg == 4 && epl == 8) { if constexpr (BINF) SPX_LAUNCH_REG(4, 8); }
@@ -973,16 +1008,19 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     else if (epl == 6) SPX_LAUNCH_REG(64, 6);
     else SPX_LAUNCH_REG(64, 8);
 #undef SPX_LAUNCH_REG
-    if (BINF) {  // usually an empty list: the kernel returns at once
+    if (BINF || ragged_reg) {  // usually an empty list: the kernel returns at once
       hipLaunchKernelGGL((k_group_mem<64, BINF>), dim3((unsigned)(ctx->num_cu * 2)), dim3(256), 0, ctx->stream, y, q, xk,
-                         sj, n, (const int64_t*)nullptr, gsize, ngroups, lambda, sigma, delta,
+                         sj, n, ragged_reg ? offsets : (const int64_t*)nullptr, gsize, ngroups, lambda, sigma, delta,
                          (const long long*)deferred);
     }
     SPX_LAUNCH_CHECK();
     return SPX_OK;
   }
   // team width: wavefront per group unless groups are large on average
-  if (!offsets && gsize <= (BINF ? kLdsGroupMax : kLdsGroupMaxPlain)) {  // 512 < gsize: LDS-resident group per workgroup
+  if (gsize > 512 && gsize <= (BINF ? kLdsGroupMax : kLdsGroupMaxPlain)) {
+    // 512 < group size (uniform) or size bound (ragged, CSR offsets): LDS-resident group per workgroup
+    if (!BINF && offsets)
+      hipLaunchKernelGGL(k_csr_uncovered, dim3(256), dim3(256), 0, ctx->stream, y, xk, sj, offsets, ngroups, n);
     const size_t dyn = (size_t)gsize * 2 * sizeof(double);
     static bool attr_set[2] = {false, false};
     if (!attr_set[BINF ? 1 : 0]) {
@@ -991,8 +1029,8 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
       attr_set[BINF ? 1 : 0] = true;
     }
     int64_t blocks = ngroups < cap_blocks ? ngroups : cap_blocks;
-    hipLaunchKernelGGL((k_group_lds<BINF>), dim3((unsigned)blocks), dim3(256), dyn, ctx->stream, y, q, xk, sj, gsize,
-                       ngroups, lambda, sigma, delta);
+    hipLaunchKernelGGL((k_group_lds<BINF>), dim3((unsigned)blocks), dim3(256), dyn, ctx->stream, y, q, xk, sj, n, offsets,
+                       gsize, ngroups, lambda, sigma, delta);
     SPX_LAUNCH_CHECK();
     return SPX_OK;
   }

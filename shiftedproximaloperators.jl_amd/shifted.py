@@ -418,7 +418,8 @@ class _GroupLayout:
             off = [bounds[0][0]] + [b for _, b in bounds] if bounds else [0]
             self.offsets = (np.asarray(off, dtype=np.int64) if device is None
                             else torch.tensor(off, dtype=torch.int64, device=device))
-            self.group_size = 0
+            # with offsets, group_size is an upper bound on the group sizes: it lets libspx pick its register-tile kernels
+            self.group_size = max(sizes) if sizes else 0
         self.lam = self._lam(h.lam, device)
 
     @staticmethod

@@ -459,6 +459,53 @@ def test_group_l2_csr_partial_cover(s, orc):
         assert (val == exp) or abs(val - exp) <= 1e-12 * abs(exp)
 
 
+@pytest.mark.parametrize("binf", [False, True])
+@pytest.mark.parametrize("maxsize", [7, 32, 100, 128, 300, 512, 1500, 4096])
+def test_group_ragged_bounded_sizes(s, orc, binf, maxsize):
+    """Ragged consecutive groups with a size bound: CSR offsets + the bound select the register-tile kernels (bound <= 512:
+    8-byte loads, per-group size) or the LDS-resident kernel (bound <= 2048 / 4096); a wrong (too small) bound still gives
+    the right answer."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(maxsize)
+    sizes = rng.integers(1, maxsize + 1, size=700 if maxsize <= 512 else 60)
+    sizes[:3] = (maxsize, 1, maxsize)
+    offsets = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(offsets[-1])
+    x, sj, q = _data(n, 9100 + maxsize)
+    lam = rng.uniform(0.2, 2.0, size=sizes.size)
+    xd, sd, qd = _dev(x, sj, q)
+    groups = [range(int(a), int(b)) for a, b in zip(offsets[:-1], offsets[1:])]
+    h = s.GroupNormL2(lam.tolist(), groups)
+    sigma, delta = 0.8, 0.9
+    if binf:
+        psi = s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd)
+        ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, offsets=offsets)
+    else:
+        psi = s.shifted(s.shifted(h, xd), sd)
+        ref = orc.prox_group_l2(q, x, sj, lam, sigma, offsets=offsets)
+    assert psi._layout.offsets is not None and psi._layout.group_size == maxsize
+    y = s.prox(psi, qd, sigma).cpu().numpy()
+    _group_check(y, ref, q, x, sj, list(offsets))
+    # y === q
+    q2 = qd.clone()
+    s.prox_bang(q2, psi, q2, sigma)
+    _group_check(q2.cpu().numpy(), ref, q, x, sj, list(offsets))
+    # a bound that is too small: the oversize groups are deferred to the general kernel, the result is the same
+    L, ctx = s._lib.load(), s.context("cuda:0")
+    lay = psi._layout
+    yy = torch.full_like(qd, float("nan"))
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    small = max(1, maxsize // 2)
+    if binf:
+        s._lib.check(L.spx_prox_group_l2_binf(ctx, p(yy), p(qd), p(xd), p(sd), n, p(lay.offsets), small, lay.ngroups,
+                                              p(lay.lam), sigma, delta))
+    else:
+        s._lib.check(L.spx_prox_group_l2(ctx, p(yy), p(qd), p(xd), p(sd), n, p(lay.offsets), small, lay.ngroups, p(lay.lam),
+                                         sigma))
+    _group_check(yy.cpu().numpy(), ref, q, x, sj, list(offsets))
+
+
 def test_group_binf_goldens_and_edge_branches(s, orc, kats):
     for name in ("group_l2_binf_single", "group_l2_binf_two"):  # test/runtests.jl:587-606, 658-705
         k = kats[name]

@@ -54,7 +54,7 @@ def test_group_layouts(s):
     g = lay([range(0, 4), range(4, 8), range(8, 12)])                    # uniform: no index array at all
     assert g.offsets is None and g.group_size == 4 and g.ngroups == 3 and g.index is None
     g = lay([range(0, 3), [3, 4, 5, 6], slice(7, 12)])                   # consecutive ragged ranges: CSR offsets
-    assert g.index is None and g.offsets.tolist() == [0, 3, 7, 12] and g.group_size == 0
+    assert g.index is None and g.offsets.tolist() == [0, 3, 7, 12] and g.group_size == 5     # size bound (hint)
     g = lay([range(2, 5), range(5, 9)])                                  # consecutive but not spanning 0:n: still CSR
     assert g.index is None and g.offsets.tolist() == [2, 5, 9]
     g = lay([[0, 2, 4], [1, 3, 5]])                                      # true index sets: gather form
