@@ -648,13 +648,16 @@ static int g_sep_nt = 1;
 static int g_sep_lds = 1;  // 1 = LDS-staged skeleton (default), 0 = register-staged
 static int g_sep_xcd = 0;  // 1 = XCD-contiguous tile ranges (experiment, see k_sep_lds)
 
+#ifndef SPX_VECB_KIB
+#define SPX_VECB_KIB 3  // KiB per wave and vector with vector bounds (5 vectors); measured at n = 1e8 (tools/bench_vecb.py): 2 -> 0.81 ms, 3 -> 0.76 ms, 4 -> 0.775 ms
+#endif
 template <class Op, bool VECB, bool MASK>
 static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d, const double* xk, const double* sj,
                       const double* l, const double* u, const uint8_t* mask, double ls, double us, int64_t n2, Op op,
                       int64_t* value_slots /* out: partial slots written (Op::kObj) */) {
   if constexpr (Op::kLdsKiB > 0) if (g_sep_lds) {
     // 3 input vectors: 6 KiB per wave and vector -> 72 KiB per workgroup; 5 vectors (vector bounds): 3 KiB -> 60 KiB
-    constexpr int U = (VECB && Op::kBox) ? (Op::kLdsKiB > 3 ? 3 : Op::kLdsKiB) : Op::kLdsKiB;  // <= 72 KiB per workgroup
+    constexpr int U = (VECB && Op::kBox) ? (Op::kLdsKiB > SPX_VECB_KIB ? SPX_VECB_KIB : Op::kLdsKiB) : Op::kLdsKiB;  // <= 72 KiB per workgroup
     int64_t blocks = (n2 + 256 * U - 1) / (256 * U);
     *value_slots = blocks * 4;  // one per wavefront
     int64_t xcd_chunk = 0;
