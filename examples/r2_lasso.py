@@ -3,7 +3,7 @@ prox! hot path on the GPU -- the caller this library is a drop-in for.  The loop
 loop in miniature, using only the mirrored API:
 
     psi = shifted(h, xk)                       # borrows xk: updating xk in place re-centres psi (shift!)
-    s, hkn = prox_value(psi, -nu * grad, nu)   # prox!(s, psi, mnu_grad, nu) and psi(s) = h(xk + s), one pass
+    s, hkn = prox_value(psi, grad, nu, q_scale=-nu)   # mnu_grad = -nu grad; prox!(s, psi, mnu_grad, nu); psi(s): one pass
     shift_bang(psi, xk)                        # after an accepted step
 
 Everything stays in device memory; torch supplies the smooth part (A x, A' r).  `backend="oracle"` runs the same loop on
@@ -25,7 +25,7 @@ def r2_lasso(A, b, lam, x0, backend, max_iter=200, tol=1e-6, eta1=1e-4, eta2=0.9
         norm2 = lambda v: float(torch.dot(v, v))
         xk = x0.clone()
         psi = spx.shifted(spx.NormL1(lam), xk)
-        prox_val = lambda q, nu: spx.prox_value(psi, q, nu)
+        prox_val = lambda grad, nu: spx.prox_value(psi, grad, nu, q_scale=-nu)   # q = -nu grad formed on the fly
         hval = lambda: psi(torch.zeros_like(xk))
     else:
         from oracle import oracle
@@ -34,8 +34,8 @@ def r2_lasso(A, b, lam, x0, backend, max_iter=200, tol=1e-6, eta1=1e-4, eta2=0.9
         xk = x0.copy()
         zero = np.zeros_like(xk)
 
-        def prox_val(q, nu):
-            s = oracle.prox_l1(q, xk, zero, lam, nu)
+        def prox_val(grad, nu):
+            s = oracle.prox_l1(-nu * grad, xk, zero, lam, nu)
             return s, oracle.obj_plain("l1", s, xk, zero, lam)
         hval = lambda: oracle.obj_plain("l1", zero, xk, zero, lam)
 
@@ -45,7 +45,7 @@ def r2_lasso(A, b, lam, x0, backend, max_iter=200, tol=1e-6, eta1=1e-4, eta2=0.9
     nu = nu0 if nu0 is not None else 1.0
     hist = []
     for it in range(max_iter):
-        s, hkn = prox_val(-nu * grad, nu)
+        s, hkn = prox_val(grad, nu)
         xi = hk - (dot(grad, s) + hkn)                      # model decrease
         if xi < 0 or np.sqrt(max(xi, 0.0) / nu) < tol:
             hist.append((it, fk + hk, nu, None))

@@ -118,22 +118,24 @@ int spx_prox_lhalf_box(spx_ctx* ctx, double* y, const double* q, const double* x
 /* One pass instead of two for the pair every solver iteration makes (R2: `prox!(s, psi, ...)` then `h(xk + s)`):
  * y as spx_prox_X, and *value = h over the selected indices of (xk + sj) + y -- lambda * sum |v|, lambda * #nonzeros,
  * lambda * sum sqrt|v| (src/ShiftedProximalOperators.jl:51-54, Box forms src/shiftedNormL1Box.jl:70-82 without the
- * feasibility scan: a prox result lies inside the box by construction).  Synchronous: *value is written on the host. */
+ * feasibility scan: a prox result lies inside the box by construction).  The prox is taken at q_scale * q[i], formed on
+ * the fly (R2's `mnu_grad .= -nu .* grad` without the extra pass; pass 1.0 for q itself; bit-identical to scaling q
+ * beforehand).  Synchronous: *value is written on the host. */
 int spx_proxval_l1(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
-                   double lambda, double sigma, double* value);
+                   double lambda, double sigma, double q_scale, double* value);
 int spx_proxval_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
-                   double lambda, double sigma, double* value);
+                   double lambda, double sigma, double q_scale, double* value);
 int spx_proxval_lhalf(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
-                      double lambda, double sigma, double* value);
+                      double lambda, double sigma, double q_scale, double* value);
 int spx_proxval_l1_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
                        double lambda, double sigma, const double* l_vec, const double* u_vec, double l_scalar,
-                       double u_scalar, const uint8_t* sel_mask, double* value);
+                       double u_scalar, const uint8_t* sel_mask, double q_scale, double* value);
 int spx_proxval_l0_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
                        double lambda, double sigma, const double* l_vec, const double* u_vec, double l_scalar,
-                       double u_scalar, const uint8_t* sel_mask, double* value);
+                       double u_scalar, const uint8_t* sel_mask, double q_scale, double* value);
 int spx_proxval_lhalf_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
                           double lambda, double sigma, const double* l_vec, const double* u_vec, double l_scalar,
-                          double u_scalar, const uint8_t* sel_mask, double* value);
+                          double u_scalar, const uint8_t* sel_mask, double q_scale, double* value);
 
 /* ---- iprox!: argmin 1/2 y'Dy + g'y + psi(y), D = diag(d)  (src/ShiftedProximalOperators.jl:154-180) ------ */
 /* Separable; reads g, d, xk, sj (40 B/element).  y may alias g.

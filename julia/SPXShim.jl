@@ -158,17 +158,18 @@ end
 # `prox!(s, ψ, mν∇fk, ν)` then `hkn = ψ(s)`): one pass over the vectors instead of two.  Headline operator shown;
 # spx_proxval_l1 / l0 / lhalf / l0_box / lhalf_box follow the same pattern.
 # ---------------------------------------------------------------------------------------------
-function prox_value!(y::DVec, ψ::ShiftedNormL1Box{Float64, <:DVec, <:DVec, <:DVec}, q::DVec, σ::Float64)
+function prox_value!(y::DVec, ψ::ShiftedNormL1Box{Float64, <:DVec, <:DVec, <:DVec}, q::DVec, σ::Float64;
+                     q_scale::Float64 = 1.0)   # prox at q_scale .* q (R2: q = ∇fk, q_scale = -ν)
   n = length(ψ.xk)
   (length(y) == n && length(q) == n) || throw(BoundsError())
   m = mask_for(ψ)
   out = Ref{Cdouble}(0.0)
   check(ccall((:spx_proxval_l1_box, libspx), Cint,
               (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cdouble,
-               Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{UInt8}, Ptr{Cdouble}),
+               Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{UInt8}, Cdouble, Ptr{Cdouble}),
               ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, ψ.λ, σ,
               dptr(vec_or_nothing(ψ.l)), dptr(vec_or_nothing(ψ.u)), scal(ψ.l), scal(ψ.u),
-              m === nothing ? Ptr{UInt8}(C_NULL) : Ptr{UInt8}(UInt(pointer(m))), out))
+              m === nothing ? Ptr{UInt8}(C_NULL) : Ptr{UInt8}(UInt(pointer(m))), q_scale, out))
   return y, out[]
 end
 

@@ -28,12 +28,12 @@ SIGNATURES = {
     "spx_prox_l1_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p],
     "spx_prox_l0_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p],
     "spx_prox_lhalf_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p],
-    "spx_proxval_l1": [_p, _p, _p, _p, _p, _i64, _d, _d, ctypes.POINTER(_d)],
-    "spx_proxval_l0": [_p, _p, _p, _p, _p, _i64, _d, _d, ctypes.POINTER(_d)],
-    "spx_proxval_lhalf": [_p, _p, _p, _p, _p, _i64, _d, _d, ctypes.POINTER(_d)],
-    "spx_proxval_l1_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p, ctypes.POINTER(_d)],
-    "spx_proxval_l0_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p, ctypes.POINTER(_d)],
-    "spx_proxval_lhalf_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p, ctypes.POINTER(_d)],
+    "spx_proxval_l1": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, ctypes.POINTER(_d)],
+    "spx_proxval_l0": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, ctypes.POINTER(_d)],
+    "spx_proxval_lhalf": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, ctypes.POINTER(_d)],
+    "spx_proxval_l1_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p, _d, ctypes.POINTER(_d)],
+    "spx_proxval_l0_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p, _d, ctypes.POINTER(_d)],
+    "spx_proxval_lhalf_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p, _d, ctypes.POINTER(_d)],
     "spx_iprox_l1": [_p, _p, _p, _p, _p, _p, _i64, _d, _int],
     "spx_iprox_l0": [_p, _p, _p, _p, _p, _p, _i64, _d, _int],
     "spx_iprox_l1_box": [_p, _p, _p, _p, _p, _p, _i64, _d, _p, _p, _d, _d, _p],

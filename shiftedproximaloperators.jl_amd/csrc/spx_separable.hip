@@ -396,6 +396,10 @@ template <class Base, class Term>
 struct WithValue : Base {
   static constexpr bool kObj = true;
   double* partials;  // one slot per wavefront (LDS skeleton) / workgroup (register skeleton, scalar kernel)
+  double qscale;     // the prox is taken at qscale * q (R2: q = -nu * grad f, formed on the fly; 1.0 = q itself)
+  __device__ __forceinline__ double operator()(double q, double x, double s, double l, double u, bool sel) const {
+    return Base::operator()(qscale * q, x, s, l, u, sel);
+  }
   __device__ __forceinline__ double hterm(double x, double s, double y, bool sel) const {
     return sel ? Term{}((x + s) + y) : 0.0;
   }
@@ -817,11 +821,11 @@ SPX_EXPORT int spx_prox_lhalf_box(spx_ctx* ctx, double* y, const double* q, cons
 template <class Base, class Term>
 static int run_proxval(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
                        const double* l, const double* u, double ls, double us, const uint8_t* mask, Base base,
-                       double lambda, double* value) {
+                       double lambda, double q_scale, double* value) {
   int rc = spx_check_common(ctx, y, q, xk, sj, n);
   if (rc) return rc;
   SPX_REQUIRE(value != nullptr, "value is NULL");
-  WithValue<Base, Term> op{base, nullptr};
+  WithValue<Base, Term> op{base, nullptr, q_scale};
   double sum = 0.0;
   rc = run_separable(ctx, y, q, xk, sj, n, l, u, ls, us, mask, op, nullptr, &sum);
   *value = lambda * sum;
@@ -829,42 +833,44 @@ static int run_proxval(spx_ctx* ctx, double* y, const double* q, const double* x
 }
 
 SPX_EXPORT int spx_proxval_l1(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
-                              double lambda, double sigma, double* value) {
-  if (y == q && lambda * sigma >= 0.0)  // the reference's two-pass body with y === q (see OpL1Aliased)
+                              double lambda, double sigma, double q_scale, double* value) {
+  if (y == q && lambda * sigma >= 0.0) {  // the reference's two-pass body with y === q (see OpL1Aliased)
+    SPX_REQUIRE(q_scale == 1.0, "q_scale != 1 with y aliasing q");
     return run_proxval<OpL1Aliased, HTermL1>(ctx, y, q, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, OpL1Aliased{},
-                                             lambda, value);
+                                             lambda, 1.0, value);
+  }
   return run_proxval<OpL1, HTermL1>(ctx, y, q, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, OpL1{lambda * sigma},
-                                    lambda, value);
+                                    lambda, q_scale, value);
 }
 SPX_EXPORT int spx_proxval_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
-                              double lambda, double sigma, double* value) {
+                              double lambda, double sigma, double q_scale, double* value) {
   return run_proxval<OpL0, HTermL0>(ctx, y, q, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr,
-                                    OpL0{std::sqrt(2 * lambda * sigma)}, lambda, value);
+                                    OpL0{std::sqrt(2 * lambda * sigma)}, lambda, q_scale, value);
 }
 SPX_EXPORT int spx_proxval_lhalf(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
-                                 double lambda, double sigma, double* value) {
+                                 double lambda, double sigma, double q_scale, double* value) {
   const double nl = sigma * lambda;
   const double p = std::pow(54.0, 1.0 / 3.0) * std::pow(2 * nl, 2.0 / 3.0) / 4;
   return run_proxval<OpLhalf, HTermLhalf>(ctx, y, q, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, OpLhalf{nl / 4, p},
-                                          lambda, value);
+                                          lambda, q_scale, value);
 }
 SPX_EXPORT int spx_proxval_l1_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
                                   double lambda, double sigma, const double* l_vec, const double* u_vec,
-                                  double l_scalar, double u_scalar, const uint8_t* sel_mask, double* value) {
+                                  double l_scalar, double u_scalar, const uint8_t* sel_mask, double q_scale, double* value) {
   return run_proxval<OpL1Box, HTermL1>(ctx, y, q, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask,
-                                       OpL1Box{sigma * lambda}, lambda, value);
+                                       OpL1Box{sigma * lambda}, lambda, q_scale, value);
 }
 SPX_EXPORT int spx_proxval_l0_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
                                   double lambda, double sigma, const double* l_vec, const double* u_vec,
-                                  double l_scalar, double u_scalar, const uint8_t* sel_mask, double* value) {
+                                  double l_scalar, double u_scalar, const uint8_t* sel_mask, double q_scale, double* value) {
   return run_proxval<OpL0Box, HTermL0>(ctx, y, q, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask,
-                                       OpL0Box{2 * lambda * sigma}, lambda, value);
+                                       OpL0Box{2 * lambda * sigma}, lambda, q_scale, value);
 }
 SPX_EXPORT int spx_proxval_lhalf_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
                                      int64_t n, double lambda, double sigma, const double* l_vec, const double* u_vec,
-                                     double l_scalar, double u_scalar, const uint8_t* sel_mask, double* value) {
+                                     double l_scalar, double u_scalar, const uint8_t* sel_mask, double q_scale, double* value) {
   return run_proxval<OpLhalfBox, HTermLhalf>(ctx, y, q, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask,
-                                             OpLhalfBox{sigma * lambda / 4, lambda, 0.5 / sigma}, lambda, value);
+                                             OpLhalfBox{sigma * lambda / 4, lambda, 0.5 / sigma}, lambda, q_scale, value);
 }
 
 // ---------------------------------------------------------------------------------------------

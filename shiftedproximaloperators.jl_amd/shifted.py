@@ -564,11 +564,12 @@ def prox(ψ, q, σ):
     return prox_bang(ψ.sol, ψ, q, σ)
 
 
-def prox_value_bang(y, ψ, q, σ):
-    """prox!(y, ψ, q, σ) and h(xk + sj + y) of the result in ONE pass over the vectors (the pair a solver iteration makes:
+def prox_value_bang(y, ψ, q, σ, q_scale=1.0):
+    """prox!(y, ψ, q_scale .* q, σ) and h(xk + sj + y) of the result in ONE pass over the vectors (the pair a solver iteration makes:
     R2's `prox!(s, ψ, …)` followed by `ψ(s)`): returns (y, value).  Device vectors, the separable operators
     (ShiftedNormL1 / NormL0 / RootNormLhalf and their Box forms); synchronises to return the value.  The Box forms
-    return the h part of ψ(y): the prox lies inside the box by construction."""
+    return the h part of ψ(y): the prox lies inside the box by construction.  q_scale: the prox is taken at q_scale * q,
+    formed on the fly (R2: `prox_value(ψ, ∇f, ν, q_scale=-ν)` instead of materialising -ν∇f)."""
     if not isinstance(ψ, (_Unboxed, _Boxed)) or ψ.host:
         raise TypeError("prox_value is available for the separable operators on device vectors")
     n = _n(ψ.xk)
@@ -582,15 +583,16 @@ def prox_value_bang(y, ψ, q, σ):
         uv = None if _is_real(ψ.u) else _vec(ψ.u, "u", n, like=y)
         _lib.check(fn(ctx, _ptr(y), _ptr(q), _ptr(ψ.xk), _ptr(ψ.sj), n, ψ.h.lam, float(σ), _ptr(lv), _ptr(uv),
                       float(ψ.l) if lv is None else 0.0, float(ψ.u) if uv is None else 0.0,
-                      _ptr(ψ._mask[0]) if ψ._mask is not None else ctypes.c_void_p(0), ctypes.byref(out)))
+                      _ptr(ψ._mask[0]) if ψ._mask is not None else ctypes.c_void_p(0), float(q_scale), ctypes.byref(out)))
     else:
-        _lib.check(fn(ctx, _ptr(y), _ptr(q), _ptr(ψ.xk), _ptr(ψ.sj), n, ψ.h.lam, float(σ), ctypes.byref(out)))
+        _lib.check(fn(ctx, _ptr(y), _ptr(q), _ptr(ψ.xk), _ptr(ψ.sj), n, ψ.h.lam, float(σ), float(q_scale),
+                      ctypes.byref(out)))
     return y, out.value
 
 
-def prox_value(ψ, q, σ):
-    """(prox(ψ, q, σ), h(xk + sj + prox)) in one pass; see prox_value_bang"""
-    return prox_value_bang(ψ.sol, ψ, q, σ)
+def prox_value(ψ, q, σ, q_scale=1.0):
+    """(prox(ψ, q_scale .* q, σ), h(xk + sj + prox)) in one pass; see prox_value_bang"""
+    return prox_value_bang(ψ.sol, ψ, q, σ, q_scale)
 
 
 def iprox_bang(y, ψ, g, d, check=True):

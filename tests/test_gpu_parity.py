@@ -914,6 +914,15 @@ def test_prox_value_fused(s, orc, n):
                 assert val == exp
             else:
                 assert abs(val - exp) <= 1e-12 * max(abs(exp), 1e-300), (type(psi).__name__, val, exp)
+    # q_scale: the prox of q_scale * q formed on the fly is bit-identical to scaling q first (R2: q = -nu grad f)
+    xd, sd, qd = _dev(x, sj, q)
+    for psi in (s.shifted(s.shifted(s.NormL1(0.7), xd, 0.9, s.NormLinf(1.0)), sd), s.shifted(s.shifted(s.NormL0(0.7), xd), sd),
+                s.shifted(s.shifted(s.RootNormLhalf(0.7), xd, ld, ud, selected), sd) if not misaligned else
+                s.shifted(s.shifted(s.RootNormLhalf(0.7), xd), sd)):
+        y1, v1 = s.prox_value(psi, qd, 1.1, q_scale=-0.37)
+        y1 = y1.clone()
+        y2, v2 = s.prox_value(psi, -0.37 * qd, 1.1)
+        assert torch.equal(y1, y2) and v1 == v2
     # y === q (ShiftedNormL1: the reference's two-pass quirk) through the fused form too
     xd, sd, qd = _dev(x, sj, q)
     psi = s.shifted(s.shifted(s.NormL1(0.7), xd), sd)
