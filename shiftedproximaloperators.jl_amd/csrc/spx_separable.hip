@@ -700,44 +700,63 @@ static int run_separable(spx_ctx* ctx, double* y, const double* q, const double*
   double* partials = nullptr;  // ws: [result | pad to 256 B | partial slots]
   int64_t used = 0;
   if constexpr (Op::kObj) {
-    const int64_t maxslots = ((n / 2) / (256 * 3) + 2) * 4 + (int64_t)ctx->num_cu * 8 + 16;
+    const int64_t maxslots = ((n / 2) / (256 * 3) + 2) * 4 + 2 * (int64_t)ctx->num_cu * 8 + 16;
     int rcw = spx_ws_reserve(ctx, 256 + (size_t)maxslots * sizeof(double));
     if (rcw) return rcw;
     partials = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + 256);
   }
-  bool vec_ok = spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj) && (!d || spx_aligned16(d)) &&
-                (!l || spx_aligned16(l)) && (!u || spx_aligned16(u)) &&
-                (!mask || (reinterpret_cast<uintptr_t>(mask) & 1u) == 0);
-  int64_t done = 0;
-  if (vec_ok && n >= 2) {
-    const int64_t n2 = n / 2;
-    int rc;
-    int64_t slots = 0;
-    if constexpr (Op::kObj) op.partials = partials;
-    if constexpr (Op::kBox) {
-      const bool vecb = (l || u);
-      const bool msk = (mask != nullptr);
-      if (vecb && msk) rc = launch_vec<Op, true, true>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op, &slots);
-      else if (vecb) rc = launch_vec<Op, true, false>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op, &slots);
-      else if (msk) rc = launch_vec<Op, false, true>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op, &slots);
-      else rc = launch_vec<Op, false, false>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op, &slots);
-    } else {
-      rc = launch_vec<Op, false, false>(ctx, y, q, d, xk, sj, l, u, mask, ls, us, n2, op, &slots);
-    }
-    if (rc) return rc;
-    used += slots;
-    done = 2 * n2;
-  }
-  if (done < n) {
-    int64_t rem = n - done;
-    int64_t blocks = (rem + 255) / 256;
+  // The vector skeletons need 16-byte aligned vectors (and a 2-byte aligned mask).  Views that all start 8 bytes off
+  // (e.g. view(x, 2:n) of aligned arrays) are peeled: element 0 through the scalar kernel, the rest aligned again.
+  auto vec_ok_at = [&](int64_t h) {
+    auto a16 = [&](const double* p) { return !p || spx_aligned16(p + h); };
+    return a16(y) && a16(q) && a16(xk) && a16(sj) && a16(d) && a16(l) && a16(u) &&
+           (!mask || ((reinterpret_cast<uintptr_t>(mask) + (uintptr_t)h) & 1u) == 0);
+  };
+  auto launch_scalar = [&](int64_t begin, int64_t end) -> int {
+    int64_t blocks = (end - begin + 255) / 256;
     const int64_t cap = (int64_t)ctx->num_cu * 8;
     if (blocks > cap) blocks = cap;
     if constexpr (Op::kObj) op.partials = partials + used;
     hipLaunchKernelGGL((k_sep_scalar<Op>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, d, xk, sj, l, u,
-                       mask, ls, us, done, n, op);
+                       mask, ls, us, begin, end, op);
     SPX_LAUNCH_CHECK();
     used += blocks;
+    return SPX_OK;
+  };
+  int64_t head = 0;
+  if (!vec_ok_at(0) && n >= 3 && vec_ok_at(1)) head = 1;
+  int64_t done = 0;
+  if (head) {
+    int rch = launch_scalar(0, head);
+    if (rch) return rch;
+    done = head;
+  }
+  if (vec_ok_at(head) && n - head >= 2) {
+    const int64_t n2 = (n - head) / 2;
+    auto sh = [&](const double* p) { return p ? p + head : p; };
+    double* yv = y + head;
+    const double *qv = sh(q), *dv = sh(d), *xv = sh(xk), *sv = sh(sj), *lv = sh(l), *uv = sh(u);
+    const uint8_t* mv = mask ? mask + head : mask;
+    int rc;
+    int64_t slots = 0;
+    if constexpr (Op::kObj) op.partials = partials + used;
+    if constexpr (Op::kBox) {
+      const bool vecb = (l || u);
+      const bool msk = (mask != nullptr);
+      if (vecb && msk) rc = launch_vec<Op, true, true>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots);
+      else if (vecb) rc = launch_vec<Op, true, false>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots);
+      else if (msk) rc = launch_vec<Op, false, true>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots);
+      else rc = launch_vec<Op, false, false>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots);
+    } else {
+      rc = launch_vec<Op, false, false>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots);
+    }
+    if (rc) return rc;
+    used += slots;
+    done = head + 2 * n2;
+  }
+  if (done < n) {
+    int rct = launch_scalar(done, n);
+    if (rct) return rct;
   }
   if constexpr (Op::kObj) {
     double* result = reinterpret_cast<double*>(ctx->ws);

@@ -1,0 +1,20 @@
+"""ShiftedNormL1Box on 8-byte-aligned views (all four vectors start 8 bytes off a 16-byte boundary), n = 1e8"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as ge
+s = ge.build(); L = s._lib.load()
+dev = torch.device("cuda:0"); ctx = s.context(dev)
+g = torch.Generator(device=dev).manual_seed(1)
+n = 100_000_000
+mk = lambda: torch.randn(n + 1, dtype=torch.float64, device=dev, generator=g)[1:]
+xk, sj, q, y = mk(), mk(), mk(), mk()
+sj.mul_(0.3)
+assert all(t.data_ptr() % 16 == 8 for t in (xk, sj, q, y))
+psi = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, s.NormLinf(1.0)), sj)
+ts = []
+for rnd in range(5):
+    ms = ctypes.c_float(); L.spx_timer_start(ctx)
+    for _ in range(10): s.prox_bang(y, psi, q, 1.0)
+    L.spx_timer_stop(ctx, ctypes.byref(ms)); ts.append(ms.value / 10)
+ts.sort(); print("misaligned views: median %.4f ms -> %.0f GB/s" % (ts[2], 32 * n / ts[2] / 1e6))
