@@ -1,0 +1,132 @@
+"""Randomised parity sweep (fixed seeds): parameters and data scales drawn over many orders of magnitude, random bounds,
+masks and group layouts; every operator family against the oracle with its parity bar."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def s():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as ge
+    return ge.build()
+
+
+def _dev(*arrs):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0") for a in arrs]
+
+
+def _bits(a, b):
+    return np.array_equal(np.asarray(a).view(np.int64), np.asarray(b).view(np.int64))
+
+
+def _logu(rng, lo, hi):
+    return float(10.0 ** rng.uniform(lo, hi))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_separable(s, orc, seed):
+    rng = np.random.default_rng(1000 + seed)
+    for trial in range(12):
+        n = int(rng.integers(1, 6000))
+        scale = _logu(rng, -6, 6)
+        x = rng.normal(size=n) * scale
+        sj = rng.normal(size=n) * scale * _logu(rng, -3, 1)
+        q = rng.normal(size=n) * scale * _logu(rng, -2, 2)
+        # exact ties with thresholds / bounds / zeros sprinkled in
+        idx = rng.integers(0, n, size=max(1, n // 10))
+        x[idx] = np.round(x[idx] / scale) * scale
+        q[rng.integers(0, n, size=max(1, n // 20))] = 0.0
+        lam, sigma = _logu(rng, -4, 4) * scale, _logu(rng, -3, 3)
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            lo, up = -abs(rng.normal()) * scale, abs(rng.normal()) * scale
+        elif kind == 1:
+            lo = rng.normal(size=n) * scale - scale
+            up = lo + np.abs(rng.normal(size=n)) * scale
+        elif kind == 2:
+            lo, up = -np.inf, abs(rng.normal()) * scale
+        else:
+            lo, up = 0.0, 0.0
+        mask = None
+        selected = None
+        if rng.random() < 0.5 and n > 2:
+            selected = sorted(rng.choice(n, size=int(rng.integers(1, n)), replace=False).tolist())
+            mask = orc.mask_from_selected([i + 1 for i in selected], n)
+        xd, sd, qd = _dev(x, sj, q)
+        ld, ud = (lo, up) if np.isscalar(lo) else _dev(lo, up)
+        with np.errstate(all="ignore"):
+            for H, name in ((s.NormL1, "l1"), (s.NormL0, "l0")):
+                y = s.prox(s.shifted(s.shifted(H(lam), xd), sd), qd, sigma).cpu().numpy()
+                assert _bits(y, getattr(orc, "prox_" + name)(q, x, sj, lam, sigma)), (name, seed, trial)
+                psi = s.shifted(s.shifted(H(lam), xd, ld, ud, selected), sd) if selected else s.shifted(s.shifted(H(lam), xd, ld, ud), sd)
+                y = s.prox(psi, qd, sigma).cpu().numpy()
+                assert _bits(y, getattr(orc, "prox_%s_box" % name)(q, x, sj, lam, sigma, lo, up, mask=mask)), (name, "box", seed, trial)
+                d = rng.choice([1.0, -1.0, 0.0], size=n) * 10.0 ** rng.uniform(-3, 3, size=n) / scale
+                dd = _dev(d)[0]
+                yi = s.iprox(psi, qd, dd).cpu().numpy()
+                assert _bits(yi, getattr(orc, "iprox_%s_box" % name)(q, d, x, sj, lam, lo, up, mask=mask)), (name, "iprox", seed, trial)
+            # RootNormLhalf(Box): 1e-12 on the operand scale
+            ref = orc.prox_lhalf(q, x, sj, lam, sigma)
+            y = s.prox(s.shifted(s.shifted(s.RootNormLhalf(lam), xd), sd), qd, sigma).cpu().numpy()
+            sc = np.maximum(np.maximum(np.abs(ref), np.abs(x + sj)), np.abs(q))
+            assert np.all(np.abs(y - ref) <= 1e-12 * sc), ("lhalf", seed, trial, float(np.max(np.abs(y - ref) / np.maximum(sc, 1e-300))))
+            psi = s.shifted(s.shifted(s.RootNormLhalf(lam), xd, ld, ud, selected), sd) if selected else s.shifted(s.shifted(s.RootNormLhalf(lam), xd, ld, ud), sd)
+            ref = orc.prox_lhalf_box(q, x, sj, lam, sigma, lo, up, mask=mask)
+            y = s.prox(psi, qd, sigma).cpu().numpy()
+            bad = np.abs(y - ref) > 1e-12 * sc
+            # a different candidate on an exact tie of candidate values is not an error: accept if the objective agrees
+            if bad.any():
+                lo_v = np.broadcast_to(lo, (n,)); up_v = np.broadcast_to(up, (n,))
+                f = lambda t: (t - q) ** 2 / 2 / sigma + lam * np.sqrt(np.abs(t + (x + sj)))
+                tie = np.abs(f(y) - f(ref)) <= 1e-13 * np.maximum(np.abs(f(ref)), 1e-300)
+                feas = (y >= lo_v - sj - 1e-12 * sc) & (y <= up_v - sj + 1e-12 * sc)
+                assert np.all(~bad | (tie & feas)), ("lhalf_box", seed, trial, int(np.sum(bad & ~(tie & feas))))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_groups_and_topr(s, orc, seed):
+    rng = np.random.default_rng(2000 + seed)
+    for trial in range(6):
+        scale = _logu(rng, -4, 4)
+        maxsize = int(rng.choice([3, 17, 64, 130, 400, 1500]))
+        sizes = rng.integers(1, maxsize + 1, size=int(rng.integers(1, 80)))
+        offsets = np.concatenate([[0], np.cumsum(sizes)])
+        n = int(offsets[-1])
+        x = rng.normal(size=n) * scale
+        sj = rng.normal(size=n) * scale * 0.3
+        q = rng.normal(size=n) * scale * _logu(rng, -1, 1)
+        lam = 10.0 ** rng.uniform(-3, 2, size=sizes.size) * scale
+        sigma, delta = _logu(rng, -2, 2), _logu(rng, -2, 2) * scale
+        xd, sd, qd = _dev(x, sj, q)
+        groups = [range(int(a), int(b)) for a, b in zip(offsets[:-1], offsets[1:])]
+        h = s.GroupNormL2(lam.tolist(), groups)
+        S = (q + x) + sj
+        with np.errstate(all="ignore"):
+            for binf in (False, True):
+                if binf:
+                    psi = s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd)
+                    ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, offsets=offsets)
+                else:
+                    psi = s.shifted(s.shifted(h, xd), sd)
+                    ref = orc.prox_group_l2(q, x, sj, lam, sigma, offsets=offsets)
+                y = s.prox(psi, qd, sigma).cpu().numpy()
+                sc = np.abs(ref).copy()
+                cancel = np.zeros(n)
+                for g, (a, b) in enumerate(zip(offsets[:-1], offsets[1:])):
+                    nS = np.linalg.norm(S[a:b])
+                    sc[a:b] = np.maximum(sc[a:b], nS)
+                    # the reference's last step alpha = 1 - sigma lambda / ||w|| cancels when sigma lambda ~ ||w||: the
+                    # achievable agreement degrades by that factor
+                    cancel[a:b] = max(1.0, sigma * lam[g] / max(nS, 1e-300))
+                err = np.abs(y - ref) / np.maximum(sc, 1e-300)
+                assert np.all(err <= 1e-12 * np.maximum(cancel, 1.0) * 10), (binf, seed, trial, float(err.max()))
+        r = int(rng.integers(1, n + 1))
+        qq = np.round(q / scale * 8) / 8 * scale if rng.random() < 0.5 else q       # many ties half of the time
+        qd2 = _dev(qq)[0]
+        y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, delta, s.NormLinf(1.0)), sd), qd2, 1.0).cpu().numpy()
+        assert _bits(y, orc.prox_indball_l0_binf(qq, x, sj, r, delta)), ("indball", seed, trial)
