@@ -345,6 +345,7 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
   // sl + ub (the iteration starts from the bound ub, not from lmax) the exact lmax is never used: skip the pass.
   const double lmax_lb = nS + sigma * (lam * nX);
   double lmax;
+  bool lmax_is_normS = false;  // lmax == ||S|| exactly in the reference: zlmax == 0 and lambda ||X|| == 0
   if (lmax_lb > lmin * (1.0 + 8 * eps) && (lmax_lb - sl) > ub * (1.0 + 8 * eps)) {
     lmax = sl + ub * (1.0 + 8 * eps);  // any point >= the root serves as the upper end from here on
   } else {
@@ -359,6 +360,7 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
     });
     sz = team_sum<TEAM>(sz, lds);
     lmax = nS + sigma * (sqrt_pos(sz) + 1.0 * lam * nX);                   // :100 (|(eps-1)/eps + 1| = 1)
+    lmax_is_normS = (sz == 0.0) && (lam * nX == 0.0);
   }
   // fl = froot(lmin) (:95): only its sign is used.  lmin sits eps above the pole of step(n): tau(lmin) ~ eps, the element
   // with the largest |X_i| has |tau S_i - X_i| >= max|X| - tau ||S||; if that exceeds Delta by a relative 1e-9 the
@@ -396,6 +398,23 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
     tau_full = tau;
   }
   {
+    // fm = froot(lmax) (:101).  When the bracket's upper end IS the root -- X = 0 and every entry thresholded at lmax,
+    // the usual state at x0 = 0 with a wide trust region: lmax = ||S|| and froot(lmax) = ||S|| - ||S|| = 0 exactly in
+    // the reference -- the A/B form returns a rounding-sized psi of either sign.  Its sign must not decide :102: such
+    // groups (and a froot(lmin) that is not safely negative) go to the literal evaluation.
+    if (!from_bound && fabs(psi) <= 1e-12 * u) {
+      // The common instance, decided here: lmax = ||S|| (zlmax = 0, lambda ||X|| = 0) and no entry active at lmax.  The
+      // reference then has froot(lmax) = ||S|| - ||-S|| = 0 exactly, fzero returns lmax, and w = S whatever the last bits
+      // of the root are (:111 with everything thresholded): root = lmax, sums of the all-inactive piece.
+      if (lmax_is_normS && sb == 0.0) {
+        root = lmax;
+        out_sa = sa;
+        out_sb = sb;
+        return BINF_ROOT;
+      }
+      return BINF_LITERAL;
+    }
+    if (fabs(fl) <= 1e-12 * lmin) return BINF_LITERAL;
     const double fm = from_bound ? ((psi > 0.0) ? psi : 1.0) : (lmax * fast_rcp(u)) * psi;
     if (fl * fm > 0) return BINF_ZERO;                      // :102
     if (!(fl < 0.0) || !(fm > 0.0)) return BINF_LITERAL;    // an exact zero at an end (or NaN)

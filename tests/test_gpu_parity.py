@@ -930,3 +930,36 @@ def test_prox_value_fused(s, orc, n):
     s.prox_bang(q1, psi, q1, 1.1)
     _, val = s.prox_value_bang(q2, psi, q2, 1.1)
     assert torch.equal(q1, q2) and abs(val - psi(q1)) <= 1e-12 * max(abs(val), 1e-300)
+
+
+@pytest.mark.parametrize("gs", [3, 16, 128, 300, 1024])
+def test_group_binf_lattice_and_zero_x(s, orc, gs):
+    """Data on a lattice (multiples of 1/4): activity boundaries |tau S - X| = Delta, equal entries, exact roots and the
+    reference's exact zero froot(lmax) = ||S|| - ||-S|| (X = 0 with everything thresholded: the state of a solver at
+    x0 = 0 inside a wide trust region) occur constantly."""
+    rng = np.random.default_rng(40 + gs)
+    ng = 150 if gs <= 300 else 24
+    n = ng * gs
+    offs = list(range(0, n + 1, gs))
+    for rep in range(6):
+        x = rng.integers(-8, 9, size=n) / 4.0
+        sj = rng.integers(-2, 3, size=n) / 4.0
+        q = rng.integers(-12, 13, size=n) / 4.0
+        if rep % 3 == 1:
+            x[: n // 2] = 0.0
+        if rep % 3 == 2:
+            x[:] = 0.0                                   # x0 = 0 everywhere
+        lam = rng.choice([0.0, 0.25, 0.5, 1.0, 2.0, 8.0], size=ng)
+        sigma = float(rng.choice([0.25, 0.5, 1.0, 2.0]))
+        delta = float(rng.choice([0.25, 1.0, 3.0, 100.0]))
+        xd, sd, qd = _dev(x, sj, q)
+        h = s.GroupNormL2.uniform(lam.tolist(), gs)
+        with np.errstate(all="ignore"):
+            ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, gsize=gs)
+        y = s.prox(s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd), qd, sigma).cpu().numpy()
+        S = ((q + x) + sj).reshape(ng, gs)
+        nS = np.linalg.norm(S, axis=1)
+        sc = np.maximum(np.abs(ref).reshape(ng, gs), nS[:, None])
+        canc = np.maximum(1.0, sigma * lam / np.maximum(nS, 1e-300))[:, None]   # the reference's own cancellation (section 4)
+        err = np.abs(y - ref).reshape(ng, gs) / np.maximum(sc, 1e-300) / canc
+        assert float(np.nanmax(err)) <= 1e-11, (gs, rep, float(np.nanmax(err)))
