@@ -68,7 +68,7 @@ __device__ __forceinline__ void team_sum2(double& a, double& b, double* lds) {
   }
 }
 
-// max over the team of a non-negative, NaN-free value
+// max over the team of a NaN-free value
 template <int TEAM>
 __device__ __forceinline__ double team_max(double v, double* lds) {
   v = fmax(v, dpp_f64<0xB1>(v));
@@ -371,6 +371,17 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
   if ((sS + sX < INFINITY) && (mX - taul * nS > delta * (1.0 + 1e-9)) && (ul < 1e-9 * delta)) {
     fl = -1.0;
   } else {
+    // No entry is safely active at lmin.  The A/B form gives the exact value of froot(lmin); the reference's own
+    // evaluation agrees with it unless some |X_i| equals Delta to the last bits: lmin sits one ulp above the pole of
+    // step(n), S/sigma - step X is formed at magnitude ~1e16, and such an entry comes out of softthres as 0, 1 or 2 by
+    // rounding alone -- which then decides the sign of froot(lmin), the bracket, and a bisection that ends on a spurious
+    // root next to the pole.  Those groups are handed to the literal evaluation, which reproduces exactly that
+    // (found by tools/fuzz_binf_scenarios.py: |X_i| = Delta gave the exact-arithmetic answer, not the reference's, in
+    // ~1 % of 2-element groups).
+    double gap = INFINITY;  // min over the group of | |X_i| - Delta |
+    grp.for_each([&](double, double X) { gap = fmin(gap, fabs(fabs(X) - delta)); });
+    gap = -team_max<TEAM>(-gap, lds);
+    if (gap <= 1e-9 * delta) return BINF_LITERAL;
     double sal, sbl;
     binf_ab<TEAM>(grp, taul, delta, lds, sal, sbl);
     fl = lmin - (lmin * fast_rcp(ul)) * sqrt_pos(__builtin_fma(taul * taul, sal, sbl));

@@ -963,3 +963,44 @@ def test_group_binf_lattice_and_zero_x(s, orc, gs):
         canc = np.maximum(1.0, sigma * lam / np.maximum(nS, 1e-300))[:, None]   # the reference's own cancellation (section 4)
         err = np.abs(y - ref).reshape(ng, gs) / np.maximum(sc, 1e-300) / canc
         assert float(np.nanmax(err)) <= 1e-11, (gs, rep, float(np.nanmax(err)))
+
+
+@pytest.mark.parametrize("gs", [2, 16, 128, 700])
+def test_group_binf_structured_scenarios(s, orc, gs):
+    """Structured data for GroupNormL2Binf: X = 0, tiny X, S = X, S = 0, data tiny / huge against lambda and Delta,
+    |X_i| = Delta EXACTLY (where the reference's froot(lmin) is decided by rounding at magnitude 1e16 and its bisection
+    ends on a spurious root next to the pole: the literal evaluation must reproduce that), constant groups, heavy tails."""
+    rng = np.random.default_rng(70 + gs)
+    ng = 400 if gs <= 16 else (120 if gs <= 128 else 20)
+    n = ng * gs
+
+    def scen(k):
+        x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
+        if k == 0: x[:] = 0.0
+        elif k == 1: x *= 1e-3
+        elif k == 2: q = -sj.copy()
+        elif k == 3: q = -(x + sj)
+        elif k == 4: q *= 1e-6; sj *= 1e-6; x *= 1e-6
+        elif k == 5: q *= 1e6
+        elif k == 6: x = np.sign(x) * 1.0
+        elif k == 7: q[:] = 0.25; x[:] = 0.5; sj[:] = 0.0
+        elif k == 8: x[::2] = 0.0; q[1::2] = 0.0
+        elif k == 9: x = rng.standard_cauchy(n); q = rng.standard_cauchy(n)
+        return x, sj, q
+
+    for k in range(10):
+        for sigma, delta in ((1.0, 1.0), (0.01, 1.0), (30.0, 0.1), (1.0, 50.0)):
+            x, sj, q = scen(k)
+            lam = 10.0 ** rng.uniform(-3, 2, size=ng)
+            xd, sd, qd = _dev(x, sj, q)
+            h = s.GroupNormL2.uniform(lam.tolist(), gs)
+            with np.errstate(all="ignore"):
+                ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, gsize=gs)
+            y = s.prox(s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd), qd, sigma).cpu().numpy()
+            S = ((q + x) + sj).reshape(ng, gs)
+            nS = np.linalg.norm(S, axis=1)
+            sc = np.maximum(np.abs(ref).reshape(ng, gs), nS[:, None])
+            canc = np.maximum(1.0, sigma * lam / np.maximum(nS, 1e-300))[:, None]
+            err = np.abs(y - ref).reshape(ng, gs) / np.maximum(sc, 1e-300) / canc
+            assert np.array_equal(np.isnan(y), np.isnan(ref))
+            assert float(np.nanmax(err)) <= 1e-10, (gs, k, sigma, delta, float(np.nanmax(err)))
