@@ -819,6 +819,7 @@ ORC_API void orc_prox_l1_b2(double* y, const double* q, const double* xk, const 
           double m = bit_middle(a, b);
           if (!(a < m && m < b)) break;
           double fm = b2_froot(&c, m);
+          if (fm == 0.0) { a = b = m; fa = fb = 0.0; break; } /* an exact zero is convergence for any find_zero method */
           if (jl_sign(fa) * jl_sign(fm) < 0) { b = m; fb = fm; } else { a = m; fa = fm; }
         }
         eta = (fabs(fa) < fabs(fb)) ? a : b;

@@ -1004,3 +1004,29 @@ def test_group_binf_structured_scenarios(s, orc, gs):
             err = np.abs(y - ref).reshape(ng, gs) / np.maximum(sc, 1e-300) / canc
             assert np.array_equal(np.isnan(y), np.isnan(ref))
             assert float(np.nanmax(err)) <= 1e-10, (gs, k, sigma, delta, float(np.nanmax(err)))
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 1000, 100_003])
+def test_l1b2_structured_scenarios(s, orc, n):
+    """x = 0, q = sj = 0, tiny / huge x, lattice data, constant vectors (the root is then hit exactly), heavy tails; tiny and
+    huge radii."""
+    rng = np.random.default_rng(300 + n)
+    for k in range(9):
+        x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
+        if k == 0: x[:] = 0.0
+        elif k == 1: q[:] = 0.0; sj[:] = 0.0
+        elif k == 2: x *= 1e-8
+        elif k == 3: x *= 1e8
+        elif k == 4: x = np.round(x * 4) / 4; q = np.round(q * 4) / 4; sj = np.round(sj * 4) / 4
+        elif k == 5: x[:] = 1.0; q[:] = -0.5; sj[:] = 0.25
+        elif k == 6: x[::2] = 0.0
+        elif k == 7: q = -sj + rng.choice([-1.0, 1.0], size=n) * 0.5
+        elif k == 8: x = rng.standard_cauchy(n)
+        xd, sd, qd = _dev(x, sj, q)
+        for lam, sigma, delta, chil in ((1.0, 1.0, 1.0, 1.0), (0.01, 1.0, 0.1, 1.0), (5.0, 2.0, 1e-3, 0.5), (0.5, 0.3, 1e3, 2.0),
+                                        (1.0, 1.0, 1e-12, 1.0)):
+            with np.errstate(all="ignore"):
+                ref = orc.prox_l1_b2(q, x, sj, lam, sigma, delta, chil)
+            y = s.prox(s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(chil)), sd), qd, sigma).cpu().numpy()
+            scale = max(np.linalg.norm(ref), np.linalg.norm(x), np.linalg.norm(sj + q), 1e-300)
+            assert float(np.max(np.abs(y - ref))) <= 1e-12 * scale, (n, k, lam, sigma, delta, chil)
