@@ -208,6 +208,10 @@ __device__ __forceinline__ void binf_ab(const G& grp, double tau, double delta, 
     sb += keep_if(b * b, act);
   });
   team_sum2<TEAM>(sa, sb, lds);
+  // keep_if leaves sub-2^-1042 residues of the masked-out terms in the sums: an empty set must sum to exactly 0 (the
+  // piece confirmation compares sums bit for bit, and sb == 0 identifies the all-inactive piece)
+  sa = (sa < 1e-300) ? 0.0 : sa;
+  sb = (sb < 1e-300) ? 0.0 : sb;
 }
 
 // Register-resident groups: true in the lanes of a team whose active set {i : |tau S_i - X_i| > Delta} is the same at
@@ -408,6 +412,11 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
     psi = u - sqrt_pos(__builtin_fma(tau * tau, sa, sb));
     tau_full = tau;
   }
+#ifdef SPX_DEBUG_BINF
+  if ((threadIdx.x % TEAM) == 0 && blockIdx.x == 0 && threadIdx.x < TEAM)
+    printf("[binf] sl %.17g lmin %.17g lmax %.17g ub %.17g nS %.17g nX %.17g mX %.17g fl %.17g from_bound %d u %.17g sa %.17g sb %.17g psi %.17g\n",
+           sl, lmin, lmax, ub, nS, nX, mX, fl, (int)from_bound, u, sa, sb, psi);
+#endif
   {
     // fm = froot(lmax) (:101).  When the bracket's upper end IS the root -- X = 0 and every entry thresholded at lmax,
     // the usual state at x0 = 0 with a wide trust region: lmax = ||S|| and froot(lmax) = ||S|| - ||S|| = 0 exactly in
@@ -432,7 +441,9 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
   }
   double pa = -1.0, pb = -1.0;  // sums of the piece solved last (A, B >= 0 always)
   for (int it = 0; it < SPX_BINF_NEWTON_MAXIT; ++it) {
-    if (psi == 0.0 || (sa == pa && sb == pb)) break;  // exact hit, or the piece just solved is confirmed
+    // converged: psi vanishes to rounding (|psi| <= 4 eps u: u is the root of its own piece to the last bits), or the piece
+    // just solved is confirmed by identical sums
+    if (fabs(psi) <= 4 * eps * u || (sa == pa && sb == pb)) break;
     if (psi < 0.0) ulo = u; else uhi = u;
     // root of the current piece: g(v) = v - sqrt(sb + sa (v / (sl + v))^2), scalar Newton from u
     // (the slope only steers the step: unrefined v_rcp/v_rsq seeds, ~1e-8 relative, are enough there; the step that
@@ -462,6 +473,9 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
         break;
       }
     }
+    // the piece's root is u itself (to rounding): converged -- must be seen BEFORE the bracket test below, which would
+    // otherwise reject v == u (u has just become a bracket end) and bisect away from the root
+    if (fabs(v - u) <= 4 * eps * fabs(u)) break;
     const bool exact_step = (v > ulo && v < uhi);  // v is the root of the piece (sa, sb)
     if (!exact_step) v = sqrt_pos(ulo) * sqrt_pos(uhi);  // safeguard: geometric bisection of the bracket
     if (!(v > ulo && v < uhi)) break;
@@ -483,6 +497,10 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
     binf_ab<TEAM>(grp, tau, delta, lds, sa, sb);
     psi = u - sqrt_pos(__builtin_fma(tau * tau, sa, sb));
     tau_full = tau;
+#ifdef SPX_DEBUG_BINF
+    if ((threadIdx.x % TEAM) == 0 && blockIdx.x == 0 && threadIdx.x < TEAM)
+      printf("[binf] it %d u %.17g sa %.17g sb %.17g psi %.17g ulo %.17g uhi %.17g exact %d\n", it, u, sa, sb, psi, ulo, uhi, (int)exact_step);
+#endif
   }
   double n0 = fmin(fmax(sl + u, lmin), lmax);
   if (u * 1000.0 > n0) {  // well conditioned in n: a few ulp of n cannot move step by more than ~1e-13
