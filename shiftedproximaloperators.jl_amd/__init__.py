@@ -10,6 +10,6 @@ from .shifted import (ShiftedGroupNormL2, ShiftedGroupNormL2Binf, ShiftedIndBall
                       ShiftedNormL0, ShiftedNormL0Box, ShiftedNormL1, ShiftedNormL1B2, ShiftedNormL1Box,
                       ShiftedProximableFunction, ShiftedRootNormLhalf, ShiftedRootNormLhalfBox, context, iprox,
                       iprox_bang, prox,
-                      prox_bang, prox_value, prox_value_bang, set_bounds_bang, set_radius_bang, shift_bang, shifted, synchronize)
+                      prox_bang, prox_value, prox_value_bang, set_bounds_bang, set_radius_bang, shift_bang, shifted, synchronize, value)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

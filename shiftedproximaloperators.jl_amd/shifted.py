@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .functions import (GroupNormL2, IndBallL0, NormL0, NormL1, NormL2, NormLinf, RootNormLhalf)
+from .functions import (GroupNormL2, IndBallL0, NormL0, NormL1, NormL2, NormLinf, ProximableFunction, RootNormLhalf)
 
 # ---------------------------------------------------------------------------------------------
 # contexts: one libspx context per (device, stream) so calls are ordered with the caller's torch work
@@ -547,9 +547,70 @@ def shifted(h, x, *args):
 # ---------------------------------------------------------------------------------------------
 # prox!, prox, shift!, set_radius!, set_bounds!
 # ---------------------------------------------------------------------------------------------
-def prox_bang(y, ψ, q, σ):
+# ---------------------------------------------------------------------------------------------
+# the unshifted value types: h(x) and prox!(y, h, x, γ)
+#   RootNormLhalf  src/rootNormLhalf.jl:27-51,  GroupNormL2  src/groupNormL2.jl:33-58 (defined by the reference itself);
+#   NormL0 / NormL1 / NormL2 / IndBallL0 evaluate like their ProximalOperators.jl namesakes [ext].
+# Run as the shifted operators with xk = sj = 0 (the same kernels: q + (0 + 0) = q and y - (0 + 0) = y are exact).
+# ---------------------------------------------------------------------------------------------
+_zero_cache = {}
+
+
+def _zeros_for(x):
+    """a zero vector of x's kind / length / device, cached (read-only use)"""
+    key = ("host", _n(x)) if _is_host(x) else (str(x.device), _n(x))
+    z = _zero_cache.get(key)
+    if z is None:
+        if len(_zero_cache) > 8:
+            _zero_cache.clear()
+        z = _zero_cache[key] = _zeros_like(x)
+    return z
+
+
+def _as_shifted(h, x):
+    z = _zeros_for(_vec(x, "x"))
+    if isinstance(h, NormL2):
+        h = GroupNormL2([h.lam])
+    if type(h) in _PLAIN:
+        ψ = _PLAIN[type(h)](h, z, z, False)
+    elif isinstance(h, IndBallL0):
+        ψ = ShiftedIndBallL0(h, z, z, False)
+    elif isinstance(h, GroupNormL2):
+        ψ = ShiftedGroupNormL2(h, z, z, False)
+    else:
+        raise TypeError("MethodError: %s has no accelerated evaluation" % type(h).__name__)
+    return ψ
+
+
+def value(h, x):
+    """h(x) for an unshifted value type, evaluated on the GPU (device tensor or host array x); a Python float."""
+    return _as_shifted(h, x)(x)
+
+
+def _unshifted_prox_bang(y, h, x, γ):
+    """prox!(y, h, x, γ) of the value types; returns what the reference's method returns: RootNormLhalf -> h(y)
+    (src/rootNormLhalf.jl:50), GroupNormL2 -> Σ λ_g ‖x_g‖ over the groups of the INPUT with a nonzero norm
+    (src/groupNormL2.jl:48-57), others -> h(y)."""
+    ψ = _as_shifted(h, x)
+    n = _n(x)
+    _vec(y, "y", n, like=x)
+    if isinstance(ψ, _Unboxed) and not ψ.host:
+        return prox_value_bang(y, ψ, x, γ)[1]           # one pass: y and h(y)
+    if isinstance(h, (GroupNormL2, NormL2)):
+        ysum = ψ(x)                                       # Σ λ_g ‖x_g‖ of the input (zero groups add nothing)
+        ψ._prox(_lib.load(), _ctx(_dev(y)), y, x, float(γ))
+        return ysum
+    ψ._prox(_lib.load(), _ctx(_dev(y)), y, x, float(γ))
+    return ψ(y)
+
+
+def prox_bang(y, ψ, q, σ=1.0):
     """prox!(y, ψ, q, σ): y <- argmin_t ½σ⁻¹‖t − q‖² + ψ(t); returns y.  Asynchronous on the current
-    torch stream.  y may be q itself or ψ.sol."""
+    torch stream.  y may be q itself or ψ.sol.
+    With an unshifted value type h in place of ψ this is the reference's prox!(y, h, x, γ) (src/rootNormLhalf.jl:31-51,
+    src/groupNormL2.jl:41-58) and returns the value that method returns."""
+    if isinstance(ψ, ProximableFunction):
+        return _unshifted_prox_bang(y, ψ, q, σ)
     if not isinstance(ψ, ShiftedProximableFunction):
         raise TypeError("ψ must be a ShiftedProximableFunction")
     n = _n(ψ.xk)
@@ -663,3 +724,8 @@ def synchronize(device=None):
     L = _lib.load()
     for c in list(_ctxs.values()):
         _lib.check(L.spx_sync(c))
+
+
+# h(x) on the value types themselves: `h(x)` as in the reference (`(f::RootNormLhalf)(x)`, `(f::GroupNormL2)(x)`, ...)
+for _T in (NormL0, NormL1, NormL2, RootNormLhalf, IndBallL0, GroupNormL2):
+    _T.__call__ = lambda self, x: value(self, x)

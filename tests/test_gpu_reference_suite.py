@@ -205,3 +205,49 @@ def test_groupnorml2_binf_flow(s, orc, kats):  # runtests.jl:558-650
     assert np.max(np.abs(sol)) <= delta * (1 + 1e-8)
     s.set_radius_bang(psi, 1.1)
     assert psi.Δ == 1.1
+
+
+def test_unshifted_rootnormlhalf(s, orc, kats):  # runtests.jl:113-126, src/rootNormLhalf.jl:27-51
+    k = kats["rootnormlhalf_unshifted"]
+    q = np.array(k["q"])
+    h = s.RootNormLhalf(k["lambda"])
+    y = np.empty_like(q)
+    ret = s.prox_bang(y, h, q, k["nu"])                    # prox!(y, h, q, ν) returns h(y)
+    assert float(np.sum((y - np.array(k["expected"])) ** 2)) <= k["sumsq_tol"]
+    yo, vo = orc.rootnormlhalf_prox(q, k["lambda"], k["nu"])
+    assert np.max(np.abs(y - yo)) <= 1e-12 and abs(ret - vo) <= 1e-12 * abs(vo)
+    assert _close(h(q), k["lambda"] * float(np.sum(np.sqrt(np.abs(q)))))      # (f::RootNormLhalf)(x)
+    # device vectors take the same path
+    import torch
+    qd = torch.from_numpy(q).cuda()
+    yd = torch.empty_like(qd)
+    retd = s.prox_bang(yd, h, qd, k["nu"])
+    assert np.array_equal(yd.cpu().numpy(), y) and retd == ret
+    with pytest.raises(ValueError):
+        s.RootNormLhalf(-1.0)
+
+
+def test_unshifted_groupnorml2(s, orc):  # runtests.jl:128-155, src/groupNormL2.jl:33-58
+    rng = np.random.default_rng(6)
+    x = rng.random(6)
+    v = [range(0, 3), [3, 4, 5]]                           # `v = [1:3, collect(4:6)]`
+    lam = rng.random(2)
+    nu = float(rng.random())
+    h = s.GroupNormL2(lam.tolist(), v)
+    y = np.empty_like(x)
+    ysum = s.prox_bang(y, h, x, nu)
+    ytrue = np.empty_like(x)
+    ysumt = 0.0
+    for l, g in zip(lam, v):                               # per group NormL2 prox [ext]: returns λ‖prox‖
+        xg = x[list(g)]
+        ng = np.linalg.norm(xg)
+        ytrue[list(g)] = max(1 - nu * l / ng, 0.0) * xg
+        ysumt += l * ng
+    assert float(np.sum((y - ytrue) ** 2)) <= 1e-11
+    assert abs(ysum - ysumt) <= 1e-12 * ysumt               # the reference returns Σ λ ‖x_g‖ of the INPUT (:52)
+    assert abs(h(x) - ysumt) <= 1e-11                       # norm value (runtests.jl:148-154)
+    # the other value types evaluate too
+    assert _close(s.NormL1(0.5)(x), 0.5 * float(np.sum(np.abs(x))))
+    assert s.NormL0(2.0)(np.array([0.0, 1.0, -0.0, 3.0])) == 4.0
+    assert s.IndBallL0(1)(np.array([0.0, 1.0, 0.0])) == 0.0 and s.IndBallL0(1)(np.array([2.0, 1.0, 0.0])) == np.inf
+    assert _close(s.NormL2(0.3)(x), 0.3 * float(np.linalg.norm(x)))
