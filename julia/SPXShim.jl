@@ -154,6 +154,27 @@ function prox!(y::DVec, ψ::ShiftedIndBallL0BInf{<:Integer, Float64, <:DVec, <:D
 end
 
 # ---------------------------------------------------------------------------------------------
+# the unshifted value types the reference defines itself: prox!(y, h, x, γ) and h(x) on device arrays
+#   RootNormLhalf  src/rootNormLhalf.jl:27-51   (returns h(y)),   GroupNormL2  src/groupNormL2.jl:33-58
+# They run the shifted kernels with xk = sj = 0 (q + (0 + 0) = q and y - (0 + 0) = y are exact).
+# ---------------------------------------------------------------------------------------------
+const ZEROS = Dict{Int, ROCVector{Float64}}()
+zeros_for(n) = get!(() -> AMDGPU.zeros(Float64, n), ZEROS, n)
+
+function prox!(y::DVec, f::ShiftedProximalOperators.RootNormLhalf{Float64}, x::DVec, γ::Real = 1.0)
+  n = length(x); z = zeros_for(n); out = Ref{Cdouble}(0.0)
+  check(ccall((:spx_proxval_lhalf, libspx), Cint,
+              (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}),
+              ctx(), dptr(y), dptr(x), dptr(z), dptr(z), n, f.lambda, Float64(γ), 1.0, out))
+  return out[]                                                   # λ Σ sqrt|y_i|, as :50
+end
+(f::ShiftedProximalOperators.RootNormLhalf{Float64})(x::DVec) =
+  (z = zeros_for(length(x)); objective(:spx_obj_lhalf, (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble),
+                                       dptr(x), dptr(z), dptr(z), length(x), f.lambda))
+# GroupNormL2: prox!(y, f, x, γ) = group_call on ψ = shifted(f, zeros) with q = x; its return value Σ λ_g ‖x_g‖ is
+# spx_obj_group_l2 of the input (layout_for(f, n) supplies offsets / gather indices / weights, as in group_call).
+
+# ---------------------------------------------------------------------------------------------
 # prox! fused with h at the result (no counterpart in the reference; what R2 does in two steps:
 # `prox!(s, ψ, mν∇fk, ν)` then `hkn = ψ(s)`): one pass over the vectors instead of two.  Headline operator shown;
 # spx_proxval_l1 / l0 / lhalf / l0_box / lhalf_box follow the same pattern.
