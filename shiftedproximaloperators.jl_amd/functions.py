@@ -106,6 +106,32 @@ class GroupNormL2(ProximableFunction):
         obj.idx = UniformGroups(int(group_size), nlam)
         return obj
 
+    @classmethod
+    def ragged(cls, lam, offsets):
+        """Consecutive groups of different sizes from their CSR offsets (length ngroups + 1, 0-based), without a Python
+        range per group; equivalent to GroupNormL2(lam, [range(o[g], o[g+1]) for g in ...])."""
+        groups = RaggedGroups(offsets)
+        obj = cls(lam, [None] * len(groups))
+        obj.idx = groups
+        return obj
+
+
+class RaggedGroups:
+    """idx of GroupNormL2.ragged: consecutive groups [offsets[g], offsets[g+1]) given by their CSR offsets."""
+
+    def __init__(self, offsets):
+        import numpy as np
+        off = np.ascontiguousarray(offsets.cpu().numpy() if hasattr(offsets, "cpu") else offsets, dtype=np.int64)
+        if off.ndim != 1 or off.size < 1 or off[0] < 0 or np.any(np.diff(off) < 0):
+            raise ValueError("offsets must be a non-decreasing 1-D sequence starting at >= 0")
+        self.offsets = off
+
+    def __len__(self):
+        return self.offsets.size - 1
+
+    def __iter__(self):
+        return (range(int(a), int(b)) for a, b in zip(self.offsets[:-1], self.offsets[1:]))
+
 
 class UniformGroups:
     """idx of GroupNormL2.uniform: `count` consecutive groups of `size` indices."""

@@ -368,6 +368,20 @@ class _GroupLayout:
             self.lam = self._lam(h.lam, device)
             return
         self.index = None  # gather mode: (ptr, index) instead of offsets
+        from .functions import RaggedGroups
+        if isinstance(h.idx, RaggedGroups):
+            off = h.idx.offsets
+            if off[-1] > n:
+                raise IndexError("BoundsError: group offsets reach %d, vector length %d" % (int(off[-1]), n))
+            self.ngroups = len(h.idx)
+            sizes = np.diff(off)
+            if self.ngroups and n > 0 and off[0] == 0 and off[-1] == n and np.all(sizes == sizes[0]):
+                self.offsets, self.group_size = None, int(sizes[0])
+            else:
+                self.offsets = off if device is None else torch.from_numpy(off).to(device)
+                self.group_size = int(sizes.max()) if self.ngroups else 0   # size bound (hint for the tile kernels)
+            self.lam = self._lam(h.lam, device)
+            return
         bounds, sets, contiguous = [], [], True
         for g in h.idx:
             if isinstance(g, slice):

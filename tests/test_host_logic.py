@@ -75,6 +75,14 @@ def test_group_layouts(s):
     assert u.group_size == 4 and u.ngroups == 3 and u.lam.tolist() == [0.5, 0.6, 0.7]
     with pytest.raises(IndexError):
         s.shifted(s.GroupNormL2.uniform([0.5, 0.6], 4), x)
+    r = s.shifted(s.GroupNormL2.ragged([1.0, 2.0, 3.0], [0, 5, 6, 12]), x)._layout        # CSR offsets, no Python ranges
+    assert r.offsets.tolist() == [0, 5, 6, 12] and r.group_size == 6 and r.ngroups == 3 and r.index is None
+    r = s.shifted(s.GroupNormL2.ragged([1.0, 2.0], [0, 6, 12]), x)._layout
+    assert r.offsets is None and r.group_size == 6                                         # uniform after all
+    with pytest.raises(ValueError):
+        s.GroupNormL2.ragged([1.0, 2.0], [0, 7, 5])
+    with pytest.raises(IndexError):
+        s.shifted(s.GroupNormL2.ragged([1.0], [0, 13]), x)
     one = s.shifted(s.NormL2(0.3), x)                                    # NormL2 -> one group [:]
     assert type(one).__name__ == "ShiftedGroupNormL2" and one._layout.ngroups == 1 and one._layout.group_size == 12
 

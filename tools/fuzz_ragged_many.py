@@ -14,7 +14,7 @@ for maxsize, ng in ((4, 150_000), (9, 100_000), (33, 50_000), (130, 20_000), (60
         lam = rng.uniform(0.05, 2.0, size=ng) * lscale
         xd, sd, qd = (torch.from_numpy(a).cuda() for a in (x, sj, q))
         groups = [range(int(a), int(b)) for a, b in zip(off[:-1], off[1:])]
-        h = s.GroupNormL2(torch.from_numpy(lam).cuda(), groups)
+        h = s.GroupNormL2.ragged(torch.from_numpy(lam).cuda(), off)
         S = (q + x) + sj
         nS = np.sqrt(np.add.reduceat(S * S, off[:-1]))
         for binf in (False, True):
