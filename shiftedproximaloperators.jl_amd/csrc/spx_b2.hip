@@ -280,9 +280,19 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   if (blocks < 1) blocks = 1;
   // y = ProjB(-xk); chi(y) = chi_lambda * ||y||: at r = 1,  ||y||^2 = P + C
   double P, C, F;
-  rc = b2_sums(ctx, q, xk, sj, n, ls, 1.0, ws, (int)blocks, vec, true, &P, &C, &F);
+  // y overlaps none of the inputs: reduction passes may store y for their own scale (see below).  The first pass does:
+  // if the trust region turns out to be inactive (Delta > chi(y), :61) its y = ProjB(-xk) - sj is the result and the call
+  // is this one pass
+  auto disjoint = [&](const double* a) { return (y + n <= a) || (a + n <= y); };
+  const bool can_spec = vec && disjoint(q) && disjoint(xk) && disjoint(sj);
+  // (a store that turns out useless costs 8 B/element: the pass only stores when the previous call on this context was
+  //  unscaled too -- 0.57 ms instead of 0.85 ms for an inactive trust region, 1.35 ms unchanged for an active one)
+  const bool store_first = can_spec && !ctx->b2_last_scaled;
+  rc = b2_sums(ctx, q, xk, sj, n, ls, 1.0, ws, (int)blocks, vec, true, &P, &C, &F, store_first ? y : nullptr, 1.0);
   if (rc) return rc;
   const double chiy = chi_lambda * std::sqrt(P + C);
+  ctx->b2_last_scaled = (delta <= chiy) ? 1 : 0;
+  if (!(delta <= chiy) && store_first) return SPX_OK;  // unscaled and already stored
   int scaled = 0;
   double eta = delta;
   double y_eta = -1.0;  // eta for which a reduction pass has stored y (speculatively), or -1
@@ -304,8 +314,6 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
     // y overlaps none of the inputs: a pass that is likely to be the last one (the step has become small) also stores y
     // for its eta; the iteration always ends on an eta that a pass has evaluated, so if that pass stored y the final
     // pass below is skipped (the call then costs the reduction passes only)
-    auto disjoint = [&](const double* a) { return (y + n <= a) || (a + n <= y); };
-    const bool can_spec = vec && disjoint(q) && disjoint(xk) && disjoint(sj);
     for (int it = 0; it < 200; ++it) {
       const double r = eta / delta;
       const double f = eta - chi_lambda * std::sqrt(r * r * P + C);

@@ -25,6 +25,9 @@ struct spx_ctx {
   // device staging area of the host-pointer entry points (spx_host.hip); grown on demand, never shrunk
   void* stage = nullptr;
   size_t stage_bytes = 0;
+  // ShiftedNormL1B2: did the last call take the scaled branch (trust region active)?  Only steers whether the first
+  // reduction pass also stores y (it is the result when the trust region is inactive); never affects results.
+  int b2_last_scaled = 0;
 };
 
 void spx_set_error(const char* fmt, ...);
