@@ -368,7 +368,8 @@ __global__ __launch_bounds__(256) void k_sel_final(double* y, const double* xk, 
 //   4. k_s2_scan_verify   the verdict  cnt_above < r <= cnt_above + candidates  and the first scan step of the
 //                    selection among the candidates; k_s2_compact + k_s2_finish resolve the
 //                    rest on a short list in one workgroup (regions are walked transposed: 64 regions per wavefront)
-//   5a. k_s2_fixup   (y disjoint) stores the kept value of the candidates that made the cut: ~0.25 % of y, scattered
+//   5a. (y disjoint) k_s2_compact / k_s2_finish also store the kept value of the candidates that make the cut
+//                    (~0.25 % of y, scattered): no further pass
 //   5b. k_sel_final_q (y aliases an input) y[i] from q, xk, sj and the thresholds (24 B read + 8 B written per element)
 // Total 32 B/element (+ ~1 % for the candidates) in the disjoint case, 56 B/element when y aliases an input, instead
 // of >= 80.  The prediction is only a performance device: if the verification fails (or a region overflows) the
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
 // band and appends the band's elements to the wave's own candidate region.
 // WRITE (y overlaps none of the inputs): the pass also stores y, speculatively -- entries above the band as kept,
 // entries below it and inside it as dropped; the kept value of a band entry travels with the candidate and
-// k_s2_fixup stores it once the cut is known.  The call then moves the algorithmic 32 B/element plus the ~0.5 % of
+// k_s2_compact / k_s2_finish store it once the cut is known.  The call then moves the algorithmic 32 B/element plus the ~0.5 % of
 // candidates, instead of 56 B/element with the separate final pass (k_sel_final_q, used when y aliases an input).
 template <bool BINF, bool WRITE>
 __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, const double* xk_, const double* sj_,
@@ -649,16 +650,6 @@ __device__ __forceinline__ void for_each_candidate(const WaveCount* counts, int6
   }
 }
 
-// the kept band entries get their value (everything else was stored by k_s2_main<.., true>)
-__global__ __launch_bounds__(256) void k_s2_fixup(double* y, const Cand* cand, const SelWs* ws, const WaveCount* counts,
-                                                   int64_t nregions) {
-  if (!ws->fs.ok) return;
-  const SelState st = ws->st;
-  for_each_candidate(counts, nregions, cand, [&](uint64_t key, int64_t i, double v) {
-    if ((key >= st.t_ge) || (key == st.t_eq && i <= st.icut)) y[i] = v;
-  });
-}
-
 // One workgroup: the verdict (is the r-th largest provably inside the band?), then the first scan step.
 __global__ __launch_bounds__(256) void k_s2_scan_verify(SelWs* ws, int64_t r) {
   __shared__ unsigned long long scratch[8];
@@ -699,25 +690,48 @@ __global__ __launch_bounds__(256) void k_s2_scan_verify(SelWs* ws, int64_t r) {
   for (int b = threadIdx.x; b < kBins; b += blockDim.x) ws->hist[b] = 0ull;
 }
 
-// after the first candidate digit: the candidates still in play (same decided prefix, or tied key) -> short list
-__global__ __launch_bounds__(256) void k_s2_compact(const Cand* cand, SelWs* ws,
-                                                     uint64_t* list_key, int64_t* list_idx, const WaveCount* counts,
+// after the first candidate digit: the candidates still in play (same decided prefix, or tied key) -> short list.
+// WRITE (single-pass form): candidates that the first digit already puts above the cut get their kept value here; the
+// short list carries the values of the rest and k_s2_finish stores those that make it -- no separate fix-up walk.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_s2_compact(double* y, const Cand* cand, SelWs* ws, uint64_t* list_key,
+                                                     int64_t* list_idx, double* list_val, const WaveCount* counts,
                                                      int64_t nregions) {
   const SelState st = ws->st;
-  if (!ws->fs.ok || st.phase == 2) return;
+  if (!ws->fs.ok) return;
+  if (!WRITE && st.phase == 2) return;
   const int hs = st.shift + st.width;
-  for_each_candidate(counts, nregions, cand, [&](uint64_t key, int64_t i, double) {
-    const bool in = (st.phase == 0) ? ((hs >= 64 ? 0ull : (key >> hs)) == st.prefix)
-                                    : (key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix);
+  for_each_candidate(counts, nregions, cand, [&](uint64_t key, int64_t i, double val) {
+    bool in = false, keep = false;
+    if (st.phase == 2) {  // resolved by the first digit already
+      keep = (key >= st.t_ge) || (key == st.t_eq && i <= st.icut);
+    } else if (st.phase == 0) {  // key digits: compare everything decided so far
+      const uint64_t top = hs >= 64 ? 0ull : (key >> hs);
+      in = top == st.prefix;
+      keep = top > st.prefix;
+    } else {  // index digits of the tied key: lower indices are kept first
+      const uint64_t itop = ((uint64_t)i) >> hs;
+      in = key == st.t_eq && itop == st.prefix;
+      keep = (key >= st.t_ge) || (key == st.t_eq && itop < st.prefix);
+    }
     if (in) {
       const unsigned int slot = atomicAdd(&ws->fs.list_count, 1u);
-      if (slot < (unsigned)kShortList) { list_key[slot] = key; list_idx[slot] = i; }
+      if (slot < (unsigned)kShortList) {
+        list_key[slot] = key;
+        list_idx[slot] = i;
+        if constexpr (WRITE) list_val[slot] = val;
+      }
+    }
+    if constexpr (WRITE) {
+      if (keep) y[i] = val;
     }
   });
 }
 
 // one workgroup: finishes the selection on the short list, entirely in LDS
-__global__ __launch_bounds__(1024) void k_s2_finish(SelWs* ws, const uint64_t* list_key, const int64_t* list_idx) {
+template <bool WRITE>
+__global__ __launch_bounds__(1024) void k_s2_finish(double* y, SelWs* ws, const uint64_t* list_key, const int64_t* list_idx,
+                                                     const double* list_val) {
   __shared__ uint64_t lk[kShortList];
   __shared__ int64_t li[kShortList];
   __shared__ unsigned int h[kBins];
@@ -756,6 +770,14 @@ __global__ __launch_bounds__(1024) void k_s2_finish(SelWs* ws, const uint64_t* l
   }
   __syncthreads();
   if (t == 0) ws->st = sst;
+  if constexpr (WRITE) {  // the short-list entries that made the cut (everything above it was stored by k_s2_compact)
+    const SelState fin = sst;
+    for (unsigned int e = t; e < m; e += 1024) {
+      const uint64_t key = lk[e];
+      const int64_t i = li[e];
+      if ((key >= fin.t_ge) || (key == fin.t_eq && i <= fin.icut)) y[i] = list_val[e];
+    }
+  }
 }
 
 // final pass of the fast path: v recomputed from q, xk, sj (y untouched so far)
@@ -825,7 +847,8 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   const size_t off_ckey = (off_cnt + (size_t)nregions * sizeof(WaveCount) + 255) & ~(size_t)255;
   const size_t off_lkey = off_ckey + (size_t)ccap * sizeof(Cand);
   const size_t off_lidx = off_lkey + (size_t)kShortList * sizeof(uint64_t);
-  rc = spx_ws_reserve(ctx, off_lidx + (size_t)kShortList * sizeof(int64_t) + 256);
+  const size_t off_lval = off_lidx + (size_t)kShortList * sizeof(int64_t);
+  rc = spx_ws_reserve(ctx, off_lval + (size_t)kShortList * sizeof(double) + 256);
   if (rc) return rc;
   SelWs* ws = reinterpret_cast<SelWs*>(ctx->ws);
   if (try_fast) {
@@ -838,6 +861,7 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     const bool write = g_sel_spec && disjoint(q) && disjoint(xk) && disjoint(sj);
     uint64_t* lkey = reinterpret_cast<uint64_t*>(wsb + off_lkey);
     int64_t* lidx = reinterpret_cast<int64_t*>(wsb + off_lidx);
+    double* lval = reinterpret_cast<double*>(wsb + off_lval);
     hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, ctx->stream, ws, n, r);
     hipLaunchKernelGGL(k_s2_sample, dim3(256), dim3(256), 0, ctx->stream, q, xk, sj, n, samp, ws);
     hipLaunchKernelGGL(k_s2_pick, dim3(1), dim3(1024), 0, ctx->stream, (const double*)samp, n, r, ws);
@@ -851,15 +875,19 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     // the main pass has already histogrammed the first candidate digit: verdict + first scan step, survivors ->
     // short list, the rest of the selection in one workgroup
     hipLaunchKernelGGL(k_s2_scan_verify, dim3(1), dim3(256), 0, ctx->stream, ws, r);
-    hipLaunchKernelGGL(k_s2_compact, dim3(512), dim3(256), 0, ctx->stream, (const Cand*)cand, ws, lkey, lidx,
-                       (const WaveCount*)counts, nregions);
-    hipLaunchKernelGGL(k_s2_finish, dim3(1), dim3(1024), 0, ctx->stream, ws, (const uint64_t*)lkey, (const int64_t*)lidx);
-    if (write)
-      hipLaunchKernelGGL(k_s2_fixup, dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, (const SelWs*)ws,
-                         (const WaveCount*)counts, nregions);
-    else
+    if (write) {
+      hipLaunchKernelGGL((k_s2_compact<true>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, ws, lkey, lidx,
+                         lval, (const WaveCount*)counts, nregions);
+      hipLaunchKernelGGL((k_s2_finish<true>), dim3(1), dim3(1024), 0, ctx->stream, y, ws, (const uint64_t*)lkey,
+                         (const int64_t*)lidx, (const double*)lval);
+    } else {
+      hipLaunchKernelGGL((k_s2_compact<false>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, ws, lkey, lidx,
+                         lval, (const WaveCount*)counts, nregions);
+      hipLaunchKernelGGL((k_s2_finish<false>), dim3(1), dim3(1024), 0, ctx->stream, y, ws, (const uint64_t*)lkey,
+                         (const int64_t*)lidx, (const double*)lval);
       hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1535) / 1536)), dim3(256), 0, ctx->stream, y, q,
                          xk, sj, n, (const SelWs*)ws, delta);
+    }
     SPX_LAUNCH_CHECK();
     // the verdict is read back AFTER the speculative final pass has been queued: the GPU never idles on the host
     int ok = 0;
