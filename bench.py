@@ -17,6 +17,9 @@ One JSON line on rank 0: metric/value/... plus
                    duration measured with HIP events on the launching stream over the timed region
   cpu_baseline  -- the CPU oracle (literal single-thread C restatement of the reference's Julia loop; the
                    reference itself cannot run here: no Julia) timed on rank 0's host core
+  other_operators         -- the other BASELINE configs and the adjacent calls (iprox!, psi(y), prox! + psi in one pass,
+                             ShiftedNormL1B2, vector bounds, the PCIe-inclusive host-pointer form) at full size
+  cpu_port_other_configs  -- the single-thread CPU port on bounded samples of the other configs
 """
 import argparse
 import ctypes
