@@ -33,7 +33,7 @@ struct SelState {
   int shift;          // low bit of the digit the next histogram pass looks at
   int width;          // its width in bits
   int pad;
-  uint64_t prefix;    // phase 0: decided high key bits (>> (shift + width)); phase 1: decided high index bits
+  uint64_t prefix;    // phase 1: decided high index bits (phase 0 carries what is decided in `base`)
   int64_t quota;      // how many elements are still to be taken from the current bucket
   uint64_t t_ge;      // keep if key >= t_ge
   uint64_t t_eq;      // keep if key == t_eq && index <= icut
@@ -41,7 +41,40 @@ struct SelState {
   int idx_bits;       // number of significant bits of n - 1
   int pad2;
   uint64_t t_floor;   // candidate mode: no kept key is below this (0 in the full-vector mode)
+  // phase 0: the part of key space still undecided is [base, base + 2^(shift + width)); keys above it are kept, keys
+  // below it dropped, and the digit of a key inside it is (key - base) >> shift.  The interval follows the DATA (first
+  // candidate digit: base = low end of the band, 2^(shift + width) just above the band's span), not the bit pattern:
+  // a band that straddles an exponent boundary still spreads over >= 2048 bins.  clamp != 0: the interval is open above
+  // and the last bin takes everything from (nb - 1) << shift on (first candidate digit when the band has no upper end).
+  uint64_t base;
+  int clamp;
+  int pad3;
 };
+
+// phase-0 position of a key (see SelState::base)
+struct KeyPos {
+  bool in, above;
+  unsigned int digit;
+};
+__device__ __forceinline__ KeyPos key_pos(uint64_t key, uint64_t base, int shift, int width, int clamp) {
+  const int hs = shift + width;
+  const uint64_t rel = key - base;
+  const bool ge = key >= base;
+  const unsigned int last = (1u << width) - 1u;
+  const uint64_t d = rel >> shift;  // shift <= 52
+  KeyPos r;
+  if (clamp) {
+    r.in = ge;
+    r.above = false;
+    r.digit = d > last ? last : (unsigned int)d;
+  } else {
+    const bool inside = hs >= 64 || (rel >> hs) == 0;
+    r.in = ge && inside;
+    r.above = ge && !inside;
+    r.digit = (unsigned int)d & last;
+  }
+  return r;
+}
 
 // state of the sample-predicted path (see "fast path" below)
 struct FastState {
@@ -52,6 +85,7 @@ struct FastState {
   int key_passes;                 // key-digit passes the candidate selection can need (host reads ok + this)
   int overflow;                   // a workgroup or the candidate buffer overflowed
   unsigned int list_count;        // entries appended to the short list by k_s2_compact
+  unsigned long long smax;        // largest FINITE sample key (k_s2_sample; zeroed by k_sel_init)
 };
 
 // totals of the main pass: fire-and-forget atomics of its wavefronts, spread over kShards lines (wave w -> shard
@@ -124,8 +158,11 @@ __global__ void k_sel_init(SelWs* ws, int64_t n, int64_t r) {
     s.prefix = 0;
     s.icut = -1;
     s.t_eq = ~0ull;
-    s.pad = s.pad2 = 0;
+    s.pad = s.pad2 = s.pad3 = 0;
     s.t_floor = 0;
+    s.base = 0;
+    s.clamp = 0;
+    ws->fs.smax = 0ull;
     if (r <= 0) {            // nothing kept
       s.phase = 2; s.t_ge = ~0ull; s.quota = 0; s.shift = 0; s.width = 0;
     } else if (r >= n) {     // everything kept
@@ -204,7 +241,8 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double* y, int64_t n, in
   auto visit = [&](double v, int64_t i) {
     const uint64_t key = key_of(v);
     if (st.phase == 0) {
-      if ((hs >= 64 ? 0ull : (key >> hs)) == st.prefix) atomicAdd(&lh[(key >> shift) & dmask], 1u);
+      const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
+      if (kp.in) atomicAdd(&lh[kp.digit], 1u);
     } else {
       if (key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix) atomicAdd(&lh[(((uint64_t)i) >> shift) & dmask], 1u);
     }
@@ -267,16 +305,17 @@ __device__ __forceinline__ void sel_scan_step(const Hist& hist, const SelState s
     const uint64_t bucket = found[0];
     const int64_t left = (int64_t)(quota - found[1]);  // to be taken from this bucket
     const uint64_t count = found[2];
-    const uint64_t newprefix = (st.width >= 64 ? 0ull : (st.prefix << st.width)) | bucket;
+    const uint64_t newprefix = (st.width >= 64 ? 0ull : (st.prefix << st.width)) | bucket;  // (phase 1)
     SelState o = st;
     if (st.phase == 0) {
+      const uint64_t lowkey = st.base + (bucket << st.shift);  // low end of the bucket (no overflow: see k_s2_pick)
+      const bool open_top = st.clamp && bucket == (uint64_t)(nb - 1);  // the bucket has no upper end
       if ((uint64_t)left == count) {                    // the whole bucket is kept: resolved, no tie
         o.phase = 2;
-        const uint64_t lowkey = newprefix << st.shift;
         o.t_ge = lowkey > st.t_floor ? lowkey : st.t_floor;
-      } else if (st.shift == 0) {                       // full key known, more equal keys than quota: tie
-        o.t_ge = newprefix + 1;                         // keys are < 2^63: no overflow
-        o.t_eq = newprefix;
+      } else if (st.shift == 0 && !open_top) {          // full key known, more equal keys than quota: tie
+        o.t_ge = lowkey + 1;                            // keys are < 2^63: no overflow
+        o.t_eq = lowkey;
         o.quota = left;
         o.phase = 1;
         o.prefix = 0;
@@ -285,11 +324,13 @@ __device__ __forceinline__ void sel_scan_step(const Hist& hist, const SelState s
         if (top == 0) { o.phase = 2; o.icut = 0; }      // n == 1 cannot get here, kept for safety
         o.shift = top - w;
         o.width = w;
-      } else {
-        o.prefix = newprefix;
+      } else {                                          // next digit inside this bucket
+        o.base = lowkey;
+        o.clamp = 0;
         o.quota = left;
-        int w = st.shift < kDigitBits ? st.shift : kDigitBits;
-        o.shift = st.shift - w;
+        const int rem = open_top ? 64 : st.shift;       // undecided bits of (key - lowkey)
+        const int w = rem < kDigitBits ? rem : kDigitBits;
+        o.shift = rem - w;
         o.width = w;
       }
     } else {
@@ -390,7 +431,15 @@ __global__ __launch_bounds__(256) void k_s2_sample(const double* q, const double
   const int64_t i = start + threadIdx.x;
   const double a = fabs((xk[i] + sj[i]) + q[i]);
   samp[c * 256 + threadIdx.x] = a;
-  atomicAdd(&lh[key_of(a) >> (64 - kDigitBits)], 1u);
+  const uint64_t key = key_of(a);
+  atomicAdd(&lh[key >> (64 - kDigitBits)], 1u);
+  // largest finite sample key: scales the first candidate digit when the band has no upper end (k_s2_pick)
+  unsigned long long m = key < kInfKey ? key : 0ull;
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(m, off, 64);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(&ws->fs.smax, m);
   flush_hist(lh, ws->hist);
 }
 
@@ -482,32 +531,47 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
     f.list_count = 0;
     // (the shard counters are zeroed below by lanes 0..kShards-1)
     // digit machinery of the candidate selection: everything that depends on the band only (the counts -- verdict,
-    // quota -- are filled in by k_s2_scan_verify).  First digit = the first one in which the band's ends differ.
+    // quota -- are filled in by k_s2_scan_verify).  The first digit spreads the band's SPAN over the bins (SelState::base).
     SelState& s = ws->st;
     s.t_floor = f.t_lo;
     s.t_eq = ~0ull;
     s.icut = -1;
     s.t_ge = ~0ull;
     s.quota = 0;
-    const uint64_t d = f.t_lo ^ f.t_hi;
-    if (d == 0) {  // one key value in the band: straight to the index tie-break
+    s.prefix = 0;
+    s.base = f.t_lo;
+    s.clamp = 0;
+    if (!active[0]) {
+      // no upper end (r is small against the sample's resolution): bins sized so that the largest finite sample sits
+      // in bin 512..1023 and the last bin (open above) starts 4-8x as far from the band's low end; whatever lies beyond
+      // (outliers, Inf, NaN) shares that last bin and is resolved on the short list
+      const uint64_t smax = f.smax > f.t_lo ? f.smax : f.t_lo;
+      const uint64_t dist = (smax - f.t_lo) | 1ull;
+      const int bits = 64 - __clzll((long long)dist);
+      int shift = bits - 10;
+      if (shift < 0) shift = 0;
+      if (shift > 51) shift = 51;  // t_lo + (4095 << 51) < 2^64
+      s.phase = 0;
+      s.shift = shift;
+      s.width = kDigitBits;
+      s.clamp = 1;
+      f.key_passes = 6;
+    } else if (f.t_lo == f.t_hi) {  // one key value in the band: straight to the index tie-break
       s.t_ge = f.t_lo + 1;
       s.t_eq = f.t_lo;
       s.phase = 1;
-      s.prefix = 0;
       const int idx_bits = s.idx_bits;
       const int w = idx_bits % kDigitBits ? idx_bits % kDigitBits : kDigitBits;
       s.shift = idx_bits - w;
       s.width = w;
     } else {
-      const int hb = 63 - __clzll((long long)d);  // highest differing bit
-      f.key_passes = (hb + 1 + kDigitBits - 1) / kDigitBits;
-      const int width = hb + 1 < kDigitBits ? hb + 1 : kDigitBits;
-      const int shift = hb + 1 - width;
+      const uint64_t span = f.t_hi - f.t_lo;      // > 0
+      const int bits = 64 - __clzll((long long)span);  // span < 2^bits: every band key is inside [base, base + 2^bits)
+      const int width = bits < kDigitBits ? bits : kDigitBits;
+      f.key_passes = (bits + kDigitBits - 1) / kDigitBits;
       s.phase = 0;
-      s.shift = shift;
+      s.shift = bits - width;
       s.width = width;
-      s.prefix = (shift + width >= 64) ? 0ull : (f.t_hi >> (shift + width));
     }
   }
   if (t < kShards) { ws->shard_above[t * kShardStride] = 0ull; ws->shard_cand[t * kShardStride] = 0ull; }
@@ -525,8 +589,9 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
   const uint64_t t_hi = ws->fs.t_hi, t_lo = ws->fs.t_lo;
   // first digit of the selection among the candidates (set up by k_s2_pick): histogrammed right here, one
   // fire-and-forget global atomic per candidate (~0.5 % of the elements, spread over the band's bins)
-  const int d_phase = ws->st.phase, d_shift = ws->st.shift, d_hs = ws->st.shift + ws->st.width;
-  const uint64_t d_mask = ((uint64_t)1 << ws->st.width) - 1, d_prefix = ws->st.prefix, d_teq = ws->st.t_eq;
+  const int d_phase = ws->st.phase, d_shift = ws->st.shift, d_width = ws->st.width, d_clamp = ws->st.clamp;
+  const int d_hs = d_shift + d_width;
+  const uint64_t d_mask = ((uint64_t)1 << d_width) - 1, d_prefix = ws->st.prefix, d_teq = ws->st.t_eq;
   const f64x2* q = reinterpret_cast<const f64x2*>(q_);
   const f64x2* xk = reinterpret_cast<const f64x2*>(xk_);
   const f64x2* sj = reinterpret_cast<const f64x2*>(sj_);
@@ -565,8 +630,8 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
         if constexpr (WRITE) cand[rbase + pos].val = kept;
       }
       if (in_band) {
-        if (d_phase == 0) {
-          if ((d_hs >= 64 ? 0ull : (key >> d_hs)) == d_prefix) atomicAdd(&ws->hist[(key >> d_shift) & d_mask], 1ull);
+        if (d_phase == 0) {  // every band key is inside the first digit's interval (base = t_lo)
+          atomicAdd(&ws->hist[key_pos(key, t_lo, d_shift, d_width, d_clamp).digit], 1ull);
         } else if (key == d_teq && (((uint64_t)i) >> d_hs) == d_prefix) {
           atomicAdd(&ws->hist[(((uint64_t)i) >> d_shift) & d_mask], 1ull);
         }
@@ -706,9 +771,9 @@ __global__ __launch_bounds__(256) void k_s2_compact(double* y, const Cand* cand,
     if (st.phase == 2) {  // resolved by the first digit already
       keep = (key >= st.t_ge) || (key == st.t_eq && i <= st.icut);
     } else if (st.phase == 0) {  // key digits: compare everything decided so far
-      const uint64_t top = hs >= 64 ? 0ull : (key >> hs);
-      in = top == st.prefix;
-      keep = top > st.prefix;
+      const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
+      in = kp.in;
+      keep = kp.above;
     } else {  // index digits of the tied key: lower indices are kept first
       const uint64_t itop = ((uint64_t)i) >> hs;
       in = key == st.t_eq && itop == st.prefix;
@@ -759,7 +824,8 @@ __global__ __launch_bounds__(1024) void k_s2_finish(double* y, SelWs* ws, const 
     for (unsigned int e = t; e < m; e += 1024) {
       const uint64_t key = lk[e];
       if (st.phase == 0) {
-        if ((hs >= 64 ? 0ull : (key >> hs)) == st.prefix) atomicAdd(&h[(key >> st.shift) & dmask], 1u);
+        const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
+        if (kp.in) atomicAdd(&h[kp.digit], 1u);
       } else if (key == st.t_eq) {
         const uint64_t i = (uint64_t)li[e];
         if ((i >> hs) == st.prefix) atomicAdd(&h[(i >> st.shift) & dmask], 1u);

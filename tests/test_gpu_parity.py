@@ -294,6 +294,31 @@ def test_indball_l0_nan_inf(s, orc):
             assert _same_or_both_nan(y0, ref0), (n, r)
 
 
+@pytest.mark.parametrize("kind", ["scaled", "cauchy", "concentrated"])
+def test_indball_l0_ranks_and_scales(s, orc, kind):
+    """Sample-predicted path (n >= 2^22) over the whole range of r and over data whose r-th magnitude sits next to an
+    exponent boundary, has heavy tails, or is packed into a 1e-9 relative range: the candidate digits follow the
+    band's span (SelState::base), so none of these may change the kept set (tools/sweep_topr.py times them at n = 1e8)."""
+    n = (1 << 22) + 4321
+    rng = np.random.default_rng({"scaled": 1, "cauchy": 2, "concentrated": 3}[kind])
+    x, sj = rng.normal(size=n), rng.uniform(-0.5, 0.5, size=n)
+    if kind == "scaled":
+        q = 1.37 * rng.normal(size=n)
+    elif kind == "cauchy":
+        q = rng.standard_cauchy(size=n)
+    else:
+        x, sj = np.zeros(n), np.zeros(n)
+        q = (1.0 + 1e-9 * rng.normal(size=n)) * rng.choice([-1.0, 1.0], size=n)
+    xd, sd, qd = _dev(x, sj, q)
+    for r in (1, 50, 5000, n // 100, n // 2, n - 5000):
+        ref = orc.prox_indball_l0_binf(q, x, sj, r, 0.9)
+        y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.9, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
+        assert _bits_equal(y, ref), (kind, r)
+    r = n // 37  # aliased form (y === q)
+    s.prox_bang(qd, s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qd, 1.0)
+    assert _bits_equal(qd.cpu().numpy(), orc.prox_indball_l0(q, x, sj, r)), kind
+
+
 # ------------------------------------------------------------------ groups
 def _group_check(y, ref, q, x, sj, offsets):
     S = (q + x) + sj
