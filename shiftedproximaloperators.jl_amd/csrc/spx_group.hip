@@ -343,6 +343,16 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
   team_sum2<TEAM>(sS, sX, lds);
   mX = team_max<TEAM>(mX, lds);
   const double nS = sqrt_pos(sS), nX = sqrt_pos(sX);
+  // X == 0 in the whole group and sigma lambda > ||S||: the group of a sparse iterate that stays zero -- the bulk of the
+  // groups in a group-lasso run, so it must not take the literal path its (usually degenerate: lmax = ||S|| + sigma zlmax
+  // < lmin) bracket would otherwise send it to.  The reference returns zeros whichever way it goes:
+  //  * lmax >= lmin: on n >= lmin every |w_i| <= |S_i|, so froot(n) >= n - ||S|| > 0 at both ends -> :102-103;
+  //  * lmax < lmin: froot(lmin) > 0 as before; froot(lmax) = lmax (1 - Delta sqrt(#S_i != 0) / (sigma lambda - lmax)) (step < 0:
+  //    softthres only ADDS |thr|); if positive -> :102-103, if negative the only sign change in (lmax, lmin] is the pole
+  //    n = sigma lambda (froot -> -inf below it, n - ||w|| > 0 above it), fzero ends on a double just above the pole, and
+  //    there :111 is l2prox(v, sigma lambda) with ||v|| <= ||S|| < sigma lambda, i.e. zeros again.
+  // (1e-9 away from the tie sigma lambda = ||S||, which stays with the general code below.)
+  if (mX == 0.0 && sl < INFINITY && sl * (1.0 - 1e-9) > nS) return BINF_ZERO;
   const double ub = sqrt_pos(sS + sX) * (1.0 + 8 * eps);  // a-priori bound on the root in u (see below)
   // lmax = ||S|| + sigma (zlmax + lambda ||X||) (:100) needs one more pass for zlmax (:99).  zlmax >= 0, so
   // lmax >= lmax_lb := ||S|| + sigma lambda ||X||.  If already lmax_lb clears both lmin (bracket not degenerate) and

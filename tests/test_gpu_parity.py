@@ -990,6 +990,40 @@ def test_group_binf_lattice_and_zero_x(s, orc, gs):
         assert float(np.nanmax(err)) <= 1e-11, (gs, rep, float(np.nanmax(err)))
 
 
+@pytest.mark.parametrize("gs", [1, 7, 128, 300, 1024])
+def test_group_binf_zero_groups_strong_lambda(s, orc, gs):
+    """The bulk of a group-lasso run: groups of the iterate that are zero (xk == 0 on the group, any sj) under a
+    sigma*lambda above ||S||.  The reference's bracket is usually reversed there (lmax < lmin) and its fzero ends next to
+    the pole of step(n), yet the result is always y = -sj; the kernels decide that without the literal evaluation
+    (tools/sweep_params.py: 27 ms -> 0.7 ms at 1e6 x 128).  Mixed with ordinary groups and with ties sigma*lambda ~ ||S||."""
+    rng = np.random.default_rng(900 + gs)
+    ng = 600 if gs <= 300 else 40
+    n = ng * gs
+    x = rng.normal(size=n).reshape(ng, gs)
+    zero_g = rng.random(ng) < 0.6
+    x[zero_g] = 0.0
+    x = x.reshape(n)
+    sj, q = rng.uniform(-0.5, 0.5, size=n), rng.normal(size=n)
+    nS = np.linalg.norm(((q + x) + sj).reshape(ng, gs), axis=1)
+    lam = nS * rng.choice([0.5, 1.0 - 1e-12, 1.0, 1.0 + 1e-12, 1.5, 4.0, 40.0], size=ng)
+    xd, sd, qd = _dev(x, sj, q)
+    h = s.GroupNormL2.uniform(lam.tolist(), gs)
+    for sigma, delta in ((1.0, 0.01), (1.0, 0.6), (0.37, 4.0), (2.0, 100.0)):
+        lam_s = lam / sigma
+        hs = s.GroupNormL2.uniform(lam_s.tolist(), gs)
+        with np.errstate(all="ignore"):
+            ref = orc.prox_group_l2_binf(q, x, sj, lam_s, sigma, delta, gsize=gs)
+        y = s.prox(s.shifted(s.shifted(hs, xd, delta, s.NormLinf(1.0)), sd), qd, sigma).cpu().numpy()
+        strong = zero_g & (sigma * lam_s * (1 - 1e-9) > nS)
+        assert strong.sum() > ng // 5
+        assert np.array_equal(y.reshape(ng, gs)[strong], -sj.reshape(ng, gs)[strong])   # exactly -sj
+        sc = np.maximum(np.abs(ref).reshape(ng, gs), nS[:, None])
+        canc = np.maximum(1.0, sigma * lam_s / np.maximum(nS, 1e-300))[:, None]
+        err = np.abs(y - ref).reshape(ng, gs) / np.maximum(sc, 1e-300) / canc
+        assert float(np.nanmax(err)) <= 1e-9, (gs, sigma, delta, float(np.nanmax(err)))
+        assert float(np.nanquantile(err, 0.99)) <= 1e-12
+
+
 @pytest.mark.parametrize("gs", [2, 16, 128, 700])
 def test_group_binf_structured_scenarios(s, orc, gs):
     """Structured data for GroupNormL2Binf: X = 0, tiny X, S = X, S = 0, data tiny / huge against lambda and Delta,
