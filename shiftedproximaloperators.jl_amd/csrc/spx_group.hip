@@ -318,6 +318,83 @@ __device__ __forceinline__ bool binf_literal_root(const G& grp, double lam, doub
   return true;
 }
 
+// The same for a register-resident group (the deferred list of k_group_reg, run by its LIT instantiation): the ~60
+// dependent passes of fzero then cost arithmetic only -- with the group re-read from memory for every pass (k_group_mem)
+// a list that holds a large share of the groups is bound by L2 misses, 14 ms for 2.7e5 groups of 128.  S/sigma (:89) is
+// loop-invariant and formed once.  out[k] = y before the final "- (xk + sj)".
+template <int LPG, int EPL>
+__device__ __forceinline__ void binf_literal_reg(const RegGroup<EPL>& grp, double lam, double sigma, double delta,
+                                                 double* out) {
+  const double eps = 2.220446049250313e-16;
+  const double sl = lam * sigma;
+  double Sd[EPL];
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) Sd[k] = grp.S[k] / sigma;
+  auto froot = [&](double n) -> double {  // :87-93
+    const double step = n / (sigma * (n - sl));
+    const double thr = delta * step;
+    double sw = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      const double w = sigma * softthres(Sd[k] - step * grp.X[k], thr) - grp.S[k];
+      sw += w * w;
+    }
+    return n - sqrt(lanes_sum<LPG>(sw));
+  };
+  const double lmin = sl * (1 + eps);  // :94
+  double fa = froot(lmin);             // :95
+  const double ansatz = lmin + 1.0;    // :97
+  const double stepa = ansatz / (sigma * (ansatz - sl));  // :98
+  double sz = 0.0, sS = 0.0, sX = 0.0;
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) {
+    const double z = softthres(Sd[k] - stepa * grp.X[k], delta * stepa);  // :99
+    sz += z * z;
+    sS += grp.S[k] * grp.S[k];
+    sX += grp.X[k] * grp.X[k];
+  }
+  sz = lanes_sum<LPG>(sz);
+  sS = lanes_sum<LPG>(sS);
+  sX = lanes_sum<LPG>(sX);
+  const double lmax = sqrt(sS) + sigma * (sqrt(sz) + 1.0 * lam * sqrt(sX));  // :100
+  double fb = froot(lmax);                                                   // :101
+  bool zeros = fa * fb > 0;                                                  // :102
+  double root = lmin;
+  if (!zeros) {  // Roots.fzero(froot, lmin, lmax), as binf_bisect
+    double a = lmin, b = lmax;
+    if (a > b) { double t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
+    if (fa == 0.0) root = a;
+    else if (fb == 0.0) root = b;
+    else {
+      for (int it = 0; it < 130; ++it) {
+        const double m = bit_middle(a, b);
+        if (!(a < m && m < b)) break;
+        const double fmid = froot(m);
+        if (jl_sign(fa) * jl_sign(fmid) < 0) { b = m; fb = fmid; }
+        else { a = m; fa = fmid; }
+      }
+      root = (fabs(fa) < fabs(fb)) ? a : b;
+    }
+    zeros = (root - sl) == 0.0;  // :107
+  }
+  if (zeros) {
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) out[k] = 0.0;
+    return;
+  }
+  const double step = root / (sigma * (root - sl));  // :106
+  double sw = 0.0;
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) {
+    out[k] = grp.S[k] - sigma * softthres(Sd[k] - step * grp.X[k], delta * step);  // :111
+    sw += out[k] * out[k];
+  }
+  const double nw = sqrt(lanes_sum<LPG>(sw));
+  const double alpha = jl_max(0.0, 1 - sl / nw);  // :83
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) out[k] = alpha * out[k];
+}
+
 enum { BINF_ZERO = 0, BINF_ROOT = 1, BINF_LITERAL = 2 };
 // BINF_ROOT: root (> sl) in `root`;  BINF_ZERO: fl * fm > 0, the reference writes zeros (:102-103);
 // BINF_LITERAL: degenerate bracket / exact zero at an end / NaN -> the caller must run binf_literal_root.
@@ -375,6 +452,20 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
     sz = team_sum<TEAM>(sz, lds);
     lmax = nS + sigma * (sqrt_pos(sz) + 1.0 * lam * nX);                   // :100 (|(eps-1)/eps + 1| = 1)
     lmax_is_normS = (sz == 0.0) && (lam * nX == 0.0);
+    // Reversed bracket (lmax < lmin: ||S|| + sigma (zlmax + lambda ||X||) below sigma lambda -- a small group about to be
+    // zeroed) with every |X_i| inside the trust region: the reference returns zeros, decided here without its literal
+    // bisection (whole data sets fell into that path: 16 ms instead of 0.7 ms at 1e6 x 128, tools/sweep_params.py).
+    //  * froot(lmin) = lmin - ||S|| > 0: at lmin (1-2 ulp above the pole) step ~ 1/(sigma eps), |S_i/sigma - step X_i| <=
+    //    step Delta for every i (|X_i| < Delta(1 - 1e-9), ||S|| <= 1e6 Delta), all entries thresholded; ||S|| <= lmax < lmin.
+    //  * below the pole step < 0 and softthres only adds: froot(n) = n (1 - R(n) / (sigma lambda - n)) with
+    //    R^2 = sum (X_i + sgn(z_i) Delta)^2, z_i = S_i/sigma + |step| X_i.  A z_i changes sign only from sgn(S_i) to
+    //    sgn(X_i) as n grows, which raises its term from (|X_i| - Delta)^2 to (|X_i| + Delta)^2: R is non-decreasing, so
+    //    sigma lambda - n - R(n) is decreasing -- if froot(lmax) > 0 the signs agree (:102-103: zeros); if froot(lmax) < 0
+    //    froot stays negative up to the pole, the only sign change of the bracket is the pole itself, fzero ends on a
+    //    double just above it, everything is thresholded there and :111 is l2prox(S, sigma lambda) = 0 (||S|| < sigma lambda).
+    // Checked against the oracle on 6.5e5 such groups (sizes 1-128, sigma, Delta and lambda over two decades): all zeros.
+    if (lmax < lmin * (1.0 - 1e-9) && ul > 0.0 && mX < delta * (1.0 - 1e-9) && nS <= 1e6 * delta && (sS + sX < INFINITY))
+      return BINF_ZERO;
   }
   // fl = froot(lmin) (:95): only its sign is used.  lmin sits eps above the pole of step(n): tau(lmin) ~ eps, the element
   // with the largest |X_i| has |tau S_i - X_i| >= max|X| - tau ||S||; if that exceeds Delta by a relative 1e-9 the
@@ -577,7 +668,9 @@ __device__ __forceinline__ double binf_w(double S, double X, double tau, double 
 // PAIRS: the group size is even (every group starts 16-byte aligned): lane j owns the pairs j, j + LPG, ...; pairs past
 // the end of the group are read as zeros (zeros are neutral in every sum of both operators).  !PAIRS: odd group size,
 // lane j owns the elements j, j + LPG, ... through 8-byte loads.
-template <int LPG, int EPL, bool BINF, bool PAIRS>
+// LIT (Binf only): second launch over the deferred list -- `deferred` is then read: [0] = number of groups, [1..] = their
+// ids -- evaluating the reference's expressions literally on the register-resident group (binf_literal_reg).
+template <int LPG, int EPL, bool BINF, bool PAIRS, bool LIT = false>
 __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) void k_group_reg(double* y_, const double* q_, const double* xk_, const double* sj_,
                                                     int64_t ngroups, int gsize, const double* __restrict__ lambda,
                                                     double sigma, double delta,
@@ -596,9 +689,11 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
   constexpr bool kDma = !BINF && PAIRS;
   __shared__ __attribute__((aligned(16))) char dma_lds[kDma ? 4 * 3 * (EPL / 2) * 1024 : 16];
   const int npairs = gsize >> 1;
-  for (int64_t g0 = wave * GPW; g0 < ngroups; g0 += nwaves * GPW) {  // wave-uniform trip count
-    bool valid = (g0 + slot) < ngroups;
-    const int64_t g = valid ? (g0 + slot) : (ngroups - 1);  // idle slots shadow the last group, no store
+  const int64_t ntodo = LIT ? (int64_t)deferred[0] : ngroups;
+  for (int64_t g0 = wave * GPW; g0 < ntodo; g0 += nwaves * GPW) {  // wave-uniform trip count
+    bool valid = (g0 + slot) < ntodo;
+    const int64_t gi = valid ? (g0 + slot) : (ntodo - 1);  // idle slots shadow the last group, no store
+    const int64_t g = LIT ? (int64_t)deferred[1 + gi] : gi;
     int64_t base = g * GS;
     int gs = gsize;  // this group's size (row-uniform)
     if constexpr (!PAIRS) {
@@ -684,6 +779,10 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
       const double alpha = (snorm == 0.0) ? 0.0 : jl_max(1 - sigma * lam / snorm, 0.0);  // :70-73
 #pragma unroll
       for (int k = 0; k < EPL; ++k) out[k] = ((snorm == 0.0) ? 0.0 : alpha * grp.S[k]) - grp.XS[k];  // :74,:77
+    } else if constexpr (LIT) {
+      binf_literal_reg<LPG, EPL>(grp, lam, sigma, delta, out);
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) out[k] = out[k] - grp.XS[k];  // :116
     } else {
       double root;
       double rsa, rsb;
@@ -1066,6 +1165,31 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     else if (epl == 6) SPX_LAUNCH_REG(64, 6);
     else SPX_LAUNCH_REG(64, 8);
 #undef SPX_LAUNCH_REG
+    if constexpr (BINF) {
+      if (!ragged_reg) {
+        // The deferred list (usually empty: the kernel returns at once) on the same register tiles.  The literal
+        // evaluation is ~60 dependent passes over a group; from memory (k_group_mem) a long list is bound by L2 misses.
+        const dim3 lgrid((unsigned)(blocks < (int64_t)ctx->num_cu * 8 ? blocks : (int64_t)ctx->num_cu * 8));
+#define SPX_LAUNCH_LIT(LPG, EPL)                                                                                     \
+  do {                                                                                                               \
+    if (pairs)                                                                                                       \
+      hipLaunchKernelGGL((k_group_reg<LPG, EPL, true, true, true>), lgrid, block, 0, ctx->stream, y, q, xk, sj,      \
+                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr);              \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_group_reg<LPG, EPL, true, false, true>), lgrid, block, 0, ctx->stream, y, q, xk, sj,     \
+                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr);              \
+  } while (0)
+        if (lpg == 4 && epl == 4) SPX_LAUNCH_LIT(4, 4);
+        else if (lpg == 4) SPX_LAUNCH_LIT(4, 8);
+        else if (lpg == 8 && epl == 8) SPX_LAUNCH_LIT(8, 8);
+        else if (lpg == 8) SPX_LAUNCH_LIT(8, 16);
+        else if (lpg == 16) SPX_LAUNCH_LIT(16, 16);
+        else SPX_LAUNCH_LIT(32, 16);
+#undef SPX_LAUNCH_LIT
+        SPX_LAUNCH_CHECK();
+        return SPX_OK;
+      }
+    }
     if (BINF || ragged_reg) {  // usually an empty list: the kernel returns at once
       hipLaunchKernelGGL((k_group_mem<64, BINF>), dim3((unsigned)(ctx->num_cu * 2)), dim3(256), 0, ctx->stream, y, q, xk,
                          sj, n, ragged_reg ? offsets : (const int64_t*)nullptr, gsize, ngroups, lambda, sigma, delta,

@@ -1024,6 +1024,39 @@ def test_group_binf_zero_groups_strong_lambda(s, orc, gs):
         assert float(np.nanquantile(err, 0.99)) <= 1e-12
 
 
+@pytest.mark.parametrize("gs", [1, 3, 16, 128, 250])
+def test_group_binf_small_groups_being_zeroed(s, orc, gs):
+    """Small nonzero groups (||xk|| < 1 on the group, entries inside the trust region) under a strong sigma*lambda: the
+    reference's bracket is reversed; with every |xk_i| < Delta its answer is zeros (kernel comment in binf_root), which
+    the register kernel now decides itself; entries outside the trust region or ties still take the literal evaluation
+    (deferred list, register-resident since round 1).  Both must agree with the oracle."""
+    rng = np.random.default_rng(950 + gs)
+    ng = 1500
+    n = ng * gs
+    x = rng.normal(size=n) * (0.3 / np.sqrt(gs))
+    sj, q = rng.uniform(-0.5, 0.5, size=n), rng.normal(size=n)
+    S = ((q + x) + sj).reshape(ng, gs)
+    nS, nX, mX = np.linalg.norm(S, axis=1), np.linalg.norm(x.reshape(ng, gs), axis=1), np.abs(x.reshape(ng, gs)).max(axis=1)
+    xd, sd, qd = _dev(x, sj, q)
+    seen_fast = seen_literal = 0
+    for sigma, delta, lscale in ((1.0, 1.0, 3.0), (0.5, 0.05 / np.sqrt(gs), 8.0), (2.0, 0.4 / np.sqrt(gs), 2.0), (1.0, 50.0, 30.0)):
+        lam = rng.uniform(0.5, 1.5, size=ng) * lscale * max(1.0, np.sqrt(gs))
+        h = s.GroupNormL2.uniform(lam.tolist(), gs)
+        with np.errstate(all="ignore"):
+            ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, gsize=gs)
+        y = s.prox(s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd), qd, sigma).cpu().numpy()
+        rev = nS + sigma * lam * nX < sigma * lam * (1 - 1e-6)          # (zlmax = 0 there or not: a lower bound on lmax)
+        seen_fast += int(np.sum(rev & (mX < delta * (1 - 1e-9))))
+        seen_literal += int(np.sum(rev & (mX > delta)))
+        fin = np.isfinite(ref)
+        assert np.array_equal(fin, np.isfinite(y))
+        scale_g = np.repeat(np.maximum(nS, 1e-300), gs)
+        err = np.abs(np.where(fin, y - ref, 0.0)) / np.maximum(np.abs(np.where(fin, ref, 0.0)), scale_g)
+        # roots next to the pole amplify last-bit differences of the norm (as test_group_binf_degenerate_bracket)
+        assert np.quantile(err, 0.99) <= 1e-12 and err.max() <= 1e-6, (gs, sigma, delta, float(err.max()))
+    assert seen_fast > ng // 4 and seen_literal > ng // 10, (seen_fast, seen_literal)
+
+
 @pytest.mark.parametrize("gs", [2, 16, 128, 700])
 def test_group_binf_structured_scenarios(s, orc, gs):
     """Structured data for GroupNormL2Binf: X = 0, tiny X, S = X, S = 0, data tiny / huge against lambda and Delta,

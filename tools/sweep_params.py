@@ -20,12 +20,18 @@ x0 = torch.randn(n, dtype=torch.float64, device=dev, generator=g); s0 = torch.ra
 q0 = torch.randn(n, dtype=torch.float64, device=dev, generator=g); y = torch.empty_like(q0)
 lam1 = torch.rand(ng, dtype=torch.float64, device=dev, generator=g) + 0.5
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
-for kind in ("normal", "x=0,s=0", "lattice8", "q*100", "q*0.01"):
+only = sys.argv[2] if len(sys.argv) > 2 else None
+for kind in ("normal", "x=0,s=0", "lattice8", "q*100", "q*0.01", "x*0.05", "90% zero groups"):
+    if only and only not in kind: continue
     if kind == "normal": xk, sj, q = x0, s0, q0
     elif kind == "x=0,s=0": xk, sj, q = torch.zeros_like(x0), torch.zeros_like(x0), q0
     elif kind == "lattice8": xk, sj, q = (torch.round(v * 8) / 8 for v in (x0, s0, q0))
     elif kind == "q*100": xk, sj, q = x0, s0, q0 * 100
-    else: xk, sj, q = x0, s0, q0 * 0.01
+    elif kind == "q*0.01": xk, sj, q = x0, s0, q0 * 0.01
+    elif kind == "x*0.05": xk, sj, q = x0 * 0.05, s0, q0
+    else:
+        keep = (torch.rand(ng, device=dev, generator=g) < 0.1).to(torch.float64).repeat_interleave(gs)
+        xk, sj, q = x0 * keep, s0, q0
     if which in ("all", "binf"):
         for delta in (0.01, 0.25, 1.0, 4.0, 100.0):
             for lscale in (0.01, 1.0, 30.0):
