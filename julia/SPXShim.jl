@@ -48,6 +48,12 @@ dptr(v::DVec) = Ptr{Cdouble}(UInt(pointer(v)))
 dptr(::Nothing) = Ptr{Cdouble}(C_NULL)
 vec_or_nothing(b) = b isa Real ? nothing : b            # `isa(ψ.l, Real) ? ψ.l : ψ.l[i]`
 scal(b) = b isa Real ? Float64(b) : 0.0
+mptr(m) = m === nothing ? Ptr{UInt8}(C_NULL) : Ptr{UInt8}(UInt(pointer(m)))   # device byte mask or NULL
+function with_value(f)                                   # entry points that return a scalar through a double*
+  out = Ref{Cdouble}(0.0)
+  check(f(out))
+  out[]
+end
 
 # ---------------------------------------------------------------------------------------------
 # separable, unboxed          src/shiftedNormL1.jl:40-54, shiftedNormL0.jl:38-55, shiftedRootNormLhalf.jl:41-63
@@ -92,14 +98,14 @@ for (T, sym) in ((:ShiftedNormL1Box, :spx_prox_l1_box), (:ShiftedNormL0Box, :spx
     n = length(ψ.xk)
     (length(y) == n && length(q) == n) || throw(BoundsError())
     (ψ.l isa Real || ψ.l isa DVec) && (ψ.u isa Real || ψ.u isa DVec) ||
-      return invoke(prox!, Tuple{AbstractVector{Float64}, $T, AbstractVector{Float64}, Float64}, y, ψ, q, σ)
+      return invoke(prox!, Tuple{AbstractVector{Float64}, $T{Float64}, AbstractVector{Float64}, Float64}, y, ψ, q, σ)
     m = mask_for(ψ)
     check(ccall(($(QuoteNode(sym)), libspx), Cint,
                 (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cdouble,
                  Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{UInt8}),
                 ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, ψ.λ, σ,
                 dptr(vec_or_nothing(ψ.l)), dptr(vec_or_nothing(ψ.u)), scal(ψ.l), scal(ψ.u),
-                m === nothing ? Ptr{UInt8}(C_NULL) : Ptr{UInt8}(UInt(pointer(m)))))
+                mptr(m)))
     return y
   end
 end
@@ -128,7 +134,7 @@ for (T, sym) in ((:ShiftedNormL1Box, :spx_iprox_l1_box), (:ShiftedNormL0Box, :sp
                  Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{UInt8}),
                 ctx(), dptr(y), dptr(g), dptr(d), dptr(ψ.xk), dptr(ψ.sj), n, ψ.λ,
                 dptr(vec_or_nothing(ψ.l)), dptr(vec_or_nothing(ψ.u)), scal(ψ.l), scal(ψ.u),
-                m === nothing ? Ptr{UInt8}(C_NULL) : Ptr{UInt8}(UInt(pointer(m)))))
+                mptr(m)))
     return y
   end
 end
@@ -168,9 +174,14 @@ function prox!(y::DVec, f::ShiftedProximalOperators.RootNormLhalf{Float64}, x::D
               ctx(), dptr(y), dptr(x), dptr(z), dptr(z), n, f.lambda, Float64(γ), 1.0, out))
   return out[]                                                   # λ Σ sqrt|y_i|, as :50
 end
-(f::ShiftedProximalOperators.RootNormLhalf{Float64})(x::DVec) =
-  (z = zeros_for(length(x)); objective(:spx_obj_lhalf, (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble),
-                                       dptr(x), dptr(z), dptr(z), length(x), f.lambda))
+function (f::ShiftedProximalOperators.RootNormLhalf{Float64})(x::DVec)
+  z = zeros_for(length(x))
+  with_value() do out
+    ccall((:spx_obj_lhalf, libspx), Cint,
+          (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Ptr{Cdouble}),
+          ctx(), dptr(x), dptr(z), dptr(z), length(x), f.lambda, out)
+  end
+end
 # GroupNormL2: prox!(y, f, x, γ) = group_call on ψ = shifted(f, zeros) with q = x; its return value Σ λ_g ‖x_g‖ is
 # spx_obj_group_l2 of the input (layout_for(f, n) supplies offsets / gather indices / weights, as in group_call).
 
@@ -190,7 +201,7 @@ function prox_value!(y::DVec, ψ::ShiftedNormL1Box{Float64, <:DVec, <:DVec, <:DV
                Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{UInt8}, Cdouble, Ptr{Cdouble}),
               ctx(), dptr(y), dptr(q), dptr(ψ.xk), dptr(ψ.sj), n, ψ.λ, σ,
               dptr(vec_or_nothing(ψ.l)), dptr(vec_or_nothing(ψ.u)), scal(ψ.l), scal(ψ.u),
-              m === nothing ? Ptr{UInt8}(C_NULL) : Ptr{UInt8}(UInt(pointer(m))), q_scale, out))
+              mptr(m), q_scale, out))
   return y, out[]
 end
 
@@ -235,10 +246,9 @@ function layout_for(h, n)
   end
 end
 
-function group_call(sym, y, ψ, q, σ, extra...)
+function group_call(y, ψ, q, σ, extra...)   # extra = (Δ,) for the Binf form
   n = length(ψ.xk)
   L = layout_for(ψ.h, n)
-  L === nothing && return nothing
   if L.gather
     ip(v) = Ptr{Int64}(UInt(pointer(v)))
     if isempty(extra)
@@ -273,48 +283,53 @@ function group_call(sym, y, ψ, q, σ, extra...)
 end
 
 function prox!(y::DVec, ψ::ShiftedGroupNormL2{Float64, RR, I, <:DVec, <:DVec, <:DVec}, q::DVec, σ::Float64) where {RR, I}
-  r = group_call(:spx_prox_group_l2, y, ψ, q, σ)
-  r === nothing ? invoke(prox!, Tuple{AbstractVector{Float64}, ShiftedGroupNormL2, AbstractVector{Float64}, Float64}, y, ψ, q, σ) : r
+  group_call(y, ψ, q, σ)
 end
 
 function prox!(y::DVec, ψ::ShiftedGroupNormL2Binf{Float64, RR, I, <:DVec, <:DVec, <:DVec}, q::DVec, σ::Float64) where {RR, I}
-  r = group_call(:spx_prox_group_l2_binf, y, ψ, q, σ, ψ.Δ)
-  r === nothing ? invoke(prox!, Tuple{AbstractVector{Float64}, ShiftedGroupNormL2Binf, AbstractVector{Float64}, Float64}, y, ψ, q, σ) : r
+  group_call(y, ψ, q, σ, ψ.Δ)
 end
 
 # ---------------------------------------------------------------------------------------------
 # ψ(y)                        src/ShiftedProximalOperators.jl:51-54, shiftedNormL1Box.jl:70-82 (idem L0Box, L½Box),
 #                             shiftedIndBallL0BInf.jl:44-49, shiftedGroupNormL2Binf.jl:34-39
 # ---------------------------------------------------------------------------------------------
-function objective(sym::Symbol, argt, args...)
-  out = Ref{Cdouble}(0.0)
-  check(ccall((sym, libspx), Cint, (Ptr{Cvoid}, argt..., Ptr{Cdouble}), ctx(), args..., out))
-  out[]
-end
+# (ccall needs a literal symbol and a literal argument-type tuple: every entry point is spelled out)
 for (T, sym) in ((:ShiftedNormL1, :spx_obj_l1), (:ShiftedNormL0, :spx_obj_l0), (:ShiftedRootNormLhalf, :spx_obj_lhalf))
-  @eval (ψ::$T{Float64, <:DVec, <:DVec, <:DVec})(y::DVec) =
-    objective($(QuoteNode(sym)), (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble),
-              dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.λ)
+  @eval (ψ::$T{Float64, <:DVec, <:DVec, <:DVec})(y::DVec) = with_value() do out
+    ccall(($(QuoteNode(sym)), libspx), Cint,
+          (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Ptr{Cdouble}),
+          ctx(), dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.λ, out)
+  end
 end
 for (T, sym) in ((:ShiftedNormL1Box, :spx_obj_l1_box), (:ShiftedNormL0Box, :spx_obj_l0_box),
                  (:ShiftedRootNormLhalfBox, :spx_obj_lhalf_box))
   @eval function (ψ::$T{Float64, <:DVec, <:DVec, <:DVec})(y::DVec)
     m = mask_for(ψ)
-    objective($(QuoteNode(sym)),
-              (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{UInt8}),
-              dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.λ, dptr(vec_or_nothing(ψ.l)), dptr(vec_or_nothing(ψ.u)),
-              scal(ψ.l), scal(ψ.u), m === nothing ? Ptr{UInt8}(C_NULL) : Ptr{UInt8}(UInt(pointer(m))))
+    with_value() do out
+      ccall(($(QuoteNode(sym)), libspx), Cint,
+            (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble,
+             Cdouble, Ptr{UInt8}, Ptr{Cdouble}),
+            ctx(), dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.λ, dptr(vec_or_nothing(ψ.l)),
+            dptr(vec_or_nothing(ψ.u)), scal(ψ.l), scal(ψ.u), mptr(m), out)
+    end
   end
 end
-(ψ::ShiftedIndBallL0{<:Integer, Float64, <:DVec, <:DVec, <:DVec})(y::DVec) =
-  objective(:spx_obj_indball_l0, (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Int64),
-            dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.r)
-(ψ::ShiftedProximalOperators.ShiftedNormL1B2{Float64, <:DVec, <:DVec, <:DVec})(y::DVec) =   # src/shiftedNormL1B2.jl:32
-  objective(:spx_obj_l1_b2, (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cdouble),
-            dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.λ, ψ.Δ)
-(ψ::ShiftedIndBallL0BInf{<:Integer, Float64, <:DVec, <:DVec, <:DVec})(y::DVec) =
-  objective(:spx_obj_indball_l0_binf, (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Int64, Cdouble),
-            dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.r, ψ.Δ)
+(ψ::ShiftedIndBallL0{<:Integer, Float64, <:DVec, <:DVec, <:DVec})(y::DVec) = with_value() do out
+  ccall((:spx_obj_indball_l0, libspx), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Int64, Ptr{Cdouble}),
+        ctx(), dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.r, out)
+end
+(ψ::ShiftedProximalOperators.ShiftedNormL1B2{Float64, <:DVec, <:DVec, <:DVec})(y::DVec) = with_value() do out  # src/shiftedNormL1B2.jl:32
+  ccall((:spx_obj_l1_b2, libspx), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Cdouble, Ptr{Cdouble}),
+        ctx(), dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.λ, ψ.Δ, out)
+end
+(ψ::ShiftedIndBallL0BInf{<:Integer, Float64, <:DVec, <:DVec, <:DVec})(y::DVec) = with_value() do out
+  ccall((:spx_obj_indball_l0_binf, libspx), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Int64, Cdouble, Ptr{Cdouble}),
+        ctx(), dptr(y), dptr(ψ.xk), dptr(ψ.sj), length(y), ψ.r, ψ.Δ, out)
+end
 # (group forms: spx_obj_group_l2 / spx_obj_group_l2_binf with the layout_for(ψ.h, n) arguments, as in group_call)
 
 # shift!, set_radius!, set_bounds!, prox (src/ShiftedProximalOperators.jl:72-111,189-190) need no methods:
