@@ -585,7 +585,11 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
 // candidates, instead of 56 B/element with the separate final pass (k_sel_final_q, used when y aliases an input).
 template <bool BINF, bool WRITE>
 __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, const double* xk_, const double* sj_,
-                                                  int64_t n, SelWs* ws, Cand* cand, WaveCount* counts, double delta) {
+                                                  int64_t n, SelWs* ws, Cand* cand, WaveCount* counts, double delta,
+                                                  int ioff) {
+  // ioff = 1: the caller's vectors start 8 bytes off a 16-byte boundary (all four alike); the pointers passed here
+  // are the aligned rest (caller's element 1 on), n counts that rest, and the caller's element 0 sits at [-1].
+  // Candidate indices are the caller's.
   const uint64_t t_hi = ws->fs.t_hi, t_lo = ws->fs.t_lo;
   // first digit of the selection among the candidates (set up by k_s2_pick): histogrammed right here, one
   // fire-and-forget global atomic per candidate (~0.5 % of the elements, spread over the band's bins)
@@ -662,17 +666,23 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
     const f64x2 c = *reinterpret_cast<const f64x2*>(wl + (2 * UNROLL + k) * 1024 + lane * 16);
     const bool valid = i < n2;
     f64x2 o;
-    o.x = visit(valid, (b.x + c.x) + a.x, 2 * i, b.x, c.x);      // shiftedIndBallL0.jl:66  xk .+ sj .+ q
-    o.y = visit(valid, (b.y + c.y) + a.y, 2 * i + 1, b.y, c.y);
+    o.x = visit(valid, (b.x + c.x) + a.x, 2 * i + ioff, b.x, c.x);      // shiftedIndBallL0.jl:66  xk .+ sj .+ q
+    o.y = visit(valid, (b.y + c.y) + a.y, 2 * i + 1 + ioff, b.y, c.y);
     if constexpr (WRITE) {
       if (valid) __builtin_nontemporal_store(o, y2 + i);
     }
   }
   if ((n & 1) && gwave == 0) {  // the odd last element rides with wave 0 (all of its lanes call visit)
     const int64_t i = n - 1;
-    const double o = visit(lane == 0, (xk_[i] + sj_[i]) + q_[i], i, xk_[i], sj_[i]);
+    const double o = visit(lane == 0, (xk_[i] + sj_[i]) + q_[i], i + ioff, xk_[i], sj_[i]);
     if constexpr (WRITE) {
       if (lane == 0) y_[i] = o;
+    }
+  }
+  if (ioff && gwave == 0) {  // and so does the caller's element 0 of an 8-byte-misaligned view
+    const double o = visit(lane == 0, (xk_[-1] + sj_[-1]) + q_[-1], 0, xk_[-1], sj_[-1]);
+    if constexpr (WRITE) {
+      if (lane == 0) y_[-1] = o;
     }
   }
   for (int off = 32; off >= 1; off >>= 1) above += __shfl_xor(above, off, 64);
@@ -849,7 +859,8 @@ __global__ __launch_bounds__(1024) void k_s2_finish(double* y, SelWs* ws, const 
 // final pass of the fast path: v recomputed from q, xk, sj (y untouched so far)
 template <bool BINF>
 __global__ __launch_bounds__(256) void k_sel_final_q(double* y_, const double* q_, const double* xk_, const double* sj_,
-                                                      int64_t n, const SelWs* ws, double delta) {
+                                                      int64_t n, const SelWs* ws, double delta, int ioff) {
+  // (ioff: as k_s2_main)
   if (!ws->fs.ok) return;  // prediction not verified: the host runs the full-vector path afterwards
   const SelState st = ws->st;
   constexpr int UNROLL = 6;  // KiB per wave and vector, as k_sep_lds
@@ -880,15 +891,17 @@ __global__ __launch_bounds__(256) void k_sel_final_q(double* y_, const double* q
     const f64x2 c = *reinterpret_cast<const f64x2*>(wl + (2 * UNROLL + k) * 1024 + lane * 16);
     if (i < n2) {
       f64x2 r;
-      r.x = sel_out<BINF>((b.x + c.x) + a.x, 2 * i, b.x, c.x, st, delta);
-      r.y = sel_out<BINF>((b.y + c.y) + a.y, 2 * i + 1, b.y, c.y, st, delta);
+      r.x = sel_out<BINF>((b.x + c.x) + a.x, 2 * i + ioff, b.x, c.x, st, delta);
+      r.y = sel_out<BINF>((b.y + c.y) + a.y, 2 * i + 1 + ioff, b.y, c.y, st, delta);
       __builtin_nontemporal_store(r, y + i);
     }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
-    y_[i] = sel_out<BINF>((xk_[i] + sj_[i]) + q_[i], i, xk_[i], sj_[i], st, delta);
+    y_[i] = sel_out<BINF>((xk_[i] + sj_[i]) + q_[i], i + ioff, xk_[i], sj_[i], st, delta);
   }
+  if (ioff && blockIdx.x == 0 && threadIdx.x == 64)
+    y_[-1] = sel_out<BINF>((xk_[-1] + sj_[-1]) + q_[-1], 0, xk_[-1], sj_[-1], st, delta);
 }
 
 static int g_sel_fast = 1;  // spx_set_tuning key 2: 0 disables the sample-predicted path
@@ -902,9 +915,13 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   if (n == 0) return SPX_OK;
   SPX_HIP(hipSetDevice(ctx->device));
   const int vec = (spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj)) ? 1 : 0;
-  const bool try_fast = g_sel_fast && vec && n >= ((int64_t)1 << 22) && r > 0 && r < n;
+  // all four vectors 8 bytes off a 16-byte boundary (a view that starts at an odd element): the sample-predicted path
+  // runs on the aligned rest and its wave 0 takes element 0 along (ioff = 1)
+  auto off8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 8u; };
+  const int ioff = (!vec && off8(y) && off8(q) && off8(xk) && off8(sj)) ? 1 : 0;
+  const bool try_fast = g_sel_fast && (vec || ioff) && (n - ioff) >= ((int64_t)1 << 22) && r > 0 && r < n;
   // fast path scratch: one candidate region + count word per wavefront of the main pass
-  const int64_t n2 = n >> 1;
+  const int64_t n2 = (n - ioff) >> 1;
   const int64_t mblocks = (n2 + kMainTilePairs - 1) / kMainTilePairs;
   const int64_t nregions = try_fast ? mblocks * 4 : 0;
   const int64_t ccap = nregions * kWaveSlots;
@@ -933,11 +950,11 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     hipLaunchKernelGGL(k_s2_pick, dim3(1), dim3(1024), 0, ctx->stream, (const double*)samp, n, r, ws);
     const dim3 mgrid((unsigned)mblocks);
     if (write)
-      hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y, q, xk, sj, n, ws, cand, counts,
-                         delta);
+      hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,
+                         sj + ioff, n - ioff, ws, cand, counts, delta, ioff);
     else
-      hipLaunchKernelGGL((k_s2_main<BINF, false>), mgrid, dim3(256), 0, ctx->stream, y, q, xk, sj, n, ws, cand, counts,
-                         delta);
+      hipLaunchKernelGGL((k_s2_main<BINF, false>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,
+                         sj + ioff, n - ioff, ws, cand, counts, delta, ioff);
     // the main pass has already histogrammed the first candidate digit: verdict + first scan step, survivors ->
     // short list, the rest of the selection in one workgroup
     hipLaunchKernelGGL(k_s2_scan_verify, dim3(1), dim3(256), 0, ctx->stream, ws, r);
@@ -951,8 +968,8 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
                          lval, (const WaveCount*)counts, nregions);
       hipLaunchKernelGGL((k_s2_finish<false>), dim3(1), dim3(1024), 0, ctx->stream, y, ws, (const uint64_t*)lkey,
                          (const int64_t*)lidx, (const double*)lval);
-      hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1535) / 1536)), dim3(256), 0, ctx->stream, y, q,
-                         xk, sj, n, (const SelWs*)ws, delta);
+      hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1535) / 1536)), dim3(256), 0, ctx->stream,
+                         y + ioff, q + ioff, xk + ioff, sj + ioff, n - ioff, (const SelWs*)ws, delta, ioff);
     }
     SPX_LAUNCH_CHECK();
     // the verdict is read back AFTER the speculative final pass has been queued: the GPU never idles on the host

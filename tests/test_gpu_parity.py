@@ -319,6 +319,37 @@ def test_indball_l0_ranks_and_scales(s, orc, kind):
     assert _bits_equal(qd.cpu().numpy(), orc.prox_indball_l0(q, x, sj, r)), kind
 
 
+def test_indball_l0_misaligned_views_fast_path(s, orc):
+    """All four vectors 8 bytes off a 16-byte boundary (a view from an odd element on): the sample-predicted path
+    runs on the aligned rest and element 0 rides with wave 0.  Element 0 as the largest / a tied / a dropped entry,
+    odd and even n, disjoint and aliased y; a mixed alignment takes the full-vector path."""
+    import torch
+    for n in ((1 << 22) + 2, (1 << 22) + 5):
+        rng = np.random.default_rng(n)
+        x, sj, q = rng.normal(size=n), rng.uniform(-0.5, 0.5, size=n), np.round(rng.normal(size=n) * 32) / 32
+        for head in (100.0, 0.0, None):
+            if head is not None:
+                x[0], sj[0], q[0] = 0.0, 0.0, head
+            else:
+                x[0], sj[0], q[0] = x[7], sj[7], q[7]            # ties with element 7: the lower index wins
+            mk = lambda a: torch.cat([torch.zeros(1, dtype=torch.float64), torch.from_numpy(a)]).cuda()[1:]
+            xd, sd, qd = mk(x), mk(sj), mk(q)
+            assert all(t.data_ptr() % 16 == 8 for t in (xd, sd, qd))
+            for r in (1, n // 50, n - 3):
+                ref = orc.prox_indball_l0_binf(q, x, sj, r, 0.7)
+                psi = s.shifted(s.shifted(s.IndBallL0(r), xd, 0.7, s.NormLinf(1.0)), sd)
+                yv = mk(np.zeros(n))
+                s.prox_bang(yv, psi, qd, 1.0)
+                assert _bits_equal(yv.cpu().numpy(), ref), (n, head, r)
+                ya = torch.from_numpy(np.zeros(n)).cuda()        # y aligned, inputs not: full-vector path
+                s.prox_bang(ya, psi, qd, 1.0)
+                assert _bits_equal(ya.cpu().numpy(), ref), (n, head, r)
+            q2 = qd.clone()
+            q2v = mk(q2.cpu().numpy())
+            s.prox_bang(q2v, s.shifted(s.shifted(s.IndBallL0(n // 9), xd), sd), q2v, 1.0)   # aliased
+            assert _bits_equal(q2v.cpu().numpy(), orc.prox_indball_l0(q, x, sj, n // 9)), (n, head)
+
+
 # ------------------------------------------------------------------ groups
 def _group_check(y, ref, q, x, sj, offsets):
     S = (q + x) + sj
