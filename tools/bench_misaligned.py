@@ -29,3 +29,27 @@ for rnd in range(5):
     L.spx_timer_stop(ctx, ctypes.byref(ms)); ts.append(ms.value / 10)
 assert torch.equal(y, ref)
 ts.sort(); print("misaligned views, ShiftedIndBallL0BInf r = n/100: median %.4f ms -> %.0f GB/s" % (ts[2], 32 * n / ts[2] / 1e6))
+# the other operator families on the same views
+def timed(f, reps=10):
+    f(); ts = []
+    for rnd in range(5):
+        ms = ctypes.c_float(); L.spx_timer_start(ctx)
+        for _ in range(reps): f()
+        L.spx_timer_stop(ctx, ctypes.byref(ms)); ts.append(ms.value / reps)
+    return sorted(ts)[2]
+ng, gs = 781_250, 128
+lam = torch.rand(ng, dtype=torch.float64, device=dev, generator=g) + 0.5
+cases = {
+    "ShiftedGroupNormL2 781250x128": (s.shifted(s.shifted(s.GroupNormL2.uniform(lam, gs), xk), sj), 32),
+    "ShiftedGroupNormL2Binf 781250x128": (s.shifted(s.shifted(s.GroupNormL2.uniform(lam, gs), xk, 1.0, s.NormLinf(1.0)), sj), 32),
+    "ShiftedNormL1B2 (active)": (s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, s.NormL2(1.0)), sj), 32),
+    "ShiftedRootNormLhalfBox": (s.shifted(s.shifted(s.RootNormLhalf(1.0), xk, 1.0, s.NormLinf(1.0)), sj), 32),
+}
+for name, (psi, bpe) in cases.items():
+    t = timed(lambda: s.prox_bang(y, psi, q, 1.0))
+    print("misaligned views, %-36s %.4f ms -> %.0f GB/s" % (name, t, bpe * n / t / 1e6), flush=True)
+psi = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, s.NormLinf(1.0)), sj)
+t = timed(lambda: psi(y)); print("misaligned views, %-36s %.4f ms -> %.0f GB/s" % ("psi(y) ShiftedNormL1Box", t, 24 * n / t / 1e6))
+t = timed(lambda: s.prox_value_bang(y, psi, q, 1.0)); print("misaligned views, %-36s %.4f ms -> %.0f GB/s" % ("prox_value ShiftedNormL1Box", t, 32 * n / t / 1e6))
+d = torch.rand(n + 1, dtype=torch.float64, device=dev, generator=g)[1:] + 0.5
+t = timed(lambda: s.iprox_bang(y, psi, q, d)); print("misaligned views, %-36s %.4f ms -> %.0f GB/s" % ("iprox ShiftedNormL1Box", t, 40 * n / t / 1e6))
