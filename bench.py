@@ -268,6 +268,9 @@ def _extra(s, L, ctx, dev, n, torch):
     del hx, hs, hq, psi_h
     r = max(1, n // 100)
     line("ShiftedIndBallL0BInf_r=n/100", s.shifted(s.shifted(s.IndBallL0(r), xk, 1.0, chi), sj), 32, n, y, q)
+    # the same operator at the two ends of r (band without an upper end / widest band): tools/sweep_topr.py has the rest
+    line("ShiftedIndBallL0BInf_r=1000", s.shifted(s.shifted(s.IndBallL0(min(1000, n)), xk, 1.0, chi), sj), 32, n, y, q)
+    line("ShiftedIndBallL0BInf_r=n/2", s.shifted(s.shifted(s.IndBallL0(max(1, n // 2)), xk, 1.0, chi), sj), 32, n, y, q)
     # group config: (n // 100) groups of 128  (10^6 x 128 at n = 10^8)
     ng = max(1, n // 100)
     m = ng * 128
@@ -282,6 +285,13 @@ def _extra(s, L, ctx, dev, n, torch):
     bpe = 32 + 8 / 128
     line("ShiftedGroupNormL2_%dx128" % ng, s.shifted(s.shifted(h, xk), sj), bpe, m, y, q)
     line("ShiftedGroupNormL2Binf_%dx128" % ng, s.shifted(s.shifted(h, xk, 1.0, chi), sj), bpe, m, y, q)
+    # a sparse iterate under a strong lambda: 90 % of the groups of xk are zero, sigma*lambda above ||S|| for most groups
+    # (the reversed-bracket regime of the reference; tools/sweep_params.py has the full sweep)
+    keep = (torch.rand(ng, dtype=torch.float64, device=dev, generator=gen) < 0.1).to(torch.float64).repeat_interleave(128)
+    xk.mul_(keep)
+    del keep
+    h30 = s.GroupNormL2.uniform(lam * 30.0, 128)
+    line("ShiftedGroupNormL2Binf_%dx128_sparse_iterate" % ng, s.shifted(s.shifted(h30, xk, 1.0, chi), sj), bpe, m, y, q)
     return res
 
 
