@@ -463,7 +463,7 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
     //    sigma lambda - n - R(n) is decreasing -- if froot(lmax) > 0 the signs agree (:102-103: zeros); if froot(lmax) < 0
     //    froot stays negative up to the pole, the only sign change of the bracket is the pole itself, fzero ends on a
     //    double just above it, everything is thresholded there and :111 is l2prox(S, sigma lambda) = 0 (||S|| < sigma lambda).
-    // Checked against the oracle on 6.5e5 such groups (sizes 1-128, sigma, Delta and lambda over two decades): all zeros.
+    // (tests/test_gpu_parity.py::test_group_binf_small_groups_being_zeroed and tools/fuzz_binf_reversed.py pin this regime.)
     if (lmax < lmin * (1.0 - 1e-9) && ul > 0.0 && mX < delta * (1.0 - 1e-9) && nS <= 1e6 * delta && (sS + sX < INFINITY))
       return BINF_ZERO;
   }
