@@ -446,14 +446,17 @@ __global__ __launch_bounds__(256) void k_s2_sample(const double* q, const double
 // One workgroup of 1024 lanes: brackets the sample's rank_hi-th and rank_lo-th largest keys to 36 bits
 // (three 12-bit digits; the first comes from the histogram k_s2_sample built) and writes the band.
 constexpr int kPickDigits = 3;
+constexpr unsigned int kPickFine = 16;  // samples per selected bucket below which no further digit is resolved
 __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n, int64_t r, SelWs* ws) {
   __shared__ unsigned int h[2][kBins];
   __shared__ unsigned long long part[4][4];  // per 256-lane group
   __shared__ unsigned long long pre[2];
   __shared__ long long quo[2];
   __shared__ int active[2];
+  __shared__ unsigned int bucket[2];  // samples in the bucket each selection sits in after the last digit
   const int t = threadIdx.x;
   if (t == 0) {
+    bucket[0] = bucket[1] = 0u;
     const double M = (double)kSample;
     const double p = (double)r / (double)n;
     const double k = p * M;
@@ -468,8 +471,13 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
   }
   int shift = 64 - kDigitBits;
   const int width = kDigitBits;
+  int ndig = 0;
   for (int digit = 0; digit < kPickDigits; ++digit) {
     __syncthreads();
+    // a third digit only when the second still leaves a crowd in a selected bucket (data packed into a narrow relative
+    // range): two digits are 2^-12 relative, far below the +-6 sigma width of the band itself
+    if (digit == 2 && bucket[0] <= kPickFine && bucket[1] <= kPickFine) break;
+    ndig = digit + 1;
     if (digit == 0) {
       for (int b = t; b < kBins; b += 1024) { const unsigned int c = (unsigned int)ws->hist[b]; h[0][b] = c; h[1][b] = c; }
     } else {
@@ -510,6 +518,7 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
         if (run < quota && run + loc[k] >= quota) {
           pre[sel] = (pre[sel] << width) | (uint64_t)(kBins - 1 - (tt * PER + k));
           quo[sel] = (long long)(quota - run);
+          bucket[sel] = (unsigned int)loc[k];
         }
         run += loc[k];
       }
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
   for (int b = t; b < kBins; b += 1024) ws->hist[b] = 0ull;  // clean for the candidate passes
   if (t == 0) {
     FastState& f = ws->fs;
-    const int low = 64 - kPickDigits * kDigitBits;  // undecided low bits: take the whole bucket
+    const int low = 64 - ndig * kDigitBits;  // undecided low bits: take the whole bucket
     f.t_hi = active[0] ? ((pre[0] << low) | (((uint64_t)1 << low) - 1)) : ~0ull;  // nothing is above all-ones
     f.t_lo = active[1] ? (pre[1] << low) : 0ull;
     f.cnt_above = 0;
