@@ -9,8 +9,9 @@
 //
 //   pass 0      v -> y (y is the reference's scratch too, :66), LDS histogram of key digit 0 (12 bits)
 //   scan        one workgroup walks the 4096 bins from the top, finds the bin holding the r-th largest,
-//               updates (prefix, quota) in device memory; no host round trip
-//   pass 1..5   re-read y (8 B/element), histogram the next digit of the keys matching the prefix
+//               updates (base, quota) in device memory -- base = low end of the bin, the undecided part of key
+//               space is [base, base + 2^(shift + width)) -- no host round trip
+//   pass 1..5   re-read y (8 B/element), histogram the next digit of key - base for the keys inside that interval
 //   tie passes  only if the threshold key T is shared by more elements than the remaining quota:
 //               the same machinery over the index digits of {i : key_i == T}, ascending
 //   final       y[i] = (keep_i ? v_i : 0) - (xk[i] + sj[i])   [clamped for BInf]
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void k_sel_pass0(double* y, const double* q, c
   if (count) flush_hist(lh, ws->hist);
 }
 
-// passes >= 1: histogram the current digit of the elements that match the decided prefix.
+// passes >= 1: histogram the current digit of the elements still undecided (SelState::base).
 __global__ __launch_bounds__(256) void k_sel_hist(const double* y, int64_t n, int vec, SelWs* ws) {
   const SelState st = ws->st;
   if (st.phase == 2) return;
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(256) void k_s2_scan_verify(SelWs* ws, int64_t r) {
   for (int b = threadIdx.x; b < kBins; b += blockDim.x) ws->hist[b] = 0ull;
 }
 
-// after the first candidate digit: the candidates still in play (same decided prefix, or tied key) -> short list.
+// after the first candidate digit: the candidates still in play (inside the chosen bin, or tied key) -> short list.
 // WRITE (single-pass form): candidates that the first digit already puts above the cut get their kept value here; the
 // short list carries the values of the rest and k_s2_finish stores those that make it -- no separate fix-up walk.
 template <bool WRITE>
