@@ -914,6 +914,9 @@ __global__ __launch_bounds__(256) void k_sel_final_q(double* y_, const double* q
     y_[-1] = sel_out<BINF>((xk_[-1] + sj_[-1]) + q_[-1], 0, xk_[-1], sj_[-1], st, delta);
 }
 
+#ifndef SPX_SEL_FAST_MIN_LOG2
+#define SPX_SEL_FAST_MIN_LOG2 20  // smallest n (log2) on the sample-predicted path: 83-98 us vs 100-123 us for the full-vector path at 2^20, behind it below (tools/exp/topr_threshold.py)
+#endif
 static int g_sel_fast = 1;  // spx_set_tuning key 2: 0 disables the sample-predicted path
 static int g_sel_spec = 1;  // spx_set_tuning key 4: 0 disables the single-pass (speculative store) form of it
 
@@ -929,7 +932,7 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   // runs on the aligned rest and its wave 0 takes element 0 along (ioff = 1)
   auto off8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 8u; };
   const int ioff = (!vec && off8(y) && off8(q) && off8(xk) && off8(sj)) ? 1 : 0;
-  const bool try_fast = g_sel_fast && (vec || ioff) && (n - ioff) >= ((int64_t)1 << 22) && r > 0 && r < n;
+  const bool try_fast = g_sel_fast && (vec || ioff) && (n - ioff) >= ((int64_t)1 << SPX_SEL_FAST_MIN_LOG2) && r > 0 && r < n;
   // fast path scratch: one candidate region + count word per wavefront of the main pass
   const int64_t n2 = (n - ioff) >> 1;
   const int64_t mblocks = (n2 + kMainTilePairs - 1) / kMainTilePairs;

@@ -167,7 +167,7 @@ def test_full_size_groups(s, orc, binf):
 
 @pytest.mark.parametrize("case", ["normal", "quant", "all_equal", "sorted", "two_values", "spike"])
 def test_indball_fast_path_and_fallback(s, orc, case):
-    """n just above the fast-path threshold (2^22): the sample-predicted band path, its verification and
+    """n = 2^22 + 12345 (the fast-path threshold is 2^20): the sample-predicted band path, its verification and
     the fallback to the full-vector radix select, bit-exact against the oracle, also with the fast path off."""
     import ctypes
     import torch

@@ -296,7 +296,7 @@ def test_indball_l0_nan_inf(s, orc):
 
 @pytest.mark.parametrize("kind", ["scaled", "cauchy", "concentrated"])
 def test_indball_l0_ranks_and_scales(s, orc, kind):
-    """Sample-predicted path (n >= 2^22) over the whole range of r and over data whose r-th magnitude sits next to an
+    """Sample-predicted path (n >= 2^20) over the whole range of r and over data whose r-th magnitude sits next to an
     exponent boundary, has heavy tails, or is packed into a 1e-9 relative range: the candidate digits follow the
     band's span (SelState::base), so none of these may change the kept set (tools/sweep_topr.py times them at n = 1e8)."""
     n = (1 << 22) + 4321
@@ -317,6 +317,21 @@ def test_indball_l0_ranks_and_scales(s, orc, kind):
     r = n // 37  # aliased form (y === q)
     s.prox_bang(qd, s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qd, 1.0)
     assert _bits_equal(qd.cpu().numpy(), orc.prox_indball_l0(q, x, sj, r)), kind
+
+
+@pytest.mark.parametrize("n", [(1 << 20) - 1, 1 << 20, (1 << 20) + 1, (1 << 20) + 3001])
+def test_indball_l0_at_the_fast_path_threshold(s, orc, n):
+    """Either side of the size at which the sample-predicted path takes over from the full-vector radix select
+    (SPX_SEL_FAST_MIN_LOG2 = 20): the sample is then 1/16 of the vector.  Lattice data (ties), all r regimes."""
+    rng = np.random.default_rng(n)
+    x, sj = np.round(rng.normal(size=n) * 16) / 16, np.round(rng.uniform(-0.5, 0.5, size=n) * 16) / 16
+    q = np.round(rng.normal(size=n) * 16) / 16
+    xd, sd, qd = _dev(x, sj, q)
+    for r in (1, 3, 777, n // 100, n // 3, n - 2):
+        y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.8, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
+        assert _bits_equal(y, orc.prox_indball_l0_binf(q, x, sj, r, 0.8)), (n, r)
+    s.prox_bang(qd, s.shifted(s.shifted(s.IndBallL0(n // 50), xd), sd), qd, 1.0)      # aliased form
+    assert _bits_equal(qd.cpu().numpy(), orc.prox_indball_l0(q, x, sj, n // 50)), n
 
 
 def test_indball_l0_misaligned_views_fast_path(s, orc):
