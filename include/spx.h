@@ -73,7 +73,8 @@ int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms); /* records stop, waits, ret
  * top-r path (1, default) or always the full-vector radix select (0), key 3 = LDS-staged (1, default) or
  * register-staged (0) separable skeleton, key 4 = single-pass form of the top-r path when y overlaps no input
  * (1, default) or always the two-pass form (0), key 5 = XCD-contiguous tile ranges in the LDS-staged skeleton (0,
- * default: tile = workgroup id).  Process-wide. */
+ * default: tile = workgroup id), key 6 = one-workgroup top-r kernel for n <= 65536 (1, default) or the multi-launch
+ * path at every size (0).  Process-wide. */
 int spx_set_tuning(int key, int value);
 
 /* ---- construction-time helpers (the reference's constructors) ---------------------------- */

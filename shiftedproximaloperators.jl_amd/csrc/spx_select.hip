@@ -395,6 +395,101 @@ __global__ __launch_bounds__(256) void k_sel_final(double* y, const double* xk, 
 }
 
 // =============================================================================================
+// Small n (<= kSmallN): the whole selection in ONE workgroup and one launch.  The multi-launch path above costs 65-70 us
+// at any small size (18-20 dependent launches); here a single CU streams the vectors (L2-resident after the first
+// touch): v -> y and the key range in pass 0, digits of key - min over the data's own span (SelState::base: no hot
+// exponent bins for the LDS atomics), index digits for ties, final pass.  Lane t owns elements t, t + 1024, ... in
+// every pass, so y needs no fence between passes.
+// =============================================================================================
+constexpr int64_t kSmallN = 1 << 16;
+template <bool BINF>
+__global__ __launch_bounds__(1024) void k_sel_small(double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                                     int64_t r, double delta) {
+  __shared__ unsigned int h[kBins];
+  __shared__ unsigned long long scratch[8];
+  __shared__ unsigned long long kmm[2];
+  __shared__ SelState sst;
+  const int t = threadIdx.x;
+  if (t == 0) { kmm[0] = ~0ull; kmm[1] = 0ull; }
+  __syncthreads();
+  uint64_t kmin = ~0ull, kmax = 0ull;
+  for (int64_t i = t; i < n; i += 1024) {
+    const double v = (xk[i] + sj[i]) + q[i];  // shiftedIndBallL0.jl:66
+    y[i] = v;
+    const uint64_t k = key_of(v);
+    kmin = k < kmin ? k : kmin;
+    kmax = k > kmax ? k : kmax;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint64_t a = __shfl_xor((unsigned long long)kmin, off, 64), b = __shfl_xor((unsigned long long)kmax, off, 64);
+    kmin = a < kmin ? a : kmin;
+    kmax = b > kmax ? b : kmax;
+  }
+  if ((t & 63) == 0) { atomicMin(&kmm[0], (unsigned long long)kmin); atomicMax(&kmm[1], (unsigned long long)kmax); }
+  __syncthreads();
+  if (t == 0) {
+    SelState s;
+    int bits = 0;
+    while (bits < 63 && ((int64_t)1 << bits) < n) ++bits;
+    s.idx_bits = bits;
+    s.prefix = 0;
+    s.icut = -1;
+    s.t_eq = ~0ull;
+    s.t_ge = ~0ull;
+    s.pad = s.pad2 = s.pad3 = 0;
+    s.t_floor = 0;
+    s.clamp = 0;
+    s.quota = r;
+    s.base = kmm[0];
+    s.shift = 0;
+    s.width = 0;
+    const uint64_t span = kmm[1] - kmm[0];
+    if (r <= 0) {  // nothing kept
+      s.phase = 2; s.quota = 0;
+    } else if (r >= n) {  // everything kept
+      s.phase = 2; s.t_ge = 0ull; s.quota = 0;
+    } else if (span == 0) {  // one key value: straight to the index tie-break
+      s.phase = 1;
+      s.t_eq = kmm[0];
+      s.t_ge = kmm[0] + 1;
+      const int w = bits % kDigitBits ? bits % kDigitBits : kDigitBits;
+      s.shift = bits - w;
+      s.width = w;
+      if (bits == 0) { s.phase = 2; s.icut = 0; }
+    } else {
+      const int sb = 64 - __clzll((long long)span);  // span < 2^sb: every key is inside [base, base + 2^sb)
+      s.phase = 0;
+      s.width = sb < kDigitBits ? sb : kDigitBits;
+      s.shift = sb - s.width;
+    }
+    sst = s;
+  }
+  for (int guard = 0; guard < 16; ++guard) {  // <= 6 key digits + <= 2 index digits
+    __syncthreads();
+    const SelState st = sst;
+    if (st.phase == 2) break;
+    for (int b = t; b < kBins; b += 1024) h[b] = 0u;
+    __syncthreads();
+    const int hs = st.shift + st.width;
+    const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
+    for (int64_t i = t; i < n; i += 1024) {
+      const uint64_t key = key_of(y[i]);
+      if (st.phase == 0) {
+        const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
+        if (kp.in) atomicAdd(&h[kp.digit], 1u);
+      } else if (key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix) {
+        atomicAdd(&h[(((uint64_t)i) >> st.shift) & dmask], 1u);
+      }
+    }
+    __syncthreads();
+    sel_scan_step(h, st, &sst, scratch);
+  }
+  __syncthreads();
+  const SelState fin = sst;
+  for (int64_t i = t; i < n; i += 1024) y[i] = sel_out<BINF>(y[i], i, xk[i], sj[i], fin, delta);
+}
+
+// =============================================================================================
 // Fast path (large n): sample-predicted band.
 //   1. k_s2_sample   65536 samples of |v| (256 chunks of 256 consecutive elements: 1.5 MB of reads)
 //   2. k_s2_pick     one workgroup: exact order statistics of the sample at ranks p*M -/+ (6 sigma + 16),
@@ -917,6 +1012,7 @@ __global__ __launch_bounds__(256) void k_sel_final_q(double* y_, const double* q
 #ifndef SPX_SEL_FAST_MIN_LOG2
 #define SPX_SEL_FAST_MIN_LOG2 20  // smallest n (log2) on the sample-predicted path: 83-98 us vs 100-123 us for the full-vector path at 2^20, behind it below (tools/exp/topr_threshold.py)
 #endif
+static int g_sel_small = 1;  // spx_set_tuning key 6: 0 disables the one-workgroup kernel for n <= kSmallN
 static int g_sel_fast = 1;  // spx_set_tuning key 2: 0 disables the sample-predicted path
 static int g_sel_spec = 1;  // spx_set_tuning key 4: 0 disables the single-pass (speculative store) form of it
 
@@ -927,6 +1023,11 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   if (rc) return rc;
   if (n == 0) return SPX_OK;
   SPX_HIP(hipSetDevice(ctx->device));
+  if (n <= kSmallN && g_sel_small) {  // one workgroup, one launch, no scratch
+    hipLaunchKernelGGL((k_sel_small<BINF>), dim3(1), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta);
+    SPX_LAUNCH_CHECK();
+    return SPX_OK;
+  }
   const int vec = (spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj)) ? 1 : 0;
   // all four vectors 8 bytes off a 16-byte boundary (a view that starts at an odd element): the sample-predicted path
   // runs on the aligned rest and its wave 0 takes element 0 along (ioff = 1)
@@ -1018,6 +1119,7 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
 
 }  // namespace
 
+void spx_select_set_small(int on) { g_sel_small = on ? 1 : 0; }
 void spx_select_set_fast(int on) { g_sel_fast = on ? 1 : 0; }
 void spx_select_set_spec(int on) { g_sel_spec = on ? 1 : 0; }
 

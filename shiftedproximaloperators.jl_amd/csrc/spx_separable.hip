@@ -646,6 +646,7 @@ __global__ __launch_bounds__(256) void k_sep_scalar(double* y, const double* q, 
 // one tile per workgroup (no cap) + non-temporal loads/stores: 6.15 TB/s vs 5.66 TB/s for 16 WG/CU, plain.
 void spx_select_set_fast(int on);
 void spx_select_set_spec(int on);  // spx_select.hip
+void spx_select_set_small(int on);
 static int g_sep_blocks_per_cu = 0;  // 0 = no cap: grid = number of tiles
 static int g_sep_nt = 1;
 
@@ -777,6 +778,7 @@ SPX_EXPORT int spx_set_tuning(int key, int value) {
   if (key == 3) { g_sep_lds = value ? 1 : 0; return SPX_OK; }
   if (key == 4) { spx_select_set_spec(value); return SPX_OK; }
   if (key == 5) { g_sep_xcd = value ? 1 : 0; return SPX_OK; }
+  if (key == 6) { spx_select_set_small(value); return SPX_OK; }
   spx_set_error("invalid argument: unknown tuning key/value");
   return SPX_ERR_INVALID_ARG;
 }

@@ -247,6 +247,36 @@ def test_indball_l0(s, orc, n, quant):
         assert _bits_equal(y, orc.prox_indball_l0_binf(q, x, sj, r, 0.6)), (n, r, quant)
 
 
+def test_indball_l0_small_n_both_kernels(s, orc):
+    """n <= 65536 runs in one workgroup (k_sel_small); spx_set_tuning key 6 = 0 sends the same sizes through the
+    multi-launch radix select that larger vectors use.  Both must give the oracle's bits, ties and NaN included."""
+    L = s._lib.load()
+    rng = np.random.default_rng(6)
+    try:
+        for mode in (1, 0):
+            L.spx_set_tuning(6, mode)
+            for n in (1, 2, 63, 1024, 1025, 5000, 65536):
+                x, sj, q = _data(n, 700 + n, 8)
+                if n >= 63:
+                    q[rng.choice(n, size=3, replace=False)] = np.nan
+                    q[rng.choice(n, size=2, replace=False)] = np.inf
+                xd, sd, qd = _dev(x, sj, q)
+                for r in sorted({1, 2, max(1, n // 7), max(1, n - 1), n, n + 3}):
+                    with np.errstate(all="ignore"):
+                        ref = orc.prox_indball_l0_binf(q, x, sj, r, 0.6)
+                    y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.6, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
+                    assert _same_or_both_nan(y, ref), (mode, n, r)
+            # constant magnitude: the key span is zero, the index digits decide alone
+            n = 3000
+            q = np.where(np.arange(n) % 3 == 0, -2.5, 2.5); x = np.zeros(n); sj = np.zeros(n)
+            xd, sd, qd = _dev(x, sj, q)
+            for r in (1, 1500, 2999):
+                y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qd, 1.0).cpu().numpy()
+                assert _bits_equal(y, orc.prox_indball_l0(q, x, sj, r)), (mode, r)
+    finally:
+        L.spx_set_tuning(6, 1)
+
+
 def test_indball_l0_ties_and_kats(s, orc, kats):
     T = kats["derived"]["tiebreak"]
     x, sj, q = (np.array(T[k]) for k in ("x", "s", "q"))
