@@ -43,11 +43,18 @@ def test_single_gpu_line():
     assert "workload" in d["config"]
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_two_rank_rehearsal():
     _gpu()
     env = dict(os.environ, SPX_NO_BUILD="1", SPX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29731", "bench.py", "--gpus", "2", "--steps", "5",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "5",
                         "--warmup", "2", "--elements", "4000000", "--no-extra", "--no-cpu"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
     assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
