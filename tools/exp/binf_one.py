@@ -5,7 +5,7 @@ import torch
 import __graft_entry__ as ge
 s = ge.build()
 dev = torch.device("cuda:0"); g = torch.Generator(device=dev).manual_seed(1)
-ng, gs = 1_000_000, 128; n = ng * gs
+gs = int(os.environ.get("SPX_GS", "128")); ng = 128_000_000 // gs; n = ng * gs
 xs, delta, ls = float(sys.argv[1]), float(sys.argv[2]), float(sys.argv[3])
 xk = torch.randn(n, dtype=torch.float64, device=dev, generator=g) * xs; sj = torch.rand(n, dtype=torch.float64, device=dev, generator=g) - 0.5
 q = torch.randn(n, dtype=torch.float64, device=dev, generator=g); y = torch.empty_like(q)

@@ -8,7 +8,7 @@ import __graft_entry__ as ge
 s = ge.build(); L = s._lib.load()
 dev = torch.device("cuda:0"); ctx = s.context(dev)
 g = torch.Generator(device=dev).manual_seed(1)
-ng, gs = 1_000_000, 128; n = ng * gs
+gs = int(os.environ.get("SPX_GS", "128")); ng = 128_000_000 // gs; n = ng * gs   # SPX_GS: other uniform group sizes
 def timed(f, reps=5):
     f(); ts = []
     for _ in range(3):
