@@ -46,7 +46,9 @@ __device__ __forceinline__ double b2_block_sum(double v, double* lds4) {
 template <bool FIRST, bool VEC>
 __global__ __launch_bounds__(256) void k_b2_pass(const double* __restrict__ q, const double* __restrict__ xk,
                                                   const double* __restrict__ sj, int64_t n, double ls, double r,
-                                                  B2Ws* ws, double* ywrite, double rinv) {
+                                                  B2Ws* ws, double* ywrite, double rinv, int head) {
+  // head = 1 (VEC only): the caller's vectors start 8 bytes off a 16-byte boundary (all alike); the pointers are the
+  // aligned rest, n counts it, and the caller's element 0 sits at [-1] (taken along by one lane of workgroup 0)
   __shared__ double lds4[4];
   double p = 0.0, c = 0.0, f = 0.0;
   auto visit = [&](double qi, double x, double s) -> double {
@@ -91,6 +93,10 @@ __global__ __launch_bounds__(256) void k_b2_pass(const double* __restrict__ q, c
       const double o = visit(q[n - 1], xk[n - 1], sj[n - 1]);
       if (ywrite) ywrite[n - 1] = o;
     }
+    if (head && blockIdx.x == 0 && threadIdx.x == 64) {
+      const double o = visit(q[-1], xk[-1], sj[-1]);
+      if (ywrite) ywrite[-1] = o;
+    }
   } else {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) visit(q[i], xk[i], sj[i]);
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256) void k_b2_reduce(B2Ws* ws, int nblocks, int fi
 // y = ProjB((-xk) r) * rinv - sj     (r = eta/Delta, rinv = Delta/eta; r = rinv = 1 with scaled == 0: y = ProjB(-xk) - sj)
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_b2_final(double* y, const double* q, const double* xk, const double* sj,
-                                                   int64_t n, double ls, double r, double rinv, int scaled) {
+                                                   int64_t n, double ls, double r, double rinv, int scaled, int head) {
   auto out = [&](double qi, double x, double s) -> double {
     const double sq = s + qi;
     const double lo = sq - ls, hi = sq + ls;
@@ -152,6 +158,7 @@ __global__ __launch_bounds__(256) void k_b2_final(double* y, const double* q, co
         __builtin_nontemporal_store(f64x2{out(a[k].x, b[k].x, d[k].x), out(a[k].y, b[k].y, d[k].y)}, y2 + base + k * 256);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = out(q[n - 1], xk[n - 1], sj[n - 1]);
+    if (head && blockIdx.x == 0 && threadIdx.x == 64) y[-1] = out(q[-1], xk[-1], sj[-1]);  // (as k_b2_pass)
   } else {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = out(q[i], xk[i], sj[i]);
@@ -160,15 +167,15 @@ __global__ __launch_bounds__(256) void k_b2_final(double* y, const double* q, co
 
 int b2_sums(spx_ctx* ctx, const double* q, const double* xk, const double* sj, int64_t n, double ls, double r, B2Ws* ws,
             int blocks, bool vec, bool first, double* P, double* C, double* F, double* ywrite = nullptr,
-            double rinv = 1.0) {
+            double rinv = 1.0, int head = 0) {
   const dim3 grid((unsigned)blocks), block(256);
   double* yw = vec ? ywrite : nullptr;
   if (first) {
-    if (vec) hipLaunchKernelGGL((k_b2_pass<true, true>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws, yw, rinv);
-    else hipLaunchKernelGGL((k_b2_pass<true, false>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws, yw, rinv);
+    if (vec) hipLaunchKernelGGL((k_b2_pass<true, true>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws, yw, rinv, head);
+    else hipLaunchKernelGGL((k_b2_pass<true, false>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws, yw, rinv, head);
   } else {
-    if (vec) hipLaunchKernelGGL((k_b2_pass<false, true>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws, yw, rinv);
-    else hipLaunchKernelGGL((k_b2_pass<false, false>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws, yw, rinv);
+    if (vec) hipLaunchKernelGGL((k_b2_pass<false, true>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws, yw, rinv, head);
+    else hipLaunchKernelGGL((k_b2_pass<false, false>), grid, block, 0, ctx->stream, q, xk, sj, n, ls, r, ws, yw, rinv, head);
   }
   hipLaunchKernelGGL(k_b2_reduce, dim3(1), dim3(256), 0, ctx->stream, ws, blocks, first ? 1 : 0);
   SPX_LAUNCH_CHECK();
@@ -274,7 +281,17 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   SPX_HIP(hipSetDevice(ctx->device));
   B2Ws* ws = reinterpret_cast<B2Ws*>(ctx->ws);
   const double ls = lambda * sigma;  // `psi.lambda * sigma`, :56
-  const bool vec = n >= 2 && spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj);
+  bool vec = n >= 2 && spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj);
+  // views from an odd element on (all four vectors 8 bytes off a 16-byte boundary): the vector kernels run on the
+  // aligned rest and take element 0 along (2.1 -> 1.4 ms at n = 1e8, tools/bench_misaligned.py)
+  auto off8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 8u; };
+  const int head = (!vec && n >= 3 && off8(y) && off8(q) && off8(xk) && off8(sj)) ? 1 : 0;
+  const double* const q0 = q;
+  const double* const xk0 = xk;
+  const double* const sj0 = sj;
+  double* const y0 = y;
+  const int64_t n0 = n;
+  if (head) { vec = true; ++y; ++q; ++xk; ++sj; --n; }
   int64_t blocks = vec ? ((n >> 1) + 1023) / 1024 : (n + 256 * 8 - 1) / (256 * 8);
   if (blocks > kB2Blocks) blocks = kB2Blocks;
   if (blocks < 1) blocks = 1;
@@ -283,12 +300,12 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   // y overlaps none of the inputs: reduction passes may store y for their own scale (see below).  The first pass does:
   // if the trust region turns out to be inactive (Delta > chi(y), :61) its y = ProjB(-xk) - sj is the result and the call
   // is this one pass
-  auto disjoint = [&](const double* a) { return (y + n <= a) || (a + n <= y); };
-  const bool can_spec = vec && disjoint(q) && disjoint(xk) && disjoint(sj);
+  auto disjoint = [&](const double* a) { return (y0 + n0 <= a) || (a + n0 <= y0); };
+  const bool can_spec = vec && disjoint(q0) && disjoint(xk0) && disjoint(sj0);
   // (a store that turns out useless costs 8 B/element: the pass only stores when the previous call on this context was
   //  unscaled too -- 0.57 ms instead of 0.85 ms for an inactive trust region, 1.35 ms unchanged for an active one)
   const bool store_first = can_spec && !ctx->b2_last_scaled;
-  rc = b2_sums(ctx, q, xk, sj, n, ls, 1.0, ws, (int)blocks, vec, true, &P, &C, &F, store_first ? y : nullptr, 1.0);
+  rc = b2_sums(ctx, q, xk, sj, n, ls, 1.0, ws, (int)blocks, vec, true, &P, &C, &F, store_first ? y : nullptr, 1.0, head);
   if (rc) return rc;
   const double chiy = chi_lambda * std::sqrt(P + C);
   ctx->b2_last_scaled = (delta <= chiy) ? 1 : 0;
@@ -308,7 +325,7 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
     const double eta_ub = chi_lambda * std::sqrt(F);
     if (eta_ub > delta && std::isfinite(eta_ub)) {
       eta = eta_ub;
-      rc = b2_sums(ctx, q, xk, sj, n, ls, eta / delta, ws, (int)blocks, vec, false, &P, &C, nullptr);
+      rc = b2_sums(ctx, q, xk, sj, n, ls, eta / delta, ws, (int)blocks, vec, false, &P, &C, nullptr, nullptr, 1.0, head);
       if (rc) return rc;
     }
     // y overlaps none of the inputs: a pass that is likely to be the last one (the step has become small) also stores y
@@ -329,7 +346,7 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
       const bool spec = can_spec && std::fabs(next - eta) <= 1e-3 * next;
       pP = P; pC = C; eta = next;
       rc = b2_sums(ctx, q, xk, sj, n, ls, eta / delta, ws, (int)blocks, vec, false, &P, &C, nullptr, spec ? y : nullptr,
-                   delta / eta);
+                   delta / eta, head);
       if (rc) return rc;
       y_eta = spec ? eta : -1.0;
     }
@@ -338,12 +355,12 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   if (vec) {
     const int64_t fblocks = ((n >> 1) + 1023) / 1024;
     hipLaunchKernelGGL((k_b2_final<true>), dim3((unsigned)(fblocks < 1 ? 1 : fblocks)), dim3(256), 0, ctx->stream, y, q,
-                       xk, sj, n, ls, eta / delta, delta / eta, scaled);
+                       xk, sj, n, ls, eta / delta, delta / eta, scaled, head);
   } else {
     int64_t fblocks = (n + 255) / 256;
     if (fblocks > (int64_t)ctx->num_cu * 16) fblocks = (int64_t)ctx->num_cu * 16;
     hipLaunchKernelGGL((k_b2_final<false>), dim3((unsigned)fblocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n, ls,
-                       eta / delta, delta / eta, scaled);
+                       eta / delta, delta / eta, scaled, 0);
   }
   SPX_LAUNCH_CHECK();
   return SPX_OK;

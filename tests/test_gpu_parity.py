@@ -866,6 +866,30 @@ def test_l1b2_large(s, orc):
         assert np.max(np.abs(y - ref)) <= 1e-12 * scale, (lam, sigma, delta)
 
 
+@pytest.mark.parametrize("n", [2, 3, 4, 1001, 1002, 300_001])
+def test_l1b2_misaligned_views(s, orc, n):
+    """All four vectors from an odd element on (8 bytes off a 16-byte boundary): the vector kernels run on the aligned
+    rest and take element 0 along (n >= 3; n = 2 stays on the scalar path).  Trust region active, barely active and
+    inactive (twice: the second inactive call stores y in its first pass), y disjoint and aliased to q."""
+    import torch
+    xh, sh, qh = _data(n, 90 + n)
+    xh[0], qh[0] = 3.0, -2.0                           # element 0 matters for the norms
+    mk = lambda a: torch.cat([torch.zeros(1, dtype=torch.float64), torch.from_numpy(a)]).cuda()[1:]
+    xd, sd, qd = mk(xh), mk(sh), mk(qh)
+    assert all(t.data_ptr() % 16 == 8 for t in (xd, sd, qd))
+    nrm = float(np.linalg.norm(xh))
+    for lam, sigma, delta in ((1.0, 1.0, 0.5), (0.3, 0.7, 0.9 * nrm), (1.0, 1.0, 1e6), (1.0, 1.0, 1e6)):
+        om = s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(1.0)), sd)
+        ref = orc.prox_l1_b2(qh, xh, sh, lam, sigma, delta, 1.0)
+        scale = max(np.linalg.norm(ref), np.linalg.norm(xh))
+        yv = mk(np.zeros(n))
+        s.prox_bang(yv, om, qd, sigma)
+        assert np.max(np.abs(yv.cpu().numpy() - ref)) <= 1e-12 * scale, (n, lam, sigma, delta)
+        q2 = mk(qh.copy())
+        s.prox_bang(q2, om, q2, sigma)                 # y === q
+        assert np.max(np.abs(q2.cpu().numpy() - ref)) <= 1e-12 * scale, (n, lam, sigma, delta, "aliased")
+
+
 # ------------------------------------------------------------------ special values
 def test_special_values_separable(s, orc):
     """+-0, +-Inf, NaN, subnormals, huge values and points exactly on the thresholds, in every combination of
