@@ -402,6 +402,7 @@ __device__ __forceinline__ void binf_literal_reg(const RegGroup<EPL>& grp, doubl
       bool decided = g0 < -1e-9 * sl;
       if (!decided && g0 > 1e-9 * sl) {
         for (int k = 0; k < 8 && !decided; ++k) {
+          if (!(sl - R > 0.0)) break;  // (R can exceed sl after a jump: leave it to the literal evaluation)
           const double r2n = rsq_at(sl - R);
           decided = (r2n == r2);
           r2 = r2n;
