@@ -302,16 +302,51 @@ __device__ __forceinline__ bool binf_literal_root(const G& grp, double lam, doub
   const double fl = binf_froot_literal<TEAM>(grp, lmin, sigma, sl, delta, lds);  // :95
   const double ansatz = lmin + 1.0;                                       // :97
   const double step = ansatz / (sigma * (ansatz - sl));                   // :98
-  double sz = 0.0, sS = 0.0, sX = 0.0;
+  double sz = 0.0, sS = 0.0, sX = 0.0, mX = 0.0, gap = INFINITY;
   grp.for_each([&](double S, double X) {
     const double z = softthres(S / sigma - step * X, delta * step);       // :99
     sz += z * z;
     sS += S * S;
     sX += X * X;
+    mX = fmax(mX, fabs(X));
+    gap = fmin(gap, fabs(fabs(X) - delta));
   });
   team_sum2<TEAM>(sz, sS, lds);
   sX = team_sum<TEAM>(sX, lds);
   const double lmax = sqrt(sS) + sigma * (sqrt(sz) + 1.0 * lam * sqrt(sX));  // :100
+  // Reversed bracket with entries outside the trust region: the piece iteration of binf_literal_reg (derivation and
+  // guards there), for the element providers of the general / LDS / gather kernels.  `false` = the reference writes zeros.
+  {
+    mX = team_max<TEAM>(mX, lds);
+    gap = -team_max<TEAM>(-gap, lds);
+    if (lmax < lmin * (1.0 - 1e-9) && lmin > sl && (sS + sX < INFINITY) && sqrt(sS) <= 1e6 * delta && sl <= 1e6 * delta &&
+        mX - delta >= 1e-6 * sl && gap > 1e-9 * delta) {
+      auto rsq_at = [&](double n) -> double {  // R(n)^2
+        const double a = n / (sigma * (sl - n));
+        double acc = 0.0;
+        grp.for_each([&](double S, double X) {
+          const double z = __builtin_fma(a, X, S / sigma);
+          const double b = (z == 0.0) ? X : X + signed_delta(delta, z);
+          acc += b * b;
+        });
+        return team_sum<TEAM>(acc, lds);
+      };
+      double r2 = rsq_at(lmax);
+      double R = sqrt(r2);
+      const double g0 = (sl - lmax) - R;
+      bool decided = g0 < -1e-9 * sl;
+      if (!decided && g0 > 1e-9 * sl) {
+        for (int k = 0; k < 8 && !decided; ++k) {
+          if (!(sl - R > 0.0)) break;
+          const double r2n = rsq_at(sl - R);
+          decided = (r2n == r2);
+          r2 = r2n;
+          R = sqrt(r2);
+        }
+      }
+      if (decided) return false;
+    }
+  }
   const double fm = binf_froot_literal<TEAM>(grp, lmax, sigma, sl, delta, lds);  // :101
   if (fl * fm > 0) return false;                                          // :102
   root = binf_bisect<TEAM>(grp, lmin, fl, lmax, fm, sigma, sl, delta, lds);  // :105
