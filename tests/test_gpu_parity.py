@@ -607,6 +607,51 @@ def test_group_ragged_bounded_sizes(s, orc, binf, maxsize):
     _group_check(yy.cpu().numpy(), ref, q, x, sj, list(offsets))
 
 
+@pytest.mark.parametrize("binf", [False, True])
+@pytest.mark.parametrize("maxsize", [40, 190, 512])
+def test_group_ragged_many_groups(s, orc, binf, maxsize):
+    """66 000 ragged groups with a size bound through the C entry points: the exact bound and one that is too small (a
+    third of the groups then exceed their tile and go to the deferred list); offsets that start after 0 and end before n
+    (plain form: the uncovered entries still get y - (xk + sj), Binf: untouched).
+    (Tried on this layout: binning the groups by size class so that each runs on the smallest tile that holds it -- the
+    extra launches and the lost streaming order cost more than the padding they save, 1.24 -> 1.56 ms at 1e6 groups of
+    64..192; dropped.)"""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(1000 + maxsize)
+    ng = 66_000
+    sizes = rng.integers(0 if maxsize == 40 else 1, maxsize + 1, size=ng)      # (an empty group or two at maxsize 40)
+    sizes[:3] = (maxsize, 1, maxsize)
+    lead, trail = 5, 7
+    offsets = lead + np.concatenate([[0], np.cumsum(sizes)])
+    n = int(offsets[-1]) + trail
+    x, sj, q = _data(n, 9300 + maxsize)
+    lam = rng.uniform(0.2, 2.0, size=ng)
+    xd, sd, qd = _dev(x, sj, q)
+    offd = torch.from_numpy(offsets.astype(np.int64)).cuda()
+    lamd = torch.from_numpy(lam).cuda()
+    sigma, delta = 0.8, 0.9
+    y0 = np.full(n, 123.0)
+    if binf:
+        ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, offsets=offsets)
+        ref[:lead] = y0[:lead]; ref[n - trail:] = y0[n - trail:]               # entries in no group keep y on entry
+    else:
+        ref = orc.prox_group_l2(q, x, sj, lam, sigma, offsets=offsets)
+        ref[:lead] = y0[:lead] - (x[:lead] + sj[:lead]); ref[n - trail:] = y0[n - trail:] - (x[n - trail:] + sj[n - trail:])
+    L, ctx = s._lib.load(), s.context("cuda:0")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    for bound in (maxsize, max(1, maxsize // 3)):
+        yy = torch.from_numpy(y0.copy()).cuda()
+        if binf:
+            s._lib.check(L.spx_prox_group_l2_binf(ctx, p(yy), p(qd), p(xd), p(sd), n, p(offd), bound, ng, p(lamd), sigma, delta))
+        else:
+            s._lib.check(L.spx_prox_group_l2(ctx, p(yy), p(qd), p(xd), p(sd), n, p(offd), bound, ng, p(lamd), sigma))
+        yh = yy.cpu().numpy()
+        assert np.array_equal(yh[:lead], ref[:lead]) and np.array_equal(yh[n - trail:], ref[n - trail:]), bound
+        _group_check(yh[lead:n - trail], ref[lead:n - trail], q[lead:n - trail], x[lead:n - trail], sj[lead:n - trail],
+                     list(offsets - lead))
+
+
 def test_group_binf_goldens_and_edge_branches(s, orc, kats):
     for name in ("group_l2_binf_single", "group_l2_binf_two"):  # test/runtests.jl:587-606, 658-705
         k = kats[name]
