@@ -227,7 +227,11 @@ const LAYOUTS = IdDict{Any, Any}()
 
 function layout_for(h, n)
   get!(LAYOUTS, h) do
-    rngs = map(g -> g isa Colon ? (1:n) : g, h.idx)
+    # `[:]` is the whole vector; an explicit index vector that is a contiguous run (`collect(4:6)`, runtests.jl:290) is a range
+    asrange(g) = g isa Colon ? (1:n) :
+                 (g isa AbstractVector{<:Integer} && !(g isa AbstractUnitRange) && !isempty(g) &&
+                  all(i -> g[i + 1] - g[i] == 1, 1:(length(g) - 1))) ? (first(g):last(g)) : g
+    rngs = map(asrange, h.idx)
     lam = ROCVector{Float64}(collect(Float64, h.lambda))
     if !(all(g -> g isa AbstractUnitRange, rngs) &&
          all(i -> first(rngs[i + 1]) == last(rngs[i]) + 1, 1:(length(rngs) - 1)))
