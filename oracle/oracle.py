@@ -348,3 +348,74 @@ def prox_l1_b2(q, xk, sj, lam, sigma, delta, chi_lambda=1.0):
     q, xk, sj, n, y = _prep(q, xk, sj)
     lib().orc_prox_l1_b2(_dp(y), _dp(q), _dp(xk), _dp(sj), n, lam, sigma, delta, chi_lambda)
     return y
+
+
+# ---- binary128 arbiter (oracle/spx_oracle_q.c) ------------------------------------------------
+# Same literal restatement evaluated in __float128: used by tests/arbiter.py to decide which side is further from
+# the exact value of the reference's formula where the HIP result and the Float64 oracle above differ by more than 1e-12.
+_SOQ = os.path.join(_HERE, "libspx_oracle_q.so")
+_libq = None
+
+
+def libq():
+    global _libq
+    if _libq is None:
+        src = os.path.join(_HERE, "spx_oracle_q.c")
+        if not os.path.exists(_SOQ) or os.path.getmtime(_SOQ) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "libspx_oracle_q.so"])
+        L = ctypes.CDLL(_SOQ)
+        d, i64, dp, ip, up = ctypes.c_double, ctypes.c_int64, _c_double_p, _c_int64_p, _c_uint8_p
+        base = [dp, dp, dp, dp, i64]
+        L.orcq_prox_lhalf.argtypes = base + [d, d]
+        L.orcq_prox_lhalf_box.argtypes = base + [d, d, dp, dp, d, d, up, ctypes.POINTER(ctypes.c_int8)]
+        L.orcq_prox_group_l2.argtypes = base + [ip, i64, i64, dp, d, ip, i64]
+        L.orcq_prox_group_l2_binf.argtypes = base + [ip, i64, i64, dp, d, d, ip, i64, ctypes.POINTER(ctypes.c_int32), dp]
+        L.orcq_prox_l1_b2.argtypes = base + [d, d, d, d]
+        for name in ("orcq_prox_lhalf", "orcq_prox_lhalf_box", "orcq_prox_group_l2", "orcq_prox_group_l2_binf",
+                     "orcq_prox_l1_b2"):
+            getattr(L, name).restype = None
+        _libq = L
+    return _libq
+
+
+def q_prox_lhalf(q, xk, sj, lam, sigma):
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    libq().orcq_prox_lhalf(_dp(y), _dp(q), _dp(xk), _dp(sj), n, lam, sigma)
+    return y
+
+
+def q_prox_lhalf_box(q, xk, sj, lam, sigma, l, u, mask=None, return_candidate=False):
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    lv, uv, ls, us = _bounds(l, u, n)
+    m, mp = _mask(mask, n)
+    cand = np.empty(n, dtype=np.int8)
+    libq().orcq_prox_lhalf_box(_dp(y), _dp(q), _dp(xk), _dp(sj), n, lam, sigma, _dp(lv), _dp(uv), ls, us, mp,
+                               cand.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)))
+    return (y, cand) if return_candidate else y
+
+
+def q_prox_group_l2(q, xk, sj, lam, sigma, which, offsets=None, gsize=0, binf_delta=None, y0=None, details=False):
+    """binary128 evaluation of ShiftedGroupNormL2 (binf_delta None) / ShiftedGroupNormL2Binf on the groups listed in
+    `which` only (it is ~1000x slower than the Float64 oracle); other entries of the result are y0 (default NaN).
+    details=True (Binf): also returns (branch, root) per listed group -- branch 0 = zeros by :102, 1 = root, 2 = zeros by :107."""
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    y[:] = np.nan if y0 is None else _f64(y0)
+    off, offp, gs, ng = _groups(n, offsets, gsize)
+    lam = _f64(lam)
+    assert lam.shape[0] == ng
+    which = np.ascontiguousarray(which, dtype=np.int64)
+    wp = which.ctypes.data_as(_c_int64_p)
+    if binf_delta is None:
+        libq().orcq_prox_group_l2(_dp(y), _dp(q), _dp(xk), _dp(sj), n, offp, gs, ng, _dp(lam), sigma, wp, which.shape[0])
+        return y
+    branch = np.zeros(which.shape[0], dtype=np.int32)
+    root = np.zeros(which.shape[0], dtype=np.float64)
+    libq().orcq_prox_group_l2_binf(_dp(y), _dp(q), _dp(xk), _dp(sj), n, offp, gs, ng, _dp(lam), sigma, float(binf_delta), wp,
+                                   which.shape[0], branch.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _dp(root))
+    return (y, branch, root) if details else y
+
+
+def q_prox_l1_b2(q, xk, sj, lam, sigma, delta, chi_lambda=1.0):
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    libq().orcq_prox_l1_b2(_dp(y), _dp(q), _dp(xk), _dp(sj), n, lam, sigma, delta, chi_lambda)
+    return y

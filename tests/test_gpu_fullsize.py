@@ -11,6 +11,8 @@ import os
 import numpy as np
 import pytest
 
+import arbiter  # tests/arbiter.py
+
 pytestmark = pytest.mark.gpu
 
 N = 100_000_000
@@ -71,24 +73,18 @@ def test_full_size_lhalf(s, orc, data, op):
     assert bool(torch.isfinite(yd).all())
     if box:
         assert float((yd + data["s"]).abs().max()) <= 1.0  # t in [l - s, u - s]
-    worst, n_loose = 0.0, 0
+    worst, n_arb = 0.0, 0
     for lo, hi in ((0, 10_000_000), (N - 1_000_000, N)):
         q, x, sj = _host(data, lo, hi)
         y = yd[lo:hi].cpu().numpy()
         ref = orc.prox_lhalf_box(q, x, sj, 1.0, 1.0, -1.0, 1.0) if box else orc.prox_lhalf(q, x, sj, 1.0, 1.0)
-        scale = np.maximum(np.maximum(np.abs(ref), np.abs(x + sj)), np.abs(q))
-        err = np.abs(y - ref) / scale
-        worst = max(worst, float(err.max()))
-        bad = err > 1e-12
-        if bad.any():
-            # only admissible next to the threshold a = 1, where acos'(a) = -1/sqrt(1 - a^2) amplifies the last-ulp
-            # difference of a (SURVEY 7 "hard parts"); bounded by 1e-16 / sqrt(2 (1 - a)) there
-            z = np.abs((x + sj) + q)[bad]
-            a = 0.25 * (z / 3) ** -1.5
-            assert np.all(np.abs(1 - a) < 1e-6) and np.all(err[bad] < 1e-9), (int(bad.sum()), float(err.max()))
-            n_loose += int(bad.sum())
-    assert n_loose <= 2, n_loose
-    print("lhalf%s worst scaled error %.3e (loose elements: %d)" % ("_box" if box else "", worst, n_loose))
+        # the plain 1e-12 bar; the handful of elements next to the threshold a = 1 (acos'(a) = -1/sqrt(1 - a^2) amplifies
+        # the last-ulp difference of a) that exceed it are adjudicated in binary128: the GPU may not be the worse side
+        v = arbiter.check_lhalf(orc, y, ref, q, x, sj, 1.0, 1.0, box=(-1.0, 1.0) if box else None, what=op)
+        worst = max(worst, v.worst_plain)
+        n_arb += v.n_checked
+    assert n_arb <= 20, n_arb
+    print("lhalf%s worst scaled difference to the Float64 oracle %.3e (adjudicated elements: %d)" % ("_box" if box else "", worst, n_arb))
 
 
 def _expected_keep(v_abs, r):
@@ -162,9 +158,9 @@ def test_full_size_groups(s, orc, binf):
         qh, xh, sh, lh = (t.cpu().numpy() for t in (q[sl], x[sl], sj[sl], lam[lo:hi]))
         ref = orc.prox_group_l2_binf(qh, xh, sh, lh, 1.0, 1.0, gsize=gs) if binf else orc.prox_group_l2(qh, xh, sh, lh, 1.0, gsize=gs)
         yh = y[sl].cpu().numpy()
-        scale = np.maximum(np.abs(ref), np.repeat(nS[lo:hi].cpu().numpy(), gs))
-        err = np.abs(yh - ref) / scale
-        assert float(err.max()) <= 1e-12, float(err.max())
+        v = arbiter.check_group(orc, yh, ref, qh, xh, sh, lh, 1.0, np.arange(0, (hi - lo) * gs + 1, gs), delta=1.0 if binf else None,
+                                what="full size groups")
+        assert v.n_checked == 0, v       # the BASELINE distribution meets the plain 1e-12 bar everywhere
 
 
 @pytest.mark.parametrize("case", ["normal", "quant", "all_equal", "sorted", "two_values", "spike"])

@@ -3,6 +3,8 @@ masks and group layouts; every operator family against the oracle with its parit
 import numpy as np
 import pytest
 
+import arbiter  # the 1e-12 bar + binary128 adjudication of whatever fails it (tests/arbiter.py)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -70,22 +72,27 @@ def test_fuzz_separable(s, orc, seed):
                 dd = _dev(d)[0]
                 yi = s.iprox(psi, qd, dd).cpu().numpy()
                 assert _bits(yi, getattr(orc, "iprox_%s_box" % name)(q, d, x, sj, lam, lo, up, mask=mask)), (name, "iprox", seed, trial)
-            # RootNormLhalf(Box): 1e-12 on the operand scale
+            # RootNormLhalf(Box): 1e-12 on the operand scale; anything above it is adjudicated in binary128
             ref = orc.prox_lhalf(q, x, sj, lam, sigma)
             y = s.prox(s.shifted(s.shifted(s.RootNormLhalf(lam), xd), sd), qd, sigma).cpu().numpy()
-            sc = np.maximum(np.maximum(np.abs(ref), np.abs(x + sj)), np.abs(q))
-            assert np.all(np.abs(y - ref) <= 1e-12 * sc), ("lhalf", seed, trial, float(np.max(np.abs(y - ref) / np.maximum(sc, 1e-300))))
+            arbiter.check_lhalf(orc, y, ref, q, x, sj, lam, sigma, what="lhalf seed %d trial %d" % (seed, trial))
             psi = s.shifted(s.shifted(s.RootNormLhalf(lam), xd, ld, ud, selected), sd) if selected else s.shifted(s.shifted(s.RootNormLhalf(lam), xd, ld, ud), sd)
             ref = orc.prox_lhalf_box(q, x, sj, lam, sigma, lo, up, mask=mask)
             y = s.prox(psi, qd, sigma).cpu().numpy()
+            sc = arbiter.lhalf_scale(ref, x, sj, q)
             bad = np.abs(y - ref) > 1e-12 * sc
-            # a different candidate on an exact tie of candidate values is not an error: accept if the objective agrees
             if bad.any():
+                # "candidate choice must match except on exact ties".  A different candidate whose objective
+                # value equals the winner's (compared in extended precision) and that is feasible is such a tie; every other
+                # element above the bar goes to the arbiter.
+                ld_ = np.longdouble
                 lo_v = np.broadcast_to(lo, (n,)); up_v = np.broadcast_to(up, (n,))
-                f = lambda t: (t - q) ** 2 / 2 / sigma + lam * np.sqrt(np.abs(t + (x + sj)))
-                tie = np.abs(f(y) - f(ref)) <= 1e-13 * np.maximum(np.abs(f(ref)), 1e-300)
+                f = lambda t: (ld_(t) - ld_(q)) ** 2 / 2 / ld_(sigma) + ld_(lam) * np.sqrt(np.abs(ld_(t) + ld_(x + sj)))
+                tie = np.abs(f(y) - f(ref)) <= 4e-16 * np.maximum(np.abs(f(ref)), 1e-300)
                 feas = (y >= lo_v - sj - 1e-12 * sc) & (y <= up_v - sj + 1e-12 * sc)
-                assert np.all(~bad | (tie & feas)), ("lhalf_box", seed, trial, int(np.sum(bad & ~(tie & feas))))
+                keep = ~(bad & tie & feas)
+                yy = np.where(keep, y, ref)
+                arbiter.check_lhalf(orc, yy, ref, q, x, sj, lam, sigma, box=(lo, up), mask=mask, what="lhalf_box seed %d trial %d" % (seed, trial))
 
 
 @pytest.mark.parametrize("seed", range(8))
@@ -105,7 +112,6 @@ def test_fuzz_groups_and_topr(s, orc, seed):
         xd, sd, qd = _dev(x, sj, q)
         groups = [range(int(a), int(b)) for a, b in zip(offsets[:-1], offsets[1:])]
         h = s.GroupNormL2(lam.tolist(), groups)
-        S = (q + x) + sj
         with np.errstate(all="ignore"):
             for binf in (False, True):
                 if binf:
@@ -115,16 +121,12 @@ def test_fuzz_groups_and_topr(s, orc, seed):
                     psi = s.shifted(s.shifted(h, xd), sd)
                     ref = orc.prox_group_l2(q, x, sj, lam, sigma, offsets=offsets)
                 y = s.prox(psi, qd, sigma).cpu().numpy()
-                sc = np.abs(ref).copy()
-                cancel = np.zeros(n)
-                for g, (a, b) in enumerate(zip(offsets[:-1], offsets[1:])):
-                    nS = np.linalg.norm(S[a:b])
-                    sc[a:b] = np.maximum(sc[a:b], nS)
-                    # the reference's last step alpha = 1 - sigma lambda / ||w|| cancels when sigma lambda ~ ||w||: the
-                    # achievable agreement degrades by that factor
-                    cancel[a:b] = max(1.0, sigma * lam[g] / max(nS, 1e-300))
-                err = np.abs(y - ref) / np.maximum(sc, 1e-300)
-                assert np.all(err <= 1e-12 * np.maximum(cancel, 1.0) * 10), (binf, seed, trial, float(err.max()))
+                # the reference's last step alpha = 1 - sigma lambda / ||w|| cancels when sigma lambda ~ ||w||: groups above the
+                # plain 1e-12 bar are adjudicated in binary128 (the GPU may not be the worse side), never loosened
+                assert np.array_equal(np.isnan(y), np.isnan(ref)) and np.array_equal(np.isfinite(y), np.isfinite(ref))
+                fin = np.isfinite(ref)
+                arbiter.check_group(orc, np.where(fin, y, 0.0), np.where(fin, ref, 0.0), q, x, sj, lam, sigma, offsets,
+                                    delta=delta if binf else None, what="fuzz groups seed %d trial %d binf %s" % (seed, trial, binf))
         r = int(rng.integers(1, n + 1))
         qq = np.round(q / scale * 8) / 8 * scale if rng.random() < 0.5 else q       # many ties half of the time
         qd2 = _dev(qq)[0]

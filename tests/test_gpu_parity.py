@@ -8,10 +8,14 @@ Bars (BASELINE.json north_star):
 import numpy as np
 import pytest
 
+import arbiter  # tests/arbiter.py: the 1e-12 bar, and the binary128 adjudication of whatever fails it
+
 pytestmark = pytest.mark.gpu
 
 LHALF_TOL = 1e-12   # |y_gpu - y_ref| <= LHALF_TOL * max(|y_ref|, |x + s|, |q|)   (y = val - (x+s): scale of the operands)
 GROUP_TOL = 1e-12   # |y_gpu - y_ref| <= GROUP_TOL * max(|y_ref|_i, ||S_group||_2)  (norm-relative inside a group)
+# No test below accepts a difference above these bars on a fixed looser tolerance: elements / groups that exceed them go
+# to the binary128 arbiter and must satisfy |y_gpu - y_q| <= 1e-12 scale + |y_oracle64 - y_q| (arbiter.py).
 
 
 @pytest.fixture(scope="module")
@@ -63,8 +67,7 @@ def test_unboxed(s, orc, op, n):
     y = s.prox(psi, qd, sigma).cpu().numpy()
     ref = getattr(orc, "prox_" + op)(q, x, sj, lam, sigma)
     if op == "lhalf":
-        scale = np.maximum(np.maximum(np.abs(ref), np.abs(x + sj)), np.abs(q))
-        assert np.all(np.abs(y - ref) <= LHALF_TOL * scale)
+        arbiter.check_lhalf(orc, y, ref, q, x, sj, lam, sigma)
     else:
         assert _bits_equal(y, ref)
     # once-shifted (sj = 0) too
@@ -72,8 +75,7 @@ def test_unboxed(s, orc, op, n):
     y1 = s.prox(psi1, qd, sigma).cpu().numpy()
     ref1 = getattr(orc, "prox_" + op)(q, x, np.zeros(n), lam, sigma)
     if op == "lhalf":
-        scale = np.maximum(np.maximum(np.abs(ref1), np.abs(x)), np.abs(q))
-        assert np.all(np.abs(y1 - ref1) <= LHALF_TOL * scale)
+        arbiter.check_lhalf(orc, y1, ref1, q, x, np.zeros(n), lam, sigma)
     else:
         assert _bits_equal(y1, ref1)
 
@@ -90,11 +92,9 @@ def test_config1_l1_n1e4_nu1(s, orc):
 BOX = {"l1_box": "NormL1", "l0_box": "NormL0", "lhalf_box": "RootNormLhalf"}
 
 
-def _check_box(op, y, ref, x, sj, q):
+def _check_box(orc, op, y, ref, x, sj, q, lam, sigma, lo, up, mask=None):
     if op == "lhalf_box":
-        scale = np.maximum(np.maximum(np.abs(ref), np.abs(x + sj)), np.abs(q))
-        bad = np.abs(y - ref) > LHALF_TOL * scale
-        assert not bad.any(), (int(bad.sum()), float(np.max(np.abs(y - ref))))
+        arbiter.check_lhalf(orc, y, ref, q, x, sj, lam, sigma, box=(lo, up), mask=mask, what=op)
     else:
         assert _bits_equal(y, ref)
 
@@ -109,7 +109,7 @@ def test_box_scalar_bounds(s, orc, op, n):
     psi = s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd)
     y = s.prox(psi, qd, sigma).cpu().numpy()
     ref = getattr(orc, "prox_" + op)(q, x, sj, lam, sigma, -delta, delta)
-    _check_box(op, y, ref, x, sj, q)
+    _check_box(orc, op, y, ref, x, sj, q, lam, sigma, -delta, delta)
 
 
 @pytest.mark.parametrize("n", [1, 2, 5, 1000, 65_537])
@@ -130,13 +130,13 @@ def test_box_vector_bounds_and_mask(s, orc, op, n, form):
     # all selected
     psi = s.shifted(s.shifted(h, xd, ld, ud), sd)
     y = s.prox(psi, qd, sigma).cpu().numpy()
-    _check_box(op, y, getattr(orc, "prox_" + op)(q, x, sj, lam, sigma, lo, uo), x, sj, q)
+    _check_box(orc, op, y, getattr(orc, "prox_" + op)(q, x, sj, lam, sigma, lo, uo), x, sj, q, lam, sigma, lo, uo)
     # selected = every other index (test/partial_prox.jl: 1:2:n) and an unsorted duplicated vector (test_allocs.jl:111)
     for selected in (range(0, n, 2), list(rng.integers(0, n, size=max(1, n // 2)))):
         mask = orc.mask_from_selected([i + 1 for i in selected], n)
         psi = s.shifted(s.shifted(h, xd, ld, ud, selected), sd)
         y = s.prox(psi, qd, sigma).cpu().numpy()
-        _check_box(op, y, getattr(orc, "prox_" + op)(q, x, sj, lam, sigma, lo, uo, mask=mask), x, sj, q)
+        _check_box(orc, op, y, getattr(orc, "prox_" + op)(q, x, sj, lam, sigma, lo, uo, mask=mask), x, sj, q, lam, sigma, lo, uo, mask)
 
 
 @pytest.mark.parametrize("op", list(BOX))
@@ -397,12 +397,23 @@ def test_indball_l0_misaligned_views_fast_path(s, orc):
 
 # ------------------------------------------------------------------ groups
 def _group_check(y, ref, q, x, sj, offsets):
-    S = (q + x) + sj
-    scale = np.abs(ref).copy()
-    for lo, hi in zip(offsets[:-1], offsets[1:]):
-        scale[lo:hi] = np.maximum(scale[lo:hi], np.linalg.norm(S[lo:hi]))
+    """The plain bar, no adjudication: every element within GROUP_TOL of the Float64 oracle."""
+    scale = arbiter.group_scale(ref, q, x, sj, offsets)
     bad = np.abs(y - ref) > GROUP_TOL * np.maximum(scale, 1e-300)
     assert not bad.any(), (int(bad.sum()), float(np.max(np.abs(y - ref))))
+
+
+def _binf_check(orc, y, ref, q, x, sj, lam, sigma, delta, offsets, what=""):
+    """ShiftedGroupNormL2Binf in the regimes where the reference's formula is ill-conditioned (sigma*lambda >> ||S||, roots
+    next to the pole of step(n), reversed brackets): the plain bar first, the binary128 arbiter for every group that fails
+    it (arbiter.check_group).  Also: NaN patterns equal, and a group the oracle zeroes that the GPU does not (or vice
+    versa) is a failure unless the arbiter sides with the GPU -- such a group fails the plain bar by construction."""
+    assert np.array_equal(np.isnan(y), np.isnan(ref)), what
+    fin = np.isfinite(ref)
+    if not fin.all():   # non-finite results (overflowing data): compared as patterns only
+        assert np.array_equal(np.isfinite(y), fin), what
+        y, ref = np.where(fin, y, 0.0), np.where(fin, ref, 0.0)
+    return arbiter.check_group(orc, y, ref, q, x, sj, lam, sigma, offsets, delta=delta, what=what)
 
 
 @pytest.mark.parametrize("gsize", [64, 128, 256, 512, 1, 2, 6, 7, 33, 66, 100, 130, 250, 257, 383, 386, 510, 511, 513,
@@ -684,10 +695,10 @@ def test_group_binf_goldens_and_edge_branches(s, orc, kats):
     well[3 * g:4 * g] = False
     _group_check(np.where(well, y, 0), np.where(well, ref, 0), q, x, sj, offs)
     # lambda = 1e6 >> ||S||: the reference's own last step alpha = 1 - sigma*lambda/||w|| cancels 6 digits
-    # (sigma*lambda/||w|| = 1 - 3.5e-6), so any other summation order moves y by ~1e-16 / 3.5e-6 = 3e-11
-    # relative.  Both sides land on the same double n (polish step); the bound below is that conditioning.
-    k = slice(3 * g, 4 * g)
-    assert np.max(np.abs(y[k] - ref[k])) <= 1e-9 * np.max(np.abs(ref[k]))
+    # (sigma*lambda/||w|| = 1 - 3.5e-6), so two Float64 evaluations with different summation orders differ by
+    # ~1e-16 / 3.5e-6 = 3e-11 relative.  Adjudicated in binary128: the GPU may not be the worse side.
+    v = _binf_check(orc, y, ref, q, x, sj, lam, 1.0, 1.0, offs, what="lambda=1e6 group")
+    print(v)
 
 
 def test_group_l2_property_vs_norml2(s):
@@ -726,12 +737,10 @@ def test_group_binf_degenerate_bracket(s, orc, gsize):
     xd, sd, qd = _dev(x, sj, q)
     h = s.GroupNormL2(lam.tolist(), [range(i, i + gsize) for i in range(0, n, gsize)])
     y = s.prox(s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd), qd, sigma).cpu().numpy()
-    assert np.all(np.isfinite(y) == np.isfinite(ref))
-    fin = np.isfinite(ref)
-    scale_g = np.repeat(np.maximum(np.linalg.norm(S, axis=1), 1e-300), gsize)
-    err = np.abs(np.where(fin, y - ref, 0.0)) / np.maximum(np.abs(np.where(fin, ref, 0.0)), scale_g)
-    # roots next to the pole amplify last-bit differences of the norm: allow 1e-9 there, 1e-12 elsewhere
-    assert np.quantile(err, 0.99) <= 1e-12 and err.max() <= 1e-6, (float(np.quantile(err, 0.99)), float(err.max()))
+    # roots next to the pole amplify last-bit differences of the norm: every group above the plain bar is adjudicated
+    v = _binf_check(orc, y, ref, q, x, sj, lam, sigma, delta, np.arange(0, n + 1, gsize), what="degenerate bracket gsize=%d" % gsize)
+    print(v)
+    assert v.n_checked <= ng // 50, v       # ... and they are rare
 
 
 # ------------------------------------------------------------------ iprox!
@@ -1041,14 +1050,8 @@ def test_group_parameter_edges(s, orc, gs):
             ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, gsize=gs)
             ref_plain = orc.prox_group_l2(q, x, sj, lam, sigma, gsize=gs)
         y = s.prox(s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd), qd, sigma).cpu().numpy()
-        S = (q + x) + sj
-        scale = np.abs(ref).copy()
-        for lo, hi in zip(offs[:-1], offs[1:]):
-            scale[lo:hi] = np.maximum(scale[lo:hi], np.linalg.norm(S[lo:hi]))
-        err = np.abs(y - ref) / np.maximum(scale, 1e-300)
-        # sigma*lambda >> ||S|| makes the reference's own last step cancel (see test_group_binf_goldens_and_edge_branches)
-        tol = 1e-9 if sigma >= 1e6 else GROUP_TOL
-        assert np.array_equal(np.isnan(y), np.isnan(ref)) and float(np.nanmax(err)) <= tol, (sigma, delta, float(np.nanmax(err)))
+        # sigma*lambda >> ||S|| (sigma = 1e6) makes the reference's own last step cancel: adjudicated, not loosened
+        _binf_check(orc, y, ref, q, x, sj, lam, sigma, delta, offs, what="edges sigma=%g delta=%g" % (sigma, delta))
         yp = s.prox(s.shifted(s.shifted(h, xd), sd), qd, sigma).cpu().numpy()
         _group_check(yp, ref_plain, q, x, sj, offs)
 
@@ -1127,12 +1130,7 @@ def test_group_binf_lattice_and_zero_x(s, orc, gs):
         with np.errstate(all="ignore"):
             ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, gsize=gs)
         y = s.prox(s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd), qd, sigma).cpu().numpy()
-        S = ((q + x) + sj).reshape(ng, gs)
-        nS = np.linalg.norm(S, axis=1)
-        sc = np.maximum(np.abs(ref).reshape(ng, gs), nS[:, None])
-        canc = np.maximum(1.0, sigma * lam / np.maximum(nS, 1e-300))[:, None]   # the reference's own cancellation (section 4)
-        err = np.abs(y - ref).reshape(ng, gs) / np.maximum(sc, 1e-300) / canc
-        assert float(np.nanmax(err)) <= 1e-11, (gs, rep, float(np.nanmax(err)))
+        _binf_check(orc, y, ref, q, x, sj, lam, sigma, delta, offs, what="lattice gs=%d rep=%d" % (gs, rep))
 
 
 @pytest.mark.parametrize("gs", [1, 7, 128, 300, 1024])
@@ -1162,11 +1160,8 @@ def test_group_binf_zero_groups_strong_lambda(s, orc, gs):
         strong = zero_g & (sigma * lam_s * (1 - 1e-9) > nS)
         assert strong.sum() > ng // 5
         assert np.array_equal(y.reshape(ng, gs)[strong], -sj.reshape(ng, gs)[strong])   # exactly -sj
-        sc = np.maximum(np.abs(ref).reshape(ng, gs), nS[:, None])
-        canc = np.maximum(1.0, sigma * lam_s / np.maximum(nS, 1e-300))[:, None]
-        err = np.abs(y - ref).reshape(ng, gs) / np.maximum(sc, 1e-300) / canc
-        assert float(np.nanmax(err)) <= 1e-9, (gs, sigma, delta, float(np.nanmax(err)))
-        assert float(np.nanquantile(err, 0.99)) <= 1e-12
+        v = _binf_check(orc, y, ref, q, x, sj, lam_s, sigma, delta, np.arange(0, n + 1, gs), what="zero groups gs=%d sigma=%g" % (gs, sigma))
+        assert v.n_checked <= max(2, ng // 50), v
 
 
 @pytest.mark.parametrize("gs", [1, 3, 16, 128, 250])
@@ -1193,12 +1188,14 @@ def test_group_binf_small_groups_being_zeroed(s, orc, gs):
         rev = nS + sigma * lam * nX < sigma * lam * (1 - 1e-6)          # (zlmax = 0 there or not: a lower bound on lmax)
         seen_fast += int(np.sum(rev & (mX < delta * (1 - 1e-9))))
         seen_literal += int(np.sum(rev & (mX > delta)))
-        fin = np.isfinite(ref)
-        assert np.array_equal(fin, np.isfinite(y))
-        scale_g = np.repeat(np.maximum(nS, 1e-300), gs)
-        err = np.abs(np.where(fin, y - ref, 0.0)) / np.maximum(np.abs(np.where(fin, ref, 0.0)), scale_g)
         # roots next to the pole amplify last-bit differences of the norm (as test_group_binf_degenerate_bracket)
-        assert np.quantile(err, 0.99) <= 1e-12 and err.max() <= 1e-6, (gs, sigma, delta, float(err.max()))
+        offs = np.arange(0, n + 1, gs)
+        v = _binf_check(orc, y, ref, q, x, sj, lam, sigma, delta, offs, what="being zeroed gs=%d sigma=%g" % (gs, sigma))
+        assert v.n_checked <= ng // 50, v
+        # a mis-decided group (zero on one side only) is never a "1 % outlier": the zero patterns agree wherever the
+        # arbiter was not needed (needed + passed = the oracle's own Float64 decision was the rounding-decided one)
+        zg, zo = arbiter.zero_pattern(y, x, sj, offs), arbiter.zero_pattern(ref, x, sj, offs)
+        assert int(np.sum(zg != zo)) <= v.n_checked, (int(np.sum(zg != zo)), v)
     assert seen_fast > ng // 4 and seen_literal > ng // 10, (seen_fast, seen_literal)
 
 
@@ -1234,13 +1231,8 @@ def test_group_binf_structured_scenarios(s, orc, gs):
             with np.errstate(all="ignore"):
                 ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, gsize=gs)
             y = s.prox(s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd), qd, sigma).cpu().numpy()
-            S = ((q + x) + sj).reshape(ng, gs)
-            nS = np.linalg.norm(S, axis=1)
-            sc = np.maximum(np.abs(ref).reshape(ng, gs), nS[:, None])
-            canc = np.maximum(1.0, sigma * lam / np.maximum(nS, 1e-300))[:, None]
-            err = np.abs(y - ref).reshape(ng, gs) / np.maximum(sc, 1e-300) / canc
-            assert np.array_equal(np.isnan(y), np.isnan(ref))
-            assert float(np.nanmax(err)) <= 1e-10, (gs, k, sigma, delta, float(np.nanmax(err)))
+            _binf_check(orc, y, ref, q, x, sj, lam, sigma, delta, np.arange(0, n + 1, gs),
+                        what="scenario %d gs=%d sigma=%g delta=%g" % (k, gs, sigma, delta))
 
 
 @pytest.mark.parametrize("n", [1, 5, 64, 1000, 100_003])
@@ -1289,11 +1281,7 @@ def test_group_binf_many_small_groups(s, orc, gs):
         h = s.GroupNormL2.uniform(torch.from_numpy(lam).cuda(), gs)
         ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, gsize=gs)
         y = s.prox(s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd), qd, sigma).cpu().numpy()
-        S = ((q + x) + sj).reshape(ng, gs)
-        nS = np.linalg.norm(S, axis=1)
-        sc = np.maximum(np.abs(ref).reshape(ng, gs), nS[:, None])
-        canc = np.maximum(1.0, sigma * lam / np.maximum(nS, 1e-300))[:, None]
-        err = (np.abs(y - ref).reshape(ng, gs) / np.maximum(sc, 1e-300) / canc).max(axis=1)
-        # 1e-9: single ill-conditioned groups (the reference's last step cancels beyond the sigma lambda / ||S|| model) reach
-        # ~1e-10; the failure this test guards against produced errors of 1e-2 .. 1e+2
-        assert int((err > 1e-9).sum()) == 0, (gs, sigma, delta, int((err > 1e-9).sum()), float(err.max()))
+        # single ill-conditioned groups (the reference's last step cancels) sit above the plain bar: each one is adjudicated
+        # in binary128; the failure this test guards against produced errors of 1e-2 .. 1e+2 in 3e-4 of the groups
+        v = _binf_check(orc, y, ref, q, x, sj, lam, sigma, delta, np.arange(0, n + 1, gs), what="many small gs=%d sigma=%g" % (gs, sigma))
+        assert v.n_checked <= ng // 100, v
