@@ -83,12 +83,29 @@ def lib():
         L.orc_prox_l1_b2.restype = None
         L.orc_rootnormlhalf_prox.argtypes = [dp, dp, i64, d, d]
         L.orc_rootnormlhalf_prox.restype = d
+        L.orc_set_perturbation.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.orc_set_perturbation.restype = None
         for name in ("orc_prox_l1", "orc_prox_l0", "orc_prox_lhalf", "orc_prox_l1_box", "orc_prox_l0_box",
                      "orc_prox_lhalf_box", "orc_prox_indball_l0", "orc_prox_indball_l0_binf",
                      "orc_prox_group_l2", "orc_prox_group_l2_binf"):
             getattr(L, name).restype = None
         _lib = L
     return _lib
+
+
+class perturbed:
+    """with oracle.perturbed(norm_ulps, pow_ulps): ...  -- sensitivity probe (spx_oracle.c, "sensitivity probes"): every
+    norm / every `^` of the RootNormLhalf closed forms is moved by that many ulps inside the block.  tests/arbiter.py only."""
+
+    def __init__(self, norm_ulps=0, pow_ulps=0):
+        self.k = (int(norm_ulps), int(pow_ulps))
+
+    def __enter__(self):
+        lib().orc_set_perturbation(*self.k)
+
+    def __exit__(self, *exc):
+        lib().orc_set_perturbation(0, 0)
+        return False
 
 
 def _f64(a):

@@ -1,0 +1,247 @@
+"""Stress runs that used to live in tools/fuzz_*.py, reduced to fixed seeds and sizes that fit the driver's GPU suite.
+
+Each test names the kernel code it guards (csrc file + function).  They were confirmed to fail on planted faults
+(tools/planted_faults.sh builds libspx with one guard flipped at a time and runs this file against it).
+Parity bars: bit-exact for the L1 / L0 / top-r families; 1e-12 for RootNormLhalf(Box) / GroupNormL2(Binf) / NormL1B2 with
+binary128 adjudication of everything above it (tests/arbiter.py) -- no fixed looser tolerance anywhere.
+"""
+import numpy as np
+import pytest
+
+import arbiter
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def s():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as ge
+    return ge.build()
+
+
+def _dev(*arrs):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0") for a in arrs]
+
+
+def _bits(a, b):
+    return np.array_equal(np.asarray(a).view(np.int64), np.asarray(b).view(np.int64))
+
+
+def _binf_run_and_check(s, orc, h, x, sj, q, lam, sigma, delta, offs, what, no_size_hint=False):
+    xd, sd, qd = _dev(x, sj, q)
+    with np.errstate(all="ignore"):
+        ref = orc.prox_group_l2_binf(q, x, sj, lam, sigma, delta, offsets=offs)
+    psi = s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd)
+    if no_size_hint:     # CSR offsets without the size bound: libspx then takes its general (memory-resident) kernel
+        assert psi._layout.offsets is not None
+        psi._layout.group_size = 0
+    y = s.prox(psi, qd, sigma).cpu().numpy()
+    assert np.array_equal(np.isnan(y), np.isnan(ref)) and np.array_equal(np.isfinite(y), np.isfinite(ref)), what
+    fin = np.isfinite(ref)
+    v = arbiter.check_group(orc, np.where(fin, y, 0.0), np.where(fin, ref, 0.0), q, x, sj, lam, sigma, offs, delta=delta, what=what)
+    return y, ref, v
+
+
+def _norms(S, x, offs):
+    ng = len(offs) - 1
+    nS = np.sqrt(np.add.reduceat(S * S, offs[:-1]))
+    nX = np.sqrt(np.add.reduceat(x * x, offs[:-1]))
+    mX = np.maximum.reduceat(np.abs(x), offs[:-1])
+    return nS[:ng], nX[:ng], mX[:ng]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# GroupNormL2Binf, reversed bracket with entries OUTSIDE the trust region (|xk_i| > Delta):
+#   csrc/spx_group.hip  binf_literal_root / binf_literal_reg "piece iteration" n <- sigma*lambda - R(n) and the literal
+#   bisection behind it (commits d6ad02e, 2795649, 16eae9b of round 1), in every kernel family that reaches them:
+#   register tiles + deferred list (uniform <= 512), LDS-resident (700, 2500), general (5000), ragged CSR with and without
+#   the size hint, gather-index groups.
+# ----------------------------------------------------------------------------------------------------------------------
+def _outside_tr_data(rng, sizes, xs):
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(offs[-1])
+    scale = 1.0 / np.sqrt(np.repeat(sizes, sizes))
+    x = rng.normal(size=n) * xs * scale
+    sj = rng.uniform(-0.5, 0.5, size=n) * scale * float(rng.choice([0.0, 4.0]))
+    q = rng.normal(size=n) * scale * float(rng.choice([4.0, 0.4, 12.0]))
+    sigma = float(10.0 ** rng.uniform(-1, 1))
+    delta = float(10.0 ** rng.uniform(-3, -0.5)) * xs / np.sqrt(np.median(sizes)) * 4
+    S = (q + x) + sj
+    nS, nX, mX = _norms(S, x, offs)
+    lam = np.maximum(nS, 1e-3) * 10.0 ** rng.uniform(0, 1.5, size=sizes.size) / sigma / np.maximum(1e-3, 1.0 - np.minimum(nX, 0.95))
+    rev = nS + sigma * lam * nX < sigma * lam
+    out = mX > delta
+    return offs, x, sj, q, lam, sigma, delta, rev & out
+
+
+@pytest.mark.parametrize("layout", ["uniform1", "uniform2", "uniform3", "uniform4", "uniform8", "uniform16", "uniform40", "uniform128",
+                                    "uniform300", "uniform512", "lds700", "lds2500", "general5000", "ragged_hint", "ragged_nohint",
+                                    "gather"])
+def test_binf_reversed_bracket_entries_outside_trust_region(s, orc, layout):
+    rng = np.random.default_rng(2025 + sum(map(ord, layout)))
+    seen = nonzero = arbitrated = 0
+    reps = 4
+    for rep in range(reps):
+        if layout.startswith(("uniform", "lds", "general")):
+            gs = int(layout.lstrip("uniformldsgenral"))
+            ng = 6000 if gs <= 16 else (1200 if gs <= 128 else (300 if gs <= 512 else 40))
+            sizes = np.full(ng, gs)
+        else:
+            ng = 3000
+            sizes = rng.integers(1, 41, size=ng)
+        xs = float(rng.choice([0.05, 0.2, 0.5]))
+        offs, x, sj, q, lam, sigma, delta, regime = _outside_tr_data(rng, sizes, xs)
+        if layout == "gather":          # the same ranges listed back to front: explicit index vectors -> gather kernel
+            h = s.GroupNormL2(lam.tolist(), [list(range(int(offs[g + 1]) - 1, int(offs[g]) - 1, -1)) for g in range(ng)])
+        elif layout.startswith("ragged"):
+            h = s.GroupNormL2.ragged(lam.tolist(), offs)
+        else:
+            h = s.GroupNormL2.uniform(lam.tolist(), int(sizes[0]))
+        y, ref, v = _binf_run_and_check(s, orc, h, x, sj, q, lam, sigma, delta, offs, "%s rep %d" % (layout, rep),
+                                        no_size_hint=(layout == "ragged_nohint"))
+        arbitrated += v.n_checked
+        seen += int(regime.sum())
+        zref = arbiter.zero_pattern(ref, x, sj, offs)
+        nonzero += int((regime & ~zref).sum())
+        # the zero / non-zero decision of every group in the regime agrees with the oracle, except where the arbiter had to
+        # be called in (and sided with the GPU)
+        zg = arbiter.zero_pattern(y, x, sj, offs)
+        assert int(np.sum((zg != zref) & regime)) <= v.n_checked, (layout, rep, int(np.sum((zg != zref) & regime)), v)
+    assert seen > 50 * reps, (layout, seen)               # the regime really occurs ...
+    if not layout.startswith(("lds", "general")):
+        assert nonzero > 0, (layout, seen, nonzero)       # ... including groups that take the non-zero literal branch
+    assert arbitrated <= max(10, seen // 20), (layout, arbitrated, seen)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# GroupNormL2Binf, reversed brackets in general (groups that are, or are about to be, zero under a strong sigma*lambda):
+#   csrc/spx_group.hip  binf_root in-kernel decisions "xk == 0 on the group" and "every |xk_i| < Delta", and the deferred
+#   literal list for what is left (entries on / outside the trust region, |xk_i| == Delta exactly).
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("gs", [1, 2, 3, 8, 16, 31, 64, 128, 200, 256, 512, 700, 2500])
+def test_binf_reversed_bracket_regimes(s, orc, gs):
+    rng = np.random.default_rng(77 + gs)
+    ng = 1500 if gs <= 64 else (400 if gs <= 512 else 24)
+    n = ng * gs
+    offs = np.arange(0, n + 1, gs)
+    nrev = arbitrated = 0
+    for rep in range(6):
+        xs = float([0.0, 1e-8, 0.02, 0.3, 1.0, 0.3][rep]) / np.sqrt(gs)
+        x = rng.normal(size=n) * xs
+        zero_g = rng.random(ng) < rng.choice([0.0, 0.5, 0.95])
+        x = np.where(np.repeat(zero_g, gs), 0.0, x)
+        sj = rng.uniform(-0.5, 0.5, size=n) * float(rng.choice([0.0, 1.0, 1e-3]))
+        q = rng.normal(size=n) * float(rng.choice([1.0, 1e-3, 30.0]))
+        sigma = float(10.0 ** rng.uniform(-2, 1.5))
+        delta = float(10.0 ** rng.uniform(-3, 2))
+        if rep % 3 == 2 and xs > 0 and np.any(np.abs(x) > 0):   # some entries exactly on the trust-region boundary
+            delta = float(np.abs(x[np.abs(x) > 0][0]))
+        S = (q + x) + sj
+        nS, nX, _ = _norms(S, x, offs)
+        lam = np.maximum(nS, 1e-3) * 10.0 ** rng.uniform(-1, 2, size=ng) / sigma
+        h = s.GroupNormL2.uniform(lam.tolist(), gs)
+        y, ref, v = _binf_run_and_check(s, orc, h, x, sj, q, lam, sigma, delta, offs, "reversed gs %d rep %d" % (gs, rep))
+        nrev += int((nS + sigma * lam * nX < sigma * lam).sum())
+        arbitrated += v.n_checked
+    assert nrev > ng, (gs, nrev)
+    assert arbitrated <= max(6, 6 * ng // 50), (gs, arbitrated)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# GroupNormL2Binf on lattice data incl. constant groups: activity boundaries |tau S - X| = Delta, exact roots, exact
+# zero froot(lmax): csrc/spx_group.hip binf_root "root at the bracket's end" / "knife edge at lmin" paths.
+# (test_gpu_parity.py::test_group_binf_lattice_and_zero_x covers x = 0; this one adds the constant-group variant and the
+#  8-lane / 32-lane tiles.)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("gs", [3, 16, 32, 100, 128, 256, 300, 1024])
+def test_binf_lattice_constant_groups(s, orc, gs):
+    rng = np.random.default_rng(11 + gs)
+    for rep in range(6):
+        ng = 200 if gs <= 300 else 30
+        n = ng * gs
+        x = rng.integers(-8, 9, size=n) / 4.0
+        sj = rng.integers(-2, 3, size=n) / 4.0
+        q = rng.integers(-12, 13, size=n) / 4.0
+        if rep % 3 == 1:
+            x[: n // 2] = 0.0
+        if rep % 3 == 2:
+            q[:] = np.repeat(rng.integers(-4, 5, size=ng) / 4.0, gs)   # constant groups
+        lam = rng.choice([0.0, 0.25, 0.5, 1.0, 2.0, 8.0], size=ng)
+        sigma = float(rng.choice([0.25, 0.5, 1.0, 2.0]))
+        delta = float(rng.choice([0.25, 0.5, 1.0, 3.0]))
+        h = s.GroupNormL2.uniform(lam.tolist(), gs)
+        _binf_run_and_check(s, orc, h, x, sj, q, lam, sigma, delta, np.arange(0, n + 1, gs), "lattice gs %d rep %d" % (gs, rep))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Top-r on 8-byte-misaligned views, every mix of alignments (csrc/spx_select.hip: scalar full-vector path, the peeled
+# sample-predicted path when all four vectors are off by 8 bytes).
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 3, 1000, 70001, (1 << 21) + 17])
+def test_topr_misaligned_views(s, orc, n):
+    import torch
+    rng = np.random.default_rng(4 + n)
+    x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = np.round(rng.normal(size=n) * 16) / 16
+    mk = lambda a: torch.cat([torch.zeros(1, dtype=torch.float64), torch.from_numpy(a)]).cuda()[1:]
+    for mis in ((True, True, True), (True, False, False), (False, False, True)):
+        xd = mk(x) if mis[0] else torch.from_numpy(x).cuda()
+        sd = mk(sj) if mis[1] else torch.from_numpy(sj).cuda()
+        qd = mk(q) if mis[2] else torch.from_numpy(q).cuda()
+        for r in sorted({1, max(1, n // 3), n}):
+            ref = orc.prox_indball_l0_binf(q, x, sj, r, 0.8)
+            psi = s.shifted(s.shifted(s.IndBallL0(r), xd, 0.8, s.NormLinf(1.0)), sd)
+            y = s.prox(psi, qd, 1.0).cpu().numpy()
+            yv = mk(np.zeros(n))
+            s.prox_bang(yv, psi, qd, 1.0)
+            assert _bits(y, ref) and _bits(yv.cpu().numpy(), ref), (n, mis, r)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Lattice data (multiples of 1/4) through the separable operators, iprox!, NormL1B2 and top-r: exact ties with every
+# threshold and bound (csrc/spx_separable.hip functors; spx_b2.hip piece roots hit exactly; spx_select.hip index digits).
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(4))
+def test_lattice_separable_b2_topr(s, orc, seed):
+    import torch
+    rng = np.random.default_rng(3 + seed)
+    for rep in range(8):
+        n = int(rng.integers(1, 20000))
+        x = rng.integers(-8, 9, size=n) / 4.0; sj = rng.integers(-4, 5, size=n) / 4.0; q = rng.integers(-12, 13, size=n) / 4.0
+        lam = float(rng.choice([0.0, 0.25, 0.5, 1.0, 2.0])); sigma = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0]))
+        lo = float(rng.choice([-2.0, -1.0, -0.5, 0.0])); up = float(rng.choice([0.0, 0.5, 1.0, 2.0]))
+        xd, sd, qd = _dev(x, sj, q)
+        with np.errstate(all="ignore"):
+            for H, nm in ((s.NormL1, "l1"), (s.NormL0, "l0")):
+                y = s.prox(s.shifted(s.shifted(H(lam), xd), sd), qd, sigma).cpu().numpy()
+                assert _bits(y, getattr(orc, "prox_" + nm)(q, x, sj, lam, sigma)), (nm, seed, rep)
+                y = s.prox(s.shifted(s.shifted(H(lam), xd, lo, up), sd), qd, sigma).cpu().numpy()
+                assert _bits(y, getattr(orc, "prox_%s_box" % nm)(q, x, sj, lam, sigma, lo, up)), (nm, "box", seed, rep)
+                d = rng.choice([-2.0, -1.0, 0.0, 0.5, 1.0, 4.0], size=n)
+                y = s.iprox(s.shifted(s.shifted(H(lam), xd, lo, up), sd), qd, _dev(d)[0]).cpu().numpy()
+                assert _bits(y, getattr(orc, "iprox_%s_box" % nm)(q, d, x, sj, lam, lo, up)), (nm, "iprox", seed, rep)
+            # RootNormLhalf: unboxed has no candidate choice -> arbiter only
+            y = s.prox(s.shifted(s.shifted(s.RootNormLhalf(lam), xd), sd), qd, sigma).cpu().numpy()
+            arbiter.check_lhalf(orc, y, orc.prox_lhalf(q, x, sj, lam, sigma), q, x, sj, lam, sigma, what="lattice lhalf")
+            # boxed: on a lattice two candidates often have EXACTLY the same objective value; findmin's first-minimum rule then
+            # depends on last-bit rounding of the candidate values (must match "except on exact ties").  An element
+            # whose candidate differs but whose objective (in extended precision) equals the oracle's is such a tie.
+            y = s.prox(s.shifted(s.shifted(s.RootNormLhalf(lam), xd, lo, up), sd), qd, sigma).cpu().numpy()
+            ref = orc.prox_lhalf_box(q, x, sj, lam, sigma, lo, up)
+            sc = arbiter.lhalf_scale(ref, x, sj, q)
+            m = np.abs(y - ref) > 1e-12 * np.maximum(sc, 1e-300)
+            if m.any():
+                ld_ = np.longdouble
+                f = lambda t: (ld_(t) - ld_(q)) ** 2 / 2 / ld_(sigma) + ld_(lam) * np.sqrt(np.abs(ld_(t) + ld_(x + sj)))
+                tie = np.abs(f(y) - f(ref)) <= 4e-16 * np.maximum(np.abs(f(ref)), 1e-300)
+                arbiter.check_lhalf(orc, np.where(m & tie, ref, y), ref, q, x, sj, lam, sigma, box=(lo, up), what="lattice lhalf_box")
+            r = int(rng.integers(1, n + 1))
+            y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.75, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
+            assert _bits(y, orc.prox_indball_l0_binf(q, x, sj, r, 0.75)), ("indball", seed, rep)
+            delta = float(rng.choice([0.5, 2.0, 50.0]))
+            y = s.prox(s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(1.0)), sd), qd, sigma).cpu().numpy()
+            ref = orc.prox_l1_b2(q, x, sj, lam, sigma, delta, 1.0)
+            assert np.max(np.abs(y - ref)) <= 1e-12 * max(np.linalg.norm(ref), np.linalg.norm(x), 1.0), ("b2", seed, rep)

@@ -71,11 +71,25 @@ def test_arbiter_inequality_rejects_planted_faults(orc):
     better[k] = yq[k] + 0.01 * (ref[k] - yq[k])
     v = arbiter.check_group(orc, better, ref, q, x, sj, lam, 1.0, offs, delta=1.0)
     assert (v.n_checked == 1 and v.gpu_closer == 1) or own <= 1e-12
-    # away from the exact value by 3e-12 * scale: rejected
+    # away from the exact value by more than the reference's own ensemble (norms moved by a few ulps) reaches: rejected
     worse = ref.copy()
-    worse[k] = ref[k] + np.sign(ref[k] - yq[k] + 1e-300) * 3e-12 * sc[k]
+    worse[k] = ref[k] + np.sign(ref[k] - yq[k] + 1e-300) * 1e-3 * np.abs(ref[k] - yq[k]).max()
     with pytest.raises(AssertionError, match="further from the binary128"):
         arbiter.check_group(orc, worse, ref, q, x, sj, lam, 1.0, offs, delta=1.0)
+    # a well-conditioned group off by 5e-12 of its scale: rejected (the ensemble is ~1e-16 wide there)
+    worse = ref.copy()
+    worse[gs:2 * gs] += 5e-12 * sc[gs:2 * gs]
+    with pytest.raises(AssertionError, match="further from the binary128"):
+        arbiter.check_group(orc, worse, ref, q, x, sj, lam, 1.0, offs, delta=1.0)
+    # the last-ulp noise of alpha = 1 - sigma*lambda/||w|| in the ill-conditioned group (6e-11 absolute, either sign: what
+    # the GPU showed against the literal oracle) is inside the ensemble: accepted
+    xs = (x + sj)[k]
+    aw = ref[k] + xs                                  # alpha * w of that group
+    for sgn in (1.0, -1.0):
+        noisy = ref.copy()
+        noisy[k] = aw * (1.0 + sgn * 4e-12 * sc[k].max() / np.abs(aw).max()) - xs
+        v = arbiter.check_group(orc, noisy, ref, q, x, sj, lam, 1.0, offs, delta=1.0)
+        assert v.n_checked == 1
     # a mis-decided group (zeros where the reference has a root) is rejected whatever its share of the data
     wrong = ref.copy()
     wrong[:gs] = -(x + sj)[:gs]
