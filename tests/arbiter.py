@@ -162,7 +162,9 @@ def check_lhalf(orc, y, ref, q, x, sj, lam, sigma, box=None, mask=None, what="lh
 
 
 def group_scale(ref, q, x, sj, offsets):
-    """|y_i| or the group's ||S||_2, whichever is larger (norm-relative inside a group)."""
+    """max(|y_i|, |xk_i + sj_i|, ||S||_2 of the group): norm-relative inside a group and, as for RootNormLhalf,
+    the scale of the operands of the last step y[idx] .-= xk[idx] + sj[idx] (:116) -- with S = 0 (q = -(xk + sj)) the group
+    norm vanishes and that subtraction is all that is left."""
     S = (q + x) + sj
     offsets = np.asarray(offsets, dtype=np.int64)
     sizes = np.diff(offsets)
@@ -171,7 +173,7 @@ def group_scale(ref, q, x, sj, offsets):
     nz = sizes > 0
     if nz.any():
         ss[nz] = np.add.reduceat((S[lo:hi] ** 2), (offsets[:-1] - lo)[nz])
-    scale = np.abs(ref).copy()
+    scale = np.maximum(np.abs(ref), np.abs(x + sj))
     scale[lo:hi] = np.maximum(scale[lo:hi], np.repeat(np.sqrt(ss), sizes))
     return scale
 

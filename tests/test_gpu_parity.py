@@ -13,7 +13,7 @@ import arbiter  # tests/arbiter.py: the 1e-12 bar, and the binary128 adjudicatio
 pytestmark = pytest.mark.gpu
 
 LHALF_TOL = 1e-12   # |y_gpu - y_ref| <= LHALF_TOL * max(|y_ref|, |x + s|, |q|)   (y = val - (x+s): scale of the operands)
-GROUP_TOL = 1e-12   # |y_gpu - y_ref| <= GROUP_TOL * max(|y_ref|_i, ||S_group||_2)  (norm-relative inside a group)
+GROUP_TOL = 1e-12   # |y_gpu - y_ref| <= GROUP_TOL * max(|y_ref_i|, |xk_i + sj_i|, ||S_group||_2)  (arbiter.group_scale)
 # No test below accepts a difference above these bars on a fixed looser tolerance: elements / groups that exceed them go
 # to the binary128 arbiter and must satisfy |y_gpu - y_q| <= 1e-12 scale + |y_oracle64 - y_q| (arbiter.py).
 

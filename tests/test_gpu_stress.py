@@ -83,7 +83,7 @@ def _outside_tr_data(rng, sizes, xs):
                                     "gather"])
 def test_binf_reversed_bracket_entries_outside_trust_region(s, orc, layout):
     rng = np.random.default_rng(2025 + sum(map(ord, layout)))
-    seen = nonzero = arbitrated = 0
+    seen = nonzero = arbitrated = total = 0
     reps = 4
     for rep in range(reps):
         if layout.startswith(("uniform", "lds", "general")):
@@ -105,13 +105,14 @@ def test_binf_reversed_bracket_entries_outside_trust_region(s, orc, layout):
                                         no_size_hint=(layout == "ragged_nohint"))
         arbitrated += v.n_checked
         seen += int(regime.sum())
+        total += ng
         zref = arbiter.zero_pattern(ref, x, sj, offs)
         nonzero += int((regime & ~zref).sum())
         # the zero / non-zero decision of every group in the regime agrees with the oracle, except where the arbiter had to
         # be called in (and sided with the GPU)
         zg = arbiter.zero_pattern(y, x, sj, offs)
         assert int(np.sum((zg != zref) & regime)) <= v.n_checked, (layout, rep, int(np.sum((zg != zref) & regime)), v)
-    assert seen > 50 * reps, (layout, seen)               # the regime really occurs ...
+    assert seen > total // 4, (layout, seen, total)       # the regime really occurs ...
     if not layout.startswith(("lds", "general")):
         assert nonzero > 0, (layout, seen, nonzero)       # ... including groups that take the non-zero literal branch
     assert arbitrated <= max(10, seen // 20), (layout, arbitrated, seen)
