@@ -632,35 +632,46 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
     // root of the current piece: g(v) = v - sqrt(sb + sa (v / (sl + v))^2), scalar Newton from u
     // (the slope only steers the step: unrefined v_rcp/v_rsq seeds, ~1e-8 relative, are enough there; the step that
     // follows a relative move below 1e-8 lands within ~1e-16 by quadratic convergence, so it is the last one)
+    // (round 2: the result now depends on u itself -- the closed form of the last step -- so the piece root must be
+    //  converged, not merely close in n.  g has a second root at v = 0; when the wanted one is small against sl the two
+    //  are close on the scale of the start, Newton halves its way down (log2(n/u) steps: 12 were not always enough and the
+    //  unconverged v was then "confirmed" by identical sums), and the all-inactive piece (sb == 0) is solved directly.)
     double v = u;
-    for (int k = 0; k < 12; ++k) {
-      const double rn = fast_rcp(sl + v);
-      const double t = v * rn;
-      const double ph2 = __builtin_fma(t * t, sa, sb);
-      const double rph = __builtin_amdgcn_rsq(ph2);
-      double ph = ph2 * rph;
-      ph = (ph2 > 0.0) ? __builtin_fma(0.5 * rph, __builtin_fma(-ph, ph, ph2), ph) : 0.0;
-      ph = (ph2 > 0.0) ? __builtin_fma(0.5 * rph, __builtin_fma(-ph, ph, ph2), ph) : 0.0;
-      const double g = v - ph;
-      const double gp = 1.0 - ((ph2 > 0.0) ? sa * t * (sl * rn * rn) * rph : 0.0);
-      const double vn = v - g * __builtin_amdgcn_rcp(gp);
-      const bool last = fabs(vn - v) <= 1e-8 * fabs(vn);
-      v = vn;
-      if (last) {
-        // one more, fully accurate step
-        const double rn2 = fast_rcp(sl + v);
-        const double t2 = v * rn2;
-        const double p2 = __builtin_fma(t2 * t2, sa, sb);
-        const double ph_ = sqrt_pos(p2);
-        const double gp2 = 1.0 - ((ph_ > 0.0) ? sa * t2 * (sl * rn2 * rn2) * fast_rcp(ph_) : 0.0);
-        v = v - (v - ph_) * fast_rcp(gp2);
-        break;
+    bool piece_ok = false;
+    if (sb == 0.0) {
+      v = sqrt_pos(sa) - sl;  // g(v) = v (1 - sqrt(sa) / (sl + v)): the reference's 1 - sl/||S|| in disguise
+      piece_ok = true;
+    } else {
+      for (int k = 0; k < 64; ++k) {
+        const double rn = fast_rcp(sl + v);
+        const double t = v * rn;
+        const double ph2 = __builtin_fma(t * t, sa, sb);
+        const double rph = __builtin_amdgcn_rsq(ph2);
+        double ph = ph2 * rph;
+        ph = (ph2 > 0.0) ? __builtin_fma(0.5 * rph, __builtin_fma(-ph, ph, ph2), ph) : 0.0;
+        ph = (ph2 > 0.0) ? __builtin_fma(0.5 * rph, __builtin_fma(-ph, ph, ph2), ph) : 0.0;
+        const double g = v - ph;
+        const double gp = 1.0 - ((ph2 > 0.0) ? sa * t * (sl * rn * rn) * rph : 0.0);
+        const double vn = v - g * __builtin_amdgcn_rcp(gp);
+        const bool last = fabs(vn - v) <= 1e-8 * fabs(vn);
+        v = vn;
+        if (last) {
+          // one more, fully accurate step
+          const double rn2 = fast_rcp(sl + v);
+          const double t2 = v * rn2;
+          const double p2 = __builtin_fma(t2 * t2, sa, sb);
+          const double ph_ = sqrt_pos(p2);
+          const double gp2 = 1.0 - ((ph_ > 0.0) ? sa * t2 * (sl * rn2 * rn2) * fast_rcp(ph_) : 0.0);
+          v = v - (v - ph_) * fast_rcp(gp2);
+          piece_ok = true;
+          break;
+        }
       }
     }
     // the piece's root is u itself (to rounding): converged -- must be seen BEFORE the bracket test below, which would
     // otherwise reject v == u (u has just become a bracket end) and bisect away from the root
     if (fabs(v - u) <= 4 * eps * fabs(u)) break;
-    const bool exact_step = (v > ulo && v < uhi);  // v is the root of the piece (sa, sb)
+    const bool exact_step = piece_ok && (v > ulo && v < uhi);  // v is the (converged) root of the piece (sa, sb)
     if (!exact_step) v = sqrt_pos(ulo) * sqrt_pos(uhi);  // safeguard: geometric bisection of the bracket
     if (!(v > ulo && v < uhi)) break;
     const bool small = fabs(v - u) <= 4 * eps * v;

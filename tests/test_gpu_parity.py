@@ -694,9 +694,9 @@ def test_group_binf_goldens_and_edge_branches(s, orc, kats):
     well = np.ones(n, bool)
     well[3 * g:4 * g] = False
     _group_check(np.where(well, y, 0), np.where(well, ref, 0), q, x, sj, offs)
-    # lambda = 1e6 >> ||S||: the reference's own last step alpha = 1 - sigma*lambda/||w|| cancels 6 digits
-    # (sigma*lambda/||w|| = 1 - 3.5e-6), so two Float64 evaluations with different summation orders differ by
-    # ~1e-16 / 3.5e-6 = 3e-11 relative.  Adjudicated in binary128: the GPU may not be the worse side.
+    # lambda = 1e6 >> ||S||: the root sits 3.5e-6 (relative) above the pole of step(n); the reference's Float64 evaluation
+    # is 2.8e-6 away from the exact value of its own formula there (granularity of the double n), the kernel's closed form
+    # (alpha = tau at the root) ~1e-16.  Adjudicated in binary128: the GPU may not be the worse side.
     v = _binf_check(orc, y, ref, q, x, sj, lam, 1.0, 1.0, offs, what="lambda=1e6 group")
     print(v)
 
@@ -1284,4 +1284,7 @@ def test_group_binf_many_small_groups(s, orc, gs):
         # single ill-conditioned groups (the reference's last step cancels) sit above the plain bar: each one is adjudicated
         # in binary128; the failure this test guards against produced errors of 1e-2 .. 1e+2 in 3e-4 of the groups
         v = _binf_check(orc, y, ref, q, x, sj, lam, sigma, delta, np.arange(0, n + 1, gs), what="many small gs=%d sigma=%g" % (gs, sigma))
-        assert v.n_checked <= ng // 100, v
+        # (lscale = 30: sigma*lambda >> ||S||, the root sits next to the pole and the REFERENCE's Float64 value is itself up to
+        #  ~5e-9 off its own formula in 1-2 % of the groups; the closed form of the kernel is within 1e-15 there: measured
+        #  "GPU closer to binary128 than the literal oracle in 1629 of 1629")
+        assert v.n_checked <= ng // 20 and v.gpu_closer >= v.n_checked - 5, v
