@@ -1,0 +1,40 @@
+#!/bin/bash
+# Confirms that the driver-run stress tests FAIL on planted faults.
+#   tools/planted_faults.sh build     (here, no GPU): patched copies of csrc/ -> lib/libspx_fault<k>.so
+#   tools/planted_faults.sh run       (on the GPU box): the named tests against each faulty library; every one must fail
+# Nothing in the product tree is modified: the patches are applied to a scratch copy under /tmp.
+set -uo pipefail
+ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+CSRC="$ROOT/shiftedproximaloperators.jl_amd/csrc"
+# id | file | sed expression | tests that must catch it
+FAULTS=(
+ "1|spx_group.hip|0,/bool decided = g0 < -1e-9 \* sl;/s//bool decided = g0 < 1e300;/|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region"
+ "2|spx_group.hip|s/decided = (r2n == r2);/decided = true;/g|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region"
+ "3|spx_group.hip|s/if (reversed \&\& mX < delta \* (1.0 - 1e-9)) return BINF_ZERO;/if (reversed) return BINF_ZERO;/|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region tests/test_gpu_stress.py::test_binf_reversed_bracket_regimes"
+ "4|spx_group.hip|s/if (sb == 0.0) {/if (false) {/;s/for (int k = 0; k < 64; ++k) {/for (int k = 0; k < 12; ++k) { piece_ok = true;/|tests/test_gpu_parity.py::test_group_binf_many_small_groups tests/test_gpu_parity.py::test_group_binf_zero_groups_strong_lambda"
+)
+case "${1:-}" in
+build)
+  for f in "${FAULTS[@]}"; do
+    IFS='|' read -r id file expr tests <<< "$f"
+    W="/tmp/spx_fault_$id"; rm -rf "$W"; mkdir -p "$W/shiftedproximaloperators.jl_amd" "$W/include"
+    cp -r "$CSRC" "$W/shiftedproximaloperators.jl_amd/csrc"; cp "$ROOT/include/spx.h" "$W/include/"
+    before=$(md5sum < "$W/shiftedproximaloperators.jl_amd/csrc/$file")
+    sed -i "$expr" "$W/shiftedproximaloperators.jl_amd/csrc/$file"
+    [ "$before" != "$(md5sum < "$W/shiftedproximaloperators.jl_amd/csrc/$file")" ] || { echo "fault $id: the pattern no longer matches $file -- update tools/planted_faults.sh"; exit 1; }
+    SPX_LIB_NAME="libspx_fault$id.so" bash "$W/shiftedproximaloperators.jl_amd/csrc/build.sh" > /dev/null || exit 1
+    cp "$W/shiftedproximaloperators.jl_amd/lib/libspx_fault$id.so" "$ROOT/shiftedproximaloperators.jl_amd/lib/"
+    echo "built libspx_fault$id.so"
+  done ;;
+run)
+  cd "$ROOT"; mkdir -p gpurun_out; bad=0
+  for f in "${FAULTS[@]}"; do
+    IFS='|' read -r id file expr tests <<< "$f"
+    SPX_LIB_NAME="libspx_fault$id.so" SPX_NO_BUILD=1 python -m pytest $tests -m gpu -q -x -p no:cacheprovider > "gpurun_out/fault$id.log" 2>&1
+    rc=$?
+    if [ $rc -eq 1 ]; then echo "fault $id: caught ($(grep -c '^FAILED' gpurun_out/fault$id.log) failing test(s), first: $(grep -m1 '^FAILED' gpurun_out/fault$id.log | cut -c1-120))"
+    else echo "fault $id: NOT CAUGHT (pytest rc $rc)"; bad=1; fi
+  done
+  exit $bad ;;
+*) echo "usage: $0 build|run"; exit 2 ;;
+esac
