@@ -68,14 +68,15 @@ int spx_sync(spx_ctx* ctx);
 int spx_timer_start(spx_ctx* ctx);
 int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms); /* records stop, waits, returns milliseconds */
 
-/* Kernel-benchmark knob, not part of the reference API: key 0 = workgroups per CU of the separable grid
- * (0 = one tile per workgroup, the default), key 1 = non-temporal loads/stores (0/1), key 2 = sample-predicted
- * top-r path (1, default) or always the full-vector radix select (0), key 3 = LDS-staged (1, default) or
- * register-staged (0) separable skeleton, key 4 = single-pass form of the top-r path when y overlaps no input
- * (1, default) or always the two-pass form (0), key 5 = XCD-contiguous tile ranges in the LDS-staged skeleton (0,
- * default: tile = workgroup id), key 6 = one-workgroup top-r kernel for n <= 65536 (1, default) or the multi-launch
- * path at every size (0).  Process-wide. */
-int spx_set_tuning(int key, int value);
+/* Kernel-benchmark / A-B knobs of ONE context (not part of the reference API; they never change results, only which of
+ * several equivalent kernels runs): key 0 = workgroups per CU of the separable grid (0 = one tile per workgroup, the
+ * default), key 1 = non-temporal loads/stores (0/1), key 2 = sample-predicted top-r path (1, default) or always the
+ * full-vector radix select (0), key 3 = LDS-staged (1, default) or register-staged (0) separable skeleton, key 4 =
+ * single-pass form of the top-r path when y overlaps no input (1, default) or always the two-pass form (0), key 5 =
+ * XCD-contiguous tile ranges in the LDS-staged skeleton (0, default: tile = workgroup id), key 6 = one-workgroup top-r
+ * kernel for n <= 65536 (1, default), key 7 = top-r kernels that synchronise inside one launch (1, default) or the
+ * multi-launch pipeline (0).  Contexts are independent; a context is used by one thread at a time. */
+int spx_ctx_set_tuning(spx_ctx* ctx, int key, int value);
 
 /* ---- construction-time helpers (the reference's constructors) ---------------------------- */
 /* any(l .> u) of the Box constructors (src/shiftedNormL1Box.jl:33-35, shiftedNormL0Box.jl:33-35).

@@ -28,10 +28,30 @@ struct spx_ctx {
   // ShiftedNormL1B2: did the last call take the scaled branch (trust region active)?  Only steers whether the first
   // reduction pass also stores y (it is the result when the trust region is inactive); never affects results.
   int b2_last_scaled = 0;
+  // Persistent device state of the multi-workgroup kernels that synchronise inside one launch (grid-barrier counters,
+  // histograms that must be zero on entry): allocated and zeroed once, never shared with `ws` (which every operator
+  // overwrites from offset 0).  coop_parity alternates per such launch: a launch uses counter/histogram set `parity`
+  // and clears set `parity ^ 1`, which the previous launch on this stream used and has finished with.
+  void* sync = nullptr;
+  size_t sync_bytes = 0;
+  int coop_parity = 0;
+  int sel_hist_next = 0;            // spx_select.hip: histogram set (0/1) the next k_sel_coop launch uses ...
+  int sel_hist_dirty[2] = {0, 0};   // ... and which sets a previous launch left non-zero
+  // tuning knobs (spx_ctx_set_tuning): per context, so that two contexts / threads never see each other's experiments
+  int tune_sep_blocks_per_cu = 0;  // key 0: 0 = no cap (one tile per workgroup)
+  int tune_sep_nt = 1;             // key 1: non-temporal loads / stores
+  int tune_sel_fast = 1;           // key 2: sample-predicted top-r path
+  int tune_sep_lds = 1;            // key 3: LDS-staged separable skeleton
+  int tune_sel_spec = 1;           // key 4: single-pass (speculative store) form of the top-r fast path
+  int tune_sep_xcd = 0;            // key 5: XCD-contiguous tile ranges (experiment)
+  int tune_sel_small = 1;          // key 6: one-workgroup top-r for n <= 65536
+  int tune_sel_coop = 1;           // key 7: in-launch synchronised top-r kernels (0 = the multi-launch pipeline of round 1)
 };
 
 void spx_set_error(const char* fmt, ...);
 int spx_ws_reserve(spx_ctx* ctx, size_t bytes);
+int spx_sync_reserve(spx_ctx* ctx, size_t bytes);  // persistent, zero-initialised (see spx_ctx::sync)
+int spx_ctx_count(int device);                     // live contexts on a device
 
 #define SPX_HIP(call)                                                                          \
   do {                                                                                         \
@@ -96,4 +116,26 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grid barrier for kernels whose workgroups are all resident (grid <= number of CUs, one workgroup per CU): one
+// monotonic counter in spx_ctx::sync.  Recipe of MI355X_MICROARCH.md ("inter-workgroup visibility"): every storing wave
+// drains its stores, workgroup barrier, ONE lane: agent-scope release (L2 write-back) -> arrive (agent-scope atomic add) ->
+// relaxed polls -> agent-scope acquire (L1 / non-coherent L2 lines invalidated), workgroup barrier, then plain loads.
+// `target` = (number of barriers passed so far in this launch + 1) * gridDim.x.  Every workgroup of the grid must call
+// it the same number of times (the exit condition every wave reaches: no early return between barriers).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void spx_grid_barrier(unsigned int* counter, unsigned int target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
 }

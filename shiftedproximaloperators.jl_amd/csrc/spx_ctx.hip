@@ -1,7 +1,10 @@
 // spx_ctx.hip -- context, errors, stopwatch and the construction-time helpers of the C ABI.
 #include "spx_common.hpp"
 
+#include <atomic>
 static thread_local char g_err[512] = "";
+static std::atomic<int> g_ctx_count[64];
+int spx_ctx_count(int device) { return g_ctx_count[device & 63].load(); }
 
 void spx_set_error(const char* fmt, ...) {
   va_list ap;
@@ -45,6 +48,7 @@ static int ctx_create_impl(int device, bool borrow, void* stream, spx_ctx** out)
     delete c;
     return SPX_ERR_HIP;
   }
+  g_ctx_count[device & 63].fetch_add(1);
   *out = c;
   return SPX_OK;
 }
@@ -59,12 +63,33 @@ SPX_EXPORT int spx_ctx_destroy(spx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->sync) (void)hipFree(ctx->sync);
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+  g_ctx_count[ctx->device & 63].fetch_sub(1);
   delete ctx;
   return SPX_OK;
+}
+
+// Per-context tuning knobs of the kernel benchmarks and A/B tests (not part of the reference's interface).  Never changes
+// results, only which of several equivalent kernels runs.
+SPX_EXPORT int spx_ctx_set_tuning(spx_ctx* ctx, int key, int value) {
+  SPX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  switch (key) {
+    case 0: if (value < 0 || value > 1024) break; ctx->tune_sep_blocks_per_cu = value; return SPX_OK;
+    case 1: ctx->tune_sep_nt = value ? 1 : 0; return SPX_OK;
+    case 2: ctx->tune_sel_fast = value ? 1 : 0; return SPX_OK;
+    case 3: ctx->tune_sep_lds = value ? 1 : 0; return SPX_OK;
+    case 4: ctx->tune_sel_spec = value ? 1 : 0; return SPX_OK;
+    case 5: ctx->tune_sep_xcd = value ? 1 : 0; return SPX_OK;
+    case 6: ctx->tune_sel_small = value ? 1 : 0; return SPX_OK;
+    case 7: ctx->tune_sel_coop = value ? 1 : 0; return SPX_OK;
+    default: break;
+  }
+  spx_set_error("invalid argument: unknown tuning key/value");
+  return SPX_ERR_INVALID_ARG;
 }
 
 SPX_EXPORT int spx_sync(spx_ctx* ctx) {
@@ -102,6 +127,29 @@ int spx_ws_reserve(spx_ctx* ctx, size_t bytes) {
     return SPX_ERR_ALLOC;
   }
   ctx->ws_bytes = bytes;
+  return SPX_OK;
+}
+
+// Persistent zero-initialised device state (spx_ctx::sync).  Growing it re-zeroes everything: callers only rely on
+// "zero when no launch of mine is in flight", which holds again after the stream has been drained.
+int spx_sync_reserve(spx_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->sync_bytes) return SPX_OK;
+  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->sync) SPX_HIP(hipFree(ctx->sync));
+  ctx->sync = nullptr;
+  ctx->sync_bytes = 0;
+  hipError_t e = hipMalloc(&ctx->sync, bytes);
+  if (e != hipSuccess) {
+    spx_set_error("sync-state hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return SPX_ERR_ALLOC;
+  }
+  SPX_HIP(hipMemsetAsync(ctx->sync, 0, bytes, ctx->stream));
+  SPX_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->sync_bytes = bytes;
+  ctx->coop_parity = 0;
+  ctx->sel_hist_next = 0;
+  ctx->sel_hist_dirty[0] = ctx->sel_hist_dirty[1] = 0;
   return SPX_OK;
 }
 

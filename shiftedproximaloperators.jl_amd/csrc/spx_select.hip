@@ -21,6 +21,8 @@
 // memory), so the usual cost is pass 0 (24 B read + 8 B write per element), 2-3 key passes (8 B) and the
 // final pass (24 B read + 8 B write).  y may alias q: pass 0 reads q[i] before it writes y[i] and q is
 // not needed afterwards.
+#include <mutex>
+
 #include "spx_common.hpp"
 
 namespace {
@@ -89,10 +91,13 @@ struct FastState {
   unsigned long long smax;        // largest FINITE sample key (k_s2_sample; zeroed by k_sel_init)
 };
 
-// totals of the main pass: fire-and-forget atomics of its wavefronts, spread over kShards lines (wave w -> shard
-// w % kShards) so that no single address serialises them; k_s2_scan_verify adds the shards up
-constexpr int kShards = 64;
-constexpr int kShardStride = 16;  // unsigned long longs between two shards (128 bytes)
+// totals of the main pass: fire-and-forget atomics of its wavefronts, spread over kShards counters (wave w -> shard
+// w % kShards) so that no single address serialises them; k_s2_scan_verify adds the shards up.  Round 2: 2048 shards
+// instead of 64 -- atomics on ONE address retire ~12 ns apart, so the 130 208 waves of an n = 1e8 pass queued ~2000 deep
+// on each of 64 addresses (~25 us of serialised traffic per address, the "13 us" the pair of atomics was measured to
+// cost the pass); at 64 per address it is gone.
+constexpr int kShards = 2048;
+constexpr int kShardStride = 1;
 
 struct SelWs {
   SelState st;
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
       s.width = width;
     }
   }
-  if (t < kShards) { ws->shard_above[t * kShardStride] = 0ull; ws->shard_cand[t * kShardStride] = 0ull; }
+  for (int k = t; k < kShards; k += 1024) { ws->shard_above[k * kShardStride] = 0ull; ws->shard_cand[k * kShardStride] = 0ull; }
 }
 
 // Main pass: one tile per workgroup, waves fully independent (no barrier, no atomics).  Counts the elements above the
@@ -688,7 +693,10 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
 // entries below it and inside it as dropped; the kept value of a band entry travels with the candidate and
 // k_s2_compact / k_s2_finish store it once the cut is known.  The call then moves the algorithmic 32 B/element plus the ~0.5 % of
 // candidates, instead of 56 B/element with the separate final pass (k_sel_final_q, used when y aliases an input).
-template <bool BINF, bool WRITE>
+// SHARD: the wave totals also go into the sharded counters of SelWs (multi-launch pipeline: k_s2_scan_verify adds 64
+// shards up).  !SHARD (in-launch synchronised pipeline): k_s2_tail sums the per-wave count words itself with its whole
+// grid, so the pass issues no atomics besides the per-candidate histogram ones.
+template <bool BINF, bool WRITE, bool SHARD = true>
 __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, const double* xk_, const double* sj_,
                                                   int64_t n, SelWs* ws, Cand* cand, WaveCount* counts, double delta,
                                                   int ioff) {
@@ -793,12 +801,14 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
   for (int off = 32; off >= 1; off >>= 1) above += __shfl_xor(above, off, 64);
   if (lane == 0) {
     counts[gwave] = WaveCount{ncand, above};
-    const int shard = (int)(gwave % kShards) * kShardStride;
-    // (measured on one box, interleaved: these two atomics per wave cost ~13 us of the pass; packing both totals into
-    //  ONE 64-bit atomic per wave was slower still, 0.645 vs 0.622 ms per call; the per-candidate histogram atomics
-    //  above cost nothing measurable)
-    if (above) atomicAdd(&ws->shard_above[shard], (unsigned long long)above);
-    if (ncand) atomicAdd(&ws->shard_cand[shard], (unsigned long long)ncand);
+    if constexpr (SHARD) {
+      const int shard = (int)(gwave % kShards) * kShardStride;
+      // (measured on one box, interleaved: these two atomics per wave cost ~13 us of the pass; packing both totals into
+      //  ONE 64-bit atomic per wave was slower still, 0.645 vs 0.622 ms per call; the per-candidate histogram atomics
+      //  above cost nothing measurable)
+      if (above) atomicAdd(&ws->shard_above[shard], (unsigned long long)above);
+      if (ncand) atomicAdd(&ws->shard_cand[shard], (unsigned long long)ncand);
+    }
     if (ncand > (unsigned)kWaveSlots) atomicExch(&ws->fs.overflow, 1);
   }
 }
@@ -836,8 +846,9 @@ __global__ __launch_bounds__(256) void k_s2_scan_verify(SelWs* ws, int64_t r) {
   __shared__ int sok;
   __shared__ SelState sst;
   unsigned long long above = 0, cand = 0;
-  if (threadIdx.x < 64) {  // wave 0 adds up the shards of the main pass
-    for (int k = threadIdx.x; k < kShards; k += 64) {
+  {  // the 256 lanes add up the shards of the main pass
+    __shared__ unsigned long long red[2][4];
+    for (int k = threadIdx.x; k < kShards; k += 256) {
       above += ws->shard_above[k * kShardStride];
       cand += ws->shard_cand[k * kShardStride];
     }
@@ -845,6 +856,10 @@ __global__ __launch_bounds__(256) void k_s2_scan_verify(SelWs* ws, int64_t r) {
       above += __shfl_xor(above, off, 64);
       cand += __shfl_xor(cand, off, 64);
     }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = above; red[1][threadIdx.x >> 6] = cand; }
+    __syncthreads();
+    above = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    cand = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
   if (threadIdx.x == 0) {
     FastState& f = ws->fs;
@@ -895,7 +910,14 @@ __global__ __launch_bounds__(256) void k_s2_compact(double* y, const Cand* cand,
       keep = (key >= st.t_ge) || (key == st.t_eq && itop < st.prefix);
     }
     if (in) {
-      const unsigned int slot = atomicAdd(&ws->fs.list_count, 1u);
+      // one atomic per wave instruction, not per survivor (they all hit one address: ~12 ns each, serialised)
+      const unsigned long long am = __ballot(1);
+      const int lane = threadIdx.x & 63;
+      const int leader = __ffsll((long long)am) - 1;
+      unsigned int base = 0;
+      if (lane == leader) base = atomicAdd(&ws->fs.list_count, (unsigned int)__popcll(am));
+      base = __shfl(base, leader, 64);
+      const unsigned int slot = base + (unsigned int)__popcll(am & ((1ull << lane) - 1ull));
       if (slot < (unsigned)kShortList) {
         list_key[slot] = key;
         list_idx[slot] = i;
@@ -1009,12 +1031,397 @@ __global__ __launch_bounds__(256) void k_sel_final_q(double* y_, const double* q
     y_[-1] = sel_out<BINF>((xk_[-1] + sj_[-1]) + q_[-1], 0, xk_[-1], sj_[-1], st, delta);
 }
 
+// =============================================================================================
+// In-launch synchronised kernels (round 2).  The multi-launch pipelines above pay for their serial chain of small
+// dependent launches and for one host read-back per call: 116 us per call at n = 1e6 against a 5 us bandwidth floor, and
+// ~90 us of the 0.62 ms at n = 1e8.  Here the workgroups of ONE launch (grid <= number of CUs, all resident) meet at grid
+// barriers (spx_grid_barrier) and every workgroup redoes the cheap scalar steps (histogram scans) for itself, so that no
+// step waits for a single workgroup of another launch:
+//   k_sel_coop   exact MSD radix select in one launch.  REG: 65536 < n <= 8 Ki x number of CUs -- v stays in registers
+//                (<= 8 elements per lane), the vectors are read once and y written once.  !REG: any n, v parked in y.
+//   k_s2_front   sample + band (replaces k_sel_init, k_s2_sample, k_s2_pick): each lane keeps its sample in a register.
+// The candidate kernels behind the main pass stay separate launches (k_s2_scan_verify, k_s2_compact, k_s2_finish): fused
+// into one in-launch synchronised "tail" (64 x 1024 lanes, two barriers) they measured 49 us against 31 us -- the walk over
+// the 130 208 per-wave candidate regions wants thousands of waves, a grid barrier wants few workgroups.  What the host no
+// longer does is read the verdict back: the exact full-vector select (k_sel_coop, fallback = 1) is queued behind them
+// unconditionally and returns at once (5 us) when the verdict is positive.
+// State that must be zero on entry lives in spx_ctx::sync (SelSync), zeroed once; each kernel leaves clean what the next
+// one expects (who clears what is noted at the fields).
+// =============================================================================================
+#ifdef SPX_SEL_PROFILE  // A/B builds only (csrc/build.sh -DSPX_SEL_PROFILE): phase time stamps of workgroup 0, 10 ns units
+__device__ unsigned long long g_sel_stamp[64];
+#define SEL_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sel_stamp[k] = wall_clock64(); } while (0)
+extern "C" __attribute__((visibility("default"))) int spx_debug_sel_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sel_stamp), sizeof(g_sel_stamp));
+}
+#else
+#define SEL_STAMP(k) do { } while (0)
+#endif
+constexpr int kCoopMaxPass = 12;  // <= 6 key digits + <= 6 index digits
+constexpr int kCoopEpl = 8;       // REG: elements per lane at most (16 spill: 1024-lane workgroups leave 128 VGPRs per lane)
+struct SelSync {
+  unsigned int bar[2][32];  // grid-barrier counters, one 128-byte line each; a launch uses [parity] and clears [parity ^ 1]
+  // One global histogram per pass.  k_sel_coop alternates between sets 0 and 1: a launch uses the clean one and clears
+  // the other (dirty from the launch before it; the host keeps the flags, spx_ctx::sel_hist_*).  Set 2 belongs to the
+  // fallback inside k_s2_tail, which clears it itself (one more barrier on a path that is rare and slow anyway).
+  unsigned long long chist[3][kCoopMaxPass][kBins];
+  unsigned long long fhist1[kBins];        // k_s2_front: top digit of the sample keys            (cleared by the fallback launch)
+  unsigned long long fhist2[2][2][kBins];  // k_s2_front: digits 2, 3 of the two rank selections  (cleared by the fallback launch)
+  SelWs ws;                                // st, fs, hist, shards (cleared by k_s2_front; fs.smax by the fallback launch)
+};
+
+struct CoopShared {
+  unsigned int lh[kBins];
+  unsigned long long scratch[8];
+  SelState sst;
+};
+
+__device__ __forceinline__ void sel_state_init(SelState& s, int64_t n, int64_t r) {
+  int bits = 0;
+  while (bits < 63 && ((int64_t)1 << bits) < n) ++bits;
+  s.idx_bits = bits;
+  s.prefix = 0;
+  s.icut = -1;
+  s.t_eq = ~0ull;
+  s.t_ge = ~0ull;
+  s.pad = s.pad2 = s.pad3 = 0;
+  s.t_floor = 0;
+  s.base = 0;
+  s.clamp = 0;
+  s.quota = 0;
+  s.shift = 0;
+  s.width = 0;
+  if (r <= 0) {            // nothing kept
+    s.phase = 2;
+  } else if (r >= n) {     // everything kept
+    s.phase = 2; s.t_ge = 0ull;
+  } else {
+    s.phase = 0; s.shift = 64 - kDigitBits; s.width = kDigitBits; s.quota = r;
+  }
+}
+
+// The exact selection, executed by every workgroup of a resident grid of 1024-lane workgroups.  hist[p] must be zero on
+// entry for every pass p that runs.  Lane (block, t) owns the elements gtid, gtid + NT, ... in every pass (so v parked in
+// y needs no fence between passes, and y may alias q: q[i] is read before y[i] is written by the same lane).
+template <bool BINF, bool REG>
+__device__ __forceinline__ void coop_select(double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                            int64_t r, double delta, unsigned long long (*hist)[kBins], unsigned int* bar,
+                                            unsigned int& nbar, CoopShared& sh) {
+  const int t = threadIdx.x;
+  const int64_t NT = (int64_t)gridDim.x * blockDim.x;
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + t;
+  double v[REG ? kCoopEpl : 1];
+  if constexpr (REG) {
+#pragma unroll
+    for (int k = 0; k < kCoopEpl; ++k) {
+      const int64_t i = gtid + (int64_t)k * NT;
+      v[k] = (i < n) ? (xk[i] + sj[i]) + q[i] : 0.0;  // shiftedIndBallL0.jl:66
+    }
+  }
+  if (t == 0) sel_state_init(sh.sst, n, r);
+  SEL_STAMP(32);
+  int p = 0;
+  for (; p < kCoopMaxPass; ++p) {
+    __syncthreads();
+    const SelState st = sh.sst;
+    if (st.phase == 2) break;  // the same in every workgroup: they all computed it from the same histograms
+    for (int b = t; b < kBins; b += blockDim.x) sh.lh[b] = 0u;
+    __syncthreads();
+    const int hs = st.shift + st.width;
+    const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
+    auto visit = [&](double vv, int64_t i) {
+      const uint64_t key = key_of(vv);
+      if (st.phase == 0) {
+        const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
+        if (kp.in) atomicAdd(&sh.lh[kp.digit], 1u);
+      } else if (key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix) {
+        atomicAdd(&sh.lh[(((uint64_t)i) >> st.shift) & dmask], 1u);
+      }
+    };
+    if constexpr (REG) {
+#pragma unroll
+      for (int k = 0; k < kCoopEpl; ++k) {
+        const int64_t i = gtid + (int64_t)k * NT;
+        if (i < n) visit(v[k], i);
+      }
+    } else {
+      if (p == 0) {
+        for (int64_t i = gtid; i < n; i += NT) {
+          const double vv = (xk[i] + sj[i]) + q[i];
+          y[i] = vv;
+          visit(vv, i);
+        }
+      } else {
+        for (int64_t i = gtid; i < n; i += NT) visit(y[i], i);
+      }
+    }
+    __syncthreads();
+    for (int b = t; b < kBins; b += blockDim.x) {
+      const unsigned int c = sh.lh[b];
+      if (c) atomicAdd(&hist[p][b], (unsigned long long)c);
+    }
+    SEL_STAMP(33 + 3 * p);
+    spx_grid_barrier(bar, (++nbar) * gridDim.x);
+    SEL_STAMP(34 + 3 * p);
+    sel_scan_step(hist[p], st, &sh.sst, sh.scratch);
+    SEL_STAMP(35 + 3 * p);
+  }
+  __syncthreads();
+  const SelState fin = sh.sst;
+  if constexpr (REG) {
+#pragma unroll
+    for (int k = 0; k < kCoopEpl; ++k) {
+      const int64_t i = gtid + (int64_t)k * NT;
+      if (i < n) y[i] = sel_out<BINF>(v[k], i, xk[i], sj[i], fin, delta);
+    }
+  } else {
+    if (p == 0) {  // resolved before any pass (r <= 0 or r >= n): v was never parked in y
+      for (int64_t i = gtid; i < n; i += NT) y[i] = sel_out<BINF>((xk[i] + sj[i]) + q[i], i, xk[i], sj[i], fin, delta);
+    } else {
+      for (int64_t i = gtid; i < n; i += NT) y[i] = sel_out<BINF>(y[i], i, xk[i], sj[i], fin, delta);
+    }
+  }
+  SEL_STAMP(63);
+}
+
+// use_set: the histogram set of this launch; clear_set >= 0: the set to zero for a later launch (never use_set).
+// fallback != 0: the launch that follows k_s2_tail -- returns at once if the prediction was verified (the flag was
+// written by an earlier launch: the same value in every workgroup), otherwise clears its own set (2) first, one more
+// barrier on a path that is rare and slow anyway.
+template <bool BINF, bool REG>
+__global__ __launch_bounds__(1024) void k_sel_coop(double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                                    int64_t r, double delta, SelSync* ss, int parity, int use_set,
+                                                    int clear_set, int fallback) {
+  __shared__ CoopShared sh;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ss->bar[parity ^ 1][0] = 0u;
+  if (fallback) {  // last launch of a sample-predicted call: clean slates for the next call's k_s2_front
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long* z1 = ss->fhist1;
+    unsigned long long* z2 = &ss->fhist2[0][0][0];
+    for (int64_t b = gt; b < kBins; b += nt) z1[b] = 0ull;
+    for (int64_t b = gt; b < 4 * kBins; b += nt) z2[b] = 0ull;
+    if (gt == 0) ss->ws.fs.smax = 0ull;
+    if (ss->ws.fs.ok) return;
+  }
+  const int64_t total = (int64_t)kCoopMaxPass * kBins;
+  unsigned int nbar = 0;
+  if (clear_set >= 0) {
+    unsigned long long* z = &ss->chist[clear_set][0][0];
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total; b += (int64_t)gridDim.x * blockDim.x) z[b] = 0ull;
+  }
+  if (fallback) {
+    unsigned long long* z = &ss->chist[use_set][0][0];
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total; b += (int64_t)gridDim.x * blockDim.x) z[b] = 0ull;
+    spx_grid_barrier(ss->bar[parity], (++nbar) * gridDim.x);
+  }
+  coop_select<BINF, REG>(y, q, xk, sj, n, r, delta, ss->chist[use_set], ss->bar[parity], nbar, sh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_s2_front: kFrontBlocks workgroups x 1024 lanes (few, fat workgroups: a grid barrier costs ~2 us with 64 arrivers,
+// ~7 us with 256 -- tools/exp/grid_barrier.hip), one sample per lane, kept in a register through all phases.
+//   A  sample, LDS histogram of the top key digit -> fhist1; clears what the main pass / tail accumulate into
+//   B  (every workgroup) scan fhist1 for the two ranks; second digit of the own sample if it sits in a selected bucket
+//   C  scan; a third digit only if a selected bucket is still crowded (as k_s2_pick); workgroup 0 writes the band and
+//      the digit machinery of the candidate selection (the tail of k_s2_pick, unchanged)
+// ---------------------------------------------------------------------------------------------
+constexpr int kFrontBlocks = kSample / 1024;  // 64
+__global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double* xk, const double* sj, int64_t n, int64_t r,
+                                                    SelSync* ss, int parity) {
+  __shared__ unsigned int lh[kBins];
+  __shared__ unsigned long long part[4][4];  // per 256-lane group
+  __shared__ unsigned long long pre[2];
+  __shared__ long long quo[2];
+  __shared__ int active[2];
+  __shared__ unsigned int bucket[2];
+  const int t = threadIdx.x, c = blockIdx.x;
+  unsigned int* bar = ss->bar[parity];
+  unsigned int nbar = 0;
+  SelWs* ws = &ss->ws;
+  if (c == 0 && t == 0) ss->bar[parity ^ 1][0] = 0u;
+  SEL_STAMP(0);
+  for (int b = t; b < kBins; b += 1024) lh[b] = 0u;
+  // clean slates for the main pass (it runs in a later launch)
+  for (int b = c * 1024 + t; b < kBins; b += 1024 * (int)gridDim.x) ws->hist[b] = 0ull;
+  for (int b = c * 1024 + t; b < kShards; b += 1024 * (int)gridDim.x) { ws->shard_above[b * kShardStride] = 0ull; ws->shard_cand[b * kShardStride] = 0ull; }
+  if (t == 0) {
+    bucket[0] = bucket[1] = 0u;
+    const double M = (double)kSample;
+    const double p = (double)r / (double)n;
+    const double k = p * M;
+    const double margin = 6.0 * sqrt(M * p * (1.0 - p)) + 16.0;
+    const long long rank_hi = (long long)floor(k - margin);  // 1-based from the largest
+    const long long rank_lo = (long long)ceil(k + margin);
+    pre[0] = pre[1] = 0;
+    active[0] = rank_hi >= 1;
+    active[1] = rank_lo <= kSample;
+    quo[0] = rank_hi;
+    quo[1] = rank_lo;
+  }
+  __syncthreads();
+  // 256 chunks of 256 consecutive elements, as k_s2_sample: workgroup c takes chunks 4c .. 4c+3
+  const int chunk = c * 4 + (t >> 8);
+  const int64_t start = (int64_t)((double)chunk * (double)(n - 256) / 255.0);
+  const int64_t i = start + (t & 255);
+  const uint64_t key = key_of(fabs((xk[i] + sj[i]) + q[i]));
+  atomicAdd(&lh[key >> (64 - kDigitBits)], 1u);
+  {
+    // largest finite sample key (see k_s2_sample) -- ONE global atomic per workgroup: the 1024 per-wave atomicMax of
+    // k_s2_sample on this one address were ~12 us of serialised traffic, most of that kernel's 14 us
+    unsigned long long m = key < kInfKey ? key : 0ull;
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long o = __shfl_xor(m, off, 64);
+      m = o > m ? o : m;
+    }
+    if ((t & 63) == 0) part[(t >> 6) >> 2][(t >> 6) & 3] = m;
+  }
+  __syncthreads();
+  if (t == 0) {
+    unsigned long long m = 0;
+    for (int k = 0; k < 16; ++k) { const unsigned long long o = part[k >> 2][k & 3]; m = o > m ? o : m; }
+    if (m) atomicMax(&ws->fs.smax, m);
+  }
+  for (int b = t; b < kBins; b += 1024) {
+    const unsigned int cnt = lh[b];
+    if (cnt) atomicAdd(&ss->fhist1[b], (unsigned long long)cnt);
+  }
+  SEL_STAMP(1);
+  spx_grid_barrier(bar, (++nbar) * gridDim.x);
+  SEL_STAMP(2);
+  // scan of a 4096-bin histogram from the top: lanes 0..255 serve selection 0, lanes 256..511 selection 1 (as k_s2_pick)
+  constexpr int PER = kBins / 256;
+  auto scan_both = [&](const unsigned long long* h0, const unsigned long long* h1) {
+    const int sel = (t >> 8) & 1, tt = t & 255, grp256 = t >> 8;
+    const unsigned long long* h = sel ? h1 : h0;
+    unsigned long long loc[PER], sum = 0;
+    if (t < 512) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) { loc[k] = h[kBins - 1 - (tt * PER + k)]; sum += loc[k]; }
+    }
+    const unsigned long long run0 = scan256_exclusive(sum, tt, part[grp256]);
+    unsigned long long npre = 0, nquo = 0;
+    unsigned int nb = 0;
+    bool hit = false;
+    if (t < 512 && active[sel]) {
+      unsigned long long run = run0;
+      const unsigned long long quota = (unsigned long long)quo[sel];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        if (run < quota && run + loc[k] >= quota) {
+          npre = (pre[sel] << kDigitBits) | (uint64_t)(kBins - 1 - (tt * PER + k));
+          nquo = quota - run;
+          nb = (unsigned int)loc[k];
+          hit = true;
+        }
+        run += loc[k];
+      }
+    }
+    __syncthreads();  // every lane has read pre / quo before the hit lanes replace them
+    if (hit) { pre[sel] = npre; quo[sel] = (long long)nquo; bucket[sel] = nb; }
+    __syncthreads();
+  };
+  scan_both(ss->fhist1, ss->fhist1);
+  SEL_STAMP(3);
+  int ndig = 1;
+  int shift = 64 - 2 * kDigitBits;
+  for (int digit = 1; digit < kPickDigits; ++digit) {
+    if (digit == 2 && bucket[0] <= kPickFine && bucket[1] <= kPickFine) break;  // uniform: same histograms everywhere
+    const int hs = shift + kDigitBits;
+    const uint64_t top = key >> hs;
+    const unsigned d = (unsigned)((key >> shift) & (kBins - 1));
+    if (active[0] && top == pre[0]) atomicAdd(&ss->fhist2[digit - 1][0][d], 1ull);
+    if (active[1] && top == pre[1]) atomicAdd(&ss->fhist2[digit - 1][1][d], 1ull);
+    SEL_STAMP(2 + 2 * digit);
+    spx_grid_barrier(bar, (++nbar) * gridDim.x);
+    SEL_STAMP(3 + 2 * digit);
+    scan_both(ss->fhist2[digit - 1][0], ss->fhist2[digit - 1][1]);
+    ndig = digit + 1;
+    shift -= kDigitBits;
+  }
+  if (c == 0 && t == 0) {
+    FastState& f = ws->fs;
+    const int low = 64 - ndig * kDigitBits;  // undecided low bits: take the whole bucket
+    f.t_hi = active[0] ? ((pre[0] << low) | (((uint64_t)1 << low) - 1)) : ~0ull;  // nothing is above all-ones
+    f.t_lo = active[1] ? (pre[1] << low) : 0ull;
+    f.cnt_above = 0;
+    f.cand_count = 0;
+    f.ok = 0;
+    f.key_passes = 0;
+    f.overflow = 0;
+    f.list_count = 0;
+    SelState& s = ws->st;
+    sel_state_init(s, n, r);
+    s.t_floor = f.t_lo;
+    s.quota = 0;
+    s.base = f.t_lo;
+    if (!active[0]) {  // no upper end: bins scaled by the largest finite sample, last bin open above (see k_s2_pick)
+      const uint64_t smax = f.smax > f.t_lo ? f.smax : f.t_lo;
+      const uint64_t dist = (smax - f.t_lo) | 1ull;
+      const int bits = 64 - __clzll((long long)dist);
+      int sh = bits - 10;
+      if (sh < 0) sh = 0;
+      if (sh > 51) sh = 51;
+      s.phase = 0;
+      s.shift = sh;
+      s.width = kDigitBits;
+      s.clamp = 1;
+      f.key_passes = 6;
+    } else if (f.t_lo == f.t_hi) {  // one key value in the band: straight to the index tie-break
+      s.t_ge = f.t_lo + 1;
+      s.t_eq = f.t_lo;
+      s.phase = 1;
+      const int idx_bits = s.idx_bits;
+      const int w = idx_bits % kDigitBits ? idx_bits % kDigitBits : kDigitBits;
+      s.shift = idx_bits - w;
+      s.width = w;
+    } else {
+      const uint64_t span = f.t_hi - f.t_lo;  // > 0
+      const int bits = 64 - __clzll((long long)span);
+      const int width = bits < kDigitBits ? bits : kDigitBits;
+      f.key_passes = (bits + kDigitBits - 1) / kDigitBits;
+      s.phase = 0;
+      s.shift = bits - width;
+      s.width = width;
+    }
+  }
+  SEL_STAMP(9);
+}
+
 #ifndef SPX_SEL_FAST_MIN_LOG2
 #define SPX_SEL_FAST_MIN_LOG2 20  // smallest n (log2) on the sample-predicted path: 83-98 us vs 100-123 us for the full-vector path at 2^20, behind it below (tools/exp/topr_threshold.py)
 #endif
-static int g_sel_small = 1;  // spx_set_tuning key 6: 0 disables the one-workgroup kernel for n <= kSmallN
-static int g_sel_fast = 1;  // spx_set_tuning key 2: 0 disables the sample-predicted path
-static int g_sel_spec = 1;  // spx_set_tuning key 4: 0 disables the single-pass (speculative store) form of it
+#ifndef SPX_SEL_REG_MAX_LOG2
+#define SPX_SEL_REG_MAX_LOG2 20  // largest n (log2) on the register-resident one-launch select; above it the sample-predicted pipeline is faster (n = 2e6: 72 vs ~58 us; n = 1e6: 48 us)
+#endif
+
+// Two launches that synchronise inside themselves must not run side by side on one device: each would hold CUs while it
+// waits for workgroups of its own that cannot be placed.  Contexts on different streams are therefore chained through one
+// event per device whenever more than one context exists on it (a stream-side dependency, the host never blocks).
+namespace {
+std::mutex g_coop_mu;
+hipEvent_t g_coop_ev[64] = {};
+const spx_ctx* g_coop_last[64] = {};
+}  // namespace
+struct CoopLaunchGuard {
+  spx_ctx* ctx;
+  bool chained;
+  explicit CoopLaunchGuard(spx_ctx* c) : ctx(c), chained(false) {
+    g_coop_mu.lock();
+    const int d = ctx->device & 63;
+    if (g_coop_last[d] != nullptr && g_coop_last[d] != ctx && g_coop_ev[d] != nullptr)
+      (void)hipStreamWaitEvent(ctx->stream, g_coop_ev[d], 0);
+    chained = (g_coop_last[d] != nullptr && g_coop_last[d] != ctx);
+  }
+  ~CoopLaunchGuard() {
+    const int d = ctx->device & 63;
+    if (chained || g_coop_last[d] == nullptr || spx_ctx_count(ctx->device) > 1) {
+      if (g_coop_ev[d] == nullptr) (void)hipEventCreateWithFlags(&g_coop_ev[d], hipEventDisableTiming);
+      if (g_coop_ev[d] != nullptr) (void)hipEventRecord(g_coop_ev[d], ctx->stream);
+    }
+    g_coop_last[d] = ctx;
+    g_coop_mu.unlock();
+  }
+};
 
 template <bool BINF>
 int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n, int64_t r,
@@ -1023,7 +1430,7 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   if (rc) return rc;
   if (n == 0) return SPX_OK;
   SPX_HIP(hipSetDevice(ctx->device));
-  if (n <= kSmallN && g_sel_small) {  // one workgroup, one launch, no scratch
+  if (n <= kSmallN && ctx->tune_sel_small) {  // one workgroup, one launch, no scratch
     hipLaunchKernelGGL((k_sel_small<BINF>), dim3(1), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta);
     SPX_LAUNCH_CHECK();
     return SPX_OK;
@@ -1033,7 +1440,42 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   // runs on the aligned rest and its wave 0 takes element 0 along (ioff = 1)
   auto off8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 8u; };
   const int ioff = (!vec && off8(y) && off8(q) && off8(xk) && off8(sj)) ? 1 : 0;
-  const bool try_fast = g_sel_fast && (vec || ioff) && (n - ioff) >= ((int64_t)1 << SPX_SEL_FAST_MIN_LOG2) && r > 0 && r < n;
+  const bool coop = ctx->tune_sel_coop && ctx->num_cu >= 32;
+  const int64_t reg_cap = (int64_t)kCoopEpl * 1024 * ctx->num_cu;  // (2 Mi elements on 256 CUs)
+  const int64_t fast_min = coop ? ((int64_t)1 << SPX_SEL_REG_MAX_LOG2) + 1 : ((int64_t)1 << SPX_SEL_FAST_MIN_LOG2);
+  const bool try_fast = ctx->tune_sel_fast && (vec || ioff) && (n - ioff) >= fast_min && r > 0 && r < n;
+  SelSync* ss = nullptr;
+  if (coop) {
+    rc = spx_sync_reserve(ctx, sizeof(SelSync));
+    if (rc) return rc;
+    ss = reinterpret_cast<SelSync*>(ctx->sync);
+  }
+  if (coop && !try_fast) {
+    // exact select in ONE launch: register-resident up to 8 Ki elements per CU, v parked in y beyond that
+    const bool reg = n <= reg_cap;
+    // as few workgroups as hold the vector at 8 elements per lane: a grid barrier costs ~2 us with 64 arrivers, ~7 us with 256
+    int64_t g = reg ? (n + (int64_t)kCoopEpl * 1024 - 1) / ((int64_t)kCoopEpl * 1024) : ctx->num_cu;
+    if (g > ctx->num_cu) g = ctx->num_cu;
+    if (g < 1) g = 1;
+    const int use_set = ctx->sel_hist_next, other = use_set ^ 1;
+    const int clear_set = ctx->sel_hist_dirty[other] ? other : -1;
+    const int parity = ctx->coop_parity;
+    {
+      CoopLaunchGuard guard(ctx);
+      if (reg)
+        hipLaunchKernelGGL((k_sel_coop<BINF, true>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r,
+                           delta, ss, parity, use_set, clear_set, 0);
+      else
+        hipLaunchKernelGGL((k_sel_coop<BINF, false>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r,
+                           delta, ss, parity, use_set, clear_set, 0);
+    }
+    ctx->coop_parity ^= 1;
+    ctx->sel_hist_dirty[use_set] = 1;
+    ctx->sel_hist_dirty[other] = 0;
+    ctx->sel_hist_next = other;
+    SPX_LAUNCH_CHECK();
+    return SPX_OK;
+  }
   // fast path scratch: one candidate region + count word per wavefront of the main pass
   const int64_t n2 = (n - ioff) >> 1;
   const int64_t mblocks = (n2 + kMainTilePairs - 1) / kMainTilePairs;
@@ -1055,14 +1497,54 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     Cand* cand = reinterpret_cast<Cand*>(wsb + off_ckey);
     // single-pass form when y overlaps none of the inputs (a failed prediction recomputes everything from them)
     auto disjoint = [&](const double* a) { return (y + n <= a) || (a + n <= y); };
-    const bool write = g_sel_spec && disjoint(q) && disjoint(xk) && disjoint(sj);
+    const bool write = ctx->tune_sel_spec && disjoint(q) && disjoint(xk) && disjoint(sj);
     uint64_t* lkey = reinterpret_cast<uint64_t*>(wsb + off_lkey);
     int64_t* lidx = reinterpret_cast<int64_t*>(wsb + off_lidx);
     double* lval = reinterpret_cast<double*>(wsb + off_lval);
+    const dim3 mgrid((unsigned)mblocks);
+    if (coop) {
+      // front (sample + band, one in-launch synchronised kernel) -> main pass -> verdict / candidates -> fallback (exact
+      // select; returns at once when the verdict is positive).  Nothing is read back.
+      SelWs* sws = &ss->ws;
+      {
+        CoopLaunchGuard guard(ctx);
+        hipLaunchKernelGGL(k_s2_front, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
+                           n - ioff, r, ss, ctx->coop_parity);
+        ctx->coop_parity ^= 1;
+        if (write)
+          hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,
+                             sj + ioff, n - ioff, sws, cand, counts, delta, ioff);
+        else
+          hipLaunchKernelGGL((k_s2_main<BINF, false>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,
+                             sj + ioff, n - ioff, sws, cand, counts, delta, ioff);
+        // (tried: verdict + first digit redone by every workgroup of the candidate walk instead of the one-workgroup launch in
+        //  front of it -- 598 vs 571 us per call at n = 1e8: 512 workgroups x 64 KiB of L2 reads and the scan chain cost more
+        //  than the launch they save)
+        hipLaunchKernelGGL(k_s2_scan_verify, dim3(1), dim3(256), 0, ctx->stream, sws, r);
+        if (write) {
+          hipLaunchKernelGGL((k_s2_compact<true>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, sws, lkey, lidx,
+                             lval, (const WaveCount*)counts, nregions);
+          hipLaunchKernelGGL((k_s2_finish<true>), dim3(1), dim3(1024), 0, ctx->stream, y, sws, (const uint64_t*)lkey,
+                             (const int64_t*)lidx, (const double*)lval);
+        } else {
+          hipLaunchKernelGGL((k_s2_compact<false>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, sws, lkey, lidx,
+                             lval, (const WaveCount*)counts, nregions);
+          hipLaunchKernelGGL((k_s2_finish<false>), dim3(1), dim3(1024), 0, ctx->stream, y, sws, (const uint64_t*)lkey,
+                             (const int64_t*)lidx, (const double*)lval);
+        }
+        hipLaunchKernelGGL((k_sel_coop<BINF, false>), dim3((unsigned)ctx->num_cu), dim3(1024), 0, ctx->stream, y, q, xk, sj, n,
+                           r, delta, ss, ctx->coop_parity, 2, -1, 1);
+        ctx->coop_parity ^= 1;
+      }
+      if (!write)
+        hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1535) / 1536)), dim3(256), 0, ctx->stream,
+                           y + ioff, q + ioff, xk + ioff, sj + ioff, n - ioff, (const SelWs*)sws, delta, ioff);
+      SPX_LAUNCH_CHECK();
+      return SPX_OK;
+    }
     hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, ctx->stream, ws, n, r);
     hipLaunchKernelGGL(k_s2_sample, dim3(256), dim3(256), 0, ctx->stream, q, xk, sj, n, samp, ws);
     hipLaunchKernelGGL(k_s2_pick, dim3(1), dim3(1024), 0, ctx->stream, (const double*)samp, n, r, ws);
-    const dim3 mgrid((unsigned)mblocks);
     if (write)
       hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,
                          sj + ioff, n - ioff, ws, cand, counts, delta, ioff);
@@ -1118,10 +1600,6 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
 }
 
 }  // namespace
-
-void spx_select_set_small(int on) { g_sel_small = on ? 1 : 0; }
-void spx_select_set_fast(int on) { g_sel_fast = on ? 1 : 0; }
-void spx_select_set_spec(int on) { g_sel_spec = on ? 1 : 0; }
 
 SPX_EXPORT int spx_prox_indball_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
                                    int64_t n, int64_t r) {

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void k_sep_lds(double* y_, const double* q_, c
   const f64x2* uv = reinterpret_cast<const f64x2*>(u_);
   const uint16_t* mk = reinterpret_cast<const uint16_t*>(mask_);
   // Workgroups are dealt to the 8 XCDs round-robin.  xcd_chunk == 0 (default): tile = workgroup id, so neighbouring tiles
-  // land on different XCDs; xcd_chunk > 0 (spx_set_tuning key 5, experiment): XCD x works through the contiguous range
+  // land on different XCDs; xcd_chunk > 0 (spx_ctx_set_tuning key 5, experiment): XCD x works through the contiguous range
   // [x * xcd_chunk, (x + 1) * xcd_chunk) of tiles.  No tile is ever re-read, so neither L2 has anything to win -- measured.
   int64_t bid = blockIdx.x;
   if (xcd_chunk > 0) {
@@ -642,16 +642,9 @@ __global__ __launch_bounds__(256) void k_sep_scalar(double* y, const double* q, 
   }
 }
 
-// Tuning knobs (spx_set_tuning).  Defaults from tools/sweep_sep.py on MI355X, n = 1e8 (profiles/r01_sweep_sep.txt):
+// Tuning knobs (spx_ctx_set_tuning).  Defaults from tools/sweep_sep.py on MI355X, n = 1e8 (profiles/r01_sweep_sep.txt):
 // one tile per workgroup (no cap) + non-temporal loads/stores: 6.15 TB/s vs 5.66 TB/s for 16 WG/CU, plain.
-void spx_select_set_fast(int on);
-void spx_select_set_spec(int on);  // spx_select.hip
-void spx_select_set_small(int on);
-static int g_sep_blocks_per_cu = 0;  // 0 = no cap: grid = number of tiles
-static int g_sep_nt = 1;
-
-static int g_sep_lds = 1;  // 1 = LDS-staged skeleton (default), 0 = register-staged
-static int g_sep_xcd = 0;  // 1 = XCD-contiguous tile ranges (experiment, see k_sep_lds)
+// (the knobs live in the context: spx_ctx::tune_sep_*, set by spx_ctx_set_tuning)
 
 #ifndef SPX_VECB_KIB
 #define SPX_VECB_KIB 3  // KiB per wave and vector with vector bounds (5 vectors); measured at n = 1e8 (tools/bench_vecb.py): 2 -> 0.81 ms, 3 -> 0.76 ms, 4 -> 0.775 ms
@@ -660,13 +653,13 @@ template <class Op, bool VECB, bool MASK>
 static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d, const double* xk, const double* sj,
                       const double* l, const double* u, const uint8_t* mask, double ls, double us, int64_t n2, Op op,
                       int64_t* value_slots /* out: partial slots written (Op::kObj) */) {
-  if constexpr (Op::kLdsKiB > 0) if (g_sep_lds) {
+  if constexpr (Op::kLdsKiB > 0) if (ctx->tune_sep_lds) {
     // 3 input vectors: 6 KiB per wave and vector -> 72 KiB per workgroup; 5 vectors (vector bounds): 3 KiB -> 60 KiB
     constexpr int U = (VECB && Op::kBox) ? (Op::kLdsKiB > SPX_VECB_KIB ? SPX_VECB_KIB : Op::kLdsKiB) : Op::kLdsKiB;  // <= 72 KiB per workgroup
     int64_t blocks = (n2 + 256 * U - 1) / (256 * U);
     *value_slots = blocks * 4;  // one per wavefront
     int64_t xcd_chunk = 0;
-    if (g_sep_xcd) {
+    if (ctx->tune_sep_xcd) {
       xcd_chunk = (blocks + 7) / 8;
       blocks = xcd_chunk * 8;
     }
@@ -678,10 +671,10 @@ static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d,
   constexpr int UNROLL = 4;
   const int64_t ntiles = (n2 + 256 * UNROLL - 1) / (256 * UNROLL);
   int64_t blocks = ntiles;
-  const int64_t cap = g_sep_blocks_per_cu > 0 ? (int64_t)ctx->num_cu * g_sep_blocks_per_cu : (int64_t)0x7fffffff;
+  const int64_t cap = ctx->tune_sep_blocks_per_cu > 0 ? (int64_t)ctx->num_cu * ctx->tune_sep_blocks_per_cu : (int64_t)0x7fffffff;
   if (blocks > cap) blocks = cap;
   *value_slots = blocks;  // one per workgroup
-  if (g_sep_nt)
+  if (ctx->tune_sep_nt)
     hipLaunchKernelGGL((k_sep_vec<Op, UNROLL, VECB, MASK, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y,
                        q, d, xk, sj, l, u, mask, ls, us, n2, op);
   else
@@ -767,20 +760,6 @@ static int run_separable(spx_ctx* ctx, double* y, const double* q, const double*
     SPX_HIP(hipStreamSynchronize(ctx->stream));
   }
   return SPX_OK;
-}
-
-// undocumented-in-reference tuning hook used by the kernel benchmarks: key 0 = workgroups per CU of the
-// separable grid, key 1 = non-temporal loads/stores on/off.
-SPX_EXPORT int spx_set_tuning(int key, int value) {
-  if (key == 0 && value >= 0 && value <= 1024) { g_sep_blocks_per_cu = value; return SPX_OK; }
-  if (key == 1) { g_sep_nt = value ? 1 : 0; return SPX_OK; }
-  if (key == 2) { spx_select_set_fast(value); return SPX_OK; }
-  if (key == 3) { g_sep_lds = value ? 1 : 0; return SPX_OK; }
-  if (key == 4) { spx_select_set_spec(value); return SPX_OK; }
-  if (key == 5) { g_sep_xcd = value ? 1 : 0; return SPX_OK; }
-  if (key == 6) { spx_select_set_small(value); return SPX_OK; }
-  spx_set_error("invalid argument: unknown tuning key/value");
-  return SPX_ERR_INVALID_ARG;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -41,7 +41,7 @@ def test_invalid_arguments_return_status_and_message(env):
         lambda: L.spx_prox_group_l2(ctx, _p(y), _p(q), _p(x), _p(sj), n, null, 0, 10, _p(x), 1.0),      # group_size 0
         lambda: L.spx_prox_group_l2_binf(ctx, _p(y), _p(q), _p(x), _p(sj), n, null, 10, 100, null, 1.0, 1.0),  # lambda NULL
         lambda: L.spx_prox_group_l2_gather(ctx, _p(y), _p(q), _p(x), _p(sj), n, null, null, 3, 0, _p(x), 1.0),  # ptr NULL
-        lambda: L.spx_set_tuning(99, 1),
+        lambda: L.spx_ctx_set_tuning(s.context("cuda:0"), 99, 1),
     ]
     for k, call in enumerate(cases):
         rc = call()

@@ -248,13 +248,15 @@ def test_indball_l0(s, orc, n, quant):
 
 
 def test_indball_l0_small_n_both_kernels(s, orc):
-    """n <= 65536 runs in one workgroup (k_sel_small); spx_set_tuning key 6 = 0 sends the same sizes through the
-    multi-launch radix select that larger vectors use.  Both must give the oracle's bits, ties and NaN included."""
+    """n <= 65536 runs in one workgroup (k_sel_small); spx_ctx_set_tuning key 6 = 0 sends the same sizes through the
+    kernels larger vectors use: the register-resident one-launch select (key 7 = 1, default) or the multi-launch radix
+    select of round 1 (key 7 = 0).  All three must give the oracle's bits, ties and NaN included."""
     L = s._lib.load()
     rng = np.random.default_rng(6)
     try:
-        for mode in (1, 0):
-            L.spx_set_tuning(6, mode)
+        for mode, coop in ((1, 1), (0, 1), (0, 0)):
+            L.spx_ctx_set_tuning(s.context("cuda:0"), 6, mode)
+            L.spx_ctx_set_tuning(s.context("cuda:0"), 7, coop)
             for n in (1, 2, 63, 1024, 1025, 5000, 65536):
                 x, sj, q = _data(n, 700 + n, 8)
                 if n >= 63:
@@ -274,7 +276,8 @@ def test_indball_l0_small_n_both_kernels(s, orc):
                 y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qd, 1.0).cpu().numpy()
                 assert _bits_equal(y, orc.prox_indball_l0(q, x, sj, r)), (mode, r)
     finally:
-        L.spx_set_tuning(6, 1)
+        L.spx_ctx_set_tuning(s.context("cuda:0"), 6, 1)
+        L.spx_ctx_set_tuning(s.context("cuda:0"), 7, 1)
 
 
 def test_indball_l0_ties_and_kats(s, orc, kats):

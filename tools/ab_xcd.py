@@ -1,4 +1,4 @@
-"""A/B of the blockIdx -> tile mapping of the LDS-staged separable kernel (spx_set_tuning key 5), interleaved in-process."""
+"""A/B of the blockIdx -> tile mapping of the LDS-staged separable kernel (spx_ctx_set_tuning key 5), interleaved in-process."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,12 +14,12 @@ ref = s.prox_bang(torch.empty_like(q), psi, q, 1.0).clone()
 res = {0: [], 1: []}
 for rnd in range(8):
     for mode in (0, 1):
-        L.spx_set_tuning(5, mode)
+        L.spx_ctx_set_tuning(s.context("cuda:0"), 5, mode)
         ms = ctypes.c_float(); L.spx_timer_start(ctx)
         for _ in range(20): s.prox_bang(y, psi, q, 1.0)
         L.spx_timer_stop(ctx, ctypes.byref(ms)); res[mode].append(ms.value / 20)
         assert torch.equal(y, ref)
-L.spx_set_tuning(5, 0)
+L.spx_ctx_set_tuning(s.context("cuda:0"), 5, 0)
 for mode in (0, 1):
     t = sorted(res[mode][1:]); med = t[len(t) // 2]
     print("%-28s median %.4f ms min %.4f  -> %.0f GB/s" % ("tile = workgroup id" if mode == 0 else "XCD-contiguous tile ranges", med, t[0], 32 * n / med / 1e6))

@@ -21,7 +21,7 @@ ts.sort(); print("misaligned views: median %.4f ms -> %.0f GB/s" % (ts[2], 32 * 
 # top-r on the same views: the sample-predicted path runs on the aligned rest (element 0 rides with wave 0)
 r = n // 100
 psi = s.shifted(s.shifted(s.IndBallL0(r), xk, 1.0, s.NormLinf(1.0)), sj)
-L.spx_set_tuning(2, 0); ref = s.prox_bang(torch.empty_like(y), psi, q, 1.0).clone(); L.spx_set_tuning(2, 1)
+L.spx_ctx_set_tuning(s.context("cuda:0"), 2, 0); ref = s.prox_bang(torch.empty_like(y), psi, q, 1.0).clone(); L.spx_ctx_set_tuning(s.context("cuda:0"), 2, 1)
 ts = []
 for rnd in range(5):
     ms = ctypes.c_float(); L.spx_timer_start(ctx)

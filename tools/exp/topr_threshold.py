@@ -16,7 +16,7 @@ for lg in (17, 18, 19, 20, 21, 22, 23):
         psi = s.shifted(s.shifted(s.IndBallL0(r), xk, 1.0, chi), sj)
         res = {}
         for mode in (0, 1):
-            L.spx_set_tuning(2, mode)
+            L.spx_ctx_set_tuning(s.context("cuda:0"), 2, mode)
             s.prox_bang(y, psi, q, 1.0); ref = y.clone() if mode == 0 else ref
             ts = []
             for rnd in range(5):
@@ -26,4 +26,4 @@ for lg in (17, 18, 19, 20, 21, 22, 23):
             res[mode] = sorted(ts)[2]
             assert torch.equal(y, ref)
         print("n = 2^%d r = %-8d full-vector %.1f us   sample-predicted %.1f us" % (lg, r, res[0] * 1e3, res[1] * 1e3), flush=True)
-L.spx_set_tuning(2, 1)
+L.spx_ctx_set_tuning(s.context("cuda:0"), 2, 1)

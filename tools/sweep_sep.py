@@ -33,10 +33,10 @@ res = {}
 for rnd in range(5):
     for name, (bpe, psi) in ops.items():
         for lds in (0, 1):
-            L.spx_set_tuning(3, lds)
+            L.spx_ctx_set_tuning(s.context("cuda:0"), 3, lds)
             if rnd == 0: t(psi, 3)
             res.setdefault((name, lds), []).append(t(psi))
-L.spx_set_tuning(3, 1)
+L.spx_ctx_set_tuning(s.context("cuda:0"), 3, 1)
 for k in sorted(res):
     v = sorted(res[k]); med = v[len(v)//2]
     print("%-16s %-9s median %.4f ms  min %.4f ms  -> %.0f GB/s" % (k[0], "lds" if k[1] else "registers", med, v[0], ops[k[0]][0]*n/med/1e6))

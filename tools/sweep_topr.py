@@ -1,5 +1,5 @@
 """Top-r (ShiftedIndBallL0BInf.prox!) over r and data scale at n = 1e8: ms per call of the sample-predicted path, checked
-bit for bit against the full-vector radix select (spx_set_tuning key 2 = 0) on the same inputs.  A time near the
+bit for bit against the full-vector radix select (spx_ctx_set_tuning key 2 = 0) on the same inputs.  A time near the
 full-vector figure means the prediction fell back."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,8 +24,8 @@ for kind in ("normal", "x1.37", "x0.69", "cauchy", "lattice64"):
     else: q = torch.round(q0 * 64) / 64
     for r in (1, 37, 1000, 100_000, n // 100, n // 10, n // 2, (9 * n) // 10, n - 100_000, n - 1000):
         psi = s.shifted(s.shifted(s.IndBallL0(r), xk, 1.0, chi), sj)
-        L.spx_set_tuning(2, 0); s.prox_bang(y, psi, q, 1.0); ref = y.clone(); t_full = timed(psi, q, 2)
-        L.spx_set_tuning(2, 1); s.prox_bang(y, psi, q, 1.0); t = timed(psi, q, 10)
+        L.spx_ctx_set_tuning(s.context("cuda:0"), 2, 0); s.prox_bang(y, psi, q, 1.0); ref = y.clone(); t_full = timed(psi, q, 2)
+        L.spx_ctx_set_tuning(s.context("cuda:0"), 2, 1); s.prox_bang(y, psi, q, 1.0); t = timed(psi, q, 10)
         ok = torch.equal(y, ref); bad += 0 if ok else 1
         print("%-10s r=%-10d fast %.4f ms  full-vector %.4f ms  %s%s" % (kind, r, t, t_full, "ok" if ok else "MISMATCH", "  (fell back)" if t > 0.8 * t_full + 0.3 else ""), flush=True)
     del q
