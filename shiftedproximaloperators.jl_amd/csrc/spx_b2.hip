@@ -12,7 +12,8 @@
 // current eta, the piece's root is taken, the next pass verifies it (identical sums = same piece = done); a bracket
 // [froot < 0, froot > 0] safeguards every step.  The iteration starts from the a-priori upper bound chi sqrt(F)
 // (F = sum of the far bounds squared, from the first pass): typically 4-5 passes of 24 B/element + the final 32 B/element pass.
-// The host drives the loop (one 16-byte read-back per pass).
+// Round 1: the host drives the loop (one 16-byte read-back per pass) -- kept for unaligned views and as the A/B baseline
+// (spx_ctx_set_tuning key 7 = 0).  Round 2: k_b2_coop runs the same iteration inside one launch.
 #include <cmath>
 
 #include "spx_common.hpp"
@@ -233,6 +234,215 @@ __global__ __launch_bounds__(256) void k_b2_obj(const double* __restrict__ y, co
   if (threadIdx.x == 0) { ws->partP[blockIdx.x] = p; ws->partC[blockIdx.x] = c; }
 }
 
+// =============================================================================================
+// The whole prox in ONE launch (round 2).  The host loop above pays one stream synchronisation per reduction pass: ~100 us
+// per call at n = 1e4 and n = 1e6 alike, and 4-5 round trips inside the 1.35 ms at n = 1e8.  Here the workgroups of a
+// resident grid (<= number of CUs x 1024 lanes) run the same iteration themselves: every pass ends in per-workgroup partial
+// sums (written, not accumulated: the order of every addition is fixed, so all workgroups form bit-identical P, C, F),
+// a grid barrier, and the scalar update of eta, which every lane redoes for itself.  REG: n <= 8 Ki x number of CUs --
+// xk, sj and sj + q stay in registers, the vectors are read once.  !REG: the passes stream from memory (16-byte pairs).
+// =============================================================================================
+constexpr int kB2Epl = 8;
+constexpr int kB2MaxPass = 64;
+struct B2Part { double p, c, f, pad; };
+
+// three sums over the 1024 lanes of a workgroup at once, every addition in a fixed order (result in every lane)
+__device__ __forceinline__ void b2_block_sum3(double& a, double& b, double& c, double (*lds)[16]) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  c = wave_sum(c);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();  // previous use of lds finished
+  if ((threadIdx.x & 63) == 0) { lds[0][w] = a; lds[1][w] = b; lds[2][w] = c; }
+  __syncthreads();
+  double ta = 0.0, tb = 0.0, tc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { ta += lds[0][k]; tb += lds[1][k]; tc += lds[2][k]; }
+  a = ta; b = tb; c = tc;
+}
+
+template <bool REG>
+__global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                                   double ls, double delta, double chil, B2Part* part /* [kB2MaxPass][grid] */,
+                                                   SpxSyncHeader* hdr, int parity, int can_spec) {
+  __shared__ double lds3[3][16];
+  const int t = threadIdx.x;
+  const int G = (int)gridDim.x;
+  const int64_t NT = (int64_t)G * blockDim.x;
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + t;
+  unsigned int* bar = hdr->bar[parity];
+  unsigned int nbar = 0;
+  if (blockIdx.x == 0 && t == 0) hdr->bar[parity ^ 1][0] = 0u;
+  const int last_scaled = hdr->b2_last_scaled;  // (written by the previous call's launch)
+  double X[REG ? kB2Epl : 1], S[REG ? kB2Epl : 1], SQ[REG ? kB2Epl : 1];
+  if constexpr (REG) {
+#pragma unroll
+    for (int k = 0; k < kB2Epl; ++k) {
+      const int64_t i = gtid + (int64_t)k * NT;
+      const bool in = i < n;
+      X[k] = in ? xk[i] : 0.0;
+      S[k] = in ? sj[i] : 0.0;
+      SQ[k] = in ? (S[k] + q[i]) : 0.0;   // `sj .+ q` (:56)
+    }
+  }
+  const f64x2* q2 = reinterpret_cast<const f64x2*>(q);
+  const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
+  const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
+  f64x2* y2 = reinterpret_cast<f64x2*>(y);
+  const int64_t n2 = n >> 1;
+  int np = 0;
+  double P = 0.0, C = 0.0, F = 0.0;
+  // one reduction pass at scale r (= eta / Delta); store: also y = ProjB((-xk) r) rinv - sj for this scale
+  auto pass = [&](double r, double rinv, bool first, bool store) {
+    double p = 0.0, c = 0.0, f = 0.0;
+    auto visit = [&](double sq, double x, double s) -> double {
+      const double lo = sq - ls, hi = sq + ls;
+      const double z = (-x) * r;
+      const double pz = jl_min(jl_max(z, lo), hi);
+      if (pz == z) p += x * x; else c += pz * pz;
+      if (first) {
+        const double far = (x < 0.0) ? hi : (x > 0.0) ? lo : pz;
+        f += far * far;
+      }
+      return pz * rinv - s;
+    };
+    if constexpr (REG) {
+#pragma unroll
+      for (int k = 0; k < kB2Epl; ++k) {
+        const int64_t i = gtid + (int64_t)k * NT;
+        if (i < n) {
+          const double o = visit(SQ[k], X[k], S[k]);
+          if (store) y[i] = o;
+        }
+      }
+    } else {
+      const int64_t ntiles = (n2 + 4095) / 4096;  // 1024 lanes x 4 pairs
+      for (int64_t tile = blockIdx.x; tile < ntiles; tile += G) {
+        const int64_t base = tile * 4096 + t;
+        f64x2 a[4], b[4], d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int64_t i = (base + k * 1024 < n2) ? base + k * 1024 : n2 - 1;
+          a[k] = __builtin_nontemporal_load(q2 + i);
+          b[k] = __builtin_nontemporal_load(x2 + i);
+          d[k] = __builtin_nontemporal_load(s2 + i);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (base + k * 1024 < n2) {
+            f64x2 o;
+            o.x = visit(d[k].x + a[k].x, b[k].x, d[k].x);
+            o.y = visit(d[k].y + a[k].y, b[k].y, d[k].y);
+            if (store) __builtin_nontemporal_store(o, y2 + base + k * 1024);
+          }
+        }
+      }
+      if ((n & 1) && blockIdx.x == 0 && t == 0) {
+        const double o = visit(sj[n - 1] + q[n - 1], xk[n - 1], sj[n - 1]);
+        if (store) y[n - 1] = o;
+      }
+    }
+    b2_block_sum3(p, c, f, lds3);
+    if (G == 1) {  // one workgroup holds the whole vector: nothing to exchange
+      P = p; C = c;
+      if (first) F = f;
+    } else {
+      // the partial sums are the ONLY data the workgroups exchange: agent-scope atomic stores / loads and a rendezvous
+      // without cache maintenance (a fenced barrier is ~4 us even for two workgroups, most of a pass at small n)
+      B2Part* row = part + (size_t)np * G;
+      if (t == 0) {
+        spx_atomic_store_f64(&row[blockIdx.x].p, p);
+        spx_atomic_store_f64(&row[blockIdx.x].c, c);
+        if (first) spx_atomic_store_f64(&row[blockIdx.x].f, f);
+      }
+      spx_grid_rendezvous(bar, (++nbar) * (unsigned)G);
+      double pp = 0.0, cc = 0.0, ff = 0.0;
+      if (t < G) {
+        pp = spx_atomic_load_f64(&row[t].p);
+        cc = spx_atomic_load_f64(&row[t].c);
+        if (first) ff = spx_atomic_load_f64(&row[t].f);
+      }
+      b2_block_sum3(pp, cc, ff, lds3);
+      P = pp; C = cc;
+      if (first) F = ff;
+    }
+    ++np;
+  };
+  // y = ProjB(-xk) (:59); chi(y) = chi_lambda ||y||: at r = 1, ||y||^2 = P + C
+  const bool store_first = can_spec && !last_scaled;
+  pass(1.0, 1.0, true, store_first);
+  const double chiy = chil * sqrt(P + C);
+  const bool scaled = delta <= chiy;  // :61
+  if (blockIdx.x == 0 && t == 0) hdr->b2_last_scaled = scaled ? 1 : 0;
+  double eta = delta;
+  bool stored = !scaled && store_first;
+  if (scaled) {
+    double lo = delta, hi = INFINITY, pP = -1.0, pC = -1.0;
+    bool exact_step = false;
+    double y_eta = -1.0;
+    const double eta_ub = chil * sqrt(F);
+    if (eta_ub > delta && eta_ub < INFINITY) {
+      eta = eta_ub;
+      pass(eta / delta, 1.0, false, false);
+    }
+    for (int it = 0; it < kB2MaxPass - 4; ++it) {
+      const double r = eta / delta;
+      const double f = eta - chil * sqrt(r * r * P + C);
+      if (f == 0.0 || (exact_step && P == pP && C == pC)) break;
+      if (f < 0.0) lo = eta; else hi = eta;
+      const double den = 1.0 - chil * chil * P / (delta * delta);
+      double next = (den > 0.0) ? chil * sqrt(C / den) : INFINITY;
+      exact_step = (next > lo && next < hi);
+      if (!exact_step) next = (hi == INFINITY) ? 2.0 * lo : 0.5 * (lo + hi);
+      if (!(next > lo && next < hi)) break;
+      if (fabs(next - eta) <= 4e-16 * next) break;
+      // The piece roots converge quadratically (measured steps 4e-2, 1e-4, 6e-10: error(next) ~ 0.06 step^2), and a breakpoint
+      // between eta and the root changes the root only to second order (the pieces join continuously).  A step below 1e-8
+      // therefore leaves `next` within ~1e-16 of the root: it is taken as it is, without the pass that would only confirm it.
+      if (exact_step && fabs(next - eta) <= 1e-8 * next) { eta = next; y_eta = -1.0; break; }
+      const bool spec = can_spec && fabs(next - eta) <= 1e-3 * next;
+      pP = P; pC = C; eta = next;
+      pass(eta / delta, delta / eta, false, spec);
+      y_eta = spec ? eta : -1.0;
+    }
+    stored = (y_eta == eta);
+  }
+  if (stored) return;  // (after the last barrier; every workgroup takes the same path)
+  // final: y = ProjB((-xk) r) rinv - sj   (:63, :65), or ProjB(-xk) - sj (:59) when the trust region is inactive
+  const double r = scaled ? eta / delta : 1.0, rinv = scaled ? delta / eta : 1.0;
+  auto out = [&](double sq, double x, double s) -> double {
+    const double lo = sq - ls, hi = sq + ls;
+    const double tt = scaled ? jl_min(jl_max((-x) * r, lo), hi) * rinv : jl_min(jl_max(-x, lo), hi);
+    return tt - s;
+  };
+  if constexpr (REG) {
+#pragma unroll
+    for (int k = 0; k < kB2Epl; ++k) {
+      const int64_t i = gtid + (int64_t)k * NT;
+      if (i < n) y[i] = out(SQ[k], X[k], S[k]);
+    }
+  } else {
+    const int64_t ntiles = (n2 + 4095) / 4096;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += G) {
+      const int64_t base = tile * 4096 + t;
+      f64x2 a[4], b[4], d[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t i = (base + k * 1024 < n2) ? base + k * 1024 : n2 - 1;
+        a[k] = __builtin_nontemporal_load(q2 + i);
+        b[k] = __builtin_nontemporal_load(x2 + i);
+        d[k] = __builtin_nontemporal_load(s2 + i);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (base + k * 1024 < n2)
+          __builtin_nontemporal_store(f64x2{out(d[k].x + a[k].x, b[k].x, d[k].x), out(d[k].y + a[k].y, b[k].y, d[k].y)}, y2 + base + k * 1024);
+      }
+    }
+    if ((n & 1) && blockIdx.x == 0 && t == 0) y[n - 1] = out(sj[n - 1] + q[n - 1], xk[n - 1], sj[n - 1]);
+  }
+}
+
 }  // namespace
 
 // ShiftedNormL1B2 as a function (src/shiftedNormL1B2.jl:32).  IndBallL2(Delta)(v) [ext: ProximalOperators.jl] is 0 iff
@@ -282,6 +492,33 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   B2Ws* ws = reinterpret_cast<B2Ws*>(ctx->ws);
   const double ls = lambda * sigma;  // `psi.lambda * sigma`, :56
   bool vec = n >= 2 && spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj);
+  if (ctx->tune_sel_coop && ctx->num_cu >= 32 && (vec || n <= (int64_t)kB2Epl * 1024 * ctx->num_cu)) {
+    // one launch, no read-back (see k_b2_coop)
+    const bool reg = n <= (int64_t)kB2Epl * 1024 * ctx->num_cu;
+    int64_t g = reg ? (n + (int64_t)kB2Epl * 1024 - 1) / ((int64_t)kB2Epl * 1024) : ctx->num_cu;
+    if (g > ctx->num_cu) g = ctx->num_cu;
+    if (g < 1) g = 1;
+    rc = spx_ws_reserve(ctx, sizeof(B2Part) * (size_t)kB2MaxPass * (size_t)g + 256);
+    if (rc) return rc;
+    rc = spx_sync_reserve(ctx, sizeof(SpxSyncHeader));
+    if (rc) return rc;
+    auto disjoint = [&](const double* a) { return (y + n <= a) || (a + n <= y); };
+    const int can_spec = (disjoint(q) && disjoint(xk) && disjoint(sj)) ? 1 : 0;
+    B2Part* part = reinterpret_cast<B2Part*>(ctx->ws);
+    SpxSyncHeader* hdr = reinterpret_cast<SpxSyncHeader*>(ctx->sync);
+    {
+      SpxCoopLaunchGuard guard(ctx);
+      if (reg)
+        hipLaunchKernelGGL((k_b2_coop<true>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, ls, delta,
+                           chi_lambda, part, hdr, ctx->coop_parity, can_spec);
+      else
+        hipLaunchKernelGGL((k_b2_coop<false>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, ls, delta,
+                           chi_lambda, part, hdr, ctx->coop_parity, can_spec);
+    }
+    ctx->coop_parity ^= 1;
+    SPX_LAUNCH_CHECK();
+    return SPX_OK;
+  }
   // views from an odd element on (all four vectors 8 bytes off a 16-byte boundary): the vector kernels run on the
   // aligned rest and take element 0 along (2.1 -> 1.4 ms at n = 1e8, tools/bench_misaligned.py)
   auto off8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 8u; };

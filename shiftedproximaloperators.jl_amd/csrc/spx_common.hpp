@@ -53,6 +53,17 @@ int spx_ws_reserve(spx_ctx* ctx, size_t bytes);
 int spx_sync_reserve(spx_ctx* ctx, size_t bytes);  // persistent, zero-initialised (see spx_ctx::sync)
 int spx_ctx_count(int device);                     // live contexts on a device
 
+// Two launches that synchronise inside themselves must not run side by side on one device: each would hold CUs while it
+// waits for workgroups of its own that cannot be placed.  Contexts on different streams are therefore chained through one
+// event per device whenever more than one context exists on it (a stream-side dependency, the host never blocks).
+// Constructed before such a launch (or a sequence that contains one), destroyed after it.  spx_ctx.hip.
+struct SpxCoopLaunchGuard {
+  spx_ctx* ctx;
+  bool chained;
+  explicit SpxCoopLaunchGuard(spx_ctx* c);
+  ~SpxCoopLaunchGuard();
+};
+
 #define SPX_HIP(call)                                                                          \
   do {                                                                                         \
     hipError_t e_ = (call);                                                                    \
@@ -118,6 +129,13 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Head of spx_ctx::sync, shared by every kernel that synchronises inside one launch.
+struct SpxSyncHeader {
+  unsigned int bar[2][32];  // grid-barrier counters, one 128-byte line each: a launch uses [parity] and clears [parity ^ 1]
+  int b2_last_scaled;       // ShiftedNormL1B2: did the previous call on this context find the trust region active?
+  int pad[31];
+};
+
 // ---------------------------------------------------------------------------------------------
 // Grid barrier for kernels whose workgroups are all resident (grid <= number of CUs, one workgroup per CU): one
 // monotonic counter in spx_ctx::sync.  Recipe of MI355X_MICROARCH.md ("inter-workgroup visibility"): every storing wave
@@ -138,4 +156,26 @@ __device__ __forceinline__ void spx_grid_barrier(unsigned int* counter, unsigned
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
+}
+
+// The same rendezvous WITHOUT cache maintenance, for kernels whose workgroups exchange nothing but words written and read
+// with agent-scope atomics (spx_atomic_store_f64 / spx_atomic_load_f64 below: `sc1` accesses that bypass the non-coherent
+// caches).  The release / acquire fences are most of a barrier's cost when few workgroups meet (3.5 of ~4 us).
+// ONE lane per workgroup must have issued all of the workgroup's atomic stores before it calls this.
+__device__ __forceinline__ void spx_grid_rendezvous(unsigned int* counter, unsigned int target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's atomic stores have left
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void spx_atomic_store_f64(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double spx_atomic_load_f64(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
 }

@@ -2,9 +2,29 @@
 #include "spx_common.hpp"
 
 #include <atomic>
+#include <mutex>
 static thread_local char g_err[512] = "";
 static std::atomic<int> g_ctx_count[64];
 int spx_ctx_count(int device) { return g_ctx_count[device & 63].load(); }
+
+static std::mutex g_coop_mu;
+static hipEvent_t g_coop_ev[64] = {};
+static const spx_ctx* g_coop_last[64] = {};
+SpxCoopLaunchGuard::SpxCoopLaunchGuard(spx_ctx* c) : ctx(c), chained(false) {
+  g_coop_mu.lock();
+  const int d = ctx->device & 63;
+  chained = (g_coop_last[d] != nullptr && g_coop_last[d] != ctx);
+  if (chained && g_coop_ev[d] != nullptr) (void)hipStreamWaitEvent(ctx->stream, g_coop_ev[d], 0);
+}
+SpxCoopLaunchGuard::~SpxCoopLaunchGuard() {
+  const int d = ctx->device & 63;
+  if (chained || g_coop_last[d] == nullptr || spx_ctx_count(ctx->device) > 1) {
+    if (g_coop_ev[d] == nullptr) (void)hipEventCreateWithFlags(&g_coop_ev[d], hipEventDisableTiming);
+    if (g_coop_ev[d] != nullptr) (void)hipEventRecord(g_coop_ev[d], ctx->stream);
+  }
+  g_coop_last[d] = ctx;
+  g_coop_mu.unlock();
+}
 
 void spx_set_error(const char* fmt, ...) {
   va_list ap;
@@ -69,6 +89,10 @@ SPX_EXPORT int spx_ctx_destroy(spx_ctx* ctx) {
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   g_ctx_count[ctx->device & 63].fetch_sub(1);
+  {
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    if (g_coop_last[ctx->device & 63] == ctx) g_coop_last[ctx->device & 63] = nullptr;
+  }
   delete ctx;
   return SPX_OK;
 }

@@ -21,8 +21,6 @@
 // memory), so the usual cost is pass 0 (24 B read + 8 B write per element), 2-3 key passes (8 B) and the
 // final pass (24 B read + 8 B write).  y may alias q: pass 0 reads q[i] before it writes y[i] and q is
 // not needed afterwards.
-#include <mutex>
-
 #include "spx_common.hpp"
 
 namespace {
@@ -1060,7 +1058,7 @@ extern "C" __attribute__((visibility("default"))) int spx_debug_sel_stamps(unsig
 constexpr int kCoopMaxPass = 12;  // <= 6 key digits + <= 6 index digits
 constexpr int kCoopEpl = 8;       // REG: elements per lane at most (16 spill: 1024-lane workgroups leave 128 VGPRs per lane)
 struct SelSync {
-  unsigned int bar[2][32];  // grid-barrier counters, one 128-byte line each; a launch uses [parity] and clears [parity ^ 1]
+  SpxSyncHeader hdr;  // grid-barrier counters (a launch uses hdr.bar[parity] and clears hdr.bar[parity ^ 1])
   // One global histogram per pass.  k_sel_coop alternates between sets 0 and 1: a launch uses the clean one and clears
   // the other (dirty from the launch before it; the host keeps the flags, spx_ctx::sel_hist_*).  Set 2 belongs to the
   // fallback inside k_s2_tail, which clears it itself (one more barrier on a path that is rare and slow anyway).
@@ -1193,7 +1191,7 @@ __global__ __launch_bounds__(1024) void k_sel_coop(double* y, const double* q, c
                                                     int64_t r, double delta, SelSync* ss, int parity, int use_set,
                                                     int clear_set, int fallback) {
   __shared__ CoopShared sh;
-  if (blockIdx.x == 0 && threadIdx.x == 0) ss->bar[parity ^ 1][0] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ss->hdr.bar[parity ^ 1][0] = 0u;
   if (fallback) {  // last launch of a sample-predicted call: clean slates for the next call's k_s2_front
     const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
     unsigned long long* z1 = ss->fhist1;
@@ -1212,9 +1210,9 @@ __global__ __launch_bounds__(1024) void k_sel_coop(double* y, const double* q, c
   if (fallback) {
     unsigned long long* z = &ss->chist[use_set][0][0];
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total; b += (int64_t)gridDim.x * blockDim.x) z[b] = 0ull;
-    spx_grid_barrier(ss->bar[parity], (++nbar) * gridDim.x);
+    spx_grid_barrier(ss->hdr.bar[parity], (++nbar) * gridDim.x);
   }
-  coop_select<BINF, REG>(y, q, xk, sj, n, r, delta, ss->chist[use_set], ss->bar[parity], nbar, sh);
+  coop_select<BINF, REG>(y, q, xk, sj, n, r, delta, ss->chist[use_set], ss->hdr.bar[parity], nbar, sh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1235,10 +1233,10 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
   __shared__ int active[2];
   __shared__ unsigned int bucket[2];
   const int t = threadIdx.x, c = blockIdx.x;
-  unsigned int* bar = ss->bar[parity];
+  unsigned int* bar = ss->hdr.bar[parity];
   unsigned int nbar = 0;
   SelWs* ws = &ss->ws;
-  if (c == 0 && t == 0) ss->bar[parity ^ 1][0] = 0u;
+  if (c == 0 && t == 0) ss->hdr.bar[parity ^ 1][0] = 0u;
   SEL_STAMP(0);
   for (int b = t; b < kBins; b += 1024) lh[b] = 0u;
   // clean slates for the main pass (it runs in a later launch)
@@ -1394,35 +1392,6 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
 #define SPX_SEL_REG_MAX_LOG2 20  // largest n (log2) on the register-resident one-launch select; above it the sample-predicted pipeline is faster (n = 2e6: 72 vs ~58 us; n = 1e6: 48 us)
 #endif
 
-// Two launches that synchronise inside themselves must not run side by side on one device: each would hold CUs while it
-// waits for workgroups of its own that cannot be placed.  Contexts on different streams are therefore chained through one
-// event per device whenever more than one context exists on it (a stream-side dependency, the host never blocks).
-namespace {
-std::mutex g_coop_mu;
-hipEvent_t g_coop_ev[64] = {};
-const spx_ctx* g_coop_last[64] = {};
-}  // namespace
-struct CoopLaunchGuard {
-  spx_ctx* ctx;
-  bool chained;
-  explicit CoopLaunchGuard(spx_ctx* c) : ctx(c), chained(false) {
-    g_coop_mu.lock();
-    const int d = ctx->device & 63;
-    if (g_coop_last[d] != nullptr && g_coop_last[d] != ctx && g_coop_ev[d] != nullptr)
-      (void)hipStreamWaitEvent(ctx->stream, g_coop_ev[d], 0);
-    chained = (g_coop_last[d] != nullptr && g_coop_last[d] != ctx);
-  }
-  ~CoopLaunchGuard() {
-    const int d = ctx->device & 63;
-    if (chained || g_coop_last[d] == nullptr || spx_ctx_count(ctx->device) > 1) {
-      if (g_coop_ev[d] == nullptr) (void)hipEventCreateWithFlags(&g_coop_ev[d], hipEventDisableTiming);
-      if (g_coop_ev[d] != nullptr) (void)hipEventRecord(g_coop_ev[d], ctx->stream);
-    }
-    g_coop_last[d] = ctx;
-    g_coop_mu.unlock();
-  }
-};
-
 template <bool BINF>
 int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n, int64_t r,
                double delta) {
@@ -1461,7 +1430,7 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     const int clear_set = ctx->sel_hist_dirty[other] ? other : -1;
     const int parity = ctx->coop_parity;
     {
-      CoopLaunchGuard guard(ctx);
+      SpxCoopLaunchGuard guard(ctx);
       if (reg)
         hipLaunchKernelGGL((k_sel_coop<BINF, true>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r,
                            delta, ss, parity, use_set, clear_set, 0);
@@ -1507,7 +1476,7 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
       // select; returns at once when the verdict is positive).  Nothing is read back.
       SelWs* sws = &ss->ws;
       {
-        CoopLaunchGuard guard(ctx);
+        SpxCoopLaunchGuard guard(ctx);
         hipLaunchKernelGGL(k_s2_front, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
                            n - ioff, r, ss, ctx->coop_parity);
         ctx->coop_parity ^= 1;
