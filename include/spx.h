@@ -64,6 +64,14 @@ int spx_ctx_create(int device, spx_ctx** out);
 int spx_ctx_create_on_stream(int device, void* stream, spx_ctx** out);
 int spx_ctx_destroy(spx_ctx* ctx);
 int spx_sync(spx_ctx* ctx);
+/* Device-resident values.  By default the value-returning entry points (spx_obj_*, spx_proxval_*) copy their double to
+ * the host and synchronise the stream.  With a non-NULL device_value they store it in that DEVICE double instead (one
+ * 8-byte store by the last kernel of the call) and return after enqueueing: the host `*value` is then set to NaN and
+ * nothing is read back -- a solver's accept / reject test can consume the value on the device, or copy it later.
+ * NULL restores the default.  (An out-of-range gather index cannot be reported from an asynchronous call: the device
+ * value is NaN then.)  Mirrors no reference function: psi(y) in the reference returns a host Float64
+ * (src/ShiftedProximalOperators.jl:51-54); this is the asynchronous form of the same value. */
+int spx_ctx_set_value_target(spx_ctx* ctx, double* device_value);
 /* HIP-event stopwatch on the context's stream (used by bench.py for per-launch durations). */
 int spx_timer_start(spx_ctx* ctx);
 int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms); /* records stop, waits, returns milliseconds */

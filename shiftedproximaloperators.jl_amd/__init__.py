@@ -8,7 +8,7 @@ from .functions import (GroupNormL2, IndBallL0, NormL0, NormL1, NormL2, NormLinf
 from .sharding import shard_range
 from .shifted import (ShiftedGroupNormL2, ShiftedGroupNormL2Binf, ShiftedIndBallL0, ShiftedIndBallL0BInf,
                       ShiftedNormL0, ShiftedNormL0Box, ShiftedNormL1, ShiftedNormL1B2, ShiftedNormL1Box,
-                      ShiftedProximableFunction, ShiftedRootNormLhalf, ShiftedRootNormLhalfBox, context, iprox,
+                      ShiftedProximableFunction, ShiftedRootNormLhalf, ShiftedRootNormLhalfBox, context, device_values, iprox,
                       iprox_bang, prox,
                       prox_bang, prox_value, prox_value_bang, set_bounds_bang, set_radius_bang, shift_bang, shifted, synchronize, value)
 

@@ -20,6 +20,7 @@ SIGNATURES = {
     "spx_timer_start": [_p],
     "spx_timer_stop": [_p, ctypes.POINTER(ctypes.c_float)],
     "spx_ctx_set_tuning": [_p, _int, _int],
+    "spx_ctx_set_value_target": [_p, _p],
     "spx_check_bounds": [_p, _p, _p, _d, _d, _i64, ctypes.POINTER(_int)],
     "spx_build_mask": [_p, _p, _i64, _p, _i64],
     "spx_prox_l1": [_p, _p, _p, _p, _p, _i64, _d, _d],

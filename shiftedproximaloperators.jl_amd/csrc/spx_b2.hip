@@ -443,6 +443,15 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
   }
 }
 
+// psi(y) from the reduced sums, on the device (spx_ctx_set_value_target)
+__global__ void k_b2_obj_value(const B2Ws* ws, double lambda, double delta, double* target) {
+  const double nrm = sqrt(ws->C);
+  const double eps = 2.220446049250313e-16;
+  const double tol = fmax(eps, sqrt(eps) * fmax(nrm, fabs(delta)));
+  const bool inside = (nrm <= delta) || (fabs(nrm - delta) <= tol);
+  *target = inside ? lambda * ws->P : __longlong_as_double(0x7ff0000000000000ll);
+}
+
 }  // namespace
 
 // ShiftedNormL1B2 as a function (src/shiftedNormL1B2.jl:32).  IndBallL2(Delta)(v) [ext: ProximalOperators.jl] is 0 iff
@@ -467,11 +476,20 @@ SPX_EXPORT int spx_obj_l1_b2(spx_ctx* ctx, const double* y, const double* xk, co
     else hipLaunchKernelGGL((k_b2_obj<false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, ws);
     hipLaunchKernelGGL(k_b2_reduce, dim3(1), dim3(256), 0, ctx->stream, ws, (int)blocks, 0);
     SPX_LAUNCH_CHECK();
+    if (ctx->value_target) {  // device-resident value: psi(y) from (P, C) on the device, nothing read back
+      hipLaunchKernelGGL(k_b2_obj_value, dim3(1), dim3(1), 0, ctx->stream, (const B2Ws*)ws, lambda, delta, ctx->value_target);
+      SPX_LAUNCH_CHECK();
+      *value = std::nan("");
+      return SPX_OK;
+    }
     double pc[2];
     SPX_HIP(hipMemcpyAsync(pc, &ws->P, sizeof(pc), hipMemcpyDeviceToHost, ctx->stream));
     SPX_HIP(hipStreamSynchronize(ctx->stream));
     P = pc[0];
     C = pc[1];
+  } else if (ctx->value_target) {
+    SPX_HIP(hipMemsetAsync(ctx->value_target, 0, sizeof(double), ctx->stream));
+    return SPX_OK;
   }
   const double nrm = std::sqrt(C);
   const double eps = 2.220446049250313e-16;

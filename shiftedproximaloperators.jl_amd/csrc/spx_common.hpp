@@ -37,6 +37,9 @@ struct spx_ctx {
   int coop_parity = 0;
   int sel_hist_next = 0;            // spx_select.hip: histogram set (0/1) the next k_sel_coop launch uses ...
   int sel_hist_dirty[2] = {0, 0};   // ... and which sets a previous launch left non-zero
+  // spx_ctx_set_value_target: when non-NULL, the value-returning entry points (spx_obj_*, spx_proxval_*) store their
+  // result in this DEVICE double and return after enqueueing, without the read-back / stream synchronisation
+  double* value_target = nullptr;
   // tuning knobs (spx_ctx_set_tuning): per context, so that two contexts / threads never see each other's experiments
   int tune_sep_blocks_per_cu = 0;  // key 0: 0 = no cap (one tile per workgroup)
   int tune_sep_nt = 1;             // key 1: non-temporal loads / stores

@@ -116,6 +116,12 @@ SPX_EXPORT int spx_ctx_set_tuning(spx_ctx* ctx, int key, int value) {
   return SPX_ERR_INVALID_ARG;
 }
 
+SPX_EXPORT int spx_ctx_set_value_target(spx_ctx* ctx, double* device_value) {
+  SPX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  ctx->value_target = device_value;
+  return SPX_OK;
+}
+
 SPX_EXPORT int spx_sync(spx_ctx* ctx) {
   SPX_REQUIRE(ctx != nullptr, "ctx is NULL");
   SPX_HIP(hipStreamSynchronize(ctx->stream));

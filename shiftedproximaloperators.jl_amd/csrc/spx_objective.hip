@@ -8,8 +8,10 @@
 // Per-lane partial sums -> wavefront butterfly -> workgroup (LDS) -> one partial per workgroup in the context
 // scratch -> a single workgroup adds the partials in index order: the value is reproducible run to run.  The
 // summation order differs from the reference's left-to-right loop, hence a 1e-12 relative tolerance in tests;
-// counts (NormL0, IndBallL0) and the +Inf decisions are exact.  The value is returned to the host: these entry
-// points synchronise the stream.
+// counts (NormL0, IndBallL0) and the +Inf decisions are exact.  The last kernel turns sum and flags into psi(y) on the
+// device.  By default the value is then returned to the host (these entry points synchronise the stream); with
+// spx_ctx_set_value_target(ctx, device_double) it is stored in the caller's device double instead and the call returns
+// after enqueueing -- a solver's accept / reject test can consume it on the device, or read it back when it needs it.
 #include <cmath>
 #include <limits>
 
@@ -178,35 +180,63 @@ __global__ __launch_bounds__(256) void k_obj_linf_scan(const double* __restrict_
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&ws->infeasible, 1);
 }
 
-// one workgroup: partials in index order (pairwise inside the wave, fixed shape) -> ws->result
-__global__ __launch_bounds__(256) void k_obj_final(ObjWs* ws, int nblocks) {
+// How the reduced sum and the infeasibility flags turn into psi(y):
+enum ObjRule {
+  kRuleScaled = 0,   // lambda * sum                                        (generic forms)
+  kRuleBox = 1,      // flag ? +Inf : lambda * sum                           (Box forms: feasibility scan)
+  kRuleCount = 2,    // (flag || sum > limit) ? +Inf : 0                     (IndBallL0, IndBallL0BInf)
+  kRuleGroup = 3,    // bad index ? NaN : flag ? +Inf : sum                  (GroupNormL2(Binf))
+};
+// one workgroup: partials in index order (pairwise inside the wave, fixed shape) -> ws->result = psi(y) by `rule`;
+// target != NULL: the value also goes to the caller's device double (spx_ctx_set_value_target)
+__global__ __launch_bounds__(256) void k_obj_final(ObjWs* ws, int nblocks, int rule, double scale, double limit, double* target) {
   __shared__ double lds4[4];
   double acc = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 256) acc += ws->partial[b];
   acc = block_sum(acc, lds4);
-  if (threadIdx.x == 0) ws->result = acc;
+  if (threadIdx.x == 0) {
+    const int flag = ws->infeasible;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double v;
+    if (rule == kRuleScaled) v = scale * acc;
+    else if (rule == kRuleBox) v = flag ? inf : scale * acc;
+    else if (rule == kRuleCount) v = (flag || acc > limit) ? inf : 0.0;
+    else v = (flag & 2) ? __longlong_as_double(0x7ff8000000000000ll) : (flag ? inf : acc);
+    ws->result = v;
+    if (target) *target = v;
+  }
 }
 
-int obj_finish(spx_ctx* ctx, ObjWs* ws, int blocks, double* sum, int* infeasible) {
-  hipLaunchKernelGGL(k_obj_final, dim3(1), dim3(256), 0, ctx->stream, ws, blocks);
+// *value = psi(y) (read back, stream synchronised) -- or, with a device value target on the context, NaN on the host and
+// the value in the target, nothing read back.  *flags = the infeasibility bits (0 in the device-target case).
+int obj_finish(spx_ctx* ctx, ObjWs* ws, int blocks, int rule, double scale, double limit, double* value, int* flags) {
+  hipLaunchKernelGGL(k_obj_final, dim3(1), dim3(256), 0, ctx->stream, ws, blocks, rule, scale, limit, ctx->value_target);
   SPX_LAUNCH_CHECK();
+  *flags = 0;
+  if (ctx->value_target) {
+    *value = std::numeric_limits<double>::quiet_NaN();
+    return SPX_OK;
+  }
   struct { double r; int f; int p; } host;
   SPX_HIP(hipMemcpyAsync(&host, &ws->result, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
   SPX_HIP(hipStreamSynchronize(ctx->stream));
-  *sum = host.r;
-  *infeasible = host.f;
+  *value = host.r;
+  *flags = host.f;
   return SPX_OK;
 }
 
 template <class Term, int MODE>
 int run_obj(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, const double* lv,
-            const double* uv, double ls, double us, const uint8_t* mask, double rad, double* sum, int* infeasible) {
+            const double* uv, double ls, double us, const uint8_t* mask, double rad, int rule, double scale, double limit,
+            double* value) {
   SPX_REQUIRE(ctx != nullptr, "ctx is NULL");
   SPX_REQUIRE(n >= 0, "n < 0");
   SPX_REQUIRE(n == 0 || (y && xk && sj), "NULL vector with n > 0");
-  *sum = 0.0;
-  *infeasible = 0;
-  if (n == 0) return SPX_OK;
+  *value = 0.0;  // h of the empty vector (count rule: 0 <= limit)
+  if (n == 0) {
+    if (ctx->value_target) SPX_HIP(hipMemsetAsync(ctx->value_target, 0, sizeof(double), ctx->stream));
+    return SPX_OK;
+  }
   int rc = spx_ws_reserve(ctx, sizeof(ObjWs) + 256);
   if (rc) return rc;
   SPX_HIP(hipSetDevice(ctx->device));
@@ -217,7 +247,8 @@ int run_obj(spx_ctx* ctx, const double* y, const double* xk, const double* sj, i
   hipLaunchKernelGGL((k_obj<Term, MODE>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, lv, uv, mask, ls,
                      us, rad, n, Term{}, ws);
   SPX_LAUNCH_CHECK();
-  return obj_finish(ctx, ws, (int)blocks, sum, infeasible);
+  int flags;
+  return obj_finish(ctx, ws, (int)blocks, rule, scale, limit, value, &flags);
 }
 
 template <int MODE>
@@ -249,15 +280,13 @@ int run_obj_group(spx_ctx* ctx, const double* y, const double* xk, const double*
     hipLaunchKernelGGL(k_obj_linf_scan, dim3((unsigned)sb), dim3(256), 0, ctx->stream, y, sj, n, rad, ws);
   }
   SPX_LAUNCH_CHECK();
-  double sum;
   int bad;
-  rc = obj_finish(ctx, ws, (int)blocks, &sum, &bad);
+  rc = obj_finish(ctx, ws, (int)blocks, kRuleGroup, 1.0, 0.0, value, &bad);
   if (rc) return rc;
-  if (bad & 2) {
+  if (bad & 2) {  // (with a device value target the value is NaN instead: nothing is read back)
     spx_set_error("invalid argument: group index outside [0, n) (BoundsError)");
     return SPX_ERR_INVALID_ARG;
   }
-  *value = bad ? std::numeric_limits<double>::infinity() : sum;
   return SPX_OK;
 }
 
@@ -270,12 +299,7 @@ const double kInf = std::numeric_limits<double>::infinity();
   SPX_EXPORT int NAME(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double lambda, \
                       double* value) {                                                                             \
     SPX_REQUIRE(value != nullptr, "value is NULL");                                                                \
-    double sum;                                                                                                    \
-    int bad;                                                                                                       \
-    int rc = run_obj<TERM, 0>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 0.0, &sum, &bad);             \
-    if (rc) return rc;                                                                                             \
-    *value = lambda * sum;                                                                                         \
-    return SPX_OK;                                                                                                 \
+    return run_obj<TERM, 0>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 0.0, kRuleScaled, lambda, 0.0, value); \
   }
 SPX_OBJ_PLAIN(spx_obj_l1, TermL1)
 SPX_OBJ_PLAIN(spx_obj_l0, TermL0)
@@ -287,12 +311,8 @@ SPX_OBJ_PLAIN(spx_obj_lhalf, TermLhalf)
                       const double* l_vec, const double* u_vec, double l_scalar, double u_scalar,                  \
                       const uint8_t* sel_mask, double* value) {                                                    \
     SPX_REQUIRE(value != nullptr, "value is NULL");                                                                \
-    double sum;                                                                                                    \
-    int bad;                                                                                                       \
-    int rc = run_obj<TERM, 1>(ctx, y, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask, 0.0, &sum, &bad);     \
-    if (rc) return rc;                                                                                             \
-    *value = bad ? kInf : lambda * sum;                                                                            \
-    return SPX_OK;                                                                                                 \
+    return run_obj<TERM, 1>(ctx, y, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask, 0.0, kRuleBox, lambda, 0.0,    \
+                            value);                                                                                \
   }
 SPX_OBJ_BOX(spx_obj_l1_box, TermL1)
 SPX_OBJ_BOX(spx_obj_l0_box, TermL0)
@@ -302,22 +322,13 @@ SPX_OBJ_BOX(spx_obj_lhalf_box, TermLhalf)
 SPX_EXPORT int spx_obj_indball_l0(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
                                   int64_t r, double* value) {
   SPX_REQUIRE(value != nullptr, "value is NULL");
-  double cnt;
-  int bad;
-  int rc = run_obj<TermL0, 0>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 0.0, &cnt, &bad);
-  if (rc) return rc;
-  *value = (cnt > (double)r) ? kInf : 0.0;
-  return SPX_OK;
+  return run_obj<TermL0, 0>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 0.0, kRuleCount, 1.0, (double)r, value);
 }
 SPX_EXPORT int spx_obj_indball_l0_binf(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
                                        int64_t r, double delta, double* value) {
   SPX_REQUIRE(value != nullptr, "value is NULL");
-  double cnt;
-  int bad;
-  int rc = run_obj<TermL0, 2>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 1.1 * delta, &cnt, &bad);
-  if (rc) return rc;
-  *value = (bad || cnt > (double)r) ? kInf : 0.0;
-  return SPX_OK;
+  return run_obj<TermL0, 2>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 1.1 * delta, kRuleCount, 1.0, (double)r,
+                            value);
 }
 
 // ---- GroupNormL2 ---------------------------------------------------------------------------------------

@@ -12,6 +12,8 @@
 // lane and no other lane touches index i, so y may alias q.
 #include <cmath>
 
+#include <limits>
+
 #include "spx_common.hpp"
 
 // ---------------------------------------------------------------------------------------------
@@ -412,7 +414,9 @@ __device__ __forceinline__ double block_sum4(double v, double* lds4) {  // 256-l
   return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 // partials[0..count) -> *out, fixed order: reproducible run to run
-__global__ __launch_bounds__(1024) void k_value_reduce(const double* partials, int64_t count, double* out) {
+// target != NULL: also *target = scale * sum (the caller's device double, spx_ctx_set_value_target)
+__global__ __launch_bounds__(1024) void k_value_reduce(const double* partials, int64_t count, double* out, double scale,
+                                                        double* target) {
   __shared__ double lds[16];
   double acc = 0.0;
   for (int64_t i = threadIdx.x; i < count; i += 1024) acc += partials[i];
@@ -423,6 +427,7 @@ __global__ __launch_bounds__(1024) void k_value_reduce(const double* partials, i
     double t = 0.0;
     for (int w = 0; w < 16; ++w) t += lds[w];
     *out = t;
+    if (target) *target = scale * t;
   }
 }
 
@@ -687,7 +692,8 @@ static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d,
 template <class Op>
 static int run_separable(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj, int64_t n,
                          const double* l, const double* u, double ls, double us, const uint8_t* mask, Op op,
-                         const double* d = nullptr, double* value = nullptr /* Op::kObj: sum of the h terms */) {
+                         const double* d = nullptr, double* value = nullptr /* Op::kObj: sum of the h terms */,
+                         double value_scale = 1.0 /* device-resident value = value_scale * sum */) {
   if constexpr (Op::kObj) *value = 0.0;
   if (n == 0) return SPX_OK;
   SPX_HIP(hipSetDevice(ctx->device));
@@ -754,8 +760,13 @@ static int run_separable(spx_ctx* ctx, double* y, const double* q, const double*
   }
   if constexpr (Op::kObj) {
     double* result = reinterpret_cast<double*>(ctx->ws);
-    hipLaunchKernelGGL(k_value_reduce, dim3(1), dim3(1024), 0, ctx->stream, (const double*)partials, used, result);
+    hipLaunchKernelGGL(k_value_reduce, dim3(1), dim3(1024), 0, ctx->stream, (const double*)partials, used, result,
+                       value_scale, ctx->value_target);
     SPX_LAUNCH_CHECK();
+    if (ctx->value_target) {  // device-resident value: nothing is read back, the call returns after enqueueing
+      *value = std::numeric_limits<double>::quiet_NaN();
+      return SPX_OK;
+    }
     SPX_HIP(hipMemcpyAsync(value, result, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SPX_HIP(hipStreamSynchronize(ctx->stream));
   }
@@ -827,8 +838,8 @@ static int run_proxval(spx_ctx* ctx, double* y, const double* q, const double* x
   SPX_REQUIRE(value != nullptr, "value is NULL");
   WithValue<Base, Term> op{base, nullptr, q_scale};
   double sum = 0.0;
-  rc = run_separable(ctx, y, q, xk, sj, n, l, u, ls, us, mask, op, nullptr, &sum);
-  *value = lambda * sum;
+  rc = run_separable(ctx, y, q, xk, sj, n, l, u, ls, us, mask, op, nullptr, &sum, lambda);
+  *value = lambda * sum;  // (NaN when the value went to the context's device target)
   return rc;
 }
 

@@ -733,6 +733,28 @@ def context(device="cuda"):
     return _ctx(d)
 
 
+class device_values:
+    """`with device_values(out):` -- inside the block psi(y), prox_value(...) and prox_value_bang(...) on `out`'s device store
+    their value in out[0] (a 1-element float64 device tensor) and return NaN: nothing is read back and the stream is not
+    synchronised (spx_ctx_set_value_target).  The accept / reject logic of a solver can then run on the device, or fetch
+    out.item() when it needs the number."""
+
+    def __init__(self, out):
+        if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float64 and out.numel() >= 1):
+            raise TypeError("device_values needs a float64 device tensor with at least one element")
+        self.out = out
+        self.ctx = None
+
+    def __enter__(self):
+        self.ctx = _ctx(self.out.device)
+        _lib.check(_lib.load().spx_ctx_set_value_target(self.ctx, ctypes.c_void_p(self.out.data_ptr())))
+        return self.out
+
+    def __exit__(self, *exc):
+        _lib.check(_lib.load().spx_ctx_set_value_target(self.ctx, None))
+        return False
+
+
 def synchronize(device=None):
     """Wait for the libspx contexts' work (same as torch.cuda.synchronize for borrowed streams)."""
     L = _lib.load()

@@ -1291,3 +1291,40 @@ def test_group_binf_many_small_groups(s, orc, gs):
         #  ~5e-9 off its own formula in 1-2 % of the groups; the closed form of the kernel is within 1e-15 there: measured
         #  "GPU closer to binary128 than the literal oracle in 1629 of 1629")
         assert v.n_checked <= ng // 20 and v.gpu_closer >= v.n_checked - 5, v
+
+
+# ------------------------------------------------------------------ device-resident values (round 2)
+def test_values_into_a_device_double(s, orc):
+    """spx_ctx_set_value_target: psi(y) and the value of prox_value land in the caller's device double, the call returns
+    NaN on the host and reads nothing back; the number is bit-identical to the synchronous one, for every operator family
+    (separable, Box incl. the +Inf of an infeasible point, IndBallL0(BInf), groups, NormL1B2)."""
+    import torch
+    n = 50_000
+    x, sj, q = _data(n, 31)
+    xd, sd, qd = _dev(x, sj, q)
+    yd = _dev(np.random.default_rng(2).uniform(-0.3, 0.3, size=n))[0]
+    lam_g = np.random.default_rng(3).uniform(0.5, 1.5, size=n // 50)
+    chi = s.NormLinf(1.0)
+    psis = [s.shifted(s.shifted(s.NormL1(0.7), xd), sd), s.shifted(s.shifted(s.NormL0(0.7), xd), sd),
+            s.shifted(s.shifted(s.RootNormLhalf(0.7), xd), sd), s.shifted(s.shifted(s.NormL1(0.7), xd, 0.9, chi), sd),
+            s.shifted(s.shifted(s.NormL0(0.7), xd, 0.9, chi), sd), s.shifted(s.shifted(s.RootNormLhalf(0.7), xd, 0.9, chi), sd),
+            s.shifted(s.shifted(s.IndBallL0(n // 3), xd), sd), s.shifted(s.shifted(s.IndBallL0(n // 3), xd, 0.9, chi), sd),
+            s.shifted(s.shifted(s.GroupNormL2.uniform(lam_g.tolist(), 50), xd), sd),
+            s.shifted(s.shifted(s.GroupNormL2.uniform(lam_g.tolist(), 50), xd, 0.9, chi), sd),
+            s.shifted(s.shifted(s.NormL1(0.7), xd, 50.0, s.NormL2(1.0)), sd)]
+    out = torch.full((1,), -1.0, dtype=torch.float64, device="cuda:0")
+    for psi in psis:
+        for yy in (yd, yd * 10.0):                     # the second one is outside every box / ball: +Inf
+            want = psi(yy)
+            with s.device_values(out):
+                got_host = psi(yy)
+            assert got_host != got_host                # NaN: the host value is not produced
+            got = float(out.item())
+            assert got == want or (np.isinf(got) and np.isinf(want)), (type(psi).__name__, got, want)
+        assert psi(yd) == psi(yd)                      # back to the synchronous form
+    for psi in psis[:6]:                               # prox fused with the value
+        y1, v1 = s.prox_value(psi, qd, 1.1)
+        y1 = y1.clone()
+        with s.device_values(out):
+            y2, v2 = s.prox_value(psi, qd, 1.1)
+        assert torch.equal(y1, y2) and v2 != v2 and float(out.item()) == v1, type(psi).__name__
