@@ -45,6 +45,17 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary operators")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one per GPU, RCCL) as a child
+        # process -- before anything here touches the GPU -- and leave with its exit code
+        import subprocess
+        port = os.environ.get("MASTER_PORT", "29517")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
+
     import torch
     import torch.distributed as dist
 
@@ -130,7 +141,9 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
+        "data": "synthetic (torch Philox on the device, seed 20250613 + rank: xk ~ N(0,1), sj ~ U(-1/2,1/2), q ~ N(0,1); the CPU "
+                "oracle is given copies of the device arrays -- SURVEY 8d's shared counter-based host/device generator is "
+                "not implemented)",
         "config": {"workload": "ShiftedNormL1Box prox!, n=%d fp64 per GPU, Delta=1.0 scalar bounds, all selected, "
                                "twice shifted, lambda=sigma=1 (BASELINE configs[1])" % n,
                    "elements_per_gpu": n, "parallelism": "replicas (independent shards, no collective)"},
@@ -138,7 +151,7 @@ def main():
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "avg_launch_ms": round(launch_ms, 5), "algorithmic_bytes_per_launch": BYTES_PER_ELEM * n,
-                     "traffic": _pmc_traffic(n)},
+                     **_pmc_traffic(n)},
     }
 
     if rank == 0 and not args.no_extra:
@@ -155,16 +168,22 @@ def main():
 
 
 def _pmc_traffic(n):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic_l1box.json, taken with
-    tools/profile.sh on this very command at the default size), or None for another size."""
+    """HBM bytes per launch of the headline kernel.  NOT measured by this run: replayed from the committed rocprofv3 --pmc
+    passes of this very command at the default size (tools/profile.sh -> profiles/traffic_l1box.json; FETCH_SIZE and
+    WRITE_SIZE in separate passes, corrections as MI355X_MICROARCH.md prescribes); null for any other size."""
     p = os.path.join(ROOT, "profiles", "traffic_l1box.json")
+    out = {"traffic": None, "traffic_source": None}
     if os.path.exists(p):
         try:
             d = json.load(open(p))
-            return d.get("hbm_bytes_per_launch") if d.get("n") == n else None
+            if d.get("n") == n:
+                out["traffic"] = d.get("hbm_bytes_per_launch")
+                out["traffic_source"] = {"from_committed_profile": True, "file": "profiles/traffic_l1box.json",
+                                         "collected": d.get("collected", time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(p)))),
+                                         "how": d.get("how", "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/profile.sh)")}
         except Exception:
-            return None
-    return None
+            pass
+    return out
 
 
 def _time_op(s, L, ctx, fn, iters=10, rounds=5):
@@ -193,27 +212,31 @@ def _extra(s, L, ctx, dev, n, torch):
     y = torch.empty_like(q)
     chi = s.NormLinf(1.0)
 
-    def line(name, psi, bytes_per_elem, nel, yy, qq):
+    def line(name, psi, bytes_per_elem, nel, yy, qq, kernel):
+        # ms = avg_launch_ms: HIP events around 10 back-to-back calls on the launching stream / 10, median of 5 rounds.
+        # kernel = the dominant kernel of the call as rocprofv3 --kernel-trace names it (profiles/r02_all_ops_kernel_stats.txt)
         ms = _time_op(s, L, ctx, lambda: s.prox_bang(yy, psi, qq, 1.0))
-        res[name] = {"ms": round(ms, 4), "gelem_s": round(nel / ms / 1e6, 2),
+        res[name] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4), "kernel": kernel, "gelem_s": round(nel / ms / 1e6, 2),
                      "gbs_algorithmic": round(bytes_per_elem * nel / ms / 1e6, 1),
                      "frac_of_peak": round(bytes_per_elem * nel / ms / 1e6 / HBM_PEAK_GBS, 4)}
 
-    line("ShiftedNormL1", s.shifted(s.shifted(s.NormL1(1.0), xk), sj), 32, n, y, q)
-    line("ShiftedNormL0", s.shifted(s.shifted(s.NormL0(1.0), xk), sj), 32, n, y, q)
-    line("ShiftedNormL0Box", s.shifted(s.shifted(s.NormL0(1.0), xk, 1.0, chi), sj), 32, n, y, q)
-    line("ShiftedRootNormLhalf", s.shifted(s.shifted(s.RootNormLhalf(1.0), xk), sj), 32, n, y, q)
-    line("ShiftedRootNormLhalfBox", s.shifted(s.shifted(s.RootNormLhalf(1.0), xk, 1.0, chi), sj), 32, n, y, q)
+    line("ShiftedNormL1", s.shifted(s.shifted(s.NormL1(1.0), xk), sj), 32, n, y, q, "k_sep_lds<OpL1,6,false,false>")
+    line("ShiftedNormL0", s.shifted(s.shifted(s.NormL0(1.0), xk), sj), 32, n, y, q, "k_sep_lds<OpL0,6,false,false>")
+    line("ShiftedNormL0Box", s.shifted(s.shifted(s.NormL0(1.0), xk, 1.0, chi), sj), 32, n, y, q, "k_sep_lds<OpL0Box,6,false,false>")
+    line("ShiftedRootNormLhalf", s.shifted(s.shifted(s.RootNormLhalf(1.0), xk), sj), 32, n, y, q, "k_sep_lds<OpLhalf,6,false,false>")
+    line("ShiftedRootNormLhalfBox", s.shifted(s.shifted(s.RootNormLhalf(1.0), xk, 1.0, chi), sj), 32, n, y, q, "k_sep_vec<OpLhalfBox,4,false,false,true>")
     lv = -1.0 - 0.1 * torch.rand(n, dtype=torch.float64, device=dev, generator=gen)
     uv = 1.0 + 0.1 * torch.rand(n, dtype=torch.float64, device=dev, generator=gen)
-    line("ShiftedNormL1Box_vector_bounds", s.shifted(s.shifted(s.NormL1(1.0), xk, lv, uv), sj), 48, n, y, q)
+    line("ShiftedNormL1Box_vector_bounds", s.shifted(s.shifted(s.NormL1(1.0), xk, lv, uv), sj), 48, n, y, q, "k_sep_lds<OpL1Box,3,true,false>")
     del lv, uv
     # iprox!: g, d, xk, sj -> y, 40 B/element
     d = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) + 0.5
 
     def iline(name, psi):
         ms = _time_op(s, L, ctx, lambda: s.iprox_bang(y, psi, q, d, check=False))
-        res[name] = {"ms": round(ms, 4), "gelem_s": round(n / ms / 1e6, 2), "gbs_algorithmic": round(40 * n / ms / 1e6, 1),
+        res[name] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4),
+                     "kernel": "k_sep_lds<OpIproxL0Box,4,false,false>" if "L0" in name else "k_sep_vec<OpIproxL1Box,4,false,false,true>",
+                     "gelem_s": round(n / ms / 1e6, 2), "gbs_algorithmic": round(40 * n / ms / 1e6, 1),
                      "frac_of_peak": round(40 * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
 
     # psi(y): reduction over y, xk, sj: 24 B/element, returns a host double (synchronous)
@@ -226,7 +249,17 @@ def _extra(s, L, ctx, dev, n, torch):
     res["objective_ShiftedNormL1Box"] = {"ms": round(ms, 4), "gelem_s": round(n / ms / 1e6, 2),
                                          "gbs_algorithmic": round(24 * n / ms / 1e6, 1),
                                          "frac_of_peak": round(24 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                         "kernel": "k_obj<TermL1,1> (+ k_obj_final)",
                                          "note": "host wall time per call incl. the read-back of the value"}
+    # the same value left on the device (spx_ctx_set_value_target): no read-back, HIP-event time of back-to-back calls
+    vout = torch.zeros(1, dtype=torch.float64, device=dev)
+    with s.device_values(vout):
+        ms = _time_op(s, L, ctx, lambda: psi_l1b(y))
+    res["objective_ShiftedNormL1Box_device_value"] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4),
+                                                      "kernel": "k_obj<TermL1,1> (+ k_obj_final)", "gelem_s": round(n / ms / 1e6, 2),
+                                                      "gbs_algorithmic": round(24 * n / ms / 1e6, 1),
+                                                      "frac_of_peak": round(24 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                                      "note": "value stored in a device double, nothing read back"}
     # prox! fused with h at the result (one pass instead of prox! + psi(y)); host wall time, the value is read back
     s.prox_value_bang(y, psi_l1b, q, 1.0)
     t0 = time.perf_counter()
@@ -236,23 +269,28 @@ def _extra(s, L, ctx, dev, n, torch):
     res["prox_value_ShiftedNormL1Box"] = {"ms": round(ms, 4), "gelem_s": round(n / ms / 1e6, 2),
                                           "gbs_algorithmic": round(32 * n / ms / 1e6, 1),
                                           "frac_of_peak": round(32 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                          "kernel": "k_sep_lds<WithValue<OpL1Box,TermL1>,6,false,false> (+ k_value_reduce)",
                                           "note": "prox! and h(xk + sj + y) in one pass (separately: the two lines above); "
                                                   "host wall time incl. the read-back of the value"}
+    with s.device_values(vout):
+        ms = _time_op(s, L, ctx, lambda: s.prox_value_bang(y, psi_l1b, q, 1.0))
+    res["prox_value_ShiftedNormL1Box_device_value"] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4),
+                                                       "kernel": "k_sep_lds<WithValue<OpL1Box,TermL1>,6,false,false> (+ k_value_reduce)",
+                                                       "gelem_s": round(n / ms / 1e6, 2), "gbs_algorithmic": round(32 * n / ms / 1e6, 1),
+                                                       "frac_of_peak": round(32 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                                       "note": "value stored in a device double, nothing read back"}
     iline("iprox_ShiftedNormL1Box", s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj))
     iline("iprox_ShiftedNormL0Box", s.shifted(s.shifted(s.NormL0(1.0), xk, 1.0, chi), sj))
     del d
-    # ShiftedNormL1B2: a few global reduction passes + the final pass, host round trips in between
+    # ShiftedNormL1B2: reduction passes + scalar root find inside ONE launch (k_b2_coop), no host round trip
     psi_b2 = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, s.NormL2(1.0)), sj)
     s.prox_bang(y, psi_b2, q, 1.0)
-    t0 = time.perf_counter()
-    for _ in range(5):
-        s.prox_bang(y, psi_b2, q, 1.0)
-    s.synchronize()
-    ms = (time.perf_counter() - t0) / 5 * 1e3
-    res["ShiftedNormL1B2"] = {"ms": round(ms, 4), "gelem_s": round(n / ms / 1e6, 2),
-                              "gbs_algorithmic": round(32 * n / ms / 1e6, 1),
+    ms = _time_op(s, L, ctx, lambda: s.prox_bang(y, psi_b2, q, 1.0), iters=5, rounds=3)
+    res["ShiftedNormL1B2"] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4), "kernel": "k_b2_coop<false>",
+                              "gelem_s": round(n / ms / 1e6, 2), "gbs_algorithmic": round(32 * n / ms / 1e6, 1),
                               "frac_of_peak": round(32 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
-                              "note": "host wall time per call (the scalar root find synchronises)"}
+                              "note": "algorithmic 32 B/element; the call streams 4 x 24 + 32 B/element (4 reduction passes, the last "
+                                      "pass also stores y)"}
     # host-pointer form of the headline operator (spx_host_prox_l1_box): PCIe-inclusive, pageable numpy vectors
     nh = min(n, 10**7)
     hx, hs, hq = (t[:nh].cpu().numpy() for t in (xk, sj, q))
@@ -267,10 +305,13 @@ def _extra(s, L, ctx, dev, n, torch):
         "note": "3 vectors H2D + y D2H per call from pageable host memory; never the headline value"}
     del hx, hs, hq, psi_h
     r = max(1, n // 100)
-    line("ShiftedIndBallL0BInf_r=n/100", s.shifted(s.shifted(s.IndBallL0(r), xk, 1.0, chi), sj), 32, n, y, q)
+    # top-r is a sequence: k_s2_front, k_s2_main (dominant, ~88 % of the time), k_s2_scan_verify, k_s2_compact, k_s2_finish and
+    # the fallback launch that returns at once; ms is the whole call
+    TOPR = "k_s2_main<true,true,true> (+ k_s2_front, k_s2_scan_verify, k_s2_compact, k_s2_finish, k_sel_coop fallback)"
+    line("ShiftedIndBallL0BInf_r=n/100", s.shifted(s.shifted(s.IndBallL0(r), xk, 1.0, chi), sj), 32, n, y, q, TOPR)
     # the same operator at the two ends of r (band without an upper end / widest band): tools/sweep_topr.py has the rest
-    line("ShiftedIndBallL0BInf_r=1000", s.shifted(s.shifted(s.IndBallL0(min(1000, n)), xk, 1.0, chi), sj), 32, n, y, q)
-    line("ShiftedIndBallL0BInf_r=n/2", s.shifted(s.shifted(s.IndBallL0(max(1, n // 2)), xk, 1.0, chi), sj), 32, n, y, q)
+    line("ShiftedIndBallL0BInf_r=1000", s.shifted(s.shifted(s.IndBallL0(min(1000, n)), xk, 1.0, chi), sj), 32, n, y, q, TOPR)
+    line("ShiftedIndBallL0BInf_r=n/2", s.shifted(s.shifted(s.IndBallL0(max(1, n // 2)), xk, 1.0, chi), sj), 32, n, y, q, TOPR)
     # group config: (n // 100) groups of 128  (10^6 x 128 at n = 10^8)
     ng = max(1, n // 100)
     m = ng * 128
@@ -283,15 +324,15 @@ def _extra(s, L, ctx, dev, n, torch):
     lam = torch.rand(ng, dtype=torch.float64, device=dev, generator=gen) + 0.5
     h = s.GroupNormL2.uniform(lam, 128)
     bpe = 32 + 8 / 128
-    line("ShiftedGroupNormL2_%dx128" % ng, s.shifted(s.shifted(h, xk), sj), bpe, m, y, q)
-    line("ShiftedGroupNormL2Binf_%dx128" % ng, s.shifted(s.shifted(h, xk, 1.0, chi), sj), bpe, m, y, q)
+    line("ShiftedGroupNormL2_%dx128" % ng, s.shifted(s.shifted(h, xk), sj), bpe, m, y, q, "k_group_reg<16,8,false,true,false>")
+    line("ShiftedGroupNormL2Binf_%dx128" % ng, s.shifted(s.shifted(h, xk, 1.0, chi), sj), bpe, m, y, q, "k_group_reg<8,16,true,true,false>")
     # a sparse iterate under a strong lambda: 90 % of the groups of xk are zero, sigma*lambda above ||S|| for most groups
     # (the reversed-bracket regime of the reference; tools/sweep_params.py has the full sweep)
     keep = (torch.rand(ng, dtype=torch.float64, device=dev, generator=gen) < 0.1).to(torch.float64).repeat_interleave(128)
     xk.mul_(keep)
     del keep
     h30 = s.GroupNormL2.uniform(lam * 30.0, 128)
-    line("ShiftedGroupNormL2Binf_%dx128_sparse_iterate" % ng, s.shifted(s.shifted(h30, xk, 1.0, chi), sj), bpe, m, y, q)
+    line("ShiftedGroupNormL2Binf_%dx128_sparse_iterate" % ng, s.shifted(s.shifted(h30, xk, 1.0, chi), sj), bpe, m, y, q, "k_group_reg<8,16,true,true,false>")
     return res
 
 

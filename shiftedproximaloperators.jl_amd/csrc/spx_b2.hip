@@ -466,7 +466,7 @@ SPX_EXPORT int spx_obj_l1_b2(spx_ctx* ctx, const double* y, const double* xk, co
     SPX_REQUIRE(y && xk && sj, "NULL vector with n > 0");
     int rc = spx_ws_reserve(ctx, sizeof(B2Ws) + 256);
     if (rc) return rc;
-    SPX_HIP(hipSetDevice(ctx->device));
+    SPX_ON_DEVICE(ctx);
     B2Ws* ws = reinterpret_cast<B2Ws*>(ctx->ws);
     const bool vec = n >= 2 && spx_aligned16(y) && spx_aligned16(xk) && spx_aligned16(sj);
     int64_t blocks = vec ? ((n >> 1) + 1023) / 1024 : (n + 256 * 8 - 1) / (256 * 8);
@@ -506,7 +506,7 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   if (n == 0) return SPX_OK;
   rc = spx_ws_reserve(ctx, sizeof(B2Ws) + 256);
   if (rc) return rc;
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   B2Ws* ws = reinterpret_cast<B2Ws*>(ctx->ws);
   const double ls = lambda * sigma;  // `psi.lambda * sigma`, :56
   bool vec = n >= 2 && spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj);

@@ -76,6 +76,24 @@ struct SpxCoopLaunchGuard {
     }                                                                                          \
   } while (0)
 
+// Entry points run on the context's device and leave the caller's current device as they found it (an array library
+// working on another GPU must not have its current device changed under it).
+struct SpxDeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit SpxDeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) err = hipSetDevice(device);
+  }
+  ~SpxDeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+#define SPX_ON_DEVICE(ctx)                      \
+  SpxDeviceGuard spx_device_guard((ctx)->device); \
+  SPX_HIP(spx_device_guard.err)
+
 #define SPX_REQUIRE(cond, msg)                 \
   do {                                         \
     if (!(cond)) {                             \

@@ -2,6 +2,7 @@
 #include "spx_common.hpp"
 
 #include <atomic>
+#include <cstring>
 #include <mutex>
 static thread_local char g_err[512] = "";
 static std::atomic<int> g_ctx_count[64];
@@ -45,9 +46,15 @@ static int ctx_create_impl(int device, bool borrow, void* stream, spx_ctx** out)
     return SPX_ERR_NO_DEVICE;
   }
   SPX_REQUIRE(device >= 0 && device < count, "device ordinal out of range");
-  SPX_HIP(hipSetDevice(device));
+  SpxDeviceGuard dev_guard(device);
+  SPX_HIP(dev_guard.err);
   hipDeviceProp_t prop;
   SPX_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {  // the code object holds gfx950 ISA only
+    spx_set_error("device %d is %s, not gfx950 (MI355X): libspx is built for gfx950 only and has no other path", device,
+                  prop.gcnArchName);
+    return SPX_ERR_NO_DEVICE;
+  }
   spx_ctx* c = new spx_ctx();
   c->device = device;
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -80,7 +87,7 @@ SPX_EXPORT int spx_ctx_create_on_stream(int device, void* stream, spx_ctx** out)
 
 SPX_EXPORT int spx_ctx_destroy(spx_ctx* ctx) {
   if (!ctx) return SPX_OK;
-  (void)hipSetDevice(ctx->device);
+  SpxDeviceGuard dev_guard(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->sync) (void)hipFree(ctx->sync);
@@ -146,7 +153,7 @@ SPX_EXPORT int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms) {
 // synchronises the stream (the old block may still be in use by earlier calls).
 int spx_ws_reserve(spx_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return SPX_OK;
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->ws) SPX_HIP(hipFree(ctx->ws));
   ctx->ws = nullptr;
@@ -164,7 +171,7 @@ int spx_ws_reserve(spx_ctx* ctx, size_t bytes) {
 // "zero when no launch of mine is in flight", which holds again after the stream has been drained.
 int spx_sync_reserve(spx_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->sync_bytes) return SPX_OK;
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->sync) SPX_HIP(hipFree(ctx->sync));
   ctx->sync = nullptr;
@@ -211,7 +218,7 @@ SPX_EXPORT int spx_check_bounds(spx_ctx* ctx, const double* l_vec, const double*
   if (n == 0) return SPX_OK;
   int rc = spx_ws_reserve(ctx, 256);
   if (rc) return rc;
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   int* flag = reinterpret_cast<int*>(ctx->ws);
   SPX_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
   int64_t blocks = (n + 255) / 256;
@@ -243,7 +250,7 @@ SPX_EXPORT int spx_build_mask(spx_ctx* ctx, uint8_t* mask, int64_t n, const int6
   if (n == 0) return SPX_OK;
   SPX_REQUIRE(mask != nullptr, "mask is NULL");
   SPX_REQUIRE(nsel == 0 || selected != nullptr, "selected is NULL");
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   SPX_HIP(hipMemsetAsync(mask, 0, (size_t)n, ctx->stream));
   if (nsel > 0) {
     int64_t blocks = (nsel + 255) / 256;

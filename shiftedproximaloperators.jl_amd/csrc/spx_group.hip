@@ -1129,7 +1129,7 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   if (n == 0) return SPX_OK;
   if (ngroups == 0) {  // no group at all: ShiftedGroupNormL2 still subtracts the shift everywhere (:77)
     if (!BINF && offsets) {
-      SPX_HIP(hipSetDevice(ctx->device));
+      SPX_ON_DEVICE(ctx);
       hipLaunchKernelGGL(k_csr_uncovered, dim3(256), dim3(256), 0, ctx->stream, y, xk, sj, offsets, ngroups, n);
       SPX_LAUNCH_CHECK();
     }
@@ -1142,7 +1142,7 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   }
   // y may alias q: every kernel finishes all reductions of a group (team barrier / wave lockstep) before
   // the group's first store, and the storing lane re-reads q[i] itself just before writing y[i].
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   const int64_t cap_blocks = (int64_t)ctx->num_cu * 8;
   const bool aligned = spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj);
   const bool ragged_reg = offsets && gsize > 0 && gsize <= 512;  // ragged groups with a size bound from the caller
@@ -1240,12 +1240,11 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     if (!BINF && offsets)
       hipLaunchKernelGGL(k_csr_uncovered, dim3(256), dim3(256), 0, ctx->stream, y, xk, sj, offsets, ngroups, n);
     const size_t dyn = (size_t)gsize * 2 * sizeof(double);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[BINF ? 1 : 0]) {
+    // per device (the attribute belongs to the function ON the current device) and cheap: set on every call that needs it,
+    // no process-wide cache that a second GPU or a second thread would find in the wrong state
+    if (dyn > 48 * 1024)
       SPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_lds<BINF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsGroupMax * 2 * (int)sizeof(double)));
-      attr_set[BINF ? 1 : 0] = true;
-    }
     int64_t blocks = ngroups < cap_blocks ? ngroups : cap_blocks;
     hipLaunchKernelGGL((k_group_lds<BINF>), dim3((unsigned)blocks), dim3(256), dyn, ctx->stream, y, q, xk, sj, n, offsets,
                        gsize, ngroups, lambda, sigma, delta);
@@ -1295,7 +1294,7 @@ static int run_group_gather(spx_ctx* ctx, double* y, const double* q, const doub
   if (n == 0) return SPX_OK;
   if (ngroups > 0) SPX_REQUIRE(ptr != nullptr && lambda != nullptr, "group_ptr or lambda_vec is NULL");
   if (nnz > 0) SPX_REQUIRE(index != nullptr, "group_index is NULL");
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   // workspace: flag (256 B) | sol (n doubles) | owner (n ints)
   const size_t sol_off = 256, own_off = sol_off + (size_t)n * sizeof(double);
   rc = spx_ws_reserve(ctx, own_off + (size_t)n * sizeof(int) + 256);

@@ -16,7 +16,7 @@ struct In {
 
 int stage_reserve(spx_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->stage_bytes) return SPX_OK;
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->stage) SPX_HIP(hipFree(ctx->stage));
   ctx->stage = nullptr;
@@ -40,7 +40,7 @@ int stage_in(spx_ctx* ctx, const In (&in)[NIN], const void* (&dev)[NIN], size_t 
     if (in[i].host && in[i].bytes) total += aligned(in[i].bytes);
   int rc = stage_reserve(ctx, total ? total : kAlign);
   if (rc) return rc;
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   char* p = static_cast<char*>(ctx->stage);
   if (dev_out) *dev_out = out_bytes ? p : nullptr;
   p += aligned(out_bytes);
@@ -81,6 +81,9 @@ int host_sep(spx_ctx* ctx, double* y, const double* q, const double* xk, const d
   void* dy;
   rc = stage_in(ctx, in, d, vbytes(n), &dy);
   if (rc) return rc;
+  // prox!(q, psi, q, sigma) on host vectors: the device twin must see the aliasing too (ShiftedNormL1's y === q body differs
+  // from the disjoint one, src/shiftedNormL1.jl:47-51; every kernel handles y === q): y is then the staged q itself
+  if (y == q && n > 0) dy = const_cast<void*>(d[0]);
   rc = f(static_cast<double*>(dy), D(d[0]), D(d[1]), D(d[2]));
   if (rc) return rc;
   return stage_out(ctx, y, dy, vbytes(n));
@@ -98,6 +101,7 @@ int host_box(spx_ctx* ctx, double* y, const double* q, const double* xk, const d
   void* dy;
   rc = stage_in(ctx, in, d, vbytes(n), &dy);
   if (rc) return rc;
+  if (y == q && n > 0) dy = const_cast<void*>(d[0]);  // y === q, as in host_sep
   rc = f(static_cast<double*>(dy), D(d[0]), D(d[1]), D(d[2]), D(d[3]), D(d[4]), static_cast<const uint8_t*>(d[5]));
   if (rc) return rc;
   return stage_out(ctx, y, dy, vbytes(n));

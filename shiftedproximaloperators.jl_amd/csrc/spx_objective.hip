@@ -239,7 +239,7 @@ int run_obj(spx_ctx* ctx, const double* y, const double* xk, const double* sj, i
   }
   int rc = spx_ws_reserve(ctx, sizeof(ObjWs) + 256);
   if (rc) return rc;
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   ObjWs* ws = reinterpret_cast<ObjWs*>(ctx->ws);
   SPX_HIP(hipMemsetAsync(&ws->infeasible, 0, sizeof(int), ctx->stream));
   int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
@@ -266,7 +266,7 @@ int run_obj_group(spx_ctx* ctx, const double* y, const double* xk, const double*
     SPX_REQUIRE(gsize > 0 && ngroups <= n / gsize && ngroups * gsize == n, "ngroups * group_size != n");
   int rc = spx_ws_reserve(ctx, sizeof(ObjWs) + 256);
   if (rc) return rc;
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   ObjWs* ws = reinterpret_cast<ObjWs*>(ctx->ws);
   SPX_HIP(hipMemsetAsync(&ws->infeasible, 0, sizeof(int), ctx->stream));
   int64_t blocks = (ngroups + 3) / 4;

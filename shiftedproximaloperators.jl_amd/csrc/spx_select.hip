@@ -1398,7 +1398,7 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   int rc = spx_check_common(ctx, y, q, xk, sj, n);
   if (rc) return rc;
   if (n == 0) return SPX_OK;
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   if (n <= kSmallN && ctx->tune_sel_small) {  // one workgroup, one launch, no scratch
     hipLaunchKernelGGL((k_sel_small<BINF>), dim3(1), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta);
     SPX_LAUNCH_CHECK();

@@ -696,7 +696,7 @@ static int run_separable(spx_ctx* ctx, double* y, const double* q, const double*
                          double value_scale = 1.0 /* device-resident value = value_scale * sum */) {
   if constexpr (Op::kObj) *value = 0.0;
   if (n == 0) return SPX_OK;
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   double* partials = nullptr;  // ws: [result | pad to 256 B | partial slots]
   int64_t used = 0;
   if constexpr (Op::kObj) {
@@ -896,7 +896,7 @@ static int run_iprox_unboxed(spx_ctx* ctx, double* y, const double* g, const dou
   if (n == 0) return SPX_OK;
   rc = spx_ws_reserve(ctx, 256);
   if (rc) return rc;
-  SPX_HIP(hipSetDevice(ctx->device));
+  SPX_ON_DEVICE(ctx);
   int* flag = reinterpret_cast<int*>(ctx->ws);
   SPX_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
   rc = run_separable(ctx, y, g, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, Op{lambda, flag}, d);

@@ -142,3 +142,28 @@ def test_host_groups_iprox_objective(s, orc):
     for make in (lambda v: s.shifted(s.NormL1(0.6), v), lambda v: s.shifted(s.NormL0(0.6), v, 5.0, s.NormLinf(1.0)),
                  lambda v: s.shifted(s.RootNormLhalf(0.6), v), lambda v: s.shifted(s.IndBallL0(n), v)):
         assert s.shifted(make(x), sj)(q * 0.1) == s.shifted(make(xd), sd)(yd_)
+
+
+def test_host_form_aliased_call_matches_device_form(s, orc):
+    """prox!(q, psi, q, sigma) on host vectors (y is q: test/test_allocs.jl:108-113).  The device form and the reference
+    run ShiftedNormL1's two-pass body there, whose broadcast overwrites q first (src/shiftedNormL1.jl:47-51): the host
+    form must give the same numbers -- it used to stage y and q separately and return the disjoint result."""
+    import torch
+    n = 4099
+    rng = np.random.default_rng(17)
+    x, sj, q = rng.normal(size=n), rng.uniform(-0.5, 0.5, size=n), rng.normal(size=n)
+    bits = lambda a, b: np.array_equal(np.asarray(a).view(np.int64), np.asarray(b).view(np.int64))
+    # ShiftedNormL1, aliased: -(xk) - sj clamped against the OVERWRITTEN q, i.e. (-x) - sj itself
+    qh = q.copy()
+    s.prox_bang(qh, s.shifted(s.shifted(s.NormL1(1.0), x), sj), qh, 1.0)
+    assert bits(qh, (-x) - sj)
+    qd = torch.from_numpy(q.copy()).cuda()
+    s.prox_bang(qd, s.shifted(s.shifted(s.NormL1(1.0), torch.from_numpy(x).cuda()), torch.from_numpy(sj).cuda()), qd, 1.0)
+    assert bits(qh, qd.cpu().numpy())
+    # Box form and top-r: aliasing does not change the result, host == oracle
+    qh = q.copy()
+    s.prox_bang(qh, s.shifted(s.shifted(s.NormL1(1.0), x, 1.0, s.NormLinf(1.0)), sj), qh, 1.0)
+    assert bits(qh, orc.prox_l1_box(q, x, sj, 1.0, 1.0, -1.0, 1.0))
+    qh = q.copy()
+    s.prox_bang(qh, s.shifted(s.shifted(s.IndBallL0(77), x), sj), qh, 1.0)
+    assert bits(qh, orc.prox_indball_l0(q, x, sj, 77))
