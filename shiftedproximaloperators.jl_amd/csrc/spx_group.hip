@@ -207,8 +207,11 @@ __device__ __forceinline__ void binf_ab(const G& grp, double tau, double delta, 
     const double z = __builtin_fma(tau, S, -X);
     const bool act = fabs(z) > delta;
     const double b = X + signed_delta(delta, z);
-    sa += keep_if(S * S, !act);
-    sb += keep_if(b * b, act);
+    // masked operand, then one fma per sum (8 VALU instructions per element instead of 10 with mul + mask + add: the
+    // kernel is VALU-bound and this loop is half of it); the leftover low dword of a masked operand squares to zero
+    const double Sm = keep_if(S, !act), bm = keep_if(b, act);
+    sa = __builtin_fma(Sm, Sm, sa);
+    sb = __builtin_fma(bm, bm, sb);
   });
   team_sum2<TEAM>(sa, sb, lds);
   // keep_if leaves sub-2^-1042 residues of the masked-out terms in the sums: an empty set must sum to exactly 0 (the
@@ -496,8 +499,8 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
   const double taul = ul * fast_rcp(lmin);
   double sS = 0.0, sX = 0.0, mX = 0.0;
   grp.for_each([&](double S, double X) {
-    sS += S * S;
-    sX += X * X;
+    sS = __builtin_fma(S, S, sS);
+    sX = __builtin_fma(X, X, sX);
     mX = fmax(mX, fabs(X));
   });
   team_sum2<TEAM>(sS, sX, lds);
@@ -724,7 +727,9 @@ __device__ __forceinline__ double binf_y(double S, double X, double tau, double 
 // lane j owns the elements j, j + LPG, ... through 8-byte loads.
 // LIT (Binf only): second launch over the deferred list -- `deferred` is then read: [0] = number of groups, [1..] = their
 // ids -- evaluating the reference's expressions literally on the register-resident group (binf_literal_reg).
-template <int LPG, int EPL, bool BINF, bool PAIRS, bool LIT = false>
+// FULL (PAIRS only): the group size is exactly LPG * EPL -- no pair of the tile is masked, which takes the zero-fill selects
+// and the clamped addresses (~7 % of the kernel's VALU instructions) out of the BASELINE shapes (128 = 8 x 16 = 16 x 8).
+template <int LPG, int EPL, bool BINF, bool PAIRS, bool LIT = false, bool FULL = false>
 __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) void k_group_reg(double* y_, const double* q_, const double* xk_, const double* sj_,
                                                     int64_t ngroups, int gsize, const double* __restrict__ lambda,
                                                     double sigma, double delta,
@@ -777,7 +782,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
           char* wl = dma_lds + (threadIdx.x >> 6) * (3 * (EPL / 2) * 1024);
 #pragma unroll
           for (int k = 0; k < EPL / 2; ++k) {
-            const int p = (k * LPG + j < npairs) ? (k * LPG + j) : 0;  // masked pairs re-read pair 0, zeroed below
+            const int p = (FULL || k * LPG + j < npairs) ? (k * LPG + j) : 0;  // masked pairs re-read pair 0, zeroed below
             __builtin_amdgcn_global_load_lds((const void*)(q2 + p), (lds_void*)(wl + (0 * (EPL / 2) + k) * 1024), 16, 0, 2);
             __builtin_amdgcn_global_load_lds((const void*)(x2 + p), (lds_void*)(wl + (1 * (EPL / 2) + k) * 1024), 16, 0, 2);
             __builtin_amdgcn_global_load_lds((const void*)(s2 + p), (lds_void*)(wl + (2 * (EPL / 2) + k) * 1024), 16, 0, 2);
@@ -792,7 +797,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
         } else {
 #pragma unroll
           for (int k = 0; k < EPL / 2; ++k) {
-            const int p = (k * LPG + j < npairs) ? (k * LPG + j) : 0;
+            const int p = (FULL || k * LPG + j < npairs) ? (k * LPG + j) : 0;
             vq[k] = __builtin_nontemporal_load(q2 + p);
             vx[k] = __builtin_nontemporal_load(x2 + p);
             vs[k] = __builtin_nontemporal_load(s2 + p);
@@ -800,7 +805,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
         }
 #pragma unroll
         for (int k = 0; k < EPL / 2; ++k) {
-          const bool in = (k * LPG + j) < npairs;
+          const bool in = FULL || (k * LPG + j) < npairs;
           const f64x2 zero2 = f64x2{0.0, 0.0};
           const f64x2 a = in ? vq[k] : zero2, b = in ? vx[k] : zero2, c = in ? vs[k] : zero2;
           grp.S[2 * k] = (a.x + b.x) + c.x;  // shiftedGroupNormL2.jl:65 / shiftedGroupNormL2Binf.jl:80
@@ -864,7 +869,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
         f64x2* y2 = reinterpret_cast<f64x2*>(y_ + base);
 #pragma unroll
         for (int k = 0; k < EPL / 2; ++k)
-          if (k * LPG + j < npairs) __builtin_nontemporal_store(f64x2{out[2 * k], out[2 * k + 1]}, y2 + k * LPG + j);
+          if (FULL || k * LPG + j < npairs) __builtin_nontemporal_store(f64x2{out[2 * k], out[2 * k + 1]}, y2 + k * LPG + j);
       } else {
 #pragma unroll
         for (int k = 0; k < EPL; ++k)
@@ -1181,7 +1186,10 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
       hipLaunchKernelGGL(k_csr_uncovered, dim3(256), dim3(256), 0, ctx->stream, y, xk, sj, offsets, ngroups, n);
 #define SPX_LAUNCH_REG(LPG, EPL)                                                                                    \
   do {                                                                                                              \
-    if (pairs)                                                                                                      \
+    if (pairs && gsize == (LPG) * (EPL))                                                                            \
+      hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, true, false, true>), grid, block, 0, ctx->stream, y, q, xk, sj, \
+                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr);             \
+    else if (pairs)                                                                                                 \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, true>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,   \
                          (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr);                      \
     else                                                                                                            \
