@@ -229,6 +229,13 @@ def _extra(s, L, ctx, dev, n, torch):
     uv = 1.0 + 0.1 * torch.rand(n, dtype=torch.float64, device=dev, generator=gen)
     line("ShiftedNormL1Box_vector_bounds", s.shifted(s.shifted(s.NormL1(1.0), xk, lv, uv), sj), 48, n, y, q, "k_sep_lds<OpL1Box,3,true,false>")
     del lv, uv
+    # Float32 form of the headline operator (the reference is generic in R <: Real): 16 B/element, bit-exact in fp32
+    x32, s32, q32 = xk.float(), sj.float(), q.float()
+    y32 = torch.empty_like(q32)
+    line("ShiftedNormL1Box_float32", s.shifted(s.shifted(s.NormL1(1.0), x32, 1.0, chi), s32), 16, n, y32, q32,
+         "k_sep_f32<F32L1Box,false,false>")
+    res["ShiftedNormL1Box_float32"]["dtype"] = "f32"
+    del x32, s32, q32, y32
     # iprox!: g, d, xk, sj -> y, 40 B/element
     d = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) + 0.5
 

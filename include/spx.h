@@ -124,6 +124,28 @@ int spx_prox_lhalf_box(spx_ctx* ctx, double* y, const double* q, const double* x
                        const double* u_vec, double l_scalar, double u_scalar,
                        const uint8_t* sel_mask);
 
+/* ---- Float32 forms (round 2) -------------------------------------------------------------------
+ * The reference's structs and prox! methods are generic in R <: Real (`prox!(y::AbstractVector{R}, psi::ShiftedNormL1Box{R,...},
+ * q::AbstractVector{R}, sigma::R)`, src/shiftedNormL1Box.jl:89-94; Float32 operators on views: test/runtests.jl:196-209).
+ * With R = Float32 every operation of the NormL1 / NormL0 bodies is a Float32 operation, so these entry points reproduce the
+ * reference BIT FOR BIT in fp32 (lambda and sigma are Float32 too: lambda * sigma, sqrt(2 lambda sigma), 2 lambda sigma are
+ * formed in Float32).  Device pointers; any 4-byte alignment (views that start at any element); y may alias q; 16 B/element.
+ * RootNormLhalf has no Float32 form: the reference's body mixes Float64 literals into it and computes in Float64. */
+/* ShiftedNormL1.prox!     src/shiftedNormL1.jl:40-54 */
+int spx_prox_l1_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, const float* sj, int64_t n, float lambda,
+                    float sigma);
+/* ShiftedNormL0.prox!     src/shiftedNormL0.jl:38-55 */
+int spx_prox_l0_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, const float* sj, int64_t n, float lambda,
+                    float sigma);
+/* ShiftedNormL1Box.prox!  src/shiftedNormL1Box.jl:89-125 */
+int spx_prox_l1_box_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, const float* sj, int64_t n, float lambda,
+                        float sigma, const float* l_vec, const float* u_vec, float l_scalar, float u_scalar,
+                        const uint8_t* sel_mask);
+/* ShiftedNormL0Box.prox!  src/shiftedNormL0Box.jl:89-131 */
+int spx_prox_l0_box_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, const float* sj, int64_t n, float lambda,
+                        float sigma, const float* l_vec, const float* u_vec, float l_scalar, float u_scalar,
+                        const uint8_t* sel_mask);
+
 /* ---- prox! fused with the value of h at the result ------------------------------------------ */
 /* One pass instead of two for the pair every solver iteration makes (R2: `prox!(s, psi, ...)` then `h(xk + s)`):
  * y as spx_prox_X, and *value = h over the selected indices of (xk + sj) + y -- lambda * sum |v|, lambda * #nonzeros,

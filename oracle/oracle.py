@@ -436,3 +436,57 @@ def q_prox_l1_b2(q, xk, sj, lam, sigma, delta, chi_lambda=1.0):
     q, xk, sj, n, y = _prep(q, xk, sj)
     libq().orcq_prox_l1_b2(_dp(y), _dp(q), _dp(xk), _dp(sj), n, lam, sigma, delta, chi_lambda)
     return y
+
+
+# ---- Float32 build (oracle/spx_oracle_f32.c): the NormL1 / NormL0 families with R = Float32 ---------------------------
+_SO32 = os.path.join(_HERE, "libspx_oracle_f32.so")
+_lib32 = None
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+
+
+def lib32():
+    global _lib32
+    if _lib32 is None:
+        src = os.path.join(_HERE, "spx_oracle_f32.c")
+        if not os.path.exists(_SO32) or os.path.getmtime(_SO32) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "libspx_oracle_f32.so"])
+        L = ctypes.CDLL(_SO32)
+        f, i64, fp, up = ctypes.c_float, ctypes.c_int64, _c_float_p, _c_uint8_p
+        L.orc32_prox_l1.argtypes = [fp, fp, fp, fp, i64, f, f]
+        L.orc32_prox_l0.argtypes = [fp, fp, fp, fp, i64, f, f]
+        L.orc32_prox_l1_box.argtypes = [fp, fp, fp, fp, i64, f, f, fp, fp, f, f, up]
+        L.orc32_prox_l0_box.argtypes = [fp, fp, fp, fp, i64, f, f, fp, fp, f, f, up]
+        for name in ("orc32_prox_l1", "orc32_prox_l0", "orc32_prox_l1_box", "orc32_prox_l0_box"):
+            getattr(L, name).restype = None
+        _lib32 = L
+    return _lib32
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_c_float_p) if a is not None else None
+
+
+def prox_f32(op, q, xk, sj, lam, sigma, l=None, u=None, mask=None, aliased=False):
+    """op in {"l1", "l0", "l1_box", "l0_box"}; Float32 arrays in, Float32 array out.  aliased=True: y is q itself
+    (prox!(q, psi, q, sigma)): ShiftedNormL1's two-pass body then reads the overwritten q."""
+    q, xk, sj = _f32(q), _f32(xk), _f32(sj)
+    n = q.shape[0]
+    y = q.copy() if aliased else np.empty(n, dtype=np.float32)
+    qq = y if aliased else q
+    lam, sigma = np.float32(lam), np.float32(sigma)
+    if op in ("l1", "l0"):
+        getattr(lib32(), "orc32_prox_" + op)(_fp(y), _fp(qq), _fp(xk), _fp(sj), n, lam, sigma)
+        return y
+    lv = uv = None
+    ls = us = np.float32(0)
+    if np.ndim(l) == 0: ls = np.float32(l)
+    else: lv = _f32(l)
+    if np.ndim(u) == 0: us = np.float32(u)
+    else: uv = _f32(u)
+    m, mp = _mask(mask, n)
+    getattr(lib32(), "orc32_prox_" + op)(_fp(y), _fp(qq), _fp(xk), _fp(sj), n, lam, sigma, _fp(lv), _fp(uv), ls, us, mp)
+    return y

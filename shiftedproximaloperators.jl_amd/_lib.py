@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("SPX_LIB_NAME", "libspx.so"
 
 c_double_p = ctypes.c_void_p  # device pointers are passed as plain addresses
 _i64, _d, _p, _int = ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_int
+_f = ctypes.c_float
 
 # name -> argtypes; must list every symbol declared in include/spx.h (tests/test_abi.py checks this)
 SIGNATURES = {
@@ -29,6 +30,10 @@ SIGNATURES = {
     "spx_prox_l1_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p],
     "spx_prox_l0_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p],
     "spx_prox_lhalf_box": [_p, _p, _p, _p, _p, _i64, _d, _d, _p, _p, _d, _d, _p],
+    "spx_prox_l1_f32": [_p, _p, _p, _p, _p, _i64, _f, _f],
+    "spx_prox_l0_f32": [_p, _p, _p, _p, _p, _i64, _f, _f],
+    "spx_prox_l1_box_f32": [_p, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _f, _f, _p],
+    "spx_prox_l0_box_f32": [_p, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _f, _f, _p],
     "spx_proxval_l1": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, ctypes.POINTER(_d)],
     "spx_proxval_l0": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, ctypes.POINTER(_d)],
     "spx_proxval_lhalf": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, ctypes.POINTER(_d)],
@@ -62,7 +67,7 @@ SIGNATURES = {
 }
 # host-pointer forms: spx_host_X has the argument list of spx_X (include/spx.h, "host-pointer forms")
 SIGNATURES.update({"spx_host_" + k[4:]: list(v) for k, v in list(SIGNATURES.items())
-                   if k.startswith(("spx_prox_", "spx_iprox_", "spx_obj_"))})
+                   if k.startswith(("spx_prox_", "spx_iprox_", "spx_obj_")) and not k.endswith("_f32")})
 
 
 class SpxError(RuntimeError):

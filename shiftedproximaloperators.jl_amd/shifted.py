@@ -79,8 +79,13 @@ def _vec(t, name, n=None, like=None):
         if not t.is_cuda:
             raise TypeError("%s must live in device memory (cuda); libspx computes nothing on the CPU (numpy arrays "
                             "are staged through the GPU)" % name)
-        if t.dtype != torch.float64:
-            raise TypeError("%s must be float64 (got %s)" % (name, t.dtype))
+        # float64, or float32 for the operators that have a Float32 form (the reference is generic in R <: Real); all the
+        # vectors of one ψ share the element type
+        want = like.dtype if isinstance(like, torch.Tensor) else None
+        if want is None and t.dtype not in (torch.float64, torch.float32):
+            raise TypeError("%s must be float64 or float32 (got %s)" % (name, t.dtype))
+        if want is not None and t.dtype != want:
+            raise TypeError("%s must be %s like ψ.xk (got %s)" % (name, want, t.dtype))
         if t.dim() != 1 or (t.numel() > 1 and t.stride(0) != 1):
             raise TypeError("%s must be a contiguous vector" % name)
     if like is not None and _dev(t) != _dev(like):
@@ -133,9 +138,15 @@ class ShiftedProximableFunction:
         self.sol = _empty_like(xk)  # `sol = similar(xk)`
         self.shifted_twice = bool(shifted_twice)
         self.host = _is_host(xk)
+        self.f32 = (not self.host) and xk.dtype == torch.float32
 
     def _sym(self, L, name):
-        """the entry point `name` of libspx, or its host-pointer form for a ψ on host arrays"""
+        """the entry point `name` of libspx, its host-pointer form for a ψ on host arrays, or its Float32 form"""
+        if self.f32:
+            if name + "_f32" not in _lib.SIGNATURES:
+                raise TypeError("MethodError: %s has no Float32 form in libspx (Float32 covers prox! of the NormL1 / NormL0 "
+                                "families; convert to float64 for the rest)" % name)
+            return getattr(L, name + "_f32")
         return getattr(L, "spx_host_" + name[4:] if self.host else name)
 
     # ψ.λ / ψ.r sugar (getproperty, :113-121)
@@ -228,6 +239,10 @@ class _Boxed(ShiftedProximableFunction):
             uv = None if _is_real(self.u) else self.u
             if self.host:  # constructor validation on the caller's host arrays: `any(l .> u)`
                 bad = bool(np.any(np.asarray(self.l) > np.asarray(self.u)))
+            elif self.f32:  # (spx_check_bounds reads Float64 vectors)
+                lt = self.l if lv is not None else torch.tensor(float(self.l), dtype=torch.float32, device=xk.device)
+                ut = self.u if uv is not None else torch.tensor(float(self.u), dtype=torch.float32, device=xk.device)
+                bad = bool((lt > ut).any())
             else:
                 flag = ctypes.c_int(0)
                 L = _lib.load()

@@ -61,6 +61,17 @@ def test_full_size_bit_exact(s, orc, data, op):
         assert float((data["y"] + data["s"]).abs().max()) <= 1.0
 
 
+@pytest.mark.parametrize("op", ["l1_box", "l0_box"])
+def test_full_size_float32_bit_exact(s, orc, data, op):
+    # the Float32 forms at n = 1e8: all elements, bitwise, against the Float32 build of the oracle
+    h = s.NormL1(1.0) if "l1" in op else s.NormL0(1.0)
+    x32, s32, q32 = (data[k].float() for k in ("x", "s", "q"))
+    psi = s.shifted(s.shifted(h, x32, 1.0, s.NormLinf(1.0)), s32)
+    y = s.prox(psi, q32, 1.0).cpu().numpy()
+    ref = orc.prox_f32(op, q32.cpu().numpy(), x32.cpu().numpy(), s32.cpu().numpy(), 1.0, 1.0, np.float32(-1.0), np.float32(1.0))
+    assert np.array_equal(y.view(np.int32), ref.view(np.int32))
+
+
 @pytest.mark.parametrize("op", ["lhalf_box", "lhalf"])
 def test_full_size_lhalf(s, orc, data, op):
     # configs[3]: ShiftedRootNormLhalfBox n = 1e8; oracle on two slices (1e7 + 1e6 elements)

@@ -361,3 +361,32 @@ def test_l1b2_objective(orc):
     yb = y / np.linalg.norm(y) * 0.01
     assert np.isfinite(orc.obj_l1_b2(yb, x, s0, 1.0, 0.01))
     assert orc.obj_l1_b2(yb * (1 + 1e-6), x, s0, 1.0, 0.01) == np.inf
+
+
+def test_f32_oracle_agrees_with_f64_on_dyadic_data(orc):
+    """The Float32 build of the L1 / L0 restatements (oracle/spx_oracle_f32.c) against the Float64 one on data where both
+    are exact: multiples of 1/16 below 2^7 with dyadic lambda, sigma -- every sum, product and square is then representable
+    in both formats and the two builds must agree value for value (the Float32 build has no reference vectors to pin it)."""
+    rng = np.random.default_rng(11)
+    n = 20_000
+    x = rng.integers(-64, 65, size=n) / 16.0
+    sj = rng.integers(-16, 17, size=n) / 16.0
+    q = rng.integers(-96, 97, size=n) / 16.0
+    l = -(rng.integers(8, 33, size=n) / 16.0)
+    u = rng.integers(8, 33, size=n) / 16.0
+    mask = (rng.random(n) < 0.7).astype(np.uint8)
+    for lam, sigma in ((0.5, 1.0), (1.0, 0.25), (2.0, 2.0)):
+        for op in ("l1", "l0"):
+            if op == "l0" and not float(np.sqrt(2 * lam * sigma)).is_integer():
+                continue                                   # sqrt(2 lambda sigma) must be exact in both formats
+            a = orc.prox_f32(op, q, x, sj, lam, sigma)
+            b = getattr(orc, "prox_" + op)(q, x, sj, lam, sigma)
+            assert np.array_equal(a.astype(np.float64), b), (op, lam, sigma)
+        for op in ("l1_box", "l0_box"):
+            for lo, uo, m in ((-1.0, 1.0, None), (l, u, None), (l, u, mask)):
+                a = orc.prox_f32(op, q, x, sj, lam, sigma, lo, uo, mask=m)
+                b = getattr(orc, "prox_" + op)(q, x, sj, lam, sigma, lo, uo, mask=m)
+                assert np.array_equal(a.astype(np.float64), b), (op, lam, sigma)
+    # aliased ShiftedNormL1
+    a = orc.prox_f32("l1", q, x, sj, 0.5, 1.0, aliased=True)
+    assert np.array_equal(a.astype(np.float64), (-x) - sj)
