@@ -336,6 +336,56 @@ end
 end
 # (group forms: spx_obj_group_l2 / spx_obj_group_l2_binf with the layout_for(ψ.h, n) arguments, as in group_call)
 
+
+# ---------------------------------------------------------------------------------------------
+# Float32 (round 2): the reference is generic in R <: Real; spx_prox_*_f32 reproduce the NormL1 / NormL0 bodies bit for bit
+# in fp32, on contiguous views that start at any element (src/shiftedNormL1Box.jl:89-94, test/runtests.jl:196-209).
+# RootNormLhalf{Float32} keeps the reference's own method (its body computes in Float64).
+# ---------------------------------------------------------------------------------------------
+const DVec32 = Union{ROCVector{Float32}, SubArray{Float32, 1, <:ROCVector{Float32}, <:Tuple{AbstractUnitRange}, true}}
+dptr32(v) = v === nothing ? Ptr{Cfloat}(C_NULL) : Ptr{Cfloat}(UInt(pointer(v)))
+vec32_or_nothing(b) = b isa Real ? nothing : b
+scal32(b) = b isa Real ? Float32(b) : 0.0f0
+
+for (T, sym) in ((:ShiftedNormL1, :spx_prox_l1_f32), (:ShiftedNormL0, :spx_prox_l0_f32))
+  @eval function prox!(y::DVec32, ψ::$T{Float32, <:DVec32, <:DVec32, <:DVec32}, q::DVec32, σ::Float32)
+    n = length(ψ.xk)
+    (length(y) == n && length(q) == n) || throw(BoundsError())
+    check(ccall(($(QuoteNode(sym)), libspx), Cint,
+                (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cfloat, Cfloat),
+                ctx(), dptr32(y), dptr32(q), dptr32(ψ.xk), dptr32(ψ.sj), n, ψ.λ, σ))
+    return y
+  end
+end
+for (T, sym) in ((:ShiftedNormL1Box, :spx_prox_l1_box_f32), (:ShiftedNormL0Box, :spx_prox_l0_box_f32))
+  @eval function prox!(y::DVec32, ψ::$T{Float32, <:DVec32, <:DVec32, <:DVec32}, q::DVec32, σ::Float32)
+    n = length(ψ.xk)
+    (length(y) == n && length(q) == n) || throw(BoundsError())
+    (ψ.l isa Real || ψ.l isa DVec32) && (ψ.u isa Real || ψ.u isa DVec32) ||
+      return invoke(prox!, Tuple{AbstractVector{Float32}, $T{Float32}, AbstractVector{Float32}, Float32}, y, ψ, q, σ)
+    m = mask_for(ψ)
+    check(ccall(($(QuoteNode(sym)), libspx), Cint,
+                (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cfloat, Cfloat,
+                 Ptr{Cfloat}, Ptr{Cfloat}, Cfloat, Cfloat, Ptr{UInt8}),
+                ctx(), dptr32(y), dptr32(q), dptr32(ψ.xk), dptr32(ψ.sj), n, ψ.λ, σ,
+                dptr32(vec32_or_nothing(ψ.l)), dptr32(vec32_or_nothing(ψ.u)), scal32(ψ.l), scal32(ψ.u), mptr(m)))
+    return y
+  end
+end
+
+# ---------------------------------------------------------------------------------------------
+# Device-resident values (round 2): `device_values(out::ROCVector{Float64}) do ... end` -- inside the block ψ(y) and prox_value!
+# store their Float64 result in out[1] and return NaN; nothing is read back (spx_ctx_set_value_target).
+# ---------------------------------------------------------------------------------------------
+function device_values(f, out::ROCVector{Float64})
+  check(ccall((:spx_ctx_set_value_target, libspx), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), ctx(), dptr(out)))
+  try
+    return f()
+  finally
+    check(ccall((:spx_ctx_set_value_target, libspx), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), ctx(), Ptr{Cdouble}(C_NULL)))
+  end
+end
+
 # shift!, set_radius!, set_bounds!, prox (src/ShiftedProximalOperators.jl:72-111,189-190) need no methods:
 # they are broadcasts / field updates on the stored (device) arrays and already work on ROCArrays.
 # The Box constructors' `any(l .> u)` (src/shiftedNormL1Box.jl:33-35) is a device reduction via broadcasting.
