@@ -361,7 +361,19 @@ def _cpu_baseline(s, psi, q, xk, sj, y, n, torch):
         reps += 1
     s.prox_bang(y, psi, q, 1.0)
     same = bool(np.array_equal(y[:m].cpu().numpy().view(np.int64), ref.view(np.int64)))
-    return {"value": round(m / best / 1e9, 4), "unit": "G-elements/s", "cores": 1, "kind": "port",
+    # all host cores on the same loop (OpenMP chunks): NOT the reference, which is single-threaded -- an upper bound for the CPU
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    out_mt = np.empty_like(ref)
+    best_mt = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oracle.prox_l1_box_mt(qh, xh, sh, 1.0, 1.0, -1.0, 1.0, ncpu, out=out_mt)
+        dt = time.perf_counter() - t0
+        best_mt = dt if best_mt is None else min(best_mt, dt)
+    all_cores = {"value": round(m / best_mt / 1e9, 4), "unit": "G-elements/s", "cores": ncpu, "kind": "port, OpenMP over all host cores",
+                 "note": "not the reference (single-threaded Julia): an upper bound for this memory-bound loop on the host",
+                 "same_bits_as_single_thread": bool(np.array_equal(out_mt.view(np.int64), ref.view(np.int64)))}
+    return {"value": round(m / best / 1e9, 4), "unit": "G-elements/s", "cores": 1, "kind": "port", "all_cores": all_cores,
             "host_cores_available": os.cpu_count(),
             "sample": "first %d elements of the same workload, best of %d runs (%.2f s each)" % (m, reps, best),
             "note": "reference (Julia) cannot run in this image; port = oracle/spx_oracle.c, gcc -O2 -ffp-contract=off",

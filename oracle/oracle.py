@@ -83,6 +83,8 @@ def lib():
         L.orc_prox_l1_b2.restype = None
         L.orc_rootnormlhalf_prox.argtypes = [dp, dp, i64, d, d]
         L.orc_rootnormlhalf_prox.restype = d
+        L.orc_prox_l1_box_mt.argtypes = box + [ctypes.c_int]
+        L.orc_prox_l1_box_mt.restype = None
         L.orc_set_perturbation.argtypes = [ctypes.c_int, ctypes.c_int]
         L.orc_set_perturbation.restype = None
         for name in ("orc_prox_l1", "orc_prox_l0", "orc_prox_lhalf", "orc_prox_l1_box", "orc_prox_l0_box",
@@ -185,6 +187,17 @@ def _box(fn, q, xk, sj, lam, sigma, l, u, mask):
 
 def prox_l1_box(q, xk, sj, lam, sigma, l, u, mask=None):
     return _box(lib().orc_prox_l1_box, q, xk, sj, lam, sigma, l, u, mask)
+
+
+def prox_l1_box_mt(q, xk, sj, lam, sigma, l, u, threads, mask=None, out=None):
+    """orc_prox_l1_box over `threads` host threads (an upper bound for the CPU, not the single-threaded reference)"""
+    q, xk, sj, n, y = _prep(q, xk, sj)
+    if out is not None:
+        y = out
+    lv, uv, ls, us = _bounds(l, u, n)
+    m, mp = _mask(mask, n)
+    lib().orc_prox_l1_box_mt(_dp(y), _dp(q), _dp(xk), _dp(sj), n, lam, sigma, _dp(lv), _dp(uv), ls, us, mp, int(threads))
+    return y
 
 
 def prox_l0_box(q, xk, sj, lam, sigma, l, u, mask=None):

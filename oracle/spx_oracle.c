@@ -124,6 +124,23 @@ ORC_API void orc_prox_l1_box(double* y, const double* q, const double* xk, const
   }
 }
 
+/* The same loop spread over `threads` host threads (OpenMP, static contiguous chunks): NOT the reference -- which is
+ * single-threaded Julia -- but a generous upper bound for what the host CPU could do on this memory-bound loop; reported
+ * by bench.py next to the single-thread figure and labelled as such ("optionally an OpenMP all-core variant").
+ * Results are bit-identical to orc_prox_l1_box (elements are independent). */
+ORC_API void orc_prox_l1_box_mt(double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                double lambda, double sigma, const double* lvec, const double* uvec,
+                                double lscal, double uscal, const uint8_t* mask, int threads) {
+  if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (int64_t c = 0; c < threads; ++c) {
+    const int64_t lo = n / threads * c + (c < n % threads ? c : n % threads);
+    const int64_t len = n / threads + (c < n % threads ? 1 : 0);
+    orc_prox_l1_box(y + lo, q + lo, xk + lo, sj + lo, len, lambda, sigma, lvec ? lvec + lo : NULL, uvec ? uvec + lo : NULL,
+                    lscal, uscal, mask ? mask + lo : NULL);
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * ShiftedNormL0.prox!  src/shiftedNormL0.jl:38-55
  * ------------------------------------------------------------------------------------------ */
