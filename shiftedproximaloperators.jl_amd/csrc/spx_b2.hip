@@ -244,28 +244,31 @@ __global__ __launch_bounds__(256) void k_b2_obj(const double* __restrict__ y, co
 // =============================================================================================
 constexpr int kB2Epl = 8;
 constexpr int kB2MaxPass = 64;
-struct B2Part { double p, c, f, pad; };
-
-// three sums over the 1024 lanes of a workgroup at once, every addition in a fixed order (result in every lane)
-__device__ __forceinline__ void b2_block_sum3(double& a, double& b, double& c, double (*lds)[16]) {
-  a = wave_sum(a);
-  b = wave_sum(b);
-  c = wave_sum(c);
+struct B2Part5 { double p, c, f, p1, c1, pad[3]; };  // one workgroup's partial sums of a pass (64 bytes)
+__device__ __forceinline__ void b2_block_sum5(double& a, double& b, double& c, double& d, double& e, double (*lds)[16]) {
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d); e = wave_sum(e);
   const int w = threadIdx.x >> 6;
-  __syncthreads();  // previous use of lds finished
-  if ((threadIdx.x & 63) == 0) { lds[0][w] = a; lds[1][w] = b; lds[2][w] = c; }
   __syncthreads();
-  double ta = 0.0, tb = 0.0, tc = 0.0;
+  if ((threadIdx.x & 63) == 0) { lds[0][w] = a; lds[1][w] = b; lds[2][w] = c; lds[3][w] = d; lds[4][w] = e; }
+  __syncthreads();
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0, t4 = 0.0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) { ta += lds[0][k]; tb += lds[1][k]; tc += lds[2][k]; }
-  a = ta; b = tb; c = tc;
+  for (int k = 0; k < 16; ++k) { t0 += lds[0][k]; t1 += lds[1][k]; t2 += lds[2][k]; t3 += lds[3][k]; t4 += lds[4][k]; }
+  a = t0; b = t1; c = t2; d = t3; e = t4;
 }
 
+// REG: n <= kB2Epl * 1024 * grid, the vectors in registers.  !REG (streaming): additionally a SAMPLE of 65 536 elements
+// (256 chunks of 256, one element per lane of the first 64 workgroups, kept in registers) is solved first -- a handful of
+// rendezvous, no streaming -- and its root eta_s (good to ~1/sqrt(65536) = 4e-3) rides along as a SECOND TRIAL in the first
+// streaming pass (the loads dominate: two sets of sums cost nothing).  The piece root of that trial is then ~1e-6 from the
+// root, one more reduction pass brings ~1e-13, and the storing pass follows: 24 + 24 + 32 = 80 B/element instead of
+// 4 x 24 + 32 = 128 when the iteration starts from the a-priori bound (which stays the fallback whenever the sample
+// misleads).  Stopping rule: the measured quadratic constant K = step_k / step_{k-1}^2 predicts error(next) = K step_k^2.
 template <bool REG>
 __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, const double* xk, const double* sj, int64_t n,
-                                                   double ls, double delta, double chil, B2Part* part /* [kB2MaxPass][grid] */,
+                                                   double ls, double delta, double chil, B2Part5* part /* [kB2MaxPass][grid] */,
                                                    SpxSyncHeader* hdr, int parity, int can_spec) {
-  __shared__ double lds3[3][16];
+  __shared__ double lds5[5][16];
   const int t = threadIdx.x;
   const int G = (int)gridDim.x;
   const int64_t NT = (int64_t)G * blockDim.x;
@@ -285,16 +288,26 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
       SQ[k] = in ? (S[k] + q[i]) : 0.0;   // `sj .+ q` (:56)
     }
   }
+  // the sample (streaming form only): chunk c = 4 * workgroup + (t >> 8) of 256, element t & 255 of it
+  constexpr int kChunks = 256;
+  const int chunk = (int)blockIdx.x * 4 + (t >> 8);
+  const bool has_sample = !REG && chunk < kChunks && n >= 65536 * 4;
+  double sx = 0.0, ss = 0.0, ssq = 0.0;
+  if (has_sample) {
+    const int64_t i = (int64_t)((double)chunk * (double)(n - 256) / (double)(kChunks - 1)) + (t & 255);
+    sx = xk[i]; ss = sj[i]; ssq = ss + q[i];
+  }
   const f64x2* q2 = reinterpret_cast<const f64x2*>(q);
   const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
   const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
   f64x2* y2 = reinterpret_cast<f64x2*>(y);
   const int64_t n2 = n >> 1;
   int np = 0;
-  double P = 0.0, C = 0.0, F = 0.0;
-  // one reduction pass at scale r (= eta / Delta); store: also y = ProjB((-xk) r) rinv - sj for this scale
-  auto pass = [&](double r, double rinv, bool first, bool store) {
-    double p = 0.0, c = 0.0, f = 0.0;
+  double P = 0.0, C = 0.0, F = 0.0, P1 = 0.0, C1 = 0.0;
+  // One reduction pass at scale r (= eta / Delta) and, if r1 > 0, at a second trial scale r1 (sums P1, C1).
+  // store: also y = ProjB((-xk) r) rinv - sj for scale r.  sample: over the sample registers instead of the vectors.
+  auto pass = [&](double r, double rinv, bool first, bool store, double r1, bool sample) {
+    double p = 0.0, c = 0.0, f = 0.0, p1 = 0.0, c1 = 0.0;
     auto visit = [&](double sq, double x, double s) -> double {
       const double lo = sq - ls, hi = sq + ls;
       const double z = (-x) * r;
@@ -304,9 +317,16 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
         const double far = (x < 0.0) ? hi : (x > 0.0) ? lo : pz;
         f += far * far;
       }
+      if (r1 > 0.0) {
+        const double z1 = (-x) * r1;
+        const double pz1 = jl_min(jl_max(z1, lo), hi);
+        if (pz1 == z1) p1 += x * x; else c1 += pz1 * pz1;
+      }
       return pz * rinv - s;
     };
-    if constexpr (REG) {
+    if (sample) {
+      if (has_sample) visit(ssq, sx, ss);
+    } else if constexpr (REG) {
 #pragma unroll
       for (int k = 0; k < kB2Epl; ++k) {
         const int64_t i = gtid + (int64_t)k * NT;
@@ -342,35 +362,64 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
         if (store) y[n - 1] = o;
       }
     }
-    b2_block_sum3(p, c, f, lds3);
+    b2_block_sum5(p, c, f, p1, c1, lds5);
     if (G == 1) {  // one workgroup holds the whole vector: nothing to exchange
-      P = p; C = c;
+      P = p; C = c; P1 = p1; C1 = c1;
       if (first) F = f;
     } else {
       // the partial sums are the ONLY data the workgroups exchange: agent-scope atomic stores / loads and a rendezvous
       // without cache maintenance (a fenced barrier is ~4 us even for two workgroups, most of a pass at small n)
-      B2Part* row = part + (size_t)np * G;
+      B2Part5* row = part + (size_t)np * G;
       if (t == 0) {
         spx_atomic_store_f64(&row[blockIdx.x].p, p);
         spx_atomic_store_f64(&row[blockIdx.x].c, c);
         if (first) spx_atomic_store_f64(&row[blockIdx.x].f, f);
+        if (r1 > 0.0) { spx_atomic_store_f64(&row[blockIdx.x].p1, p1); spx_atomic_store_f64(&row[blockIdx.x].c1, c1); }
       }
       spx_grid_rendezvous(bar, (++nbar) * (unsigned)G);
-      double pp = 0.0, cc = 0.0, ff = 0.0;
+      double pp = 0.0, cc = 0.0, ff = 0.0, pp1 = 0.0, cc1 = 0.0;
       if (t < G) {
         pp = spx_atomic_load_f64(&row[t].p);
         cc = spx_atomic_load_f64(&row[t].c);
         if (first) ff = spx_atomic_load_f64(&row[t].f);
+        if (r1 > 0.0) { pp1 = spx_atomic_load_f64(&row[t].p1); cc1 = spx_atomic_load_f64(&row[t].c1); }
       }
-      b2_block_sum3(pp, cc, ff, lds3);
-      P = pp; C = cc;
+      b2_block_sum5(pp, cc, ff, pp1, cc1, lds5);
+      P = pp; C = cc; P1 = pp1; C1 = cc1;
       if (first) F = ff;
     }
     ++np;
   };
-  // y = ProjB(-xk) (:59); chi(y) = chi_lambda ||y||: at r = 1, ||y||^2 = P + C
+  // ---- the sample's root (streaming form): same iteration, chi scaled by sqrt(n / 65536), nothing stored
+  double eta_s = -1.0;
+  if (!REG && n >= 65536 * 4) {
+    const double chis = chil * sqrt((double)n / 65536.0);
+    pass(1.0, 1.0, true, false, -1.0, true);
+    if (delta <= chis * sqrt(P + C)) {
+      double lo = delta, hi = INFINITY, pP = -1.0, pC = -1.0, eta = delta;
+      bool exact_step = false;
+      const double ub = chis * sqrt(F);
+      if (ub > delta && ub < INFINITY) { eta = ub; pass(eta / delta, 1.0, false, false, -1.0, true); }
+      for (int it = 0; it < 24; ++it) {
+        const double r = eta / delta;
+        const double f = eta - chis * sqrt(r * r * P + C);
+        if (f == 0.0 || (exact_step && P == pP && C == pC)) break;
+        if (f < 0.0) lo = eta; else hi = eta;
+        const double den = 1.0 - chis * chis * P / (delta * delta);
+        double next = (den > 0.0) ? chis * sqrt(C / den) : INFINITY;
+        exact_step = (next > lo && next < hi);
+        if (!exact_step) next = (hi == INFINITY) ? 2.0 * lo : 0.5 * (lo + hi);
+        if (!(next > lo && next < hi)) break;
+        if (fabs(next - eta) <= 1e-6 * next) { eta = next; break; }  // far below the sample's own statistical error
+        pP = P; pC = C; eta = next;
+        pass(eta / delta, 1.0, false, false, -1.0, true);
+      }
+      if (eta > delta && eta < INFINITY) eta_s = eta;
+    }
+  }
+  // ---- y = ProjB(-xk) (:59); chi(y) = chi_lambda ||y||: at r = 1, ||y||^2 = P + C.  The sample's root rides along.
   const bool store_first = can_spec && !last_scaled;
-  pass(1.0, 1.0, true, store_first);
+  pass(1.0, 1.0, true, store_first, eta_s > 0.0 ? eta_s / delta : -1.0, false);
   const double chiy = chil * sqrt(P + C);
   const bool scaled = delta <= chiy;  // :61
   if (blockIdx.x == 0 && t == 0) hdr->b2_last_scaled = scaled ? 1 : 0;
@@ -380,12 +429,21 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
     double lo = delta, hi = INFINITY, pP = -1.0, pC = -1.0;
     bool exact_step = false;
     double y_eta = -1.0;
+    double prev_step = -1.0;  // relative size of the previous exact step (for the quadratic-convergence estimate)
     const double eta_ub = chil * sqrt(F);
-    if (eta_ub > delta && eta_ub < INFINITY) {
-      eta = eta_ub;
-      pass(eta / delta, 1.0, false, false);
+    const bool ub_ok = eta_ub > delta && eta_ub < INFINITY;
+    bool have_eval = false;
+    if (eta_s > 0.0 && ub_ok && eta_s < eta_ub) {
+      // the second trial of the first pass IS an evaluation at eta_s; froot(eta_ub) >= 0 is known without evaluating it
+      hi = eta_ub;
+      eta = eta_s; P = P1; C = C1;
+      have_eval = true;
     }
-    for (int it = 0; it < kB2MaxPass - 4; ++it) {
+    if (!have_eval && ub_ok) {
+      eta = eta_ub;
+      pass(eta / delta, 1.0, false, false, -1.0, false);
+    }
+    for (int it = 0; it < kB2MaxPass - 34; ++it) {
       const double r = eta / delta;
       const double f = eta - chil * sqrt(r * r * P + C);
       if (f == 0.0 || (exact_step && P == pP && C == pC)) break;
@@ -395,19 +453,32 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
       exact_step = (next > lo && next < hi);
       if (!exact_step) next = (hi == INFINITY) ? 2.0 * lo : 0.5 * (lo + hi);
       if (!(next > lo && next < hi)) break;
-      if (fabs(next - eta) <= 4e-16 * next) break;
-      // The piece roots converge quadratically (measured steps 4e-2, 1e-4, 6e-10: error(next) ~ 0.06 step^2), and a breakpoint
-      // between eta and the root changes the root only to second order (the pieces join continuously).  A step below 1e-8
-      // therefore leaves `next` within ~1e-16 of the root: it is taken as it is, without the pass that would only confirm it.
-      if (exact_step && fabs(next - eta) <= 1e-8 * next) { eta = next; y_eta = -1.0; break; }
-      const bool spec = can_spec && fabs(next - eta) <= 1e-3 * next;
+      const double step = fabs(next - eta) / next;
+      if (step <= 4e-16) break;
+      // The piece roots converge quadratically (measured steps 4e-2, 1e-4, 6e-10: error(next) ~ K step^2 with K ~ 0.06), and a
+      // breakpoint between eta and the root changes the root only to second order (the pieces join continuously).  With the
+      // constant measured on the spot, K = step / prev_step^2 (capped at 1e3), `next` is taken without the pass that would only
+      // confirm it as soon as K step^2 <= 2e-13 (a fifth of the 1e-12 bar); without a previous step only below 1e-8.
+      bool done = false;
+      if (exact_step) {
+        if (prev_step > 0.0) {
+          double K = step / (prev_step * prev_step);
+          if (!(K < 1e3)) K = 1e3;
+          done = step <= 1e-4 && K * step * step <= 2e-13;
+        } else {
+          done = step <= 1e-8;
+        }
+      }
+      if (done) { eta = next; y_eta = -1.0; break; }
+      prev_step = exact_step ? step : -1.0;
+      const bool spec = can_spec && step <= 1e-9;  // (a step this small is normally taken without a pass: see above)
       pP = P; pC = C; eta = next;
-      pass(eta / delta, delta / eta, false, spec);
+      pass(eta / delta, delta / eta, false, spec, -1.0, false);
       y_eta = spec ? eta : -1.0;
     }
     stored = (y_eta == eta);
   }
-  if (stored) return;  // (after the last barrier; every workgroup takes the same path)
+  if (stored) return;  // (after the last rendezvous; every workgroup takes the same path)
   // final: y = ProjB((-xk) r) rinv - sj   (:63, :65), or ProjB(-xk) - sj (:59) when the trust region is inactive
   const double r = scaled ? eta / delta : 1.0, rinv = scaled ? delta / eta : 1.0;
   auto out = [&](double sq, double x, double s) -> double {
@@ -516,13 +587,13 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
     int64_t g = reg ? (n + (int64_t)kB2Epl * 1024 - 1) / ((int64_t)kB2Epl * 1024) : ctx->num_cu;
     if (g > ctx->num_cu) g = ctx->num_cu;
     if (g < 1) g = 1;
-    rc = spx_ws_reserve(ctx, sizeof(B2Part) * (size_t)kB2MaxPass * (size_t)g + 256);
+    rc = spx_ws_reserve(ctx, sizeof(B2Part5) * (size_t)kB2MaxPass * (size_t)g + 256);
     if (rc) return rc;
     rc = spx_sync_reserve(ctx, sizeof(SpxSyncHeader));
     if (rc) return rc;
     auto disjoint = [&](const double* a) { return (y + n <= a) || (a + n <= y); };
     const int can_spec = (disjoint(q) && disjoint(xk) && disjoint(sj)) ? 1 : 0;
-    B2Part* part = reinterpret_cast<B2Part*>(ctx->ws);
+    B2Part5* part = reinterpret_cast<B2Part5*>(ctx->ws);
     SpxSyncHeader* hdr = reinterpret_cast<SpxSyncHeader*>(ctx->sync);
     {
       SpxCoopLaunchGuard guard(ctx);
