@@ -308,20 +308,33 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
   // store: also y = ProjB((-xk) r) rinv - sj for scale r.  sample: over the sample registers instead of the vectors.
   auto pass = [&](double r, double rinv, bool first, bool store, double r1, bool sample) {
     double p = 0.0, c = 0.0, f = 0.0, p1 = 0.0, c1 = 0.0;
+    // The sums take v_max_f64 / v_min_f64 and masked fma operands (the Julia-semantics min / max cost six instructions each
+    // and matter only for the bits of a STORED y: signed zeros, NaN propagation); a NaN operand -- which v_max / v_min would
+    // drop -- is tracked separately and poisons P, as the reference's norm would be NaN.
+    bool bad = false;
     auto visit = [&](double sq, double x, double s) -> double {
       const double lo = sq - ls, hi = sq + ls;
       const double z = (-x) * r;
-      const double pz = jl_min(jl_max(z, lo), hi);
-      if (pz == z) p += x * x; else c += pz * pz;
+      bad |= (z != z) | (sq != sq);
+      const double pzf = fmin(fmax(z, lo), hi);
+      const bool un = (pzf == z);
+      const double xm = un ? x : 0.0, cm = un ? 0.0 : pzf;
+      p = __builtin_fma(xm, xm, p);
+      c = __builtin_fma(cm, cm, c);
       if (first) {
-        const double far = (x < 0.0) ? hi : (x > 0.0) ? lo : pz;
-        f += far * far;
+        const double far = (x < 0.0) ? hi : (x > 0.0) ? lo : pzf;
+        f = __builtin_fma(far, far, f);
       }
       if (r1 > 0.0) {
         const double z1 = (-x) * r1;
-        const double pz1 = jl_min(jl_max(z1, lo), hi);
-        if (pz1 == z1) p1 += x * x; else c1 += pz1 * pz1;
+        const double pz1 = fmin(fmax(z1, lo), hi);
+        const bool un1 = (pz1 == z1);
+        const double xm1 = un1 ? x : 0.0, cm1 = un1 ? 0.0 : pz1;
+        p1 = __builtin_fma(xm1, xm1, p1);
+        c1 = __builtin_fma(cm1, cm1, c1);
       }
+      if (!store) return 0.0;
+      const double pz = jl_min(jl_max(z, lo), hi);  // :56, bit-faithful for the stored value
       return pz * rinv - s;
     };
     if (sample) {
@@ -336,32 +349,53 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
         }
       }
     } else {
-      const int64_t ntiles = (n2 + 4095) / 4096;  // 1024 lanes x 4 pairs
-      for (int64_t tile = blockIdx.x; tile < ntiles; tile += G) {
-        const int64_t base = tile * 4096 + t;
-        f64x2 a[4], b[4], d[4];
+      // software-pipelined stream: the loads of the next tile are issued before the current one is evaluated (two register
+      // sets of 2 x 16-byte pairs per vector, ping-pong); a persistent lane otherwise serialises load latency and arithmetic
+      constexpr int KP = 2;
+      constexpr int64_t kTilePairs = 1024 * KP;
+      const int64_t ntiles = (n2 + kTilePairs - 1) / kTilePairs;
+      auto ld = [&](int64_t tile, f64x2* a, f64x2* b, f64x2* d) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int64_t i = (base + k * 1024 < n2) ? base + k * 1024 : n2 - 1;
+        for (int k = 0; k < KP; ++k) {
+          int64_t i = tile * kTilePairs + t + k * 1024;
+          if (i >= n2) i = n2 - 1;
           a[k] = __builtin_nontemporal_load(q2 + i);
           b[k] = __builtin_nontemporal_load(x2 + i);
           d[k] = __builtin_nontemporal_load(s2 + i);
         }
+      };
+      auto comp = [&](int64_t tile, const f64x2* a, const f64x2* b, const f64x2* d) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (base + k * 1024 < n2) {
+        for (int k = 0; k < KP; ++k) {
+          const int64_t i = tile * kTilePairs + t + k * 1024;
+          if (i < n2) {
             f64x2 o;
             o.x = visit(d[k].x + a[k].x, b[k].x, d[k].x);
             o.y = visit(d[k].y + a[k].y, b[k].y, d[k].y);
-            if (store) __builtin_nontemporal_store(o, y2 + base + k * 1024);
+            if (store) __builtin_nontemporal_store(o, y2 + i);
           }
         }
+      };
+      f64x2 a0[KP], b0[KP], d0[KP], a1[KP], b1[KP], d1[KP];
+      int64_t tile = blockIdx.x;
+      if (tile < ntiles) ld(tile, a0, b0, d0);
+      while (tile < ntiles) {
+        const int64_t t1 = tile + G;
+        if (t1 < ntiles) ld(t1, a1, b1, d1);
+        comp(tile, a0, b0, d0);
+        const int64_t t2 = t1 + G;
+        if (t1 < ntiles) {
+          if (t2 < ntiles) ld(t2, a0, b0, d0);
+          comp(t1, a1, b1, d1);
+        }
+        tile = t2;
       }
       if ((n & 1) && blockIdx.x == 0 && t == 0) {
         const double o = visit(sj[n - 1] + q[n - 1], xk[n - 1], sj[n - 1]);
         if (store) y[n - 1] = o;
       }
     }
+    if (bad) p = __longlong_as_double(0x7ff8000000000000ll);
     b2_block_sum5(p, c, f, p1, c1, lds5);
     if (G == 1) {  // one workgroup holds the whole vector: nothing to exchange
       P = p; C = c; P1 = p1; C1 = c1;
