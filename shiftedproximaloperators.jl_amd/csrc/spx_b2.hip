@@ -257,9 +257,9 @@ __device__ __forceinline__ void b2_block_sum5(double& a, double& b, double& c, d
   a = t0; b = t1; c = t2; d = t3; e = t4;
 }
 
-// REG: n <= kB2Epl * 1024 * grid, the vectors in registers.  !REG (streaming): additionally a SAMPLE of 65 536 elements
-// (256 chunks of 256, one element per lane of the first 64 workgroups, kept in registers) is solved first -- a handful of
-// rendezvous, no streaming -- and its root eta_s (good to ~1/sqrt(65536) = 4e-3) rides along as a SECOND TRIAL in the first
+// REG: n <= kB2Epl * 1024 * grid, the vectors in registers.  !REG (streaming): additionally a SAMPLE of one element per lane
+// of the grid (1024 chunks of 256 = 262 144 elements on 256 CUs, kept in registers) is solved first -- a handful of
+// rendezvous, no streaming -- and its root eta_s (good to ~1/sqrt(262144) = 2e-3) rides along as a SECOND TRIAL in the first
 // streaming pass (the loads dominate: two sets of sums cost nothing).  The piece root of that trial is then ~1e-6 from the
 // root, one more reduction pass brings ~1e-13, and the storing pass follows: 24 + 24 + 32 = 80 B/element instead of
 // 4 x 24 + 32 = 128 when the iteration starts from the a-priori bound (which stays the fallback whenever the sample
@@ -288,10 +288,12 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
       SQ[k] = in ? (S[k] + q[i]) : 0.0;   // `sj .+ q` (:56)
     }
   }
-  // the sample (streaming form only): chunk c = 4 * workgroup + (t >> 8) of 256, element t & 255 of it
-  constexpr int kChunks = 256;
+  // the sample (streaming form only): one element per lane of the grid -- chunk c = 4 * workgroup + (t >> 8) of 4 G chunks
+  // of 256 consecutive elements, element t & 255 of it (262 144 elements on 256 CUs: statistical error of its root ~2e-3)
+  const int kChunks = 4 * G;
   const int chunk = (int)blockIdx.x * 4 + (t >> 8);
-  const bool has_sample = !REG && chunk < kChunks && n >= 65536 * 4;
+  const int64_t nsample = (int64_t)kChunks * 256;
+  const bool has_sample = !REG && n >= 4 * nsample;
   double sx = 0.0, ss = 0.0, ssq = 0.0;
   if (has_sample) {
     const int64_t i = (int64_t)((double)chunk * (double)(n - 256) / (double)(kChunks - 1)) + (t & 255);
@@ -426,8 +428,8 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
   };
   // ---- the sample's root (streaming form): same iteration, chi scaled by sqrt(n / 65536), nothing stored
   double eta_s = -1.0;
-  if (!REG && n >= 65536 * 4) {
-    const double chis = chil * sqrt((double)n / 65536.0);
+  if (has_sample) {
+    const double chis = chil * sqrt((double)n / (double)nsample);
     pass(1.0, 1.0, true, false, -1.0, true);
     if (delta <= chis * sqrt(P + C)) {
       double lo = delta, hi = INFINITY, pP = -1.0, pC = -1.0, eta = delta;
@@ -462,6 +464,7 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
   if (scaled) {
     double lo = delta, hi = INFINITY, pP = -1.0, pC = -1.0;
     bool exact_step = false;
+    bool hi_closed = false;   // hi is the a-priori bound, NOT evaluated: froot(hi) >= 0, possibly = 0 (x = 0: the bound IS the root)
     double y_eta = -1.0;
     double prev_step = -1.0;  // relative size of the previous exact step (for the quadratic-convergence estimate)
     const double eta_ub = chil * sqrt(F);
@@ -470,6 +473,7 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
     if (eta_s > 0.0 && ub_ok && eta_s < eta_ub) {
       // the second trial of the first pass IS an evaluation at eta_s; froot(eta_ub) >= 0 is known without evaluating it
       hi = eta_ub;
+      hi_closed = true;
       eta = eta_s; P = P1; C = C1;
       have_eval = true;
     }
@@ -481,12 +485,12 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
       const double r = eta / delta;
       const double f = eta - chil * sqrt(r * r * P + C);
       if (f == 0.0 || (exact_step && P == pP && C == pC)) break;
-      if (f < 0.0) lo = eta; else hi = eta;
+      if (f < 0.0) lo = eta; else { hi = eta; hi_closed = false; }
       const double den = 1.0 - chil * chil * P / (delta * delta);
       double next = (den > 0.0) ? chil * sqrt(C / den) : INFINITY;
-      exact_step = (next > lo && next < hi);
+      exact_step = (next > lo && (next < hi || (hi_closed && next == hi)));
       if (!exact_step) next = (hi == INFINITY) ? 2.0 * lo : 0.5 * (lo + hi);
-      if (!(next > lo && next < hi)) break;
+      if (!(next > lo && (next < hi || (hi_closed && next == hi)))) break;
       const double step = fabs(next - eta) / next;
       if (step <= 4e-16) break;
       // The piece roots converge quadratically (measured steps 4e-2, 1e-4, 6e-10: error(next) ~ K step^2 with K ~ 0.06), and a
