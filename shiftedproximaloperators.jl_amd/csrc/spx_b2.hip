@@ -452,6 +452,9 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
       }
       if (eta > delta && eta < INFINITY) eta_s = eta;
     }
+#ifdef SPX_B2_DEBUG
+    if (blockIdx.x == 0 && t == 0) printf("[b2] sample: chis %.17g P %.6g C %.6g F %.6g eta_s %.17g np %d\n", chis, P, C, F, eta_s, np);
+#endif
   }
   // ---- y = ProjB(-xk) (:59); chi(y) = chi_lambda ||y||: at r = 1, ||y||^2 = P + C.  The sample's root rides along.
   const bool store_first = can_spec && !last_scaled;
@@ -484,6 +487,9 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
     for (int it = 0; it < kB2MaxPass - 34; ++it) {
       const double r = eta / delta;
       const double f = eta - chil * sqrt(r * r * P + C);
+#ifdef SPX_B2_DEBUG
+      if (blockIdx.x == 0 && t == 0) printf("[b2] it %d eta %.17g P %.6g C %.17g f %.6g lo %.17g hi %.17g closed %d ub %.17g\n", it, eta, P, C, f, lo, hi, (int)hi_closed, eta_ub);
+#endif
       if (f == 0.0 || (exact_step && P == pP && C == pC)) break;
       if (f < 0.0) lo = eta; else { hi = eta; hi_closed = false; }
       const double den = 1.0 - chil * chil * P / (delta * delta);
@@ -519,6 +525,9 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
   if (stored) return;  // (after the last rendezvous; every workgroup takes the same path)
   // final: y = ProjB((-xk) r) rinv - sj   (:63, :65), or ProjB(-xk) - sj (:59) when the trust region is inactive
   const double r = scaled ? eta / delta : 1.0, rinv = scaled ? delta / eta : 1.0;
+#ifdef SPX_B2_DEBUG
+  if (blockIdx.x == 0 && t == 0) printf("[b2] final: scaled %d eta %.17g r %.6g rinv %.6g stored %d G %d n2 %lld\n", (int)scaled, eta, r, rinv, (int)stored, G, (long long)n2);
+#endif
   auto out = [&](double sq, double x, double s) -> double {
     const double lo = sq - ls, hi = sq + ls;
     const double tt = scaled ? jl_min(jl_max((-x) * r, lo), hi) * rinv : jl_min(jl_max(-x, lo), hi);
@@ -531,21 +540,28 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
       if (i < n) y[i] = out(SQ[k], X[k], S[k]);
     }
   } else {
-    const int64_t ntiles = (n2 + 4095) / 4096;
+    // The SAME element -> lane mapping as the reduction passes (tiles of 1024 lanes x 2 pairs, workgroup-strided): a pass may
+    // have stored y speculatively, and two stores to one address are ordered only when the same lane issues them -- the
+    // rendezvous between the passes does no cache maintenance, so a stale line of another XCD's L2 could otherwise land last
+    // (seen: 256 wrong elements at n = 2.3e6 when this loop used tiles of 4 pairs).
+    constexpr int KP = 2;
+    constexpr int64_t kTilePairs = 1024 * KP;
+    const int64_t ntiles = (n2 + kTilePairs - 1) / kTilePairs;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += G) {
-      const int64_t base = tile * 4096 + t;
-      f64x2 a[4], b[4], d[4];
+      f64x2 a[KP], b[KP], d[KP];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int64_t i = (base + k * 1024 < n2) ? base + k * 1024 : n2 - 1;
+      for (int k = 0; k < KP; ++k) {
+        int64_t i = tile * kTilePairs + t + k * 1024;
+        if (i >= n2) i = n2 - 1;
         a[k] = __builtin_nontemporal_load(q2 + i);
         b[k] = __builtin_nontemporal_load(x2 + i);
         d[k] = __builtin_nontemporal_load(s2 + i);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (base + k * 1024 < n2)
-          __builtin_nontemporal_store(f64x2{out(d[k].x + a[k].x, b[k].x, d[k].x), out(d[k].y + a[k].y, b[k].y, d[k].y)}, y2 + base + k * 1024);
+      for (int k = 0; k < KP; ++k) {
+        const int64_t i = tile * kTilePairs + t + k * 1024;
+        if (i < n2)
+          __builtin_nontemporal_store(f64x2{out(d[k].x + a[k].x, b[k].x, d[k].x), out(d[k].y + a[k].y, b[k].y, d[k].y)}, y2 + i);
       }
     }
     if ((n & 1) && blockIdx.x == 0 && t == 0) y[n - 1] = out(sj[n - 1] + q[n - 1], xk[n - 1], sj[n - 1]);

@@ -246,3 +246,31 @@ def test_lattice_separable_b2_topr(s, orc, seed):
             y = s.prox(s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(1.0)), sd), qd, sigma).cpu().numpy()
             ref = orc.prox_l1_b2(q, x, sj, lam, sigma, delta, 1.0)
             assert np.max(np.abs(y - ref)) <= 1e-12 * max(np.linalg.norm(ref), np.linalg.norm(x), 1.0), ("b2", seed, rep)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ShiftedNormL1B2, streaming form of the one-launch kernel (n > 2^21: csrc/spx_b2.hip k_b2_coop<false>): the sample's root as
+# a second trial of the first pass, the bracket closed at the unevaluated a-priori bound (x = 0: the bound IS the root --
+# a version without that bisected for 30 passes), the quadratic stopping rule.  Against the Float64 oracle, 1e-12 of the norms.
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["normal", "x=0", "lattice8", "q*0.01", "x*0.05", "sparse_x"])
+def test_b2_streaming_form_scenarios(s, orc, kind):
+    rng = np.random.default_rng(sum(map(ord, kind)))
+    n = 2_300_001
+    x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
+    if kind == "x=0": x[:] = 0.0; sj[:] = 0.0
+    elif kind == "lattice8": x, sj, q = (np.round(v * 8) / 8 for v in (x, sj, q))
+    elif kind == "q*0.01": q *= 0.01
+    elif kind == "x*0.05": x *= 0.05
+    elif kind == "sparse_x": x[rng.random(n) < 0.9] = 0.0
+    xd, sd, qd = _dev(x, sj, q)
+    for lam, delta in ((0.01, 1e-3), (1.0, 1.0), (30.0, 1.0), (1.0, 1000.0), (0.01, 1e6)):
+        with np.errstate(all="ignore"):
+            ref = orc.prox_l1_b2(q, x, sj, lam, 1.0, delta, 1.0)
+        y = s.prox(s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(1.0)), sd), qd, 1.0).cpu().numpy()
+        scale = max(np.linalg.norm(ref), np.linalg.norm(x), np.linalg.norm(sj + q), 1e-300)
+        assert float(np.max(np.abs(y - ref))) <= 1e-12 * scale, (kind, lam, delta, float(np.max(np.abs(y - ref))) / scale)
+        # y === q (no speculative stores, the final pass reads q before it writes y)
+        q2 = qd.clone()
+        s.prox_bang(q2, s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(1.0)), sd), q2, 1.0)
+        assert float(np.max(np.abs(q2.cpu().numpy() - ref))) <= 1e-12 * scale, (kind, lam, delta, "aliased")
