@@ -1,5 +1,5 @@
 /*
- * spx.h -- C ABI of libspx: MI355X (gfx950) shifted proximal operators, fp64.
+ * spx.h -- C ABI of libspx: MI355X (gfx950) shifted proximal operators, fp64 (NormL1 / NormL0 families also fp32).
  *
  * This is the drop-in boundary for the prox!() hot path of ShiftedProximalOperators.jl v0.2.2
  * (reference paths below are relative to the reference repository).  In the reference the path sits
@@ -18,16 +18,23 @@
  *   - `y` may alias `q` exactly (test/test_allocs.jl:108-113) and may be the operator's own `sol`
  *     (prox(), src/ShiftedProximalOperators.jl:189-190).  Partial overlap is undefined.
  *   - Calls are asynchronous on the context's HIP stream and ordered on it; spx_sync() waits.  Exceptions
- *     (they return a value or a verdict to the host and therefore synchronise): spx_check_bounds, spx_obj_*,
- *     the unboxed spx_iprox_* with check_d != 0, the top-r operators (one 4-byte read-back per call),
- *     spx_prox_l1_b2 (one read-back per reduction pass), the gather-index group forms (index validation) and
- *     every spx_host_* form.
+ *     (they return a value or a verdict to the host and therefore synchronise): spx_check_bounds, spx_obj_* and
+ *     spx_proxval_* unless the context has a device value target (spx_ctx_set_value_target), the unboxed
+ *     spx_iprox_* with check_d != 0, the gather-index group forms (index validation) and every spx_host_* form.
+ *     (Since round 2 the top-r operators and spx_prox_l1_b2 read nothing back.)
  *     A context is not re-entrant (neither is a reference psi: shared scratch sol/xsy/p).
  *   - Return value: 0 = SPX_OK, else an spx_status; spx_last_error() gives a thread-local message.
  *   - Indices handed over in arrays (selected sets, group offsets) are 0-BASED int64.
  *   - Floating-point semantics: no FMA contraction, reference operation order; min/max follow
- *     Julia (IEEE-754-2019 minimum/maximum).  L1/L0 families and the IndBallL0 selection are
- *     bit-exact w.r.t. the reference formulas; Lhalf and group-L2 families agree to <= 1e-12 relative.
+ *     Julia (IEEE-754-2019 minimum/maximum).  L1/L0 families and the IndBallL0 selection are bit-exact w.r.t. the
+ *     reference FORMULAS as restated in oracle/spx_oracle.c; Lhalf and group-L2 families agree with that restatement
+ *     to <= 1e-12 (operand-scale relative), and where the reference's own Float64 evaluation is further than that from
+ *     the exact value of its formula (roots next to the pole of step(n)) they are the closer side (binary128 arbiter,
+ *     tests/arbiter.py).  What the reference's own tests pin: the Box operators, RootNormLhalf (unshifted) and
+ *     GroupNormL2(Binf) (golden vectors, test/runtests.jl:113-126,449-494,587-606,658-705, test/testsbox.jl).  PARITY
+ *     UNPINNED by reference vectors (its tests say `# test prox # TODO`, runtests.jl:179-180,382-383,772-773): unboxed
+ *     ShiftedNormL0 / L1 / RootNormLhalf, ShiftedIndBallL0(BInf) incl. the sortperm tie-break, and every Float32 form --
+ *     for these "bit-exact" means: against the literal restatement of the source text.
  */
 #ifndef SPX_H
 #define SPX_H
