@@ -94,3 +94,37 @@ def test_no_gpu_means_loud_failure(s):
     psi = s.shifted(s.NormL1(1.0), np.ones(4))
     with pytest.raises(Exception):
         s.prox(psi, np.ones(4), 1.0)                                     # host vectors are staged through a GPU: none here
+
+
+def test_build_fails_loudly_on_a_stale_library_without_a_compiler(tmp_path, monkeypatch):
+    """build() must rebuild when a source is newer than the shipped libspx.so -- and raise, not run the old
+    binary, when there is no hipcc to rebuild with."""
+    import os
+    import time
+    import __graft_entry__ as ge
+    lib = os.path.join(ge.PKG, "lib", "libspx.so")
+    if not os.path.exists(lib):
+        pytest.skip("libspx.so not built yet")
+    src = os.path.join(ge.PKG, "csrc", "spx_common.hpp")
+    st = os.stat(src)
+    monkeypatch.setenv("HIPCC", str(tmp_path / "no_such_hipcc"))
+    monkeypatch.delenv("SPX_NO_BUILD", raising=False)
+    try:
+        os.utime(src, (time.time() + 5, time.time() + 5))      # the source is now newer than the library
+        with pytest.raises(RuntimeError, match="no hipcc"):
+            ge.build(with_oracle=False)
+    finally:
+        os.utime(src, (st.st_atime, st.st_mtime))
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    """`--gpus` used to be parsed and ignored.  Under a launcher whose WORLD_SIZE differs it now exits non-zero
+    (before anything touches the GPU); without a launcher and --gpus > 1 it starts the ranks itself (GPU box only)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)
