@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 BYTES_PER_ELEM = 32    # read q, xk, sj + write y (scalar bounds, no mask)
+SYNTH_SEED = 20250613  # spx_synth_fill seed (+ rank); streams: 0 = xk, 1 = sj, 2 = q
 
 
 def main():
@@ -83,13 +84,15 @@ def main():
     L = s._lib.load()
 
     n = args.n
-    gen = torch.Generator(device=dev).manual_seed(20250613 + rank)
-    xk = torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
-    sj = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) - 0.5
-    q = torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
+    # SURVEY 8d's shared generator: spx_synth_fill(seed, stream, kind) on the device; the cpu_baseline leg regenerates the
+    # same bits on the host (oracle.synth_fill) instead of copying them back
+    ctx = s.context(dev)
+    seed = SYNTH_SEED + rank
+    xk, sj, q = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
+    for t, stream, kind in ((xk, 0, 1), (sj, 1, 0), (q, 2, 1)):
+        s._lib.check(L.spx_synth_fill(ctx, ctypes.c_void_p(t.data_ptr()), n, seed, stream, kind, 1.0))
     y = torch.empty_like(q)
     psi = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, s.NormLinf(1.0)), sj)
-    ctx = s.context(dev)
 
     def barrier():
         if world > 1:
@@ -141,9 +144,9 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic (torch Philox on the device, seed 20250613 + rank: xk ~ N(0,1), sj ~ U(-1/2,1/2), q ~ N(0,1); the CPU "
-                "oracle is given copies of the device arrays -- SURVEY 8d's shared counter-based host/device generator is "
-                "not implemented)",
+        "data": "synthetic (spx_synth_fill: counter-based splitmix64 generator, seed %d + rank, streams 0/1/2: xk ~ N(0,1) "
+                "[Irwin-Hall of 12], sj ~ U(-1/2,1/2), q ~ N(0,1); the CPU leg regenerates the same bits on the host and checks "
+                "them against the device arrays by checksum; other_operators draw from torch's Philox)" % SYNTH_SEED,
         "config": {"workload": "ShiftedNormL1Box prox!, n=%d fp64 per GPU, Delta=1.0 scalar bounds, all selected, "
                                "twice shifted, lambda=sigma=1 (BASELINE configs[1])" % n,
                    "elements_per_gpu": n, "parallelism": "replicas (independent shards, no collective)"},
@@ -349,7 +352,11 @@ def _cpu_baseline(s, psi, q, xk, sj, y, n, torch):
     from oracle import oracle
     import numpy as np
     m = min(n, 100_000_000)
-    qh, xh, sh = (t[:m].cpu().numpy() for t in (q, xk, sj))
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    xh, sh, qh = (oracle.synth_fill(m, SYNTH_SEED, stream, kind, 1.0, ncpu) for stream, kind in ((0, 1), (1, 0), (2, 1)))
+    with np.errstate(over="ignore"):  # wrap-around sum of the bit patterns, host vs device: same inputs without a copy
+        inputs_match = all(int(h.view(np.int64).sum()) == int(t[:m].view(torch.int64).sum())
+                           for h, t in ((xh, xk), (sh, sj), (qh, q)))
     best = None
     reps = 0
     t_all = time.perf_counter()
@@ -362,7 +369,6 @@ def _cpu_baseline(s, psi, q, xk, sj, y, n, torch):
     s.prox_bang(y, psi, q, 1.0)
     same = bool(np.array_equal(y[:m].cpu().numpy().view(np.int64), ref.view(np.int64)))
     # all host cores on the same loop (OpenMP chunks): NOT the reference, which is single-threaded -- an upper bound for the CPU
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     out_mt = np.empty_like(ref)
     best_mt = None
     for _ in range(3):
@@ -377,7 +383,7 @@ def _cpu_baseline(s, psi, q, xk, sj, y, n, torch):
             "host_cores_available": os.cpu_count(),
             "sample": "first %d elements of the same workload, best of %d runs (%.2f s each)" % (m, reps, best),
             "note": "reference (Julia) cannot run in this image; port = oracle/spx_oracle.c, gcc -O2 -ffp-contract=off",
-            "gpu_bit_exact_on_sample": same}
+            "inputs_regenerated_on_host_match_device": inputs_match, "gpu_bit_exact_on_sample": same}
 
 
 def _cpu_other_configs():

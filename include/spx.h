@@ -79,6 +79,11 @@ int spx_sync(spx_ctx* ctx);
  * value is NaN then.)  Mirrors no reference function: psi(y) in the reference returns a host Float64
  * (src/ShiftedProximalOperators.jl:51-54); this is the asynchronous form of the same value. */
 int spx_ctx_set_value_target(spx_ctx* ctx, double* device_value);
+/* Synthetic benchmark / test inputs: out[i] = scale * value(seed, stream, i) from a counter-based generator
+ * (splitmix64, integer arithmetic and exact binary64 additions only) that the checker's synth.py reproduces on the host bit for
+ * bit, so a CPU check needs no copy of the device data and no torch.  kind 0: U(-1/2, 1/2); kind 1: ~N(0, 1) as the sum of
+ * 12 uniforms minus 6 (Irwin-Hall).  Not part of the reference's interface. */
+int spx_synth_fill(spx_ctx* ctx, double* out, int64_t n, uint64_t seed, uint64_t stream, int kind, double scale);
 /* HIP-event stopwatch on the context's stream (used by bench.py for per-launch durations). */
 int spx_timer_start(spx_ctx* ctx);
 int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms); /* records stop, waits, returns milliseconds */

@@ -85,6 +85,9 @@ def lib():
         L.orc_rootnormlhalf_prox.restype = d
         L.orc_prox_l1_box_mt.argtypes = box + [ctypes.c_int]
         L.orc_prox_l1_box_mt.restype = None
+        L.orc_synth_fill.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int,
+                                     ctypes.c_double, ctypes.c_int]
+        L.orc_synth_fill.restype = None
         L.orc_set_perturbation.argtypes = [ctypes.c_int, ctypes.c_int]
         L.orc_set_perturbation.restype = None
         for name in ("orc_prox_l1", "orc_prox_l0", "orc_prox_lhalf", "orc_prox_l1_box", "orc_prox_l0_box",
@@ -198,6 +201,13 @@ def prox_l1_box_mt(q, xk, sj, lam, sigma, l, u, threads, mask=None, out=None):
     m, mp = _mask(mask, n)
     lib().orc_prox_l1_box_mt(_dp(y), _dp(q), _dp(xk), _dp(sj), n, lam, sigma, _dp(lv), _dp(uv), ls, us, mp, int(threads))
     return y
+
+
+def synth_fill(n, seed, stream, kind, scale=1.0, threads=1):
+    """host twin of the library's spx_synth_fill (C; oracle/synth.py is the same thing in numpy)"""
+    out = np.empty(int(n), dtype=np.float64)
+    lib().orc_synth_fill(_dp(out), int(n), int(seed), int(stream), int(kind), float(scale), int(threads))
+    return out
 
 
 def prox_l0_box(q, xk, sj, lam, sigma, l, u, mask=None):

@@ -892,3 +892,32 @@ ORC_API double orc_obj_l1_b2(const double* y, const double* xk, const double* sj
 }
 
 ORC_API int orc_abi_version(void) { return 4; }
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic inputs: host twin of the library's spx_synth_fill -- splitmix64 of a counter keyed by
+ * (seed, stream), integer arithmetic and exact binary64 additions only, so host and device agree bit for bit.
+ * kind 0: U(-1/2, 1/2); kind 1: ~N(0, 1) as the sum of 12 uniforms on [0, 1) minus 6.  Not in the reference: benchmark and
+ * test plumbing (the reference's tests draw from Julia's RNG).
+ * ------------------------------------------------------------------------------------------ */
+static uint64_t orc_splitmix64(uint64_t x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+ORC_API void orc_synth_fill(double* out, int64_t n, uint64_t seed, uint64_t stream, int kind, double scale, int threads) {
+  const uint64_t key = orc_splitmix64(seed ^ (stream * 0xd1342543de82ef95ull));
+  if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    double v;
+    if (kind == 0) {
+      v = (double)(orc_splitmix64(key + (uint64_t)i) >> 11) * 0x1.0p-53 - 0.5;
+    } else {
+      double acc = 0.0;
+      for (int k = 0; k < 12; ++k) acc += (double)(orc_splitmix64(key + (uint64_t)i * 12ull + (uint64_t)k) >> 11) * 0x1.0p-53;
+      v = acc - 6.0;
+    }
+    out[i] = scale * v;
+  }
+}

@@ -260,3 +260,48 @@ SPX_EXPORT int spx_build_mask(spx_ctx* ctx, uint8_t* mask, int64_t n, const int6
   }
   return SPX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic inputs: a counter-based generator keyed by (seed, stream, i) that the host can reproduce
+// bit for bit WITHOUT a GPU or torch (the checker's synth.py, numpy): splitmix64 of the counter, integer arithmetic and exact
+// binary64 additions only -- no libm call whose last ulp differs between host and device.
+//   kind 0: U(-1/2, 1/2)   = (top 53 bits of one draw) * 2^-53 - 1/2
+//   kind 1: ~N(0, 1)       = sum of 12 such uniforms on [0, 1) minus 6 (Irwin-Hall: mean 0, variance 1, support +-6; every
+//                            partial sum is a multiple of 2^-53 below 16, so the additions are exact in any order)
+// out[i] = scale * value(i).  Benchmark / test plumbing, not part of the reference's interface.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t spx_splitmix64(uint64_t x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void k_synth_fill(double* out, int64_t n, uint64_t seed, uint64_t stream, int kind,
+                                                     double scale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const uint64_t key = spx_splitmix64(seed ^ (stream * 0xd1342543de82ef95ull));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double v;
+    if (kind == 0) {
+      v = (double)(spx_splitmix64(key + (uint64_t)i) >> 11) * 0x1.0p-53 - 0.5;
+    } else {
+      double acc = 0.0;
+      for (int k = 0; k < 12; ++k) acc += (double)(spx_splitmix64(key + (uint64_t)i * 12ull + (uint64_t)k) >> 11) * 0x1.0p-53;
+      v = acc - 6.0;
+    }
+    out[i] = scale * v;
+  }
+}
+
+SPX_EXPORT int spx_synth_fill(spx_ctx* ctx, double* out, int64_t n, uint64_t seed, uint64_t stream, int kind, double scale) {
+  SPX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  SPX_REQUIRE(n >= 0 && (n == 0 || out != nullptr), "bad output vector");
+  SPX_REQUIRE(kind == 0 || kind == 1, "kind must be 0 (uniform) or 1 (normal-like)");
+  if (n == 0) return SPX_OK;
+  SPX_ON_DEVICE(ctx);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > (int64_t)ctx->num_cu * 32) blocks = (int64_t)ctx->num_cu * 32;
+  hipLaunchKernelGGL(k_synth_fill, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, out, n, seed, stream, kind, scale);
+  SPX_LAUNCH_CHECK();
+  return SPX_OK;
+}

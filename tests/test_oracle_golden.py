@@ -390,3 +390,24 @@ def test_f32_oracle_agrees_with_f64_on_dyadic_data(orc):
     # aliased ShiftedNormL1
     a = orc.prox_f32("l1", q, x, sj, 0.5, 1.0, aliased=True)
     assert np.array_equal(a.astype(np.float64), (-x) - sj)
+
+
+def test_synthetic_generator_twins_agree(orc):
+    """SURVEY 8d's shared generator: the C host twin (oracle.synth_fill) and the numpy one (oracle/synth.py) give the same
+    bits; the draws have the advertised moments; streams and seeds are independent of each other."""
+    from oracle import synth
+    oracle = orc
+    n = 200_003
+    for kind in (0, 1):
+        a = oracle.synth_fill(n, 20250613, 2, kind, 0.75, threads=3)
+        b = synth.fill(n, 20250613, 2, kind, 0.75)
+        assert np.array_equal(a.view(np.int64), b.view(np.int64))
+        # a window of the same stream equals the slice (counter-based: no state)
+        w = synth.fill(1000, 20250613, 2, kind, 0.75, start=77_000)
+        assert np.array_equal(w.view(np.int64), a[77_000:78_000].view(np.int64))
+    u = oracle.synth_fill(n, 1, 0, 0)
+    g = oracle.synth_fill(n, 1, 0, 1)
+    assert u.min() >= -0.5 and u.max() < 0.5 and abs(u.mean()) < 5e-3 and abs(u.var() - 1 / 12) < 2e-3
+    assert abs(g.mean()) < 1e-2 and abs(g.var() - 1.0) < 2e-2 and np.abs(g).max() <= 6.0
+    assert abs(np.corrcoef(g, oracle.synth_fill(n, 1, 1, 1))[0, 1]) < 1e-2
+    assert abs(np.corrcoef(g, oracle.synth_fill(n, 2, 0, 1))[0, 1]) < 1e-2

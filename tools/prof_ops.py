@@ -6,7 +6,7 @@ import __graft_entry__ as ge
 s = ge.build()
 dev = torch.device("cuda:0")
 n = int(os.environ.get("SPX_N", "100000000"))
-which = os.environ.get("SPX_OPS", "l1box,l0box,lhalf,lhalfbox,indball,iprox,objective,b2,group,binf").split(",")
+which = os.environ.get("SPX_OPS", "l1box,l0box,lhalf,lhalfbox,indball,iprox,objective,b2,f32,group,binf").split(",")
 g = torch.Generator(device=dev).manual_seed(1)
 chi = s.NormLinf(1.0)
 def vecs(m):
@@ -32,6 +32,11 @@ if "iprox" in which:
 if "objective" in which:
     psi = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj)
     for _ in range(5): psi(y)
+if "f32" in which:
+    x32, s32, q32 = (t.to(torch.float32) for t in (xk, sj, q)); y32 = torch.empty_like(q32)
+    psi = s.shifted(s.shifted(s.NormL1(1.0), x32, 1.0, chi), s32)
+    for _ in range(5): s.prox_bang(y32, psi, q32, 1.0)
+    del x32, s32, q32, y32
 if "b2" in which:
     psi = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, s.NormL2(1.0)), sj)
     for _ in range(5): s.prox_bang(y, psi, q, 1.0)
