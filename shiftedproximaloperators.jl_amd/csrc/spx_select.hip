@@ -270,6 +270,88 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double* y, int64_t n, in
 // 4096-bin histogram and advances the selection state.  Called by all lanes of a workgroup (>= 256 lanes);
 // lanes 0..255 do the work.  `scratch` = 8 unsigned long long of shared memory.  The new state is returned in
 // *out by lane 0 (out may be global or shared memory); no barrier after that write.
+// Folded first digit of the in-launch selection (k_sel_coop, SelState::pad == 1): the top 12 key bits are sign + exponent,
+// i.e. ONE bin per binade -- the bucket of the r-th largest then still holds a few per cent of the vector and two more
+// digits are needed.  Folded: 62 binades around 1.0 (2^-31 .. 2^30) x 64 mantissa steps each, everything below in bin 0,
+// everything above in bin 4095 -- monotone in the key, bucket = n / 64 of a binade, one more digit (bits 45..34) resolves it
+// (measured at n = 1e6, r = n/100: 3 digit passes -> 2, 48 -> 3x us).  A threshold in one of the two catch-all bins restarts
+// with the plain top digit (one pass lost, on data 2^31 away from 1.0).
+constexpr int kFoldLoExp = 991;    // biased exponent of the last binade that falls into bin 0
+constexpr int kFoldHiExp = 1054;   // ... of the first binade that falls into bin 4095
+__device__ __forceinline__ unsigned int fold_digit(uint64_t key) {
+  const int e = (int)(key >> 52);
+  if (e <= kFoldLoExp) return 0u;
+  if (e >= kFoldHiExp) return (unsigned int)kBins - 1u;
+  return ((unsigned int)(e - kFoldLoExp) << 6) | (unsigned int)((key >> 46) & 63u);
+}
+
+// The state after a scan located the bucket of the quota-th element: `before` elements precede the bucket in scan order,
+// `count` are in it.
+__device__ __forceinline__ SelState sel_advance(const SelState st, uint64_t bucket, uint64_t before, uint64_t count) {
+  const int nb = 1 << st.width;
+  const unsigned long long quota = (unsigned long long)st.quota;
+  const int64_t left = (int64_t)(quota - before);  // to be taken from this bucket
+  const uint64_t newprefix = (st.width >= 64 ? 0ull : (st.prefix << st.width)) | bucket;  // (phase 1)
+  SelState o = st;
+  if (st.phase == 0 && st.pad == 1) {                   // folded first digit (fold_digit)
+    o.pad = 0;
+    const bool catch_all = bucket < 64 || bucket >= (uint64_t)(kBins - 64);
+    const uint64_t lowkey = bucket < 64 ? 0ull
+                          : bucket >= (uint64_t)(kBins - 64) ? ((uint64_t)kFoldHiExp << 52)
+                          : (((bucket >> 6) + (uint64_t)kFoldLoExp) << 52) | ((bucket & 63ull) << 46);
+    if ((uint64_t)left == count) {                      // the whole bucket is kept
+      o.phase = 2;
+      o.t_ge = lowkey > st.t_floor ? lowkey : st.t_floor;
+    } else if (!catch_all) {                            // next digit: bits 45..34 of this bucket
+      o.base = lowkey;
+      o.clamp = 0;
+      o.quota = left;
+      o.shift = 46 - kDigitBits;
+      o.width = kDigitBits;
+    }                                                   // else: start over with the plain top digit (o = st, pad = 0)
+    return o;
+  }
+  if (st.phase == 0) {
+    const uint64_t lowkey = st.base + (bucket << st.shift);  // low end of the bucket (no overflow: see k_s2_pick)
+    const bool open_top = st.clamp && bucket == (uint64_t)(nb - 1);  // the bucket has no upper end
+    if ((uint64_t)left == count) {                    // the whole bucket is kept: resolved, no tie
+      o.phase = 2;
+      o.t_ge = lowkey > st.t_floor ? lowkey : st.t_floor;
+    } else if (st.shift == 0 && !open_top) {          // full key known, more equal keys than quota: tie
+      o.t_ge = lowkey + 1;                            // keys are < 2^63: no overflow
+      o.t_eq = lowkey;
+      o.quota = left;
+      o.phase = 1;
+      o.prefix = 0;
+      int top = st.idx_bits;                          // index digits, most significant first
+      int w = top % kDigitBits ? top % kDigitBits : kDigitBits;
+      if (top == 0) { o.phase = 2; o.icut = 0; }      // n == 1 cannot get here, kept for safety
+      o.shift = top - w;
+      o.width = w;
+    } else {                                          // next digit inside this bucket
+      o.base = lowkey;
+      o.clamp = 0;
+      o.quota = left;
+      const int rem = open_top ? 64 : st.shift;       // undecided bits of (key - lowkey)
+      const int w = rem < kDigitBits ? rem : kDigitBits;
+      o.shift = rem - w;
+      o.width = w;
+    }
+  } else {
+    if ((uint64_t)left == count || st.shift == 0) {   // all indices of this bucket are kept
+      o.phase = 2;
+      o.icut = (int64_t)(((newprefix + 1) << st.shift) - 1);
+    } else {
+      o.prefix = newprefix;
+      o.quota = left;
+      int w = st.shift < kDigitBits ? st.shift : kDigitBits;
+      o.shift = st.shift - w;
+      o.width = w;
+    }
+  }
+  return o;
+}
+
 template <class Hist>
 __device__ __forceinline__ void sel_scan_step(const Hist& hist, const SelState st, SelState* out,
                                               unsigned long long* scratch) {
@@ -305,52 +387,7 @@ __device__ __forceinline__ void sel_scan_step(const Hist& hist, const SelState s
     }
   }
   __syncthreads();
-  if (t == 0) {
-    const uint64_t bucket = found[0];
-    const int64_t left = (int64_t)(quota - found[1]);  // to be taken from this bucket
-    const uint64_t count = found[2];
-    const uint64_t newprefix = (st.width >= 64 ? 0ull : (st.prefix << st.width)) | bucket;  // (phase 1)
-    SelState o = st;
-    if (st.phase == 0) {
-      const uint64_t lowkey = st.base + (bucket << st.shift);  // low end of the bucket (no overflow: see k_s2_pick)
-      const bool open_top = st.clamp && bucket == (uint64_t)(nb - 1);  // the bucket has no upper end
-      if ((uint64_t)left == count) {                    // the whole bucket is kept: resolved, no tie
-        o.phase = 2;
-        o.t_ge = lowkey > st.t_floor ? lowkey : st.t_floor;
-      } else if (st.shift == 0 && !open_top) {          // full key known, more equal keys than quota: tie
-        o.t_ge = lowkey + 1;                            // keys are < 2^63: no overflow
-        o.t_eq = lowkey;
-        o.quota = left;
-        o.phase = 1;
-        o.prefix = 0;
-        int top = st.idx_bits;                          // index digits, most significant first
-        int w = top % kDigitBits ? top % kDigitBits : kDigitBits;
-        if (top == 0) { o.phase = 2; o.icut = 0; }      // n == 1 cannot get here, kept for safety
-        o.shift = top - w;
-        o.width = w;
-      } else {                                          // next digit inside this bucket
-        o.base = lowkey;
-        o.clamp = 0;
-        o.quota = left;
-        const int rem = open_top ? 64 : st.shift;       // undecided bits of (key - lowkey)
-        const int w = rem < kDigitBits ? rem : kDigitBits;
-        o.shift = rem - w;
-        o.width = w;
-      }
-    } else {
-      if ((uint64_t)left == count || st.shift == 0) {   // all indices of this bucket are kept
-        o.phase = 2;
-        o.icut = (int64_t)(((newprefix + 1) << st.shift) - 1);
-      } else {
-        o.prefix = newprefix;
-        o.quota = left;
-        int w = st.shift < kDigitBits ? st.shift : kDigitBits;
-        o.shift = st.shift - w;
-        o.width = w;
-      }
-    }
-    *out = o;
-  }
+  if (t == 0) *out = sel_advance(st, found[0], found[1], found[2]);
 }
 
 // One workgroup: scan step on the global histogram, then clear it for the next pass.
@@ -1056,6 +1093,10 @@ extern "C" __attribute__((visibility("default"))) int spx_debug_sel_stamps(unsig
 #define SEL_STAMP(k) do { } while (0)
 #endif
 constexpr int kCoopMaxPass = 12;  // <= 6 key digits + <= 6 index digits
+#ifndef SPX_COOP_FOLD
+#define SPX_COOP_FOLD 1
+#endif
+constexpr bool kCoopFold = SPX_COOP_FOLD != 0;
 constexpr int kCoopEpl = 8;       // REG: elements per lane at most (16 spill: 1024-lane workgroups leave 128 VGPRs per lane)
 struct SelSync {
   SpxSyncHeader hdr;  // grid-barrier counters (a launch uses hdr.bar[parity] and clears hdr.bar[parity ^ 1])
@@ -1070,9 +1111,54 @@ struct SelSync {
 
 struct CoopShared {
   unsigned int lh[kBins];
-  unsigned long long scratch[8];
+  unsigned long long scratch[24];
   SelState sst;
 };
+
+// sel_scan_step for the 1024-lane workgroups of k_sel_coop: four bins per lane, read with agent-scope atomic loads -- the
+// histogram is written with agent-scope atomic adds only, so the passes meet in spx_grid_rendezvous, without the L2
+// write-back / invalidate of a fenced barrier (most of its cost: 6.7 -> 3.x us per pass at 123 workgroups).
+// scratch = 24 words of shared memory; the new state is written to *out (shared) by lane 0, no barrier after that.
+__device__ __forceinline__ void coop_scan_step(unsigned long long* hist, const SelState st, SelState* out,
+                                               unsigned long long* scratch) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int nb = 1 << st.width;
+  const bool desc = (st.phase == 0);
+  constexpr int PER = kBins / 1024;
+  unsigned long long loc[PER];
+  unsigned long long sum = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int pos = t * PER + k;
+    const int bin = desc ? (kBins - 1 - pos) : pos;
+    loc[k] = (bin < nb) ? __hip_atomic_load(hist + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    sum += loc[k];
+  }
+  unsigned long long inc = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long up = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += up;
+  }
+  if (lane == 63) scratch[w] = inc;
+  __syncthreads();
+  unsigned long long run = inc - sum;
+  for (int k = 0; k < w; ++k) run += scratch[k];
+  const unsigned long long quota = (unsigned long long)st.quota;
+  unsigned long long* found = scratch + 16;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (run < quota && run + loc[k] >= quota) {
+      const int pos = t * PER + k;
+      found[0] = (unsigned long long)(desc ? (kBins - 1 - pos) : pos);
+      found[1] = run;
+      found[2] = loc[k];
+    }
+    run += loc[k];
+  }
+  __syncthreads();
+  if (t == 0) *out = sel_advance(st, found[0], found[1], found[2]);
+}
 
 __device__ __forceinline__ void sel_state_init(SelState& s, int64_t n, int64_t r) {
   int bits = 0;
@@ -1116,7 +1202,10 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
       v[k] = (i < n) ? (xk[i] + sj[i]) + q[i] : 0.0;  // shiftedIndBallL0.jl:66
     }
   }
-  if (t == 0) sel_state_init(sh.sst, n, r);
+  if (t == 0) {
+    sel_state_init(sh.sst, n, r);
+    if (sh.sst.phase == 0 && kCoopFold) sh.sst.pad = 1;  // first digit: fold_digit
+  }
   SEL_STAMP(32);
   int p = 0;
   for (; p < kCoopMaxPass; ++p) {
@@ -1130,8 +1219,12 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
     auto visit = [&](double vv, int64_t i) {
       const uint64_t key = key_of(vv);
       if (st.phase == 0) {
-        const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
-        if (kp.in) atomicAdd(&sh.lh[kp.digit], 1u);
+        if (st.pad == 1) {
+          atomicAdd(&sh.lh[fold_digit(key)], 1u);
+        } else {
+          const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
+          if (kp.in) atomicAdd(&sh.lh[kp.digit], 1u);
+        }
       } else if (key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix) {
         atomicAdd(&sh.lh[(((uint64_t)i) >> st.shift) & dmask], 1u);
       }
@@ -1159,9 +1252,11 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
       if (c) atomicAdd(&hist[p][b], (unsigned long long)c);
     }
     SEL_STAMP(33 + 3 * p);
-    spx_grid_barrier(bar, (++nbar) * gridDim.x);
+    // the histogram atomics of every wave have been performed (vmcnt) before its workgroup arrives; nothing else is exchanged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    spx_grid_rendezvous(bar, (++nbar) * gridDim.x);
     SEL_STAMP(34 + 3 * p);
-    sel_scan_step(hist[p], st, &sh.sst, sh.scratch);
+    coop_scan_step(hist[p], st, &sh.sst, sh.scratch);
     SEL_STAMP(35 + 3 * p);
   }
   __syncthreads();
@@ -1389,7 +1484,7 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
 #define SPX_SEL_FAST_MIN_LOG2 20  // smallest n (log2) on the sample-predicted path: 83-98 us vs 100-123 us for the full-vector path at 2^20, behind it below (tools/exp/topr_threshold.py)
 #endif
 #ifndef SPX_SEL_REG_MAX_LOG2
-#define SPX_SEL_REG_MAX_LOG2 20  // largest n (log2) on the register-resident one-launch select; above it the sample-predicted pipeline is faster (n = 2e6: 72 vs ~58 us; n = 1e6: 48 us)
+#define SPX_SEL_REG_MAX_LOG2 21  // largest n (log2) on the register-resident one-launch select = what 256 CUs hold at 8 elements per lane (n = 2e6: 37 us vs 57 us for the sample-predicted pipeline; beyond it the one-launch form parks v in y and is no faster: tools/r2/topr_midn.py)
 #endif
 
 template <bool BINF>

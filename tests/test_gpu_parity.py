@@ -352,10 +352,12 @@ def test_indball_l0_ranks_and_scales(s, orc, kind):
     assert _bits_equal(qd.cpu().numpy(), orc.prox_indball_l0(q, x, sj, r)), kind
 
 
-@pytest.mark.parametrize("n", [(1 << 20) - 1, 1 << 20, (1 << 20) + 1, (1 << 20) + 3001])
+@pytest.mark.parametrize("n", [(1 << 20) - 1, 1 << 20, (1 << 20) + 1, (1 << 20) + 3001, (1 << 21) - 1, 1 << 21, (1 << 21) + 1,
+                               (1 << 21) + 3001])
 def test_indball_l0_at_the_fast_path_threshold(s, orc, n):
-    """Either side of the size at which the sample-predicted path takes over from the full-vector radix select
-    (SPX_SEL_FAST_MIN_LOG2 = 20): the sample is then 1/16 of the vector.  Lattice data (ties), all r regimes."""
+    """Either side of the sizes at which the sample-predicted path takes over: from the register-resident one-launch select
+    (SPX_SEL_REG_MAX_LOG2 = 21) and, with the in-launch forms switched off, from the full-vector radix select
+    (SPX_SEL_FAST_MIN_LOG2 = 20: the sample is then 1/16 of the vector).  Lattice data (ties), all r regimes."""
     rng = np.random.default_rng(n)
     x, sj = np.round(rng.normal(size=n) * 16) / 16, np.round(rng.uniform(-0.5, 0.5, size=n) * 16) / 16
     q = np.round(rng.normal(size=n) * 16) / 16

@@ -202,6 +202,56 @@ def test_topr_misaligned_views(s, orc, n):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# Top-r, one-launch select (k_sel_coop): its first digit is FOLDED (csrc/spx_select.hip fold_digit: 62 binades around 1.0 x
+# 64 mantissa steps, catch-all bins below 2^-31 and above 2^30).  Data that puts the threshold into a catch-all bin (restart
+# with the plain top digit), onto a bin edge, into ties at key 0 / Inf / NaN, or all of the vector into one bin.
+# Sizes: register-resident grid of 9, 37 and 256 workgroups; the form that parks v in y (mixed alignment, n > 2^21).
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["tiny", "huge", "tiny+normal", "normal+huge", "zeros", "inf_nan", "constant", "binade_edges",
+                                  "wide_exponents"])
+@pytest.mark.parametrize("n", [70_001, 300_000, (1 << 21) - 5, (1 << 21) + 4099])
+def test_topr_folded_first_digit(s, orc, kind, n):
+    import torch
+    rng = np.random.default_rng(sum(map(ord, kind)) + n)
+    x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
+    if kind == "tiny":
+        x, sj, q = x * 2.0 ** -60, sj * 2.0 ** -60, q * 2.0 ** -60
+    elif kind == "huge":
+        x, sj, q = x * 2.0 ** 70, sj * 2.0 ** 70, q * 2.0 ** 70
+    elif kind == "tiny+normal":
+        m = rng.random(n) < 0.5
+        x, sj, q = np.where(m, x * 2.0 ** -45, x), np.where(m, sj * 2.0 ** -45, sj), np.where(m, q * 2.0 ** -45, q)
+    elif kind == "normal+huge":
+        m = rng.random(n) < 0.3
+        x, sj, q = np.where(m, x * 2.0 ** 40, x), np.where(m, sj * 2.0 ** 40, sj), np.where(m, q * 2.0 ** 40, q)
+    elif kind == "zeros":
+        m = rng.random(n) < 0.7
+        x, sj, q = np.where(m, 0.0, x), np.where(m, 0.0, sj), np.where(m, 0.0, q)
+    elif kind == "inf_nan":
+        q = q.copy()
+        q[rng.integers(0, n, size=40)] = np.inf
+        q[rng.integers(0, n, size=40)] = -np.inf
+        q[rng.integers(0, n, size=25)] = np.nan
+    elif kind == "constant":
+        x, sj, q = np.full(n, 0.5), np.full(n, 0.25), np.full(n, -2.0)
+    elif kind == "binade_edges":  # |v| on the edges of the folded bins: 2^k (1 + j/64), exactly
+        k = rng.integers(-3, 4, size=n); j = rng.integers(0, 64, size=n)
+        v = 2.0 ** k * (1.0 + j / 64.0) * rng.choice([-1.0, 1.0], size=n)
+        x, sj = np.zeros(n), np.zeros(n); q = v
+    elif kind == "wide_exponents":
+        e = rng.integers(-80, 80, size=n)
+        x, sj, q = x * 2.0 ** e, sj * 2.0 ** e, q * 2.0 ** e
+    mixed = n > (1 << 21)  # one vector 8 bytes off: the one-launch form that parks v in y
+    mk = lambda a: torch.cat([torch.zeros(1, dtype=torch.float64), torch.from_numpy(a)]).cuda()[1:]
+    xd, sd, qd = (mk(x) if mixed else torch.from_numpy(x).cuda()), torch.from_numpy(sj).cuda(), torch.from_numpy(q).cuda()
+    for r in sorted({1, 2, 26, 70, n // 100, n // 3, n // 2, int(0.7 * n), n - 1}):
+        ref = orc.prox_indball_l0_binf(q, x, sj, r, 0.8)
+        psi = s.shifted(s.shifted(s.IndBallL0(r), xd, 0.8, s.NormLinf(1.0)), sd)
+        y = s.prox(psi, qd, 1.0).cpu().numpy()
+        assert _bits(y, ref), (kind, n, r, int(np.sum(y.view(np.int64) != ref.view(np.int64))))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # Lattice data (multiples of 1/4) through the separable operators, iprox!, NormL1B2 and top-r: exact ties with every
 # threshold and bound (csrc/spx_separable.hip functors; spx_b2.hip piece roots hit exactly; spx_select.hip index digits).
 # ----------------------------------------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@ FAULTS=(
  "1|spx_group.hip|0,/bool decided = g0 < -1e-9 \* sl;/s//bool decided = g0 < 1e300;/|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region"
  "2|spx_group.hip|s/decided = (r2n == r2);/decided = true;/g|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region"
  "3|spx_group.hip|s/if (reversed \&\& mX < delta \* (1.0 - 1e-9)) return BINF_ZERO;/if (reversed) return BINF_ZERO;/|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region tests/test_gpu_stress.py::test_binf_reversed_bracket_regimes"
+ "5|spx_select.hip|s/} else if (!catch_all) {  /} else if (true) {  /|tests/test_gpu_stress.py::test_topr_folded_first_digit"
  "4|spx_group.hip|s/if (sb == 0.0) {/if (false) {/;s/for (int k = 0; k < 64; ++k) {/for (int k = 0; k < 12; ++k) { piece_ok = true;/|tests/test_gpu_parity.py::test_group_binf_many_small_groups tests/test_gpu_parity.py::test_group_binf_zero_groups_strong_lambda"
 )
 case "${1:-}" in
