@@ -299,8 +299,8 @@ def _extra(s, L, ctx, dev, n, torch):
     res["ShiftedNormL1B2"] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4), "kernel": "k_b2_coop<false>",
                               "gelem_s": round(n / ms / 1e6, 2), "gbs_algorithmic": round(32 * n / ms / 1e6, 1),
                               "frac_of_peak": round(32 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
-                              "note": "algorithmic 32 B/element; the call streams 4 x 24 + 32 B/element (4 reduction passes, the last "
-                                      "pass also stores y)"}
+                              "note": "algorithmic 32 B/element; the call streams 24 + 24 + 32 = 80 B/element (two reduction passes, "
+                                      "the sample's root riding along in the first, then the storing pass)"}
     # host-pointer form of the headline operator (spx_host_prox_l1_box): PCIe-inclusive, pageable numpy vectors
     nh = min(n, 10**7)
     hx, hs, hq = (t[:nh].cpu().numpy() for t in (xk, sj, q))
@@ -322,6 +322,20 @@ def _extra(s, L, ctx, dev, n, torch):
     # the same operator at the two ends of r (band without an upper end / widest band): tools/sweep_topr.py has the rest
     line("ShiftedIndBallL0BInf_r=1000", s.shifted(s.shifted(s.IndBallL0(min(1000, n)), xk, 1.0, chi), sj), 32, n, y, q, TOPR)
     line("ShiftedIndBallL0BInf_r=n/2", s.shifted(s.shifted(s.IndBallL0(max(1, n // 2)), xk, 1.0, chi), sj), 32, n, y, q, TOPR)
+    # per-call latency at solver-iteration sizes: the two operators with a data-dependent scalar (r-th largest, trust-region
+    # root) run as ONE launch with in-launch rendezvous, nothing read back (us per call, HIP events over 50 back-to-back calls)
+    for nn in (1_000_000, 10_000):
+        if nn > n:
+            continue
+        xs, ss_, qs, ys = xk[:nn], sj[:nn], q[:nn], y[:nn]
+        for name, psi_s, kern in (
+                ("ShiftedIndBallL0BInf_r=n/100_n=%d" % nn, s.shifted(s.shifted(s.IndBallL0(max(1, nn // 100)), xs, 1.0, chi), ss_),
+                 "k_sel_coop<true,true>" if nn > 65536 else "k_sel_small<true>"),
+                ("ShiftedNormL1B2_n=%d" % nn, s.shifted(s.shifted(s.NormL1(1.0), xs, 1.0, s.NormL2(1.0)), ss_), "k_b2_coop<true>")):
+            s.prox_bang(ys, psi_s, qs, 1.0)
+            ms = _time_op(s, L, ctx, lambda: s.prox_bang(ys, psi_s, qs, 1.0), iters=50, rounds=5)
+            res[name] = {"us": round(ms * 1e3, 2), "avg_launch_ms": round(ms, 5), "kernel": kern, "n": nn,
+                         "note": "one launch per call; 32 B/element at 8 TB/s would be %.2f us" % (32 * nn / 8e6)}
     # group config: (n // 100) groups of 128  (10^6 x 128 at n = 10^8)
     ng = max(1, n // 100)
     m = ng * 128
