@@ -242,9 +242,31 @@ __global__ __launch_bounds__(256) void k_b2_obj(const double* __restrict__ y, co
 // a grid barrier, and the scalar update of eta, which every lane redoes for itself.  REG: n <= 8 Ki x number of CUs --
 // xk, sj and sj + q stay in registers, the vectors are read once.  !REG: the passes stream from memory (16-byte pairs).
 // =============================================================================================
-constexpr int kB2Epl = 8;
+// register-resident form: 512 lanes x 16 elements per workgroup (256 VGPRs per lane).  1024 lanes x 8 spill under their 128
+// VGPRs (loop invariants the compiler keeps per element: the box ends, the store addresses), and the first touch of a wave's
+// scratch memory costs microseconds at the start of every launch; 1024 x 16 spill 120 registers and run 2x slower.
+constexpr int kB2Epl = 16;
+constexpr int kB2RegThreads = 512;
+constexpr int kB2RegBlock = kB2Epl * kB2RegThreads;  // elements per workgroup of the register-resident form
 constexpr int kB2MaxPass = 64;
-struct B2Part5 { double p, c, f, p1, c1, pad[3]; };  // one workgroup's partial sums of a pass (64 bytes)
+// One workgroup's partial sums of a pass: 8 words (p, c, f, p1, c1, 3 unused) in spx_ctx::sync, at a FIXED place (set, pass,
+// workgroup), written once per launch.  A word is its own "ready" flag: the sync area starts out zero, a sum v is stored as
+// bits(v) + 1 (never 0: NaNs are canonicalised first), and a reader polls the word until it is non-zero -- no counter, no
+// rendezvous, one memory round trip per pass instead of four (store + wait, arrive, poll, load: 2.6-3.6 -> ~1.x us per
+// pass, which is most of a call at n <= 1e6).  Launches alternate between two sets; a launch zeroes what the launch before
+// the previous one left in the other set (the host knows how many workgroups that was).
+constexpr int kB2Cols = 256;   // workgroups at most
+constexpr int kB2Words = 8;
+constexpr size_t kB2SetWords = (size_t)kB2MaxPass * kB2Cols * kB2Words;
+constexpr size_t kB2SyncBytes = 2 * kB2SetWords * sizeof(unsigned long long);   // 2 MiB, behind the select state
+__device__ __forceinline__ void b2_put(unsigned long long* slot, double v) {
+  const unsigned long long b = (v != v) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(v);
+#ifdef SPX_B2_PUT_SWAP
+  (void)__hip_atomic_exchange(slot, b + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  __hip_atomic_store(slot, b + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 __device__ __forceinline__ void b2_block_sum5(double& a, double& b, double& c, double& d, double& e, double (*lds)[16]) {
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d); e = wave_sum(e);
   const int w = threadIdx.x >> 6;
@@ -257,37 +279,62 @@ __device__ __forceinline__ void b2_block_sum5(double& a, double& b, double& c, d
   a = t0; b = t1; c = t2; d = t3; e = t4;
 }
 
-// REG: n <= kB2Epl * 1024 * grid, the vectors in registers.  !REG (streaming): additionally a SAMPLE of one element per lane
+// REG: n <= kB2RegBlock * grid, the vectors in registers.  !REG (streaming): additionally a SAMPLE of one element per lane
 // of the grid (1024 chunks of 256 = 262 144 elements on 256 CUs, kept in registers) is solved first -- a handful of
 // rendezvous, no streaming -- and its root eta_s (good to ~1/sqrt(262144) = 2e-3) rides along as a SECOND TRIAL in the first
 // streaming pass (the loads dominate: two sets of sums cost nothing).  The piece root of that trial is then ~1e-6 from the
 // root, one more reduction pass brings ~1e-13, and the storing pass follows: 24 + 24 + 32 = 80 B/element instead of
 // 4 x 24 + 32 = 128 when the iteration starts from the a-priori bound (which stays the fallback whenever the sample
 // misleads).  Stopping rule: the measured quadratic constant K = step_k / step_{k-1}^2 predicts error(next) = K step_k^2.
-template <bool REG>
-__global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, const double* xk, const double* sj, int64_t n,
-                                                   double ls, double delta, double chil, B2Part5* part /* [kB2MaxPass][grid] */,
-                                                   SpxSyncHeader* hdr, int parity, int can_spec) {
+#ifdef SPX_B2_PROFILE  // A/B builds only: time stamps of workgroup 0 (10 ns units), read with spx_debug_b2_stamps
+__device__ unsigned long long g_b2_stamp[64];
+__device__ int g_b2_nstamp;
+#define B2_STAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0 && nst < 64) g_b2_stamp[nst++] = wall_clock64(); } while (0)
+extern "C" __attribute__((visibility("default"))) int spx_debug_b2_stamps(unsigned long long* out, int* count) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_b2_stamp), sizeof(g_b2_stamp));
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(count, HIP_SYMBOL(g_b2_nstamp), sizeof(int));
+  return (int)e;
+}
+#else
+#define B2_STAMP() do { } while (0)
+#endif
+
+template <bool REG, int EPL, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                                   double ls, double delta, double chil, unsigned long long* rows,
+                                                   unsigned long long* clear_rows, int clear_g, SpxSyncHeader* hdr,
+                                                   int can_spec) {
   __shared__ double lds5[5][16];
   const int t = threadIdx.x;
   const int G = (int)gridDim.x;
   const int64_t NT = (int64_t)G * blockDim.x;
   const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + t;
-  unsigned int* bar = hdr->bar[parity];
-  unsigned int nbar = 0;
-  if (blockIdx.x == 0 && t == 0) hdr->bar[parity ^ 1][0] = 0u;
+  // the other set, for the launch after this one: passes x (workgroups of the launch that used it) x words, plain stores
+  for (int64_t idx = gtid; idx < (int64_t)kB2MaxPass * clear_g * kB2Words; idx += NT) {
+    const int64_t pass_i = idx / (clear_g * kB2Words), rem = idx % (clear_g * kB2Words);
+    clear_rows[pass_i * kB2Cols * kB2Words + rem] = 0ull;
+  }
+  if (t < 80) (&lds5[0][0])[t] = 0.0;  // (workgroups of fewer than 16 wavefronts leave the upper slots alone)
+  int nst = 0;
+  B2_STAMP();
   const int last_scaled = hdr->b2_last_scaled;  // (written by the previous call's launch)
-  double X[REG ? kB2Epl : 1], S[REG ? kB2Epl : 1], SQ[REG ? kB2Epl : 1];
+  // (sj itself is needed only where a y is stored: reloaded there, so that 16 elements per lane fit the 128 VGPRs)
+  double X[REG ? EPL : 1], LO[REG ? EPL : 1], HI[REG ? EPL : 1];  // xk and the box (sj + q) -+ lambda sigma of each element
   if constexpr (REG) {
 #pragma unroll
-    for (int k = 0; k < kB2Epl; ++k) {
+    for (int k = 0; k < EPL; ++k) {
+      // clamped index, unconditional loads: all 3 EPL loads in flight at once (a guarded load per element compiles to EPL
+      // dependent branch blocks, each waiting for its own loads: ~1.5 us apiece)
       const int64_t i = gtid + (int64_t)k * NT;
-      const bool in = i < n;
-      X[k] = in ? xk[i] : 0.0;
-      S[k] = in ? sj[i] : 0.0;
-      SQ[k] = in ? (S[k] + q[i]) : 0.0;   // `sj .+ q` (:56)
+      const int64_t ic = i < n ? i : n - 1;
+      const double xv = xk[ic], sv = sj[ic], qv = q[ic];
+      const double sq = i < n ? (sv + qv) : 0.0;   // `sj .+ q` (:56)
+      X[k] = i < n ? xv : 0.0;
+      LO[k] = sq - ls;
+      HI[k] = sq + ls;
     }
   }
+  B2_STAMP();  // (register-resident form: the vectors are in)
   // the sample (streaming form only): one element per lane of the grid -- chunk c = 4 * workgroup + (t >> 8) of 4 G chunks
   // of 256 consecutive elements, element t & 255 of it (262 144 elements on 256 CUs: statistical error of its root ~2e-3)
   const int kChunks = 4 * G;
@@ -314,10 +361,9 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
     // and matter only for the bits of a STORED y: signed zeros, NaN propagation); a NaN operand -- which v_max / v_min would
     // drop -- is tracked separately and poisons P, as the reference's norm would be NaN.
     bool bad = false;
-    auto visit = [&](double sq, double x, double s) -> double {
-      const double lo = sq - ls, hi = sq + ls;
+    auto visit = [&](double lo, double hi, double x, double s) -> double {
       const double z = (-x) * r;
-      bad |= (z != z) | (sq != sq);
+      bad |= (z != z) | (lo != lo) | (hi != hi);
       const double pzf = fmin(fmax(z, lo), hi);
       const bool un = (pzf == z);
       const double xm = un ? x : 0.0, cm = un ? 0.0 : pzf;
@@ -340,15 +386,16 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
       return pz * rinv - s;
     };
     if (sample) {
-      if (has_sample) visit(ssq, sx, ss);
+      if (has_sample) visit(ssq - ls, ssq + ls, sx, ss);
     } else if constexpr (REG) {
 #pragma unroll
-      for (int k = 0; k < kB2Epl; ++k) {
+      for (int k = 0; k < EPL; ++k) {
         const int64_t i = gtid + (int64_t)k * NT;
         if (i < n) {
-          const double o = visit(SQ[k], X[k], S[k]);
+          const double o = visit(LO[k], HI[k], X[k], store ? sj[i] : 0.0);
           if (store) y[i] = o;
         }
+        __builtin_amdgcn_sched_barrier(0);  // one element at a time: interleaved, the unrolled visits spill
       }
     } else {
       // software-pipelined stream: the loads of the next tile are issued before the current one is evaluated (two register
@@ -372,8 +419,9 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
           const int64_t i = tile * kTilePairs + t + k * 1024;
           if (i < n2) {
             f64x2 o;
-            o.x = visit(d[k].x + a[k].x, b[k].x, d[k].x);
-            o.y = visit(d[k].y + a[k].y, b[k].y, d[k].y);
+            const double sq0 = d[k].x + a[k].x, sq1 = d[k].y + a[k].y;
+            o.x = visit(sq0 - ls, sq0 + ls, b[k].x, d[k].x);
+            o.y = visit(sq1 - ls, sq1 + ls, b[k].y, d[k].y);
             if (store) __builtin_nontemporal_store(o, y2 + i);
           }
         }
@@ -393,37 +441,54 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
         tile = t2;
       }
       if ((n & 1) && blockIdx.x == 0 && t == 0) {
-        const double o = visit(sj[n - 1] + q[n - 1], xk[n - 1], sj[n - 1]);
+        const double sql = sj[n - 1] + q[n - 1];
+        const double o = visit(sql - ls, sql + ls, xk[n - 1], sj[n - 1]);
         if (store) y[n - 1] = o;
       }
     }
+    B2_STAMP();  // visits done
     if (bad) p = __longlong_as_double(0x7ff8000000000000ll);
     b2_block_sum5(p, c, f, p1, c1, lds5);
+    B2_STAMP();  // own sums
     if (G == 1) {  // one workgroup holds the whole vector: nothing to exchange
       P = p; C = c; P1 = p1; C1 = c1;
       if (first) F = f;
     } else {
-      // the partial sums are the ONLY data the workgroups exchange: agent-scope atomic stores / loads and a rendezvous
-      // without cache maintenance (a fenced barrier is ~4 us even for two workgroups, most of a pass at small n)
-      B2Part5* row = part + (size_t)np * G;
+      // the partial sums are the ONLY data the workgroups exchange: agent-scope atomic stores / loads (`sc1`, past the
+      // non-coherent caches) of words that carry their own ready flag (see b2_put)
+      unsigned long long* row = rows + (size_t)np * kB2Cols * kB2Words;
       if (t == 0) {
-        spx_atomic_store_f64(&row[blockIdx.x].p, p);
-        spx_atomic_store_f64(&row[blockIdx.x].c, c);
-        if (first) spx_atomic_store_f64(&row[blockIdx.x].f, f);
-        if (r1 > 0.0) { spx_atomic_store_f64(&row[blockIdx.x].p1, p1); spx_atomic_store_f64(&row[blockIdx.x].c1, c1); }
+        unsigned long long* mine = row + (size_t)blockIdx.x * kB2Words;
+        b2_put(mine + 0, p);
+        b2_put(mine + 1, c);
+        if (first) b2_put(mine + 2, f);
+        if (r1 > 0.0) { b2_put(mine + 3, p1); b2_put(mine + 4, c1); }
       }
-      spx_grid_rendezvous(bar, (++nbar) * (unsigned)G);
       double pp = 0.0, cc = 0.0, ff = 0.0, pp1 = 0.0, cc1 = 0.0;
       if (t < G) {
-        pp = spx_atomic_load_f64(&row[t].p);
-        cc = spx_atomic_load_f64(&row[t].c);
-        if (first) ff = spx_atomic_load_f64(&row[t].f);
-        if (r1 > 0.0) { pp1 = spx_atomic_load_f64(&row[t].p1); cc1 = spx_atomic_load_f64(&row[t].c1); }
+        const unsigned long long* theirs = row + (size_t)t * kB2Words;
+        unsigned long long w0, w1, w2 = 1ull, w3 = 1ull, w4 = 1ull;
+        for (;;) {  // (every workgroup of the grid is resident and stores these words once per pass: the exit condition)
+          w0 = __hip_atomic_load(theirs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w1 = __hip_atomic_load(theirs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (first) w2 = __hip_atomic_load(theirs + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (r1 > 0.0) {
+            w3 = __hip_atomic_load(theirs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w4 = __hip_atomic_load(theirs + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (w0 && w1 && w2 && w3 && w4) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        pp = __longlong_as_double((long long)(w0 - 1ull));
+        cc = __longlong_as_double((long long)(w1 - 1ull));
+        if (first) ff = __longlong_as_double((long long)(w2 - 1ull));
+        if (r1 > 0.0) { pp1 = __longlong_as_double((long long)(w3 - 1ull)); cc1 = __longlong_as_double((long long)(w4 - 1ull)); }
       }
       b2_block_sum5(pp, cc, ff, pp1, cc1, lds5);
       P = pp; C = cc; P1 = pp1; C1 = cc1;
       if (first) F = ff;
     }
+    B2_STAMP();  // exchanged
     ++np;
   };
   // ---- the sample's root (streaming form): same iteration, chi scaled by sqrt(n / 65536), nothing stored
@@ -525,22 +590,24 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
     }
     stored = (y_eta == eta);
   }
+#ifdef SPX_B2_PROFILE
+  if (stored && blockIdx.x == 0 && t == 0) g_b2_nstamp = nst;
+#endif
   if (stored) return;  // (after the last rendezvous; every workgroup takes the same path)
   // final: y = ProjB((-xk) r) rinv - sj   (:63, :65), or ProjB(-xk) - sj (:59) when the trust region is inactive
   const double r = scaled ? eta / delta : 1.0, rinv = scaled ? delta / eta : 1.0;
 #ifdef SPX_B2_DEBUG
   if (blockIdx.x == 0 && t == 0) printf("[b2] final: scaled %d eta %.17g r %.6g rinv %.6g stored %d G %d n2 %lld\n", (int)scaled, eta, r, rinv, (int)stored, G, (long long)n2);
 #endif
-  auto out = [&](double sq, double x, double s) -> double {
-    const double lo = sq - ls, hi = sq + ls;
+  auto out = [&](double lo, double hi, double x, double s) -> double {
     const double tt = scaled ? jl_min(jl_max((-x) * r, lo), hi) * rinv : jl_min(jl_max(-x, lo), hi);
     return tt - s;
   };
   if constexpr (REG) {
 #pragma unroll
-    for (int k = 0; k < kB2Epl; ++k) {
+    for (int k = 0; k < EPL; ++k) {
       const int64_t i = gtid + (int64_t)k * NT;
-      if (i < n) y[i] = out(SQ[k], X[k], S[k]);
+      if (i < n) y[i] = out(LO[k], HI[k], X[k], sj[i]);
     }
   } else {
     // The SAME element -> lane mapping as the reduction passes (tiles of 1024 lanes x 2 pairs, workgroup-strided): a pass may
@@ -564,11 +631,22 @@ __global__ __launch_bounds__(1024) void k_b2_coop(double* y, const double* q, co
       for (int k = 0; k < KP; ++k) {
         const int64_t i = tile * kTilePairs + t + k * 1024;
         if (i < n2)
-          __builtin_nontemporal_store(f64x2{out(d[k].x + a[k].x, b[k].x, d[k].x), out(d[k].y + a[k].y, b[k].y, d[k].y)}, y2 + i);
+        {
+          const double sq0 = d[k].x + a[k].x, sq1 = d[k].y + a[k].y;
+          __builtin_nontemporal_store(f64x2{out(sq0 - ls, sq0 + ls, b[k].x, d[k].x), out(sq1 - ls, sq1 + ls, b[k].y, d[k].y)}, y2 + i);
+        }
       }
     }
-    if ((n & 1) && blockIdx.x == 0 && t == 0) y[n - 1] = out(sj[n - 1] + q[n - 1], xk[n - 1], sj[n - 1]);
+    if ((n & 1) && blockIdx.x == 0 && t == 0) {
+      const double sql = sj[n - 1] + q[n - 1];
+      y[n - 1] = out(sql - ls, sql + ls, xk[n - 1], sj[n - 1]);
+    }
   }
+#ifdef SPX_B2_PROFILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  B2_STAMP();
+  if (blockIdx.x == 0 && t == 0) g_b2_nstamp = nst;
+#endif
 }
 
 // psi(y) from the reduced sums, on the device (spx_ctx_set_value_target)
@@ -638,30 +716,35 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   B2Ws* ws = reinterpret_cast<B2Ws*>(ctx->ws);
   const double ls = lambda * sigma;  // `psi.lambda * sigma`, :56
   bool vec = n >= 2 && spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj);
-  if (ctx->tune_sel_coop && ctx->num_cu >= 32 && (vec || n <= (int64_t)kB2Epl * 1024 * ctx->num_cu)) {
+  if (ctx->tune_sel_coop && ctx->num_cu >= 32 &&
+      (vec || n <= (int64_t)kB2RegBlock * (ctx->num_cu < kB2Cols ? ctx->num_cu : kB2Cols))) {
     // one launch, no read-back (see k_b2_coop)
-    const bool reg = n <= (int64_t)kB2Epl * 1024 * ctx->num_cu;
-    int64_t g = reg ? (n + (int64_t)kB2Epl * 1024 - 1) / ((int64_t)kB2Epl * 1024) : ctx->num_cu;
-    if (g > ctx->num_cu) g = ctx->num_cu;
+    const int64_t gmax = ctx->num_cu < kB2Cols ? ctx->num_cu : kB2Cols;
+    const bool reg = n <= (int64_t)kB2RegBlock * gmax;
+    int64_t g = reg ? (n + kB2RegBlock - 1) / kB2RegBlock : gmax;
     if (g < 1) g = 1;
-    rc = spx_ws_reserve(ctx, sizeof(B2Part5) * (size_t)kB2MaxPass * (size_t)g + 256);
-    if (rc) return rc;
-    rc = spx_sync_reserve(ctx, sizeof(SpxSyncHeader));
+    rc = spx_sync_reserve(ctx, kSpxSyncSelBytes + kB2SyncBytes);
     if (rc) return rc;
     auto disjoint = [&](const double* a) { return (y + n <= a) || (a + n <= y); };
     const int can_spec = (disjoint(q) && disjoint(xk) && disjoint(sj)) ? 1 : 0;
-    B2Part5* part = reinterpret_cast<B2Part5*>(ctx->ws);
     SpxSyncHeader* hdr = reinterpret_cast<SpxSyncHeader*>(ctx->sync);
+    unsigned long long* sets = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->sync) + kSpxSyncSelBytes);
+    const int use = ctx->b2_set, other = use ^ 1;
+    unsigned long long* rows = sets + (size_t)use * kB2SetWords;
+    unsigned long long* clear_rows = sets + (size_t)other * kB2SetWords;
+    const int clear_g = ctx->b2_dirty_g[other];
     {
       SpxCoopLaunchGuard guard(ctx);
       if (reg)
-        hipLaunchKernelGGL((k_b2_coop<true>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, ls, delta,
-                           chi_lambda, part, hdr, ctx->coop_parity, can_spec);
+        hipLaunchKernelGGL((k_b2_coop<true, kB2Epl, kB2RegThreads>), dim3((unsigned)g), dim3(kB2RegThreads), 0, ctx->stream, y, q, xk, sj, n, ls, delta,
+                           chi_lambda, rows, clear_rows, clear_g, hdr, can_spec);
       else
-        hipLaunchKernelGGL((k_b2_coop<false>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, ls, delta,
-                           chi_lambda, part, hdr, ctx->coop_parity, can_spec);
+        hipLaunchKernelGGL((k_b2_coop<false, 1, 1024>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, ls, delta,
+                           chi_lambda, rows, clear_rows, clear_g, hdr, can_spec);
     }
-    ctx->coop_parity ^= 1;
+    ctx->b2_dirty_g[use] = (g > 1) ? (int)g : 0;  // (one workgroup exchanges nothing)
+    ctx->b2_dirty_g[other] = 0;
+    ctx->b2_set = other;
     SPX_LAUNCH_CHECK();
     return SPX_OK;
   }

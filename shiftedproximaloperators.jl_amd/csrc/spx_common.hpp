@@ -35,6 +35,8 @@ struct spx_ctx {
   void* sync = nullptr;
   size_t sync_bytes = 0;
   int coop_parity = 0;
+  int b2_set = 0;                 // ShiftedNormL1B2: the set of partial-sum words the next launch uses (spx_b2.hip, b2_put)
+  int b2_dirty_g[2] = {0, 0};     // ... and how many workgroups wrote into each set (0 = clean)
   int sel_hist_next = 0;            // spx_select.hip: histogram set (0/1) the next k_sel_coop launch uses ...
   int sel_hist_dirty[2] = {0, 0};   // ... and which sets a previous launch left non-zero
   // spx_ctx_set_value_target: when non-NULL, the value-returning entry points (spx_obj_*, spx_proxval_*) store their
@@ -149,6 +151,10 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+
+// spx_ctx::sync: [0, kSpxSyncSelBytes) belongs to spx_select.hip (SelSync, whose head is the SpxSyncHeader below), the
+// partial-sum words of spx_b2.hip follow.  Zero-filled when (re)allocated; the host-side flags are reset with it.
+constexpr size_t kSpxSyncSelBytes = (size_t)3 << 19;  // 1.5 MiB >= sizeof(SelSync) (static_assert in spx_select.hip)
 
 // Head of spx_ctx::sync, shared by every kernel that synchronises inside one launch.
 struct SpxSyncHeader {

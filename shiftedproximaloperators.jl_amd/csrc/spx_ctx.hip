@@ -185,6 +185,8 @@ int spx_sync_reserve(spx_ctx* ctx, size_t bytes) {
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   ctx->sync_bytes = bytes;
   ctx->coop_parity = 0;
+  ctx->b2_set = 0;
+  ctx->b2_dirty_g[0] = ctx->b2_dirty_g[1] = 0;
   ctx->sel_hist_next = 0;
   ctx->sel_hist_dirty[0] = ctx->sel_hist_dirty[1] = 0;
   return SPX_OK;

@@ -1109,6 +1109,8 @@ struct SelSync {
   SelWs ws;                                // st, fs, hist, shards (cleared by k_s2_front; fs.smax by the fallback launch)
 };
 
+static_assert(sizeof(SelSync) <= kSpxSyncSelBytes, "SelSync outgrew its share of spx_ctx::sync");
+
 struct CoopShared {
   unsigned int lh[kBins];
   unsigned long long scratch[24];
@@ -1199,7 +1201,9 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
 #pragma unroll
     for (int k = 0; k < kCoopEpl; ++k) {
       const int64_t i = gtid + (int64_t)k * NT;
-      v[k] = (i < n) ? (xk[i] + sj[i]) + q[i] : 0.0;  // shiftedIndBallL0.jl:66
+      const int64_t ic = i < n ? i : n - 1;            // clamped, unconditional: all the loads in flight at once
+      const double xv = xk[ic], sv = sj[ic], qv = q[ic];
+      v[k] = (i < n) ? (xv + sv) + qv : 0.0;           // shiftedIndBallL0.jl:66
     }
   }
   if (t == 0) {
