@@ -1317,6 +1317,8 @@ __global__ __launch_bounds__(1024) void k_sel_coop(double* y, const double* q, c
 // ---------------------------------------------------------------------------------------------
 // k_s2_front: kFrontBlocks workgroups x 1024 lanes (few, fat workgroups: a grid barrier costs ~2 us with 64 arrivers,
 // ~7 us with 256 -- tools/exp/grid_barrier.hip), one sample per lane, kept in a register through all phases.
+// (The fenced barrier stays here: the fence-free rendezvous of coop_select needs the histograms read with agent-scope atomic
+//  loads, and 16 of those per lane cost the scan more (3.6 -> 6.3 us) than the rendezvous saves (4.1 -> 3.1 us); measured.)
 //   A  sample, LDS histogram of the top key digit -> fhist1; clears what the main pass / tail accumulate into
 //   B  (every workgroup) scan fhist1 for the two ranks; second digit of the own sample if it sits in a selected bucket
 //   C  scan; a third digit only if a selected bucket is still crowded (as k_s2_pick); workgroup 0 writes the band and
