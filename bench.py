@@ -296,7 +296,7 @@ def _extra(s, L, ctx, dev, n, torch):
     psi_b2 = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, s.NormL2(1.0)), sj)
     s.prox_bang(y, psi_b2, q, 1.0)
     ms = _time_op(s, L, ctx, lambda: s.prox_bang(y, psi_b2, q, 1.0), iters=5, rounds=3)
-    res["ShiftedNormL1B2"] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4), "kernel": "k_b2_coop<false>",
+    res["ShiftedNormL1B2"] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4), "kernel": "k_b2_coop<false,1,1024>",
                               "gelem_s": round(n / ms / 1e6, 2), "gbs_algorithmic": round(32 * n / ms / 1e6, 1),
                               "frac_of_peak": round(32 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
                               "note": "algorithmic 32 B/element; the call streams 24 + 24 + 32 = 80 B/element (two reduction passes, "
@@ -331,7 +331,7 @@ def _extra(s, L, ctx, dev, n, torch):
         for name, psi_s, kern in (
                 ("ShiftedIndBallL0BInf_r=n/100_n=%d" % nn, s.shifted(s.shifted(s.IndBallL0(max(1, nn // 100)), xs, 1.0, chi), ss_),
                  "k_sel_coop<true,true>" if nn > 65536 else "k_sel_small<true>"),
-                ("ShiftedNormL1B2_n=%d" % nn, s.shifted(s.shifted(s.NormL1(1.0), xs, 1.0, s.NormL2(1.0)), ss_), "k_b2_coop<true>")):
+                ("ShiftedNormL1B2_n=%d" % nn, s.shifted(s.shifted(s.NormL1(1.0), xs, 1.0, s.NormL2(1.0)), ss_), "k_b2_coop<true,16,512>")):
             s.prox_bang(ys, psi_s, qs, 1.0)
             ms = _time_op(s, L, ctx, lambda: s.prox_bang(ys, psi_s, qs, 1.0), iters=50, rounds=5)
             res[name] = {"us": round(ms * 1e3, 2), "avg_launch_ms": round(ms, 5), "kernel": kern, "n": nn,

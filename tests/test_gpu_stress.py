@@ -324,3 +324,51 @@ def test_b2_streaming_form_scenarios(s, orc, kind):
         q2 = qd.clone()
         s.prox_bang(q2, s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(1.0)), sd), q2, 1.0)
         assert float(np.max(np.abs(q2.cpu().numpy() - ref))) <= 1e-12 * scale, (kind, lam, delta, "aliased")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ShiftedNormL1B2, one-launch forms (csrc/spx_b2.hip k_b2_coop): the register-resident form holds 8192 elements per workgroup
+# (512 lanes x 16) and exchanges partial sums through words that carry their own ready flag (b2_put); sizes either side of
+# one / two / many / all 256 workgroups and of the switch to the streaming form, each with the trust region active,
+# inactive twice in a row (the second call stores y in its first pass), active again, and y aliased to q.  Two sets of
+# words alternate between launches and a launch zeroes the other set: the sequence of sizes exercises that too.
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 511, 8191, 8192, 8193, 16385, 65_537, 1_000_003, (1 << 21) - 1, 1 << 21, (1 << 21) + 2])
+def test_b2_one_launch_forms_at_their_boundaries(s, orc, n):
+    import torch
+    rng = np.random.default_rng(77 + n)
+    x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
+    xd, sd, qd = _dev(x, sj, q)
+    nrm = float(np.linalg.norm(x))
+    for lam, sigma, delta in ((1.0, 1.0, 1.0), (1.0, 1.0, 1e9), (1.0, 1.0, 1e9), (0.3, 0.7, 0.5 * nrm + 1e-3), (2.0, 1.0, 1e-3)):
+        psi = s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(1.0)), sd)
+        ref = orc.prox_l1_b2(q, x, sj, lam, sigma, delta, 1.0)
+        scale = max(np.linalg.norm(ref), nrm, 1e-300)
+        y = s.prox(psi, qd, sigma).cpu().numpy()
+        assert np.max(np.abs(y - ref)) <= 1e-12 * scale, (n, lam, sigma, delta)
+        qa = qd.clone()
+        s.prox_bang(qa, psi, qa, sigma)
+        assert np.max(np.abs(qa.cpu().numpy() - ref)) <= 1e-12 * scale, (n, lam, sigma, delta, "aliased")
+    # a NaN anywhere poisons the norm, as in the reference (every entry of the scaled branch becomes NaN)
+    if n >= 3:
+        qn = q.copy(); qn[n // 2] = np.nan
+        psi = s.shifted(s.shifted(s.NormL1(1.0), xd, 1.0, s.NormL2(1.0)), sd)
+        y = s.prox(psi, torch.from_numpy(qn).cuda(), 1.0).cpu().numpy()
+        ref = orc.prox_l1_b2(qn, x, sj, 1.0, 1.0, 1.0, 1.0)
+        assert np.array_equal(np.isnan(y), np.isnan(ref)), n
+
+
+def test_b2_alternating_sizes_share_the_exchange_words(s, orc):
+    """Calls of different sizes on one context, interleaved: the partial-sum words of a 256-workgroup launch must be clean
+    again when a 2-workgroup launch (and then another 256-workgroup one) comes to use the same set."""
+    rng = np.random.default_rng(5)
+    data = {}
+    for n in (12_000, (1 << 21) - 7, 3_000_001, 70_000):
+        x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
+        data[n] = (x, sj, q) + tuple(_dev(x, sj, q)) + (orc.prox_l1_b2(q, x, sj, 1.0, 1.0, 1.0, 1.0),)
+    order = [12_000, (1 << 21) - 7, 12_000, 3_000_001, (1 << 21) - 7, 70_000, 12_000, 70_000, 3_000_001, 12_000]
+    for n in order:
+        x, sj, q, xd, sd, qd, ref = data[n]
+        psi = s.shifted(s.shifted(s.NormL1(1.0), xd, 1.0, s.NormL2(1.0)), sd)
+        y = s.prox(psi, qd, 1.0).cpu().numpy()
+        assert np.max(np.abs(y - ref)) <= 1e-12 * max(np.linalg.norm(ref), np.linalg.norm(x)), n
