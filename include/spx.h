@@ -94,8 +94,8 @@ int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms); /* records stop, waits, ret
  * full-vector radix select (0), key 3 = LDS-staged (1, default) or register-staged (0) separable skeleton, key 4 =
  * single-pass form of the top-r path when y overlaps no input (1, default) or always the two-pass form (0), key 5 =
  * XCD-contiguous tile ranges in the LDS-staged skeleton (0, default: tile = workgroup id), key 6 = one-workgroup top-r
- * kernel for n <= 65536 (1, default), key 7 = top-r / ShiftedNormL1B2 kernels that synchronise inside one launch (1,
- * default) or the multi-launch pipeline (0).  Contexts are independent; a context is used by one thread at a time. */
+ * kernel for n <= 8192 (n <= 65536 under key 7 = 0) (1, default), key 7 = top-r / ShiftedNormL1B2 kernels that
+ * synchronise inside one launch (1, default) or the multi-launch pipeline (0).  Contexts are independent; a context is used by one thread at a time. */
 int spx_ctx_set_tuning(spx_ctx* ctx, int key, int value);
 
 /* ---- construction-time helpers (the reference's constructors) ---------------------------- */

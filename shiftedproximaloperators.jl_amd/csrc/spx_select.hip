@@ -442,6 +442,7 @@ __global__ __launch_bounds__(256) void k_sel_final(double* y, const double* xk, 
 // every pass, so y needs no fence between passes.
 // =============================================================================================
 constexpr int64_t kSmallN = 1 << 16;
+constexpr int64_t kSmallNCoop = 1 << 13;  // ... when k_sel_coop serves the sizes above (see run_select)
 template <bool BINF>
 __global__ __launch_bounds__(1024) void k_sel_small(double* y, const double* q, const double* xk, const double* sj, int64_t n,
                                                      int64_t r, double delta) {
@@ -1500,7 +1501,10 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   if (rc) return rc;
   if (n == 0) return SPX_OK;
   SPX_ON_DEVICE(ctx);
-  if (n <= kSmallN && ctx->tune_sel_small) {  // one workgroup, one launch, no scratch
+  // one workgroup, one launch, no scratch -- up to 8192 elements when the register-resident grid-wide select is there to take
+  // over (n = 16 384: 32 us in one workgroup, 21 us on two; n = 65 536: 84 vs 19 us -- tools/r2/topr_small.py)
+  const int64_t small_max = (ctx->tune_sel_coop && ctx->num_cu >= 32) ? kSmallNCoop : kSmallN;
+  if (n <= small_max && ctx->tune_sel_small) {
     hipLaunchKernelGGL((k_sel_small<BINF>), dim3(1), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta);
     SPX_LAUNCH_CHECK();
     return SPX_OK;

@@ -248,7 +248,7 @@ def test_indball_l0(s, orc, n, quant):
 
 
 def test_indball_l0_small_n_both_kernels(s, orc):
-    """n <= 65536 runs in one workgroup (k_sel_small); spx_ctx_set_tuning key 6 = 0 sends the same sizes through the
+    """n <= 8192 (65536 without the in-launch kernels) runs in one workgroup (k_sel_small); key 6 = 0 sends the same sizes through the
     kernels larger vectors use: the register-resident one-launch select (key 7 = 1, default) or the multi-launch radix
     select of round 1 (key 7 = 0).  All three must give the oracle's bits, ties and NaN included."""
     L = s._lib.load()
@@ -257,7 +257,7 @@ def test_indball_l0_small_n_both_kernels(s, orc):
         for mode, coop in ((1, 1), (0, 1), (0, 0)):
             L.spx_ctx_set_tuning(s.context("cuda:0"), 6, mode)
             L.spx_ctx_set_tuning(s.context("cuda:0"), 7, coop)
-            for n in (1, 2, 63, 1024, 1025, 5000, 65536):
+            for n in (1, 2, 63, 1024, 1025, 5000, 8192, 8193, 65536):
                 x, sj, q = _data(n, 700 + n, 8)
                 if n >= 63:
                     q[rng.choice(n, size=3, replace=False)] = np.nan
