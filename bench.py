@@ -159,6 +159,10 @@ def main():
 
     if rank == 0 and not args.no_extra:
         out["other_operators"] = _extra(s, L, ctx, dev, n, torch)
+        try:
+            out["solver_iteration_in_a_graph"] = _graph_iteration(s, dev, torch)
+        except Exception as e:  # reported, never fatal for the headline line
+            out["solver_iteration_in_a_graph"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and not args.no_cpu:
         out["cpu_baseline"] = _cpu_baseline(s, psi, q, xk, sj, y, n, torch)
         if not args.no_extra:
@@ -357,6 +361,61 @@ def _extra(s, L, ctx, dev, n, torch):
     del keep
     h30 = s.GroupNormL2.uniform(lam * 30.0, 128)
     line("ShiftedGroupNormL2Binf_%dx128_sparse_iterate" % ng, s.shifted(s.shifted(h30, xk, 1.0, chi), sj), bpe, m, y, q, "k_group_reg<8,16,true,true,false>")
+    return res
+
+
+def _graph_iteration(s, dev, torch):
+    """One solver-style iteration at solver-iteration sizes -- prox!(ShiftedNormL1Box), psi(y) left on the device,
+    prox!(ShiftedIndBallL0BInf), prox!(ShiftedNormL1B2) -- issued call by call from Python and replayed as ONE captured graph
+    (hipGraph through torch.cuda.CUDAGraph; libspx's graph-safe mode): wall time per iteration, 200 iterations, one
+    synchronisation at the end."""
+    res = {}
+    side = torch.cuda.Stream(device=dev)
+    for nn in (10_000, 1_000_000):
+        with torch.cuda.stream(side):
+            gen = torch.Generator(device=dev).manual_seed(7)
+            xk = torch.randn(nn, dtype=torch.float64, device=dev, generator=gen)
+            sj = torch.rand(nn, dtype=torch.float64, device=dev, generator=gen) - 0.5
+            q = torch.randn(nn, dtype=torch.float64, device=dev, generator=gen)
+            ys = [torch.empty_like(q) for _ in range(3)]
+            val = torch.zeros(1, dtype=torch.float64, device=dev)
+            chi = s.NormLinf(1.0)
+            p_box = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj)
+            p_top = s.shifted(s.shifted(s.IndBallL0(max(1, nn // 100)), xk, 1.0, chi), sj)
+            p_b2 = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, s.NormL2(1.0)), sj)
+
+            def iteration():
+                s.prox_bang(ys[0], p_box, q, 1.0)
+                with s.device_values(val):
+                    p_box(ys[0])
+                s.prox_bang(ys[1], p_top, q, 1.0)
+                s.prox_bang(ys[2], p_b2, q, 1.0)
+
+            for _ in range(3):
+                iteration()
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                iteration()
+            reps = 200
+            for _ in range(5):
+                g.replay()
+            side.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                g.replay()
+            side.synchronize()
+            t_graph = (time.perf_counter() - t0) / reps
+            for _ in range(5):
+                iteration()
+            side.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                iteration()
+            side.synchronize()
+            t_eager = (time.perf_counter() - t0) / reps
+        res["n=%d" % nn] = {"us_per_iteration_python_calls": round(t_eager * 1e6, 1), "us_per_iteration_graph_replay": round(t_graph * 1e6, 1),
+                            "kernels": "4 calls: k_sep_lds<OpL1Box>, k_obj<TermL1,1> + k_obj_final, k_sel_coop / k_sel_small, k_b2_coop (+ zero-fill nodes)"}
     return res
 
 

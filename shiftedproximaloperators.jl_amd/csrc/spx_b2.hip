@@ -181,6 +181,7 @@ int b2_sums(spx_ctx* ctx, const double* q, const double* xk, const double* sj, i
   hipLaunchKernelGGL(k_b2_reduce, dim3(1), dim3(256), 0, ctx->stream, ws, blocks, first ? 1 : 0);
   SPX_LAUNCH_CHECK();
   double pcf[3];
+  { const int rcc = spx_require_not_capturing(ctx, "the host-driven ShiftedNormL1B2 iteration (spx_ctx_set_tuning key 7 = 0 or a mixed alignment)"); if (rcc) return rcc; }
   SPX_HIP(hipMemcpyAsync(pcf, &ws->P, sizeof(pcf), hipMemcpyDeviceToHost, ctx->stream));
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   *P = pcf[0];
@@ -689,12 +690,13 @@ SPX_EXPORT int spx_obj_l1_b2(spx_ctx* ctx, const double* y, const double* xk, co
       return SPX_OK;
     }
     double pc[2];
+    { const int rcc = spx_require_not_capturing(ctx, "returning psi(y) to the host"); if (rcc) return rcc; }
     SPX_HIP(hipMemcpyAsync(pc, &ws->P, sizeof(pc), hipMemcpyDeviceToHost, ctx->stream));
     SPX_HIP(hipStreamSynchronize(ctx->stream));
     P = pc[0];
     C = pc[1];
   } else if (ctx->value_target) {
-    SPX_HIP(hipMemsetAsync(ctx->value_target, 0, sizeof(double), ctx->stream));
+    { const int rz = spx_zero_async(ctx, ctx->value_target, sizeof(double)); if (rz) return rz; }
     return SPX_OK;
   }
   const double nrm = std::sqrt(C);
@@ -729,10 +731,20 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
     const int can_spec = (disjoint(q) && disjoint(xk) && disjoint(sj)) ? 1 : 0;
     SpxSyncHeader* hdr = reinterpret_cast<SpxSyncHeader*>(ctx->sync);
     unsigned long long* sets = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->sync) + kSpxSyncSelBytes);
-    const int use = ctx->b2_set, other = use ^ 1;
+    int use = ctx->b2_set, other = use ^ 1;
+    int clear_g = ctx->b2_dirty_g[other];
+    const bool graph_safe = spx_capture_check(ctx) || ctx->graph_safe;  // (see spx_ctx::graph_safe)
+    if (graph_safe) {  // set 0, its g columns zeroed by a node in front of the launch; nothing alternates
+      use = 0; other = 1; clear_g = 0;
+      if (g > 1)
+      {
+        rc = spx_zero2d_async(ctx, sets, (size_t)kB2Cols * kB2Words * sizeof(unsigned long long),
+                              (size_t)g * kB2Words * sizeof(unsigned long long), (size_t)kB2MaxPass);
+        if (rc) return rc;
+      }
+    }
     unsigned long long* rows = sets + (size_t)use * kB2SetWords;
     unsigned long long* clear_rows = sets + (size_t)other * kB2SetWords;
-    const int clear_g = ctx->b2_dirty_g[other];
     {
       SpxCoopLaunchGuard guard(ctx);
       if (reg)
@@ -742,9 +754,13 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
         hipLaunchKernelGGL((k_b2_coop<false, 1, 1024>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, ls, delta,
                            chi_lambda, rows, clear_rows, clear_g, hdr, can_spec);
     }
-    ctx->b2_dirty_g[use] = (g > 1) ? (int)g : 0;  // (one workgroup exchanges nothing)
-    ctx->b2_dirty_g[other] = 0;
-    ctx->b2_set = other;
+    if (graph_safe) {  // both sets count as used by the widest grid from here on (a replay may have touched set 0)
+      ctx->b2_dirty_g[0] = ctx->b2_dirty_g[1] = kB2Cols;
+    } else {
+      ctx->b2_dirty_g[use] = (g > 1) ? (int)g : 0;  // (one workgroup exchanges nothing)
+      ctx->b2_dirty_g[other] = 0;
+      ctx->b2_set = other;
+    }
     SPX_LAUNCH_CHECK();
     return SPX_OK;
   }

@@ -35,6 +35,11 @@ struct spx_ctx {
   void* sync = nullptr;
   size_t sync_bytes = 0;
   int coop_parity = 0;
+  // Graph-safe mode (sticky, set the first time a call finds its stream capturing: spx_capture_check).  The kernels that
+  // synchronise inside one launch keep device state between launches (barrier counters, histogram sets, exchange words) that
+  // the host tracks by alternating sets -- a captured launch would replay ONE set for ever.  In graph-safe mode every such
+  // launch is preceded by a memset of exactly the state it uses (a node of the same graph) and the sets are fixed.
+  int graph_safe = 0;
   int b2_set = 0;                 // ShiftedNormL1B2: the set of partial-sum words the next launch uses (spx_b2.hip, b2_put)
   int b2_dirty_g[2] = {0, 0};     // ... and how many workgroups wrote into each set (0 = clean)
   int sel_hist_next = 0;            // spx_select.hip: histogram set (0/1) the next k_sel_coop launch uses ...
@@ -57,6 +62,15 @@ void spx_set_error(const char* fmt, ...);
 int spx_ws_reserve(spx_ctx* ctx, size_t bytes);
 int spx_sync_reserve(spx_ctx* ctx, size_t bytes);  // persistent, zero-initialised (see spx_ctx::sync)
 int spx_ctx_count(int device);                     // live contexts on a device
+// Is ctx's stream being captured into a graph?  Sets spx_ctx::graph_safe (sticky) when it is.  Calls that would have to
+// synchronise the stream or (re)allocate refuse to run while capturing (SPX_ERR_INVALID_ARG, spx_require_not_capturing).
+// Zero-fill on the context's stream by a KERNEL (4-byte words): used instead of hipMemsetAsync / hipMemset2DAsync wherever
+// a call may be captured into a graph -- a captured iteration replayed through torch.cuda.CUDAGraph faulted in a way that
+// implicated the runtime's memset nodes (round 2; plain kernel nodes replay fine).  bytes, pitch, width: multiples of 4.
+int spx_zero_async(spx_ctx* ctx, void* ptr, size_t bytes);
+int spx_zero2d_async(spx_ctx* ctx, void* ptr, size_t pitch_bytes, size_t width_bytes, size_t rows);
+bool spx_capture_check(spx_ctx* ctx);
+int spx_require_not_capturing(spx_ctx* ctx, const char* what);
 
 // Two launches that synchronise inside themselves must not run side by side on one device: each would hold CUs while it
 // waits for workgroups of its own that cannot be placed.  Contexts on different streams are therefore chained through one

@@ -149,10 +149,46 @@ SPX_EXPORT int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms) {
   return SPX_OK;
 }
 
+__global__ __launch_bounds__(256) void k_zero_words(unsigned int* p, size_t pitch_words, size_t width_words, size_t rows) {
+  const size_t total = width_words * rows;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    p[(i / width_words) * pitch_words + (i % width_words)] = 0u;
+}
+int spx_zero2d_async(spx_ctx* ctx, void* ptr, size_t pitch_bytes, size_t width_bytes, size_t rows) {
+  SPX_REQUIRE(ptr != nullptr && (reinterpret_cast<uintptr_t>(ptr) & 3u) == 0 && (pitch_bytes & 3u) == 0 && (width_bytes & 3u) == 0 &&
+              width_bytes <= pitch_bytes, "spx_zero2d_async: unaligned range");
+  const size_t total = (width_bytes / 4) * rows;
+  if (total == 0) return SPX_OK;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > (size_t)ctx->num_cu * 8) blocks = (size_t)ctx->num_cu * 8;
+  hipLaunchKernelGGL(k_zero_words, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, static_cast<unsigned int*>(ptr),
+                     pitch_bytes / 4, width_bytes / 4, rows);
+  SPX_LAUNCH_CHECK();
+  return SPX_OK;
+}
+int spx_zero_async(spx_ctx* ctx, void* ptr, size_t bytes) { return spx_zero2d_async(ctx, ptr, bytes, bytes, 1); }
+
+bool spx_capture_check(spx_ctx* ctx) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  if (st != hipStreamCaptureStatusNone) ctx->graph_safe = 1;
+  return st != hipStreamCaptureStatusNone;
+}
+int spx_require_not_capturing(spx_ctx* ctx, const char* what) {
+  if (!spx_capture_check(ctx)) return SPX_OK;
+  spx_set_error("invalid argument: %s is not possible while the stream is being captured into a graph "
+                "(run the same call once before capturing; keep values on the device with spx_ctx_set_value_target)", what);
+  return SPX_ERR_INVALID_ARG;
+}
+
 // Grows the context scratch.  Called from entry points BEFORE any launch of that call; growing
 // synchronises the stream (the old block may still be in use by earlier calls).
 int spx_ws_reserve(spx_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return SPX_OK;
+  { const int rc = spx_require_not_capturing(ctx, "growing the workspace"); if (rc) return rc; }
   SPX_ON_DEVICE(ctx);
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->ws) SPX_HIP(hipFree(ctx->ws));
@@ -171,6 +207,7 @@ int spx_ws_reserve(spx_ctx* ctx, size_t bytes) {
 // "zero when no launch of mine is in flight", which holds again after the stream has been drained.
 int spx_sync_reserve(spx_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->sync_bytes) return SPX_OK;
+  { const int rc = spx_require_not_capturing(ctx, "growing the synchronisation state"); if (rc) return rc; }
   SPX_ON_DEVICE(ctx);
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->sync) SPX_HIP(hipFree(ctx->sync));
@@ -228,6 +265,7 @@ SPX_EXPORT int spx_check_bounds(spx_ctx* ctx, const double* l_vec, const double*
   hipLaunchKernelGGL(k_check_bounds, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, l_vec, u_vec, l_scalar,
                      u_scalar, n, flag);
   SPX_LAUNCH_CHECK();
+  { const int rcc = spx_require_not_capturing(ctx, "spx_check_bounds (synchronous)"); if (rcc) return rcc; }
   SPX_HIP(hipMemcpyAsync(any_l_gt_u, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   return SPX_OK;
@@ -307,3 +345,16 @@ SPX_EXPORT int spx_synth_fill(spx_ctx* ctx, double* out, int64_t n, uint64_t see
   SPX_LAUNCH_CHECK();
   return SPX_OK;
 }
+
+#ifdef SPX_DEBUG_PEEK  // diagnostic builds only: bytes of the context's workspace (which = 0) or synchronisation state (1)
+SPX_EXPORT int spx_debug_peek(spx_ctx* ctx, int which, size_t offset, size_t nbytes, void* out) {
+  SPX_REQUIRE(ctx != nullptr && out != nullptr, "NULL argument");
+  const char* base = static_cast<const char*>(which ? ctx->sync : ctx->ws);
+  const size_t cap = which ? ctx->sync_bytes : ctx->ws_bytes;
+  SPX_REQUIRE(base != nullptr && offset + nbytes <= cap, "range outside the buffer");
+  SPX_ON_DEVICE(ctx);
+  SPX_HIP(hipStreamSynchronize(ctx->stream));
+  SPX_HIP(hipMemcpy(out, base + offset, nbytes, hipMemcpyDeviceToHost));
+  return SPX_OK;
+}
+#endif

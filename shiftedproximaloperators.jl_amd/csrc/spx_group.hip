@@ -748,11 +748,17 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
   constexpr bool kDma = !BINF && PAIRS;
   __shared__ __attribute__((aligned(16))) char dma_lds[kDma ? 4 * 3 * (EPL / 2) * 1024 : 16];
   const int npairs = gsize >> 1;
-  const int64_t ntodo = LIT ? (int64_t)deferred[0] : ngroups;
+  // (the list can hold at most every group once: a count outside [0, ngroups] is never followed into memory)
+  const int64_t nlist = LIT ? (int64_t)deferred[0] : 0;
+  const int64_t ntodo = LIT ? ((nlist < 0 || nlist > ngroups) ? 0 : nlist) : ngroups;
   for (int64_t g0 = wave * GPW; g0 < ntodo; g0 += nwaves * GPW) {  // wave-uniform trip count
     bool valid = (g0 + slot) < ntodo;
     const int64_t gi = valid ? (g0 + slot) : (ntodo - 1);  // idle slots shadow the last group, no store
-    const int64_t g = LIT ? (int64_t)deferred[1 + gi] : gi;
+    int64_t g = gi;
+    if constexpr (LIT) {
+      g = (int64_t)deferred[1 + gi];
+      if (g < 0 || g >= ngroups) { g = 0; valid = false; }  // (never an id from outside the layout)
+    }
     int64_t base = g * GS;
     int gs = gsize;  // this group's size (row-uniform)
     if constexpr (!PAIRS) {
@@ -969,9 +975,11 @@ __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, c
   const int lane = threadIdx.x % TEAM;
   const int64_t team = (int64_t)blockIdx.x * TPB + threadIdx.x / TEAM;
   const int64_t nteams = (int64_t)gridDim.x * TPB;
-  const int64_t ntodo = list ? (int64_t)list[0] : ngroups;
+  const int64_t nlist = list ? (int64_t)list[0] : 0;
+  const int64_t ntodo = list ? ((nlist < 0 || nlist > ngroups) ? 0 : nlist) : ngroups;
   for (int64_t t = team; t < ntodo; t += nteams) {  // for TEAM == 256 the trip count is block-uniform
     const int64_t g = list ? (int64_t)list[1 + t] : t;
+    if (g < 0 || g >= ngroups) continue;  // (never an id from outside the layout; block-uniform for TEAM == 256)
     int64_t lo, hi;
     if (offsets) { lo = offsets[g]; hi = offsets[g + 1]; }
     else { lo = g * gsize; hi = lo + gsize; }
@@ -1179,7 +1187,7 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
       rc = spx_ws_reserve(ctx, (size_t)(ngroups + 1) * sizeof(long long) + 256);
       if (rc) return rc;
       deferred = reinterpret_cast<long long*>(ctx->ws);
-      SPX_HIP(hipMemsetAsync(deferred, 0, sizeof(long long), ctx->stream));
+      { rc = spx_zero_async(ctx, deferred, sizeof(long long)); if (rc) return rc; }
     }
     const bool pairs = !ragged_reg && (gsize & 1) == 0 && aligned;  // otherwise 8-byte loads
     if (!BINF && ragged_reg)  // offsets need not span 0:n (src/shiftedGroupNormL2.jl:77 runs over every index)
@@ -1323,6 +1331,7 @@ static int run_group_gather(spx_ctx* ctx, double* y, const double* q, const doub
                        flag);
     SPX_LAUNCH_CHECK();
     int hflag = 0;  // the reference throws BoundsError before touching y: check before the stores
+    { const int rcc = spx_require_not_capturing(ctx, "validating a group layout"); if (rcc) return rcc; }
     SPX_HIP(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SPX_HIP(hipStreamSynchronize(ctx->stream));
     if (hflag & 2) { spx_set_error("invalid argument: group_ptr is not a non-decreasing sequence inside [0, nnz]"); return SPX_ERR_INVALID_ARG; }

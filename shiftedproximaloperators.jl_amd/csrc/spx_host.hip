@@ -38,7 +38,9 @@ int stage_in(spx_ctx* ctx, const In (&in)[NIN], const void* (&dev)[NIN], size_t 
   size_t total = aligned(out_bytes);
   for (int i = 0; i < NIN; ++i)
     if (in[i].host && in[i].bytes) total += aligned(in[i].bytes);
-  int rc = stage_reserve(ctx, total ? total : kAlign);
+  int rc = spx_require_not_capturing(ctx, "a host-pointer call (it copies and synchronises)");
+  if (rc) return rc;
+  rc = stage_reserve(ctx, total ? total : kAlign);
   if (rc) return rc;
   SPX_ON_DEVICE(ctx);
   char* p = static_cast<char*>(ctx->stage);

@@ -218,6 +218,7 @@ int obj_finish(spx_ctx* ctx, ObjWs* ws, int blocks, int rule, double scale, doub
     return SPX_OK;
   }
   struct { double r; int f; int p; } host;
+  { const int rcc = spx_require_not_capturing(ctx, "returning psi(y) to the host"); if (rcc) return rcc; }
   SPX_HIP(hipMemcpyAsync(&host, &ws->result, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   *value = host.r;
@@ -234,14 +235,14 @@ int run_obj(spx_ctx* ctx, const double* y, const double* xk, const double* sj, i
   SPX_REQUIRE(n == 0 || (y && xk && sj), "NULL vector with n > 0");
   *value = 0.0;  // h of the empty vector (count rule: 0 <= limit)
   if (n == 0) {
-    if (ctx->value_target) SPX_HIP(hipMemsetAsync(ctx->value_target, 0, sizeof(double), ctx->stream));
+    if (ctx->value_target) { const int rz = spx_zero_async(ctx, ctx->value_target, sizeof(double)); if (rz) return rz; }
     return SPX_OK;
   }
   int rc = spx_ws_reserve(ctx, sizeof(ObjWs) + 256);
   if (rc) return rc;
   SPX_ON_DEVICE(ctx);
   ObjWs* ws = reinterpret_cast<ObjWs*>(ctx->ws);
-  SPX_HIP(hipMemsetAsync(&ws->infeasible, 0, sizeof(int), ctx->stream));
+  { const int rz = spx_zero_async(ctx, &ws->infeasible, sizeof(int)); if (rz) return rz; }
   int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
   if (blocks > kObjBlocks) blocks = kObjBlocks;
   hipLaunchKernelGGL((k_obj<Term, MODE>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, lv, uv, mask, ls,
@@ -268,7 +269,7 @@ int run_obj_group(spx_ctx* ctx, const double* y, const double* xk, const double*
   if (rc) return rc;
   SPX_ON_DEVICE(ctx);
   ObjWs* ws = reinterpret_cast<ObjWs*>(ctx->ws);
-  SPX_HIP(hipMemsetAsync(&ws->infeasible, 0, sizeof(int), ctx->stream));
+  { const int rz = spx_zero_async(ctx, &ws->infeasible, sizeof(int)); if (rz) return rz; }
   int64_t blocks = (ngroups + 3) / 4;
   if (blocks > kObjBlocks) blocks = kObjBlocks;
   if (blocks < 1) blocks = 1;

@@ -1524,6 +1524,7 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     if (rc) return rc;
     ss = reinterpret_cast<SelSync*>(ctx->sync);
   }
+  const bool graph_safe = coop && (spx_capture_check(ctx) || ctx->graph_safe);  // (see spx_ctx::graph_safe)
   if (coop && !try_fast) {
     // exact select in ONE launch: register-resident up to 8 Ki elements per CU, v parked in y beyond that
     const bool reg = n <= reg_cap;
@@ -1531,9 +1532,16 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     int64_t g = reg ? (n + (int64_t)kCoopEpl * 1024 - 1) / ((int64_t)kCoopEpl * 1024) : ctx->num_cu;
     if (g > ctx->num_cu) g = ctx->num_cu;
     if (g < 1) g = 1;
-    const int use_set = ctx->sel_hist_next, other = use_set ^ 1;
-    const int clear_set = ctx->sel_hist_dirty[other] ? other : -1;
-    const int parity = ctx->coop_parity;
+    int use_set = ctx->sel_hist_next, other = use_set ^ 1;
+    int clear_set = ctx->sel_hist_dirty[other] ? other : -1;
+    int parity = ctx->coop_parity;
+    if (graph_safe) {  // the counters and histogram set 0, zeroed by a node in front of the launch; nothing alternates
+      rc = spx_zero_async(ctx, &ss->hdr, sizeof(ss->hdr.bar));
+      if (rc) return rc;
+      rc = spx_zero_async(ctx, &ss->chist[0][0][0], sizeof(ss->chist[0]));
+      if (rc) return rc;
+      use_set = 0; other = 1; clear_set = -1; parity = 0;
+    }
     {
       SpxCoopLaunchGuard guard(ctx);
       if (reg)
@@ -1543,10 +1551,14 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
         hipLaunchKernelGGL((k_sel_coop<BINF, false>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r,
                            delta, ss, parity, use_set, clear_set, 0);
     }
-    ctx->coop_parity ^= 1;
-    ctx->sel_hist_dirty[use_set] = 1;
-    ctx->sel_hist_dirty[other] = 0;
-    ctx->sel_hist_next = other;
+    if (graph_safe) {  // whatever the host believed about the sets no longer holds: both count as used
+      ctx->sel_hist_dirty[0] = ctx->sel_hist_dirty[1] = 1;
+    } else {
+      ctx->coop_parity ^= 1;
+      ctx->sel_hist_dirty[use_set] = 1;
+      ctx->sel_hist_dirty[other] = 0;
+      ctx->sel_hist_next = other;
+    }
     SPX_LAUNCH_CHECK();
     return SPX_OK;
   }
@@ -1580,6 +1592,15 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
       // front (sample + band, one in-launch synchronised kernel) -> main pass -> verdict / candidates -> fallback (exact
       // select; returns at once when the verdict is positive).  Nothing is read back.
       SelWs* sws = &ss->ws;
+      if (graph_safe) {
+        // counters, the front kernel's histograms and the pipeline's workspace header, zeroed by nodes in front of the
+        // launches (in eager mode the previous call's last launch leaves them clean); parities 0 / 1 fixed
+        rc = spx_zero_async(ctx, &ss->hdr, sizeof(ss->hdr.bar));
+        if (rc) return rc;
+        rc = spx_zero_async(ctx, &ss->fhist1[0], sizeof(SelSync) - offsetof(SelSync, fhist1));
+        if (rc) return rc;
+        ctx->coop_parity = 0;
+      }
       {
         SpxCoopLaunchGuard guard(ctx);
         hipLaunchKernelGGL(k_s2_front, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
@@ -1643,6 +1664,8 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     }
     SPX_LAUNCH_CHECK();
     // the verdict is read back AFTER the speculative final pass has been queued: the GPU never idles on the host
+    rc = spx_require_not_capturing(ctx, "the multi-launch top-r path (spx_ctx_set_tuning key 7 = 0), which reads its verdict back,");
+    if (rc) return rc;
     int ok = 0;
     SPX_HIP(hipMemcpyAsync(&ok, &ws->fs.ok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SPX_HIP(hipStreamSynchronize(ctx->stream));

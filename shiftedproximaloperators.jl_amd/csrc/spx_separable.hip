@@ -767,6 +767,7 @@ static int run_separable(spx_ctx* ctx, double* y, const double* q, const double*
       *value = std::numeric_limits<double>::quiet_NaN();
       return SPX_OK;
     }
+    { const int rcc = spx_require_not_capturing(ctx, "returning the value of prox_value to the host"); if (rcc) return rcc; }
     SPX_HIP(hipMemcpyAsync(value, result, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SPX_HIP(hipStreamSynchronize(ctx->stream));
   }
@@ -898,10 +899,11 @@ static int run_iprox_unboxed(spx_ctx* ctx, double* y, const double* g, const dou
   if (rc) return rc;
   SPX_ON_DEVICE(ctx);
   int* flag = reinterpret_cast<int*>(ctx->ws);
-  SPX_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+  { const int rz = spx_zero_async(ctx, flag, sizeof(int)); if (rz) return rz; }
   rc = run_separable(ctx, y, g, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, Op{lambda, flag}, d);
   if (rc || !check_d) return rc;
   int bad = 0;
+  { const int rcc = spx_require_not_capturing(ctx, "the d > 0 check of iprox! (pass check = 0)"); if (rcc) return rcc; }
   SPX_HIP(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   if (bad) {

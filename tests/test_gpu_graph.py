@@ -1,0 +1,114 @@
+"""A solver iteration captured into a graph (hipGraph through torch.cuda.CUDAGraph) and replayed on new data.
+
+The kernels that synchronise inside one launch (top-r, ShiftedNormL1B2) keep device state between launches that the host
+tracks by alternating sets; a captured launch would replay one set for ever.  csrc: spx_ctx::graph_safe -- once a call finds
+its stream capturing, every such launch is preceded by a memset node for exactly the state it uses.  Calls that would
+synchronise or allocate refuse to run while capturing."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def s():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as ge
+    return ge.build()
+
+
+def _bits(a, b):
+    return np.array_equal(np.asarray(a).view(np.int64), np.asarray(b).view(np.int64))
+
+
+@pytest.mark.parametrize("n", [6_000, 50_000, 1_000_000, 2_600_000])
+def test_iteration_in_a_graph_replays_on_new_data(s, orc, n):
+    """n = 6e3: one-workgroup top-r, one-workgroup B2; 5e4 / 1e6: the register-resident one-launch forms (7 / 123 workgroups);
+    2.6e6: the sample-predicted top-r pipeline and the streaming B2 form."""
+    import torch
+    rng = np.random.default_rng(n)
+    ng = n // 128
+    m = ng * 128
+    x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n)
+    lam_g = rng.uniform(0.5, 1.5, size=ng)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        xd, sd = torch.from_numpy(x).cuda(), torch.from_numpy(sj).cuda()
+        qd = torch.zeros(n, dtype=torch.float64, device="cuda")
+        ys = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(4)]
+        val = torch.zeros(1, dtype=torch.float64, device="cuda")
+        chi = s.NormLinf(1.0)
+        r = max(1, n // 50)
+        psi_box = s.shifted(s.shifted(s.NormL1(1.0), xd, 1.0, chi), sd)
+        psi_top = s.shifted(s.shifted(s.IndBallL0(r), xd, 0.8, chi), sd)
+        psi_b2 = s.shifted(s.shifted(s.NormL1(1.0), xd, 1.0, s.NormL2(1.0)), sd)
+        psi_grp = s.shifted(s.shifted(s.GroupNormL2.uniform(torch.from_numpy(lam_g).cuda(), 128), xd[:m], 1.0, chi), sd[:m])
+
+        def iteration():
+            s.prox_bang(ys[0], psi_box, qd, 1.0)
+            with s.device_values(val):
+                psi_box(ys[0])
+            s.prox_bang(ys[1], psi_top, qd, 1.0)
+            s.prox_bang(ys[2], psi_b2, qd, 1.0)
+            s.prox_bang(ys[3][:m], psi_grp, qd[:m], 1.0)
+
+        qd.copy_(torch.from_numpy(rng.normal(size=n)))
+        iteration(); iteration()           # warm-up on the capture stream: the workspaces reach their sizes
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        iteration()
+
+    def check(q, what):
+        torch.cuda.synchronize()
+        assert _bits(ys[0].cpu().numpy(), orc.prox_l1_box(q, x, sj, 1.0, 1.0, -1.0, 1.0)), what
+        exp = orc.obj_box("l1", ys[0].cpu().numpy(), x, sj, 1.0, -1.0, 1.0)
+        got = float(val.item())
+        assert got == exp or abs(got - exp) <= 1e-12 * abs(exp), (what, got, exp)
+        assert _bits(ys[1].cpu().numpy(), orc.prox_indball_l0_binf(q, x, sj, r, 0.8)), what
+        ref = orc.prox_l1_b2(q, x, sj, 1.0, 1.0, 1.0, 1.0)
+        assert np.max(np.abs(ys[2].cpu().numpy() - ref)) <= 1e-12 * max(np.linalg.norm(ref), np.linalg.norm(x)), what
+        ref = orc.prox_group_l2_binf(q[:m], x[:m], sj[:m], lam_g, 1.0, 1.0, gsize=128)
+        err = np.max(np.abs(ys[3][:m].cpu().numpy() - ref))
+        assert err <= 1e-9 * max(1.0, np.max(np.abs(ref))), (what, err)   # (the arbiter-based bar lives in test_gpu_parity.py)
+
+    for rep in range(4):
+        q = rng.normal(size=n) * (1.0 + rep)
+        qd.copy_(torch.from_numpy(q))
+        for t in ys:
+            t.fill_(-777.0)
+        torch.cuda.synchronize()
+        g.replay()
+        check(q, "replay %d" % rep)
+    # eager calls on the same context after the replays (graph-safe mode is sticky), then one more replay
+    q = rng.normal(size=n)
+    qd.copy_(torch.from_numpy(q))
+    with torch.cuda.stream(side):
+        iteration(); iteration()
+    check(q, "eager after replays")
+    q = rng.normal(size=n) * 0.5
+    qd.copy_(torch.from_numpy(q))
+    torch.cuda.synchronize()
+    g.replay()
+    check(q, "replay after eager")
+
+
+def test_calls_that_synchronise_refuse_to_be_captured(s):
+    import torch
+    n = 10_000
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        xd = torch.randn(n, dtype=torch.float64, device="cuda"); sd = torch.zeros_like(xd); qd = torch.randn_like(xd)
+        y = torch.empty_like(qd)
+        psi = s.shifted(s.shifted(s.NormL1(1.0), xd, 1.0, s.NormLinf(1.0)), sd)
+        s.prox_bang(y, psi, qd, 1.0); psi(y)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        s.prox_bang(y, psi, qd, 1.0)
+        with pytest.raises(s._lib.SpxError, match="captured"):
+            psi(y)                      # returns a host double: would have to synchronise
+    g.replay()
+    torch.cuda.synchronize()
