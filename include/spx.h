@@ -79,6 +79,14 @@ int spx_sync(spx_ctx* ctx);
  * value is NaN then.)  Mirrors no reference function: psi(y) in the reference returns a host Float64
  * (src/ShiftedProximalOperators.jl:51-54); this is the asynchronous form of the same value. */
 int spx_ctx_set_value_target(spx_ctx* ctx, double* device_value);
+/* Stream capture (hipGraph): calls on a context whose stream is being captured are recorded, not run.  Capturable: every
+ * prox / iprox (check = 0) / objective / prox-value entry point on device pointers, provided values go to a device double
+ * (spx_ctx_set_value_target) and the same call has run once before on this context (workspaces do not grow while
+ * capturing).  Not capturable (SPX_ERR_INVALID_ARG, nothing launched): host-valued results, spx_check_bounds, index-set
+ * (gather) group layouts, host-pointer forms, the tuning key 7 = 0 paths.  The first capture puts the context into a
+ * graph-safe mode for good: the kernels that synchronise inside one launch are then preceded by a zero-fill of the state
+ * they use (in the graph and in eager calls alike), ~2-4 us per such call. */
+
 /* Synthetic benchmark / test inputs: out[i] = scale * value(seed, stream, i) from a counter-based generator
  * (splitmix64, integer arithmetic and exact binary64 additions only) that the checker's synth.py reproduces on the host bit for
  * bit, so a CPU check needs no copy of the device data and no torch.  kind 0: U(-1/2, 1/2); kind 1: ~N(0, 1) as the sum of
