@@ -54,7 +54,10 @@ typedef enum spx_status {
   SPX_ERR_HIP = 3,         /* a HIP runtime call failed (message has the HIP error string)        */
   SPX_ERR_ALLOC = 4,       /* workspace allocation failed                                         */
   SPX_ERR_NO_DEVICE = 5,   /* no usable gfx950 device                                             */
-  SPX_ERR_ASSERT = 6       /* the reference's `@assert d[i] > 0` failed (unboxed iprox!)           */
+  SPX_ERR_ASSERT = 6,      /* the reference's `@assert d[i] > 0` failed (unboxed iprox!)           */
+  SPX_ERR_INTERNAL = 7     /* spx_sync: a kernel that synchronises inside one launch gave up waiting for its own
+                              workgroups (corrupt synchronisation state, e.g. a context shared by two threads); the
+                              results of that context since the previous spx_sync are undefined              */
 } spx_status;
 
 typedef struct spx_ctx spx_ctx; /* opaque: device id, HIP stream, library-owned scratch */

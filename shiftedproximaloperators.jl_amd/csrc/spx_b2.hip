@@ -469,7 +469,8 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
       if (t < G) {
         const unsigned long long* theirs = row + (size_t)t * kB2Words;
         unsigned long long w0, w1, w2 = 1ull, w3 = 1ull, w4 = 1ull;
-        for (;;) {  // (every workgroup of the grid is resident and stores these words once per pass: the exit condition)
+        unsigned int spins = 0;
+        for (;;) {  // (every workgroup of the grid is resident and stores these words once per pass; bounded all the same)
           w0 = __hip_atomic_load(theirs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           w1 = __hip_atomic_load(theirs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (first) w2 = __hip_atomic_load(theirs + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -478,6 +479,7 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
             w4 = __hip_atomic_load(theirs + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           if (w0 && w1 && w2 && w3 && w4) break;
+          if (spx_wait_expired(spins, &hdr->timed_out)) break;  // (the sums come out as garbage / NaN: see kSpxPollLimit)
           __builtin_amdgcn_s_sleep(1);
         }
         pp = __longlong_as_double((long long)(w0 - 1ull));

@@ -174,8 +174,22 @@ constexpr size_t kSpxSyncSelBytes = (size_t)3 << 19;  // 1.5 MiB >= sizeof(SelSy
 struct SpxSyncHeader {
   unsigned int bar[2][32];  // grid-barrier counters, one 128-byte line each: a launch uses [parity] and clears [parity ^ 1]
   int b2_last_scaled;       // ShiftedNormL1B2: did the previous call on this context find the trust region active?
-  int pad[31];
+  int timed_out;            // sticky: a workgroup gave up waiting for the others (kSpxPollLimit); reported by spx_sync
+  int pad[30];
 };
+
+// Every wait of one workgroup for others is bounded: kSpxPollLimit polls (each a memory round trip plus a short sleep: a few
+// seconds in all, against microseconds of legitimate waiting).  A workgroup that gives up sets SpxSyncHeader::timed_out,
+// after which no workgroup of that context waits any more: the grid drains with undefined results instead of hanging the
+// device, and spx_sync reports SPX_ERR_INTERNAL.  It can only happen when the synchronisation state is corrupt (a context
+// shared by two threads, device memory overwritten) -- or in tools/planted_faults.sh.
+constexpr unsigned int kSpxPollLimit = 1u << 22;
+__device__ __forceinline__ bool spx_wait_expired(unsigned int& spins, int* timed_out) {
+  if (++spins < 64u) return false;                       // (cheap path: the flag is not even read for short waits)
+  if ((spins & 63u) != 0u && spins < kSpxPollLimit) return false;
+  if (spins >= kSpxPollLimit) { __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
+  return __hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Grid barrier for kernels whose workgroups are all resident (grid <= number of CUs, one workgroup per CU): one
@@ -185,14 +199,18 @@ struct SpxSyncHeader {
 // `target` = (number of barriers passed so far in this launch + 1) * gridDim.x.  Every workgroup of the grid must call
 // it the same number of times (the exit condition every wave reaches: no early return between barriers).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void spx_grid_barrier(unsigned int* counter, unsigned int target) {
+__device__ __forceinline__ void spx_grid_barrier(unsigned int* counter, unsigned int target, int* timed_out) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    unsigned int spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (spx_wait_expired(spins, timed_out)) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -203,12 +221,16 @@ __device__ __forceinline__ void spx_grid_barrier(unsigned int* counter, unsigned
 // with agent-scope atomics (spx_atomic_store_f64 / spx_atomic_load_f64 below: `sc1` accesses that bypass the non-coherent
 // caches).  The release / acquire fences are most of a barrier's cost when few workgroups meet (3.5 of ~4 us).
 // ONE lane per workgroup must have issued all of the workgroup's atomic stores before it calls this.
-__device__ __forceinline__ void spx_grid_rendezvous(unsigned int* counter, unsigned int target) {
+__device__ __forceinline__ void spx_grid_rendezvous(unsigned int* counter, unsigned int target, int* timed_out) {
   __syncthreads();
   if (threadIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's atomic stores have left
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    unsigned int spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (spx_wait_expired(spins, timed_out)) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
   }
   __syncthreads();
 }

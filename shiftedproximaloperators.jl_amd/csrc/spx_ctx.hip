@@ -132,6 +132,17 @@ SPX_EXPORT int spx_ctx_set_value_target(spx_ctx* ctx, double* device_value) {
 SPX_EXPORT int spx_sync(spx_ctx* ctx) {
   SPX_REQUIRE(ctx != nullptr, "ctx is NULL");
   SPX_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->sync && ctx->sync_bytes >= sizeof(SpxSyncHeader)) {  // did a workgroup give up waiting (kSpxPollLimit)?
+    SPX_ON_DEVICE(ctx);
+    int flag = 0;
+    SPX_HIP(hipMemcpy(&flag, &reinterpret_cast<const SpxSyncHeader*>(ctx->sync)->timed_out, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) {
+      SPX_HIP(hipMemset(&reinterpret_cast<SpxSyncHeader*>(ctx->sync)->timed_out, 0, sizeof(int)));  // reported once
+      spx_set_error("internal error: a kernel that synchronises inside one launch timed out waiting for its own workgroups; "
+                    "results of this context since the last spx_sync are undefined (was the context used by two threads?)");
+      return SPX_ERR_INTERNAL;
+    }
+  }
   return SPX_OK;
 }
 

@@ -1193,7 +1193,7 @@ __device__ __forceinline__ void sel_state_init(SelState& s, int64_t n, int64_t r
 template <bool BINF, bool REG>
 __device__ __forceinline__ void coop_select(double* y, const double* q, const double* xk, const double* sj, int64_t n,
                                             int64_t r, double delta, unsigned long long (*hist)[kBins], unsigned int* bar,
-                                            unsigned int& nbar, CoopShared& sh) {
+                                            unsigned int& nbar, CoopShared& sh, int* timed_out) {
   const int t = threadIdx.x;
   const int64_t NT = (int64_t)gridDim.x * blockDim.x;
   const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + t;
@@ -1259,7 +1259,7 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
     SEL_STAMP(33 + 3 * p);
     // the histogram atomics of every wave have been performed (vmcnt) before its workgroup arrives; nothing else is exchanged
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    spx_grid_rendezvous(bar, (++nbar) * gridDim.x);
+    spx_grid_rendezvous(bar, (++nbar) * gridDim.x, timed_out);
     SEL_STAMP(34 + 3 * p);
     coop_scan_step(hist[p], st, &sh.sst, sh.scratch);
     SEL_STAMP(35 + 3 * p);
@@ -1310,9 +1310,9 @@ __global__ __launch_bounds__(1024) void k_sel_coop(double* y, const double* q, c
   if (fallback) {
     unsigned long long* z = &ss->chist[use_set][0][0];
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total; b += (int64_t)gridDim.x * blockDim.x) z[b] = 0ull;
-    spx_grid_barrier(ss->hdr.bar[parity], (++nbar) * gridDim.x);
+    spx_grid_barrier(ss->hdr.bar[parity], (++nbar) * gridDim.x, &ss->hdr.timed_out);
   }
-  coop_select<BINF, REG>(y, q, xk, sj, n, r, delta, ss->chist[use_set], ss->hdr.bar[parity], nbar, sh);
+  coop_select<BINF, REG>(y, q, xk, sj, n, r, delta, ss->chist[use_set], ss->hdr.bar[parity], nbar, sh, &ss->hdr.timed_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     if (cnt) atomicAdd(&ss->fhist1[b], (unsigned long long)cnt);
   }
   SEL_STAMP(1);
-  spx_grid_barrier(bar, (++nbar) * gridDim.x);
+  spx_grid_barrier(bar, (++nbar) * gridDim.x, &ss->hdr.timed_out);
   SEL_STAMP(2);
   // scan of a 4096-bin histogram from the top: lanes 0..255 serve selection 0, lanes 256..511 selection 1 (as k_s2_pick)
   constexpr int PER = kBins / 256;
@@ -1432,7 +1432,7 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     if (active[0] && top == pre[0]) atomicAdd(&ss->fhist2[digit - 1][0][d], 1ull);
     if (active[1] && top == pre[1]) atomicAdd(&ss->fhist2[digit - 1][1][d], 1ull);
     SEL_STAMP(2 + 2 * digit);
-    spx_grid_barrier(bar, (++nbar) * gridDim.x);
+    spx_grid_barrier(bar, (++nbar) * gridDim.x, &ss->hdr.timed_out);
     SEL_STAMP(3 + 2 * digit);
     scan_both(ss->fhist2[digit - 1][0], ss->fhist2[digit - 1][1]);
     ndig = digit + 1;

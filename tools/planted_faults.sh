@@ -12,6 +12,8 @@ FAULTS=(
  "2|spx_group.hip|s/decided = (r2n == r2);/decided = true;/g|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region"
  "3|spx_group.hip|s/if (reversed \&\& mX < delta \* (1.0 - 1e-9)) return BINF_ZERO;/if (reversed) return BINF_ZERO;/|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region tests/test_gpu_stress.py::test_binf_reversed_bracket_regimes"
  "5|spx_select.hip|s/} else if (!catch_all) {  /} else if (true) {  /|tests/test_gpu_stress.py::test_topr_folded_first_digit"
+ "6|spx_b2.hip|s/clear_rows\[pass_i \* kB2Cols \* kB2Words + rem\] = 0ull;/(void)rem;/|tests/test_gpu_stress.py::test_b2_alternating_sizes_share_the_exchange_words tests/test_gpu_stress.py::test_b2_one_launch_forms_at_their_boundaries"
+ "7|spx_select.hip|s/rc = spx_zero_async(ctx, &ss->chist\[0\]\[0\]\[0\], sizeof(ss->chist\[0\]));/rc = 0;/|tests/test_gpu_graph.py::test_iteration_in_a_graph_replays_on_new_data"
  "4|spx_group.hip|s/if (sb == 0.0) {/if (false) {/;s/for (int k = 0; k < 64; ++k) {/for (int k = 0; k < 12; ++k) { piece_ok = true;/|tests/test_gpu_parity.py::test_group_binf_many_small_groups tests/test_gpu_parity.py::test_group_binf_zero_groups_strong_lambda"
 )
 case "${1:-}" in
@@ -31,7 +33,7 @@ run)
   cd "$ROOT"; mkdir -p gpurun_out; bad=0
   for f in "${FAULTS[@]}"; do
     IFS='|' read -r id file expr tests <<< "$f"
-    SPX_LIB_NAME="libspx_fault$id.so" SPX_NO_BUILD=1 python -m pytest $tests -m gpu -q -x -p no:cacheprovider > "gpurun_out/fault$id.log" 2>&1
+    SPX_LIB_NAME="libspx_fault$id.so" SPX_NO_BUILD=1 timeout -k 10 300 python -m pytest $tests -m gpu -q -x -p no:cacheprovider > "gpurun_out/fault$id.log" 2>&1
     rc=$?
     if [ $rc -eq 1 ]; then echo "fault $id: caught ($(grep -c '^FAILED' gpurun_out/fault$id.log) failing test(s), first: $(grep -m1 '^FAILED' gpurun_out/fault$id.log | cut -c1-120))"
     else echo "fault $id: NOT CAUGHT (pytest rc $rc)"; bad=1; fi
