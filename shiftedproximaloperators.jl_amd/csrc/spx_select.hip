@@ -1325,7 +1325,12 @@ __global__ __launch_bounds__(1024) void k_sel_coop(double* y, const double* q, c
 //   C  scan; a third digit only if a selected bucket is still crowded (as k_s2_pick); workgroup 0 writes the band and
 //      the digit machinery of the candidate selection (the tail of k_s2_pick, unchanged)
 // ---------------------------------------------------------------------------------------------
-constexpr int kFrontBlocks = kSample / 1024;  // 64
+// kFrontSpl samples per lane: the band's margin is 6 sigma of the SAMPLE rank, so four times the sample halves the candidates
+// of the main pass (n = 1e8: r = n/2 670 -> 619 us, r = n/100 575 -> 568 us) for ~2 us more here -- and costs more than it
+// saves while the sample is a sizeable part of the vector (n = 3e6: 63 -> 70 us): 1 below 2^23, 2 below 2^25, 4 from there on
+// (tools/r2/topr_big.py).
+constexpr int kFrontBlocks = 64;
+template <int kFrontSpl>
 __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double* xk, const double* sj, int64_t n, int64_t r,
                                                     SelSync* ss, int parity) {
   __shared__ unsigned int lh[kBins];
@@ -1346,7 +1351,8 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
   for (int b = c * 1024 + t; b < kShards; b += 1024 * (int)gridDim.x) { ws->shard_above[b * kShardStride] = 0ull; ws->shard_cand[b * kShardStride] = 0ull; }
   if (t == 0) {
     bucket[0] = bucket[1] = 0u;
-    const double M = (double)kSample;
+    constexpr int kFrontSample = kFrontBlocks * 1024 * kFrontSpl;
+    const double M = (double)kFrontSample;
     const double p = (double)r / (double)n;
     const double k = p * M;
     const double margin = 6.0 * sqrt(M * p * (1.0 - p)) + 16.0;
@@ -1354,21 +1360,32 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     const long long rank_lo = (long long)ceil(k + margin);
     pre[0] = pre[1] = 0;
     active[0] = rank_hi >= 1;
-    active[1] = rank_lo <= kSample;
+    active[1] = rank_lo <= kFrontSample;
     quo[0] = rank_hi;
     quo[1] = rank_lo;
   }
   __syncthreads();
-  // 256 chunks of 256 consecutive elements, as k_s2_sample: workgroup c takes chunks 4c .. 4c+3
-  const int chunk = c * 4 + (t >> 8);
-  const int64_t start = (int64_t)((double)chunk * (double)(n - 256) / 255.0);
-  const int64_t i = start + (t & 255);
-  const uint64_t key = key_of(fabs((xk[i] + sj[i]) + q[i]));
-  atomicAdd(&lh[key >> (64 - kDigitBits)], 1u);
+  // 256 kFrontSpl chunks of 256 consecutive elements, spread evenly over the vector: sample s of lane t of workgroup c comes
+  // from chunk (s * 64 + c) * 4 + (t >> 8)
+  constexpr int kChunks = kFrontBlocks * 4 * kFrontSpl;
+  uint64_t keys[kFrontSpl];
+  unsigned long long m = 0ull;
+#pragma unroll
+  for (int sidx = 0; sidx < kFrontSpl; ++sidx) {
+    const int chunk = (sidx * kFrontBlocks + c) * 4 + (t >> 8);
+    const int64_t start = (int64_t)((double)chunk * (double)(n - 256) / (double)(kChunks - 1));
+    const int64_t i = start + (t & 255);
+    keys[sidx] = key_of(fabs((xk[i] + sj[i]) + q[i]));
+  }
+#pragma unroll
+  for (int sidx = 0; sidx < kFrontSpl; ++sidx) {
+    atomicAdd(&lh[keys[sidx] >> (64 - kDigitBits)], 1u);
+    const unsigned long long fk = keys[sidx] < kInfKey ? keys[sidx] : 0ull;
+    m = fk > m ? fk : m;
+  }
   {
     // largest finite sample key (see k_s2_sample) -- ONE global atomic per workgroup: the 1024 per-wave atomicMax of
     // k_s2_sample on this one address were ~12 us of serialised traffic, most of that kernel's 14 us
-    unsigned long long m = key < kInfKey ? key : 0ull;
     for (int off = 32; off >= 1; off >>= 1) {
       const unsigned long long o = __shfl_xor(m, off, 64);
       m = o > m ? o : m;
@@ -1427,10 +1444,13 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
   for (int digit = 1; digit < kPickDigits; ++digit) {
     if (digit == 2 && bucket[0] <= kPickFine && bucket[1] <= kPickFine) break;  // uniform: same histograms everywhere
     const int hs = shift + kDigitBits;
-    const uint64_t top = key >> hs;
-    const unsigned d = (unsigned)((key >> shift) & (kBins - 1));
-    if (active[0] && top == pre[0]) atomicAdd(&ss->fhist2[digit - 1][0][d], 1ull);
-    if (active[1] && top == pre[1]) atomicAdd(&ss->fhist2[digit - 1][1][d], 1ull);
+#pragma unroll
+    for (int sidx = 0; sidx < kFrontSpl; ++sidx) {
+      const uint64_t top = keys[sidx] >> hs;
+      const unsigned d = (unsigned)((keys[sidx] >> shift) & (kBins - 1));
+      if (active[0] && top == pre[0]) atomicAdd(&ss->fhist2[digit - 1][0][d], 1ull);
+      if (active[1] && top == pre[1]) atomicAdd(&ss->fhist2[digit - 1][1][d], 1ull);
+    }
     SEL_STAMP(2 + 2 * digit);
     spx_grid_barrier(bar, (++nbar) * gridDim.x, &ss->hdr.timed_out);
     SEL_STAMP(3 + 2 * digit);
@@ -1603,8 +1623,15 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
       }
       {
         SpxCoopLaunchGuard guard(ctx);
-        hipLaunchKernelGGL(k_s2_front, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
-                           n - ioff, r, ss, ctx->coop_parity);
+        if (n >= ((int64_t)1 << 25))
+          hipLaunchKernelGGL(k_s2_front<4>, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
+                             n - ioff, r, ss, ctx->coop_parity);
+        else if (n >= ((int64_t)1 << 23))
+          hipLaunchKernelGGL(k_s2_front<2>, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
+                             n - ioff, r, ss, ctx->coop_parity);
+        else
+          hipLaunchKernelGGL(k_s2_front<1>, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
+                             n - ioff, r, ss, ctx->coop_parity);
         ctx->coop_parity ^= 1;
         if (write)
           hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,

@@ -1330,3 +1330,19 @@ def test_values_into_a_device_double(s, orc):
         with s.device_values(out):
             y2, v2 = s.prox_value(psi, qd, 1.1)
         assert torch.equal(y1, y2) and v2 != v2 and float(out.item()) == v1, type(psi).__name__
+
+
+def test_indball_l0_front_sample_sizes(s, orc):
+    """The sample-predicted pipeline draws 1, 2 or 4 samples per lane of its front kernel (n below 2^23, below 2^25, beyond:
+    csrc/spx_select.hip k_s2_front<SPL>); the full-size tests cover 4, most others 1 -- this one the size class in between,
+    on continuous and on lattice data (ties), at both ends and in the middle of r."""
+    n = (1 << 23) + 3
+    rng = np.random.default_rng(823)
+    for quant in (None, 16):
+        x, sj, q = rng.normal(size=n), rng.uniform(-0.5, 0.5, size=n), rng.normal(size=n)
+        if quant:
+            x, sj, q = (np.round(v * quant) / quant for v in (x, sj, q))
+        xd, sd, qd = _dev(x, sj, q)
+        for r in (5, n // 100, n // 2, n - 1000):
+            y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.8, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
+            assert _bits_equal(y, orc.prox_indball_l0_binf(q, x, sj, r, 0.8)), (quant, r)
