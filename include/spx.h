@@ -169,6 +169,35 @@ int spx_prox_l0_box_f32(spx_ctx* ctx, float* y, const float* q, const float* xk,
                         float sigma, const float* l_vec, const float* u_vec, float l_scalar, float u_scalar,
                         const uint8_t* sel_mask);
 
+/* psi(y) on Float32 vectors, for every operator (the reference's tests evaluate each shifted operator built on Float32
+ * data: test/runtests.jl:196-209, 268-282, 346-360, 397-412, 524-550, 630-646).  Every element operation is a Float32
+ * operation as in the reference ((xk + sj) + y, sj + y, the box ends -+ sqrt(eps(Float32)), each square root); `1.1 * Delta`
+ * and the comparison against it are Float64 (Julia promotes the literal); the SUM is formed in Float64 and *value is a
+ * double -- round it to Float32 to compare with the reference's Float32 result (counts and +Inf decisions are exact, sums
+ * agree to Float32 rounding of the reference's own pairwise Float32 summation).  Device value targets and the host
+ * read-back behave as for the Float64 forms. */
+int spx_obj_l1_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n, float lambda, double* value);
+int spx_obj_l0_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n, float lambda, double* value);
+int spx_obj_lhalf_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n, float lambda, double* value);
+int spx_obj_l1_box_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n, float lambda,
+                       const float* l_vec, const float* u_vec, float l_scalar, float u_scalar, const uint8_t* sel_mask,
+                       double* value);
+int spx_obj_l0_box_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n, float lambda,
+                       const float* l_vec, const float* u_vec, float l_scalar, float u_scalar, const uint8_t* sel_mask,
+                       double* value);
+int spx_obj_lhalf_box_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n, float lambda,
+                          const float* l_vec, const float* u_vec, float l_scalar, float u_scalar, const uint8_t* sel_mask,
+                          double* value);
+int spx_obj_indball_l0_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n, int64_t r, double* value);
+int spx_obj_indball_l0_binf_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n, int64_t r,
+                                float delta, double* value);
+int spx_obj_group_l2_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n,
+                         const int64_t* group_offsets, int64_t group_size, int64_t ngroups, const float* lambda_vec,
+                         double* value);
+int spx_obj_group_l2_binf_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n,
+                              const int64_t* group_offsets, int64_t group_size, int64_t ngroups, const float* lambda_vec,
+                              float delta, double* value);
+
 /* ---- prox! fused with the value of h at the result ------------------------------------------ */
 /* One pass instead of two for the pair every solver iteration makes (R2: `prox!(s, psi, ...)` then `h(xk + s)`):
  * y as spx_prox_X, and *value = h over the selected indices of (xk + sj) + y -- lambda * sum |v|, lambda * #nonzeros,

@@ -373,6 +373,39 @@ for (T, sym) in ((:ShiftedNormL1Box, :spx_prox_l1_box_f32), (:ShiftedNormL0Box, 
   end
 end
 
+# ψ(y) on Float32 vectors (spx_obj_*_f32): element operations in Float32 as in the reference, the sum in Float64, the result
+# rounded to the Float32 the reference returns.  test/runtests.jl:196-209, 268-282, 346-360, 397-412, 524-550.
+for (T, sym) in ((:ShiftedNormL1, :spx_obj_l1_f32), (:ShiftedNormL0, :spx_obj_l0_f32), (:ShiftedRootNormLhalf, :spx_obj_lhalf_f32))
+  @eval (ψ::$T{Float32, <:DVec32, <:DVec32, <:DVec32})(y::DVec32) = Float32(with_value() do out
+    ccall(($(QuoteNode(sym)), libspx), Cint, (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cfloat, Ptr{Cdouble}),
+          ctx(), dptr32(y), dptr32(ψ.xk), dptr32(ψ.sj), length(y), ψ.λ, out)
+  end)
+end
+for (T, sym) in ((:ShiftedNormL1Box, :spx_obj_l1_box_f32), (:ShiftedNormL0Box, :spx_obj_l0_box_f32),
+                 (:ShiftedRootNormLhalfBox, :spx_obj_lhalf_box_f32))
+  @eval function (ψ::$T{Float32, <:DVec32, <:DVec32, <:DVec32})(y::DVec32)
+    m = mask_for(ψ)
+    v = with_value() do out
+      ccall(($(QuoteNode(sym)), libspx), Cint,
+            (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cfloat, Ptr{Cfloat}, Ptr{Cfloat}, Cfloat, Cfloat, Ptr{UInt8},
+             Ptr{Cdouble}),
+            ctx(), dptr32(y), dptr32(ψ.xk), dptr32(ψ.sj), length(y), ψ.λ, dptr32(vec32_or_nothing(ψ.l)),
+            dptr32(vec32_or_nothing(ψ.u)), scal32(ψ.l), scal32(ψ.u), mptr(m), out)
+    end
+    return isinf(v) ? Inf : Float32(v)   # (the reference returns the Float64 literal Inf on an infeasible point, :78)
+  end
+end
+(ψ::ShiftedIndBallL0{<:Integer, Float32, <:DVec32, <:DVec32, <:DVec32})(y::DVec32) = with_value() do out
+  ccall((:spx_obj_indball_l0_f32, libspx), Cint, (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Int64, Ptr{Cdouble}),
+        ctx(), dptr32(y), dptr32(ψ.xk), dptr32(ψ.sj), length(y), ψ.r, out)
+end
+(ψ::ShiftedIndBallL0BInf{<:Integer, Float32, <:DVec32, <:DVec32, <:DVec32})(y::DVec32) = with_value() do out
+  ccall((:spx_obj_indball_l0_binf_f32, libspx), Cint,
+        (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Int64, Cfloat, Ptr{Cdouble}),
+        ctx(), dptr32(y), dptr32(ψ.xk), dptr32(ψ.sj), length(y), ψ.r, ψ.Δ, out)
+end
+# (group forms: spx_obj_group_l2_f32 / spx_obj_group_l2_binf_f32 with the layout_for(ψ.h, n) arguments and a Float32 λ vector)
+
 # ---------------------------------------------------------------------------------------------
 # Device-resident values (round 2): `device_values(out::ROCVector{Float64}) do ... end` -- inside the block ψ(y) and prox_value!
 # store their Float64 result in out[1] and return NaN; nothing is read back (spx_ctx_set_value_target).

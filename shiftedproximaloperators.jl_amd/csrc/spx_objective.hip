@@ -29,9 +29,20 @@ struct ObjWs {
 };
 
 // element terms of h
-struct TermL1 { __device__ __forceinline__ double operator()(double v) const { return fabs(v); } };          // NormL1 [ext]
-struct TermL0 { __device__ __forceinline__ double operator()(double v) const { return (v != 0.0) ? 1.0 : 0.0; } };  // NormL0, IndBallL0 [ext]
-struct TermLhalf { __device__ __forceinline__ double operator()(double v) const { return sqrt(fabs(v)); } };  // src/rootNormLhalf.jl:27-29
+// (float overloads: the Float32 forms.  The reference forms xsy and every term in Float32 -- which entries are exactly zero,
+//  the rounding of each square root -- and adds them up in Float32; here the terms are Float32 values, the SUM is Float64.)
+struct TermL1 {  // NormL1 [ext]
+  __device__ __forceinline__ double operator()(double v) const { return fabs(v); }
+  __device__ __forceinline__ double operator()(float v) const { return (double)fabsf(v); }
+};
+struct TermL0 {  // NormL0, IndBallL0 [ext]
+  __device__ __forceinline__ double operator()(double v) const { return (v != 0.0) ? 1.0 : 0.0; }
+  __device__ __forceinline__ double operator()(float v) const { return (v != 0.0f) ? 1.0 : 0.0; }
+};
+struct TermLhalf {  // src/rootNormLhalf.jl:27-29
+  __device__ __forceinline__ double operator()(double v) const { return sqrt(fabs(v)); }
+  __device__ __forceinline__ double operator()(float v) const { return (double)__builtin_sqrtf(fabsf(v)); }
+};
 
 __device__ __forceinline__ double block_sum(double v, double* lds4) {
   v = wave_sum(v);
@@ -46,34 +57,40 @@ __device__ __forceinline__ double block_sum(double v, double* lds4) {
 // MODE 1: Box: the same over the selected indices, plus the feasibility scan of sj + y against
 //         [l - sqrt(eps), u + sqrt(eps)] over EVERY index                  (shiftedNormL1Box.jl:70-82)
 // MODE 2: BInf: xsy = (sj + y) + xk, plus |sj + y| <= 1.1 Delta (strict IndBox test) (shiftedIndBallL0BInf.jl:44-49)
-template <class Term, int MODE>
-__global__ __launch_bounds__(256) void k_obj(const double* __restrict__ y, const double* __restrict__ xk,
-                                              const double* __restrict__ sj, const double* __restrict__ lv,
-                                              const double* __restrict__ uv, const uint8_t* __restrict__ mask,
-                                              double ls, double us, double rad, int64_t n, Term term, ObjWs* ws) {
+// T = double, or float (Float32 forms: every element operation in Float32 as in the reference, `1.1 * Delta` and the
+// comparison against it in Float64 -- Julia promotes the Float64 literal --, the sum in Float64).
+template <class T, class Term, int MODE>
+__global__ __launch_bounds__(256) void k_obj(const T* __restrict__ y, const T* __restrict__ xk,
+                                              const T* __restrict__ sj, const T* __restrict__ lv,
+                                              const T* __restrict__ uv, const uint8_t* __restrict__ mask,
+                                              T ls, T us, double rad, int64_t n, Term term, ObjWs* ws) {
   __shared__ double lds4[4];
-  const double slack = 1.4901161193847656e-08;  // sqrt(eps(Float64))
+  const T slack = sizeof(T) == 8 ? (T)1.4901161193847656e-08 : (T)3.4526698300124393e-04;  // sqrt(eps(T))
   double acc = 0.0;
   bool bad = false;
-  auto visit = [&](double yi, double xi, double si, double lo, double up, bool sel) {
+  auto visit = [&](T yi, T xi, T si, T lo, T up, bool sel) {
     if constexpr (MODE == 2) {
-      const double t = si + yi;
-      bad |= (t < -rad) || (t > rad);
-      acc += term(t + xi);
+      const T t = si + yi;
+      bad |= ((double)t < -rad) || ((double)t > rad);
+      acc += term((T)(t + xi));
     } else {
       if constexpr (MODE == 1) {
-        const double t = si + yi;
-        bad |= !((lo - slack <= t) && (t <= up + slack));
+        const T t = si + yi;
+        bad |= !(((T)(lo - slack) <= t) && (t <= (T)(up + slack)));
         if (!sel) return;
       }
-      acc += term((xi + si) + yi);
+      acc += term((T)((T)(xi + si) + yi));
     }
   };
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const bool vec = (((uintptr_t)y | (uintptr_t)xk | (uintptr_t)sj | (uintptr_t)lv | (uintptr_t)uv) & 15) == 0 &&
+  const bool vec = sizeof(T) == 8 && (((uintptr_t)y | (uintptr_t)xk | (uintptr_t)sj | (uintptr_t)lv | (uintptr_t)uv) & 15) == 0 &&
                    (((uintptr_t)mask) & 1) == 0;
-  if (vec && n >= 2) {  // 16-byte non-temporal loads, four pairs in flight per vector and lane
+  if constexpr (sizeof(T) != 8) {  // Float32: 4-byte loads, a wavefront reads 256 contiguous bytes per vector
+    for (int64_t i = tid; i < n; i += stride)
+      visit(y[i], xk[i], sj[i], (MODE == 1 && lv) ? lv[i] : ls, (MODE == 1 && uv) ? uv[i] : us,
+            (MODE == 1 && mask) ? mask[i] != 0 : true);
+  } else if (vec && n >= 2) {  // 16-byte non-temporal loads, four pairs in flight per vector and lane
     const int64_t n2 = n >> 1;
     const f64x2* y2 = reinterpret_cast<const f64x2*>(y);
     const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
@@ -123,12 +140,12 @@ __global__ __launch_bounds__(256) void k_obj(const double* __restrict__ y, const
 }
 
 // GroupNormL2: sum_g lambda_g ||xsy[idx_g]||_2, one wavefront per group  (src/groupNormL2.jl:33-39)
-template <int MODE>
-__global__ __launch_bounds__(256) void k_obj_group(const double* __restrict__ y, const double* __restrict__ xk,
-                                                    const double* __restrict__ sj, int64_t n,
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void k_obj_group(const T* __restrict__ y, const T* __restrict__ xk,
+                                                    const T* __restrict__ sj, int64_t n,
                                                     const int64_t* __restrict__ offsets, int64_t gsize, int64_t ngroups,
                                                     const int64_t* __restrict__ index /* NULL: contiguous groups */,
-                                                    int64_t nnz, const double* __restrict__ lambda, double rad,
+                                                    int64_t nnz, const T* __restrict__ lambda, double rad,
                                                     ObjWs* ws) {
   __shared__ double lds4[4];
   const int lane = threadIdx.x & 63;
@@ -149,18 +166,18 @@ __global__ __launch_bounds__(256) void k_obj_group(const double* __restrict__ y,
         i = index[p];
         if (i < 0 || i >= n) { bad_index = true; continue; }
       }
-      double v;
+      T v;
       if constexpr (MODE == 2) {
-        const double t = sj[i] + y[i];
-        bad |= (t < -rad) || (t > rad);
+        const T t = sj[i] + y[i];
+        bad |= ((double)t < -rad) || ((double)t > rad);
         v = t + xk[i];
       } else {
-        v = (xk[i] + sj[i]) + y[i];
+        v = (T)(xk[i] + sj[i]) + y[i];
       }
-      ss += v * v;
+      ss += (double)v * (double)v;
     }
     ss = wave_sum(ss);
-    if (lane == 0) acc += lambda[g] * sqrt(ss);
+    if (lane == 0) acc += (double)lambda[g] * sqrt(ss);
   }
   acc = block_sum(acc, lds4);
   if (threadIdx.x == 0) ws->partial[blockIdx.x] = acc;
@@ -169,13 +186,14 @@ __global__ __launch_bounds__(256) void k_obj_group(const double* __restrict__ y,
 }
 
 // IndBallLinf(1.1 Delta)(sj + y) over EVERY index (src/shiftedGroupNormL2Binf.jl:35-36), for groups that need not tile 1:n
-__global__ __launch_bounds__(256) void k_obj_linf_scan(const double* __restrict__ y, const double* __restrict__ sj,
+template <class T>
+__global__ __launch_bounds__(256) void k_obj_linf_scan(const T* __restrict__ y, const T* __restrict__ sj,
                                                         int64_t n, double rad, ObjWs* ws) {
   bool bad = false;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double t = sj[i] + y[i];
-    bad |= (t < -rad) || (t > rad);
+    const T t = sj[i] + y[i];
+    bad |= ((double)t < -rad) || ((double)t > rad);
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&ws->infeasible, 1);
 }
@@ -226,9 +244,9 @@ int obj_finish(spx_ctx* ctx, ObjWs* ws, int blocks, int rule, double scale, doub
   return SPX_OK;
 }
 
-template <class Term, int MODE>
-int run_obj(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, const double* lv,
-            const double* uv, double ls, double us, const uint8_t* mask, double rad, int rule, double scale, double limit,
+template <class T, class Term, int MODE>
+int run_obj(spx_ctx* ctx, const T* y, const T* xk, const T* sj, int64_t n, const T* lv,
+            const T* uv, T ls, T us, const uint8_t* mask, double rad, int rule, double scale, double limit,
             double* value) {
   SPX_REQUIRE(ctx != nullptr, "ctx is NULL");
   SPX_REQUIRE(n >= 0, "n < 0");
@@ -245,17 +263,17 @@ int run_obj(spx_ctx* ctx, const double* y, const double* xk, const double* sj, i
   { const int rz = spx_zero_async(ctx, &ws->infeasible, sizeof(int)); if (rz) return rz; }
   int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
   if (blocks > kObjBlocks) blocks = kObjBlocks;
-  hipLaunchKernelGGL((k_obj<Term, MODE>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, lv, uv, mask, ls,
+  hipLaunchKernelGGL((k_obj<T, Term, MODE>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, lv, uv, mask, ls,
                      us, rad, n, Term{}, ws);
   SPX_LAUNCH_CHECK();
   int flags;
   return obj_finish(ctx, ws, (int)blocks, rule, scale, limit, value, &flags);
 }
 
-template <int MODE>
-int run_obj_group(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
+template <class T, int MODE>
+int run_obj_group(spx_ctx* ctx, const T* y, const T* xk, const T* sj, int64_t n,
                   const int64_t* offsets, int64_t gsize, int64_t ngroups, const int64_t* index, int64_t nnz,
-                  const double* lambda, double rad, double* value) {
+                  const T* lambda, double rad, double* value) {
   SPX_REQUIRE(ctx != nullptr && value != nullptr, "ctx or value is NULL");
   SPX_REQUIRE(n >= 0 && ngroups >= 0 && nnz >= 0, "negative size");
   *value = 0.0;
@@ -273,12 +291,12 @@ int run_obj_group(spx_ctx* ctx, const double* y, const double* xk, const double*
   int64_t blocks = (ngroups + 3) / 4;
   if (blocks > kObjBlocks) blocks = kObjBlocks;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((k_obj_group<MODE>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, offsets, gsize,
+  hipLaunchKernelGGL((k_obj_group<T, MODE>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, offsets, gsize,
                      ngroups, index, nnz, lambda, rad, ws);
   if (MODE == 2 && offsets) {  // the groups need not tile 0:n: the trust-region indicator covers every index
     int64_t sb = (n + 256 * 8 - 1) / (256 * 8);
     if (sb > kObjBlocks) sb = kObjBlocks;
-    hipLaunchKernelGGL(k_obj_linf_scan, dim3((unsigned)sb), dim3(256), 0, ctx->stream, y, sj, n, rad, ws);
+    hipLaunchKernelGGL(k_obj_linf_scan<T>, dim3((unsigned)sb), dim3(256), 0, ctx->stream, y, sj, n, rad, ws);
   }
   SPX_LAUNCH_CHECK();
   int bad;
@@ -300,7 +318,7 @@ const double kInf = std::numeric_limits<double>::infinity();
   SPX_EXPORT int NAME(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n, double lambda, \
                       double* value) {                                                                             \
     SPX_REQUIRE(value != nullptr, "value is NULL");                                                                \
-    return run_obj<TERM, 0>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 0.0, kRuleScaled, lambda, 0.0, value); \
+    return run_obj<double, TERM, 0>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 0.0, kRuleScaled, lambda, 0.0, value); \
   }
 SPX_OBJ_PLAIN(spx_obj_l1, TermL1)
 SPX_OBJ_PLAIN(spx_obj_l0, TermL0)
@@ -312,7 +330,7 @@ SPX_OBJ_PLAIN(spx_obj_lhalf, TermLhalf)
                       const double* l_vec, const double* u_vec, double l_scalar, double u_scalar,                  \
                       const uint8_t* sel_mask, double* value) {                                                    \
     SPX_REQUIRE(value != nullptr, "value is NULL");                                                                \
-    return run_obj<TERM, 1>(ctx, y, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask, 0.0, kRuleBox, lambda, 0.0,    \
+    return run_obj<double, TERM, 1>(ctx, y, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask, 0.0, kRuleBox, lambda, 0.0,    \
                             value);                                                                                \
   }
 SPX_OBJ_BOX(spx_obj_l1_box, TermL1)
@@ -323,12 +341,12 @@ SPX_OBJ_BOX(spx_obj_lhalf_box, TermLhalf)
 SPX_EXPORT int spx_obj_indball_l0(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
                                   int64_t r, double* value) {
   SPX_REQUIRE(value != nullptr, "value is NULL");
-  return run_obj<TermL0, 0>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 0.0, kRuleCount, 1.0, (double)r, value);
+  return run_obj<double, TermL0, 0>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 0.0, kRuleCount, 1.0, (double)r, value);
 }
 SPX_EXPORT int spx_obj_indball_l0_binf(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
                                        int64_t r, double delta, double* value) {
   SPX_REQUIRE(value != nullptr, "value is NULL");
-  return run_obj<TermL0, 2>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 1.1 * delta, kRuleCount, 1.0, (double)r,
+  return run_obj<double, TermL0, 2>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0, 0.0, nullptr, 1.1 * delta, kRuleCount, 1.0, (double)r,
                             value);
 }
 
@@ -336,12 +354,12 @@ SPX_EXPORT int spx_obj_indball_l0_binf(spx_ctx* ctx, const double* y, const doub
 SPX_EXPORT int spx_obj_group_l2(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
                                 const int64_t* group_offsets, int64_t group_size, int64_t ngroups,
                                 const double* lambda_vec, double* value) {
-  return run_obj_group<0>(ctx, y, xk, sj, n, group_offsets, group_size, ngroups, nullptr, 0, lambda_vec, 0.0, value);
+  return run_obj_group<double, 0>(ctx, y, xk, sj, n, group_offsets, group_size, ngroups, nullptr, 0, lambda_vec, 0.0, value);
 }
 SPX_EXPORT int spx_obj_group_l2_binf(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
                                      const int64_t* group_offsets, int64_t group_size, int64_t ngroups,
                                      const double* lambda_vec, double delta, double* value) {
-  return run_obj_group<2>(ctx, y, xk, sj, n, group_offsets, group_size, ngroups, nullptr, 0, lambda_vec, 1.1 * delta,
+  return run_obj_group<double, 2>(ctx, y, xk, sj, n, group_offsets, group_size, ngroups, nullptr, 0, lambda_vec, 1.1 * delta,
                           value);
 }
 
@@ -350,11 +368,59 @@ SPX_EXPORT int spx_obj_group_l2_gather(spx_ctx* ctx, const double* y, const doub
                                        const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups,
                                        int64_t nnz, const double* lambda_vec, double* value) {
   SPX_REQUIRE(group_ptr != nullptr || ngroups == 0, "group_ptr is NULL");
-  return run_obj_group<0>(ctx, y, xk, sj, n, group_ptr, 0, ngroups, group_index, nnz, lambda_vec, 0.0, value);
+  return run_obj_group<double, 0>(ctx, y, xk, sj, n, group_ptr, 0, ngroups, group_index, nnz, lambda_vec, 0.0, value);
 }
 SPX_EXPORT int spx_obj_group_l2_binf_gather(spx_ctx* ctx, const double* y, const double* xk, const double* sj, int64_t n,
                                             const int64_t* group_ptr, const int64_t* group_index, int64_t ngroups,
                                             int64_t nnz, const double* lambda_vec, double delta, double* value) {
   SPX_REQUIRE(group_ptr != nullptr || ngroups == 0, "group_ptr is NULL");
-  return run_obj_group<2>(ctx, y, xk, sj, n, group_ptr, 0, ngroups, group_index, nnz, lambda_vec, 1.1 * delta, value);
+  return run_obj_group<double, 2>(ctx, y, xk, sj, n, group_ptr, 0, ngroups, group_index, nnz, lambda_vec, 1.1 * delta, value);
+}
+
+// ---- Float32 forms (the reference is generic in R <: Real and its tests evaluate every shifted operator on Float32 vectors:
+// test/runtests.jl:196-209, 268-282, 346-360, 397-412, 524-550).  Element arithmetic in Float32 as in the reference
+// ((xk + sj) + y, sj + y, the box ends -+ sqrt(eps(Float32)), each sqrt), `1.1 * Delta` and the comparison against it in
+// Float64 (Julia promotes the literal), sums in Float64; the value comes back as a double (round it to Float32 to compare).
+#define SPX_OBJ_PLAIN_F32(NAME, TERM)                                                                              \
+  SPX_EXPORT int NAME(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n, float lambda,     \
+                      double* value) {                                                                             \
+    SPX_REQUIRE(value != nullptr, "value is NULL");                                                                \
+    return run_obj<float, TERM, 0>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0f, 0.0f, nullptr, 0.0, kRuleScaled,     \
+                                   (double)lambda, 0.0, value);                                                    \
+  }
+SPX_OBJ_PLAIN_F32(spx_obj_l1_f32, TermL1)
+SPX_OBJ_PLAIN_F32(spx_obj_l0_f32, TermL0)
+SPX_OBJ_PLAIN_F32(spx_obj_lhalf_f32, TermLhalf)
+#define SPX_OBJ_BOX_F32(NAME, TERM)                                                                                \
+  SPX_EXPORT int NAME(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n, float lambda,     \
+                      const float* l_vec, const float* u_vec, float l_scalar, float u_scalar,                      \
+                      const uint8_t* sel_mask, double* value) {                                                    \
+    SPX_REQUIRE(value != nullptr, "value is NULL");                                                                \
+    return run_obj<float, TERM, 1>(ctx, y, xk, sj, n, l_vec, u_vec, l_scalar, u_scalar, sel_mask, 0.0, kRuleBox,   \
+                                   (double)lambda, 0.0, value);                                                    \
+  }
+SPX_OBJ_BOX_F32(spx_obj_l1_box_f32, TermL1)
+SPX_OBJ_BOX_F32(spx_obj_l0_box_f32, TermL0)
+SPX_OBJ_BOX_F32(spx_obj_lhalf_box_f32, TermLhalf)
+SPX_EXPORT int spx_obj_indball_l0_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n, int64_t r,
+                                      double* value) {
+  SPX_REQUIRE(value != nullptr, "value is NULL");
+  return run_obj<float, TermL0, 0>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0f, 0.0f, nullptr, 0.0, kRuleCount, 1.0, (double)r, value);
+}
+SPX_EXPORT int spx_obj_indball_l0_binf_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n,
+                                           int64_t r, float delta, double* value) {
+  SPX_REQUIRE(value != nullptr, "value is NULL");
+  return run_obj<float, TermL0, 2>(ctx, y, xk, sj, n, nullptr, nullptr, 0.0f, 0.0f, nullptr, 1.1 * (double)delta, kRuleCount, 1.0,
+                                   (double)r, value);
+}
+SPX_EXPORT int spx_obj_group_l2_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n,
+                                    const int64_t* group_offsets, int64_t group_size, int64_t ngroups,
+                                    const float* lambda_vec, double* value) {
+  return run_obj_group<float, 0>(ctx, y, xk, sj, n, group_offsets, group_size, ngroups, nullptr, 0, lambda_vec, 0.0, value);
+}
+SPX_EXPORT int spx_obj_group_l2_binf_f32(spx_ctx* ctx, const float* y, const float* xk, const float* sj, int64_t n,
+                                         const int64_t* group_offsets, int64_t group_size, int64_t ngroups,
+                                         const float* lambda_vec, float delta, double* value) {
+  return run_obj_group<float, 2>(ctx, y, xk, sj, n, group_offsets, group_size, ngroups, nullptr, 0, lambda_vec,
+                                 1.1 * (double)delta, value);
 }

@@ -144,8 +144,8 @@ class ShiftedProximableFunction:
         """the entry point `name` of libspx, its host-pointer form for a ψ on host arrays, or its Float32 form"""
         if self.f32:
             if name + "_f32" not in _lib.SIGNATURES:
-                raise TypeError("MethodError: %s has no Float32 form in libspx (Float32 covers prox! of the NormL1 / NormL0 "
-                                "families; convert to float64 for the rest)" % name)
+                raise TypeError("MethodError: %s has no Float32 form in libspx (Float32 covers psi(y) of every operator and prox! "
+                                "of the NormL1 / NormL0 families; convert to float64 for the rest)" % name)
             return getattr(L, name + "_f32")
         return getattr(L, "spx_host_" + name[4:] if self.host else name)
 
@@ -169,7 +169,8 @@ class ShiftedProximableFunction:
         _vec(y, "y", _n(self.xk), like=self.xk)
         out = ctypes.c_double(0.0)
         self._obj(_lib.load(), _ctx(_dev(y)), y, ctypes.byref(out))
-        return out.value
+        # Float32 ψ: the reference returns a Float32 (every term is one; libspx adds them up in Float64): rounded here
+        return float(np.float32(out.value)) if self.f32 else out.value
 
     def _obj(self, L, ctx, y, out):
         raise TypeError("MethodError: objects of type %s are not callable" % type(self).__name__)
@@ -374,13 +375,14 @@ class ShiftedIndBallL0BInf(_TopR):  # src/shiftedIndBallL0BInf.jl
 class _GroupLayout:
     """Device-side description of GroupNormL2.idx / .lambda for a vector of length n."""
 
-    def __init__(self, h, n, device):
+    def __init__(self, h, n, device, dtype=None):
         from .functions import UniformGroups
+        self._dtype = dtype if dtype is not None else torch.float64
         if isinstance(h.idx, UniformGroups):
             if h.idx.size * h.idx.count != n:
                 raise IndexError("BoundsError: %d groups of %d do not tile a vector of length %d" % (h.idx.count, h.idx.size, n))
             self.ngroups, self.offsets, self.group_size, self.index = h.idx.count, None, h.idx.size, None
-            self.lam = self._lam(h.lam, device)
+            self.lam = self._lam(h.lam, device, self._dtype)
             return
         self.index = None  # gather mode: (ptr, index) instead of offsets
         from .functions import RaggedGroups
@@ -395,7 +397,7 @@ class _GroupLayout:
             else:
                 self.offsets = off if device is None else torch.from_numpy(off).to(device)
                 self.group_size = int(sizes.max()) if self.ngroups else 0   # size bound (hint for the tile kernels)
-            self.lam = self._lam(h.lam, device)
+            self.lam = self._lam(h.lam, device, self._dtype)
             return
         bounds, sets, contiguous = [], [], True
         for g in h.idx:
@@ -437,7 +439,7 @@ class _GroupLayout:
             self.offsets = ptr if device is None else torch.from_numpy(ptr).to(device)
             self.index = index if device is None else torch.from_numpy(index).to(device)
             self.group_size = 0
-            self.lam = self._lam(h.lam, device)
+            self.lam = self._lam(h.lam, device, self._dtype)
             return
         sizes = {b - a for a, b in bounds}
         if self.ngroups and len(sizes) == 1 and bounds[0][0] == 0 and bounds[-1][1] == n and n > 0:
@@ -449,21 +451,21 @@ class _GroupLayout:
                             else torch.tensor(off, dtype=torch.int64, device=device))
             # with offsets, group_size is an upper bound on the group sizes: it lets libspx pick its register-tile kernels
             self.group_size = max(sizes) if sizes else 0
-        self.lam = self._lam(h.lam, device)
+        self.lam = self._lam(h.lam, device, self._dtype)
 
     @staticmethod
-    def _lam(lam, device):
+    def _lam(lam, device, dtype=torch.float64):
         if device is None:  # host ψ
             return np.ascontiguousarray(lam.cpu().numpy() if isinstance(lam, torch.Tensor) else lam, dtype=np.float64)
         if isinstance(lam, torch.Tensor):
-            return lam.to(device=device, dtype=torch.float64).contiguous()
-        return torch.tensor(lam, dtype=torch.float64, device=device)
+            return lam.to(device=device, dtype=dtype).contiguous()
+        return torch.tensor(lam, dtype=dtype, device=device)
 
 
 class ShiftedGroupNormL2(ShiftedProximableFunction):  # src/shiftedGroupNormL2.jl
     def __init__(self, h, xk, sj, shifted_twice, _layout=None):
         super().__init__(h, xk, sj, shifted_twice)
-        self._layout = _layout or _GroupLayout(h, _n(xk), _dev(xk))
+        self._layout = _layout or _GroupLayout(h, _n(xk), _dev(xk), None if _is_host(xk) else xk.dtype)
 
     def _prox(self, L, ctx, y, q, sigma):
         g = self._layout
@@ -491,7 +493,7 @@ class ShiftedGroupNormL2Binf(ShiftedProximableFunction):  # src/shiftedGroupNorm
         super().__init__(h, xk, sj, shifted_twice)
         self.Δ = float(Δ)
         self.χ = χ
-        self._layout = _layout or _GroupLayout(h, _n(xk), _dev(xk))
+        self._layout = _layout or _GroupLayout(h, _n(xk), _dev(xk), None if _is_host(xk) else xk.dtype)
 
     def _prox(self, L, ctx, y, q, sigma):
         g = self._layout
@@ -587,7 +589,7 @@ _zero_cache = {}
 
 def _zeros_for(x):
     """a zero vector of x's kind / length / device, cached (read-only use)"""
-    key = ("host", _n(x)) if _is_host(x) else (str(x.device), _n(x))
+    key = ("host", _n(x)) if _is_host(x) else (str(x.device), _n(x), x.dtype)
     z = _zero_cache.get(key)
     if z is None:
         if len(_zero_cache) > 8:

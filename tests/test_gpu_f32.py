@@ -143,5 +143,102 @@ def test_f32_type_rules(s):
         s.shifted(psi, x64)
     with pytest.raises(TypeError, match="no Float32 form"):
         s.prox(s.shifted(s.RootNormLhalf(1.0), x32), x32, 1.0)   # computed in Float64 by the reference itself
-    with pytest.raises(TypeError, match="no Float32 form"):
-        psi(x32)                                               # psi(y): Float64 only
+    assert psi(x32) == 16.0                                    # psi(y) has a Float32 form: |1 + 0 + 1| x 8
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# psi(y) on Float32 vectors, every operator (spx_obj_*_f32).  The reference's tests build each shifted operator on Float32
+# data and evaluate it (test/runtests.jl:196-209, 268-282, 346-360, 397-412, 524-550, 630-646).  Expected values: numpy with
+# every element operation in float32, as the reference does them, sums in float64, rounded to float32 at the end (the
+# reference sums pairwise in Float32: agreement to a few float32 ulps); counts and +Inf decisions exact.
+# ----------------------------------------------------------------------------------------------------------------------
+F32 = np.float32
+EPS32 = F32(np.sqrt(np.finfo(np.float32).eps))
+
+
+def _close32(got, exp):
+    if np.isinf(exp) or np.isinf(got):
+        return got == exp
+    return abs(got - exp) <= 4 * np.finfo(np.float32).eps * max(abs(exp), 1e-30)
+
+
+@pytest.mark.parametrize("n", [1, 5, 1000, 300_001])
+def test_f32_objective_every_operator(s, n):
+    import torch
+    rng = np.random.default_rng(3200 + n)
+    x = rng.normal(size=n).astype(F32); sj = rng.uniform(-0.5, 0.5, size=n).astype(F32)
+    lam = F32(1.2)
+    xd, sd = torch.from_numpy(x).cuda(), torch.from_numpy(sj).cuda()
+    for scale in (0.0, 0.3, 1.0):
+        y = (rng.normal(size=n) * scale).astype(F32)
+        if n >= 5:
+            y[1] = -(x[1] + sj[1])           # an exact zero of xk + sj + y in Float32 (NormL0 / IndBallL0 count it out)
+        yd = torch.from_numpy(y).cuda()
+        xsy = (x + sj) + y                    # float32 + float32, as `@. xsy = xk + sj + y`
+        assert xsy.dtype == np.float32
+        t = sj + y
+        # unboxed forms (src/ShiftedProximalOperators.jl:51-54)
+        exp = {"l1": np.sum(np.abs(xsy), dtype=np.float64), "l0": float(np.count_nonzero(xsy)),
+               "lhalf": np.sum(np.sqrt(np.abs(xsy)), dtype=np.float64)}
+        for H, key in ((s.NormL1, "l1"), (s.NormL0, "l0"), (s.RootNormLhalf, "lhalf")):
+            psi = s.shifted(s.shifted(H(float(lam)), xd), sd)
+            assert _close32(psi(yd), float(F32(float(lam) * exp[key]))), (key, n, scale)
+            # Box forms: feasibility of sj + y against [l - sqrt(eps32), u + sqrt(eps32)], all in Float32 (shiftedNormL1Box.jl:70-82)
+            for lo, up in ((-10.0, 10.0), (float(t.min()), float(t.max())), (float(t.min()) + 1e-3, 10.0),
+                           (float(F32(t.min()) + F32(0.5) * EPS32), 10.0)):
+                lo32, up32 = F32(lo), F32(up)
+                feasible = bool(np.all((F32(lo32 - EPS32) <= t) & (t <= F32(up32 + EPS32))))
+                pb = s.shifted(s.shifted(H(float(lam)), xd, float(lo32), float(up32)), sd)
+                want = float(F32(float(lam) * exp[key])) if feasible else np.inf
+                assert _close32(pb(yd), want), (key, "box", n, scale, lo, up, feasible)
+        # IndBallL0 / IndBallL0BInf (count <= r; |sj + y| <= 1.1 Delta with the product in Float64: shiftedIndBallL0BInf.jl:44-49)
+        nnz = int(np.count_nonzero(xsy))
+        for r in (max(nnz - 1, 0), nnz, n):
+            if r < 1:
+                continue
+            pi = s.shifted(s.shifted(s.IndBallL0(r), xd), sd)
+            assert pi(yd) == (0.0 if nnz <= r else np.inf), (n, scale, r)
+            for delta in (F32(0.25), F32(np.abs(t).max() / 1.1 * 1.0001), F32(10.0)):
+                inside = bool(np.all(np.abs(t.astype(np.float64)) <= 1.1 * float(delta)))
+                pbi = s.shifted(s.shifted(s.IndBallL0(r), xd, float(delta), s.NormLinf(1.0)), sd)
+                assert pbi(yd) == (0.0 if (nnz <= r and inside) else np.inf), (n, scale, r, float(delta))
+        # GroupNormL2 / GroupNormL2Binf on uniform groups
+        for gs in (1, 5, 100):
+            if n % gs:
+                continue
+            ng = n // gs
+            lam_g = rng.uniform(0.5, 1.5, size=ng).astype(F32)
+            norms = np.sqrt(np.sum(xsy.astype(np.float64).reshape(ng, gs) ** 2, axis=1))
+            want = float(F32(np.sum(lam_g.astype(np.float64) * norms)))
+            h = s.GroupNormL2.uniform(torch.from_numpy(lam_g).cuda(), gs)
+            pg = s.shifted(s.shifted(h, xd), sd)
+            assert _close32(pg(yd), want), ("group", n, gs)
+            for delta in (F32(0.25), F32(10.0)):
+                inside = bool(np.all(np.abs(t.astype(np.float64)) <= 1.1 * float(delta)))
+                pgb = s.shifted(s.shifted(h, xd, float(delta), s.NormLinf(1.0)), sd)
+                assert _close32(pgb(yd), want if inside else np.inf), ("group binf", n, gs, float(delta))
+
+
+def test_f32_reference_type_block(s):
+    """The "test different types" block the reference runs for every shifted operator: h = Op(Float32(1.2)), x Float32,
+    psi = shifted(h, x); psi.lambda == h.lambda; psi(zeros(Float32, n)) == h(x).  (The reference builds x as the strided view
+    y[1:2:10]; libspx takes unit-stride views only: a strided tensor raises TypeError, a packed copy of it works.)"""
+    import torch
+    base = torch.rand(10, dtype=torch.float32, device="cuda")
+    with pytest.raises(TypeError, match="contiguous"):
+        s.shifted(s.NormL1(1.2), base[0::2])
+    x = base[0::2].contiguous()
+    z = torch.zeros(5, dtype=torch.float32, device="cuda")
+    chi = s.NormLinf(1.0)
+    for h in (s.NormL0(1.2), s.NormL1(1.2), s.RootNormLhalf(1.2), s.IndBallL0(3), s.GroupNormL2.uniform([1.2], 5)):
+        psi = s.shifted(h, x)
+        assert psi.xk.dtype == torch.float32 and psi.sj.dtype == torch.float32 and psi.sol.dtype == torch.float32
+        assert psi(z) == h(x), type(h).__name__
+        if not isinstance(h, s.IndBallL0):
+            assert psi.λ == h.lam or list(np.atleast_1d(psi.λ)) == list(np.atleast_1d(h.lam))
+    for h in (s.NormL0(1.2), s.NormL1(1.2), s.RootNormLhalf(1.2)):
+        for psi in (s.shifted(h, x, -0.5, 0.5), s.shifted(h, x, 0.5, chi)):   # runtests.jl:524-550
+            assert psi(z) == h(x), type(h).__name__
+    for h in (s.IndBallL0(3), s.GroupNormL2.uniform([1.2], 5)):
+        psi = s.shifted(h, x, 0.5, chi)                                        # runtests.jl:630-646, 749-
+        assert psi(z) == h(x), type(h).__name__
