@@ -90,6 +90,13 @@ int spx_ctx_set_value_target(spx_ctx* ctx, double* device_value);
  * graph-safe mode for good: the kernels that synchronise inside one launch are then preceded by a zero-fill of the state
  * they use (in the graph and in eager calls alike), ~2-4 us per such call. */
 
+/* Strided views (the reference accepts `view(y, 1:2:10)` as xk: test/runtests.jl:196-209).  Every entry point takes
+ * unit-stride vectors; a host binding keeps a packed copy of a strided xk, refreshes it with this copy before a call and
+ * writes through it after shift! (8 or 16 B/element of extra traffic per call -- correctness, not speed).
+ * dst[i * dst_stride] = src[i * src_stride] for i < n; strides in ELEMENTS, >= 1; elem_bytes 4 or 8; device pointers. */
+int spx_copy_strided(spx_ctx* ctx, void* dst, int64_t dst_stride, const void* src, int64_t src_stride, int64_t n,
+                     int elem_bytes);
+
 /* Synthetic benchmark / test inputs: out[i] = scale * value(seed, stream, i) from a counter-based generator
  * (splitmix64, integer arithmetic and exact binary64 additions only) that the checker's synth.py reproduces on the host bit for
  * bit, so a CPU check needs no copy of the device data and no torch.  kind 0: U(-1/2, 1/2); kind 1: ~N(0, 1) as the sum of

@@ -22,6 +22,7 @@ SIGNATURES = {
     "spx_timer_stop": [_p, ctypes.POINTER(ctypes.c_float)],
     "spx_ctx_set_tuning": [_p, _int, _int],
     "spx_ctx_set_value_target": [_p, _p],
+    "spx_copy_strided": [_p, _p, _i64, _p, _i64, _i64, _int],
     "spx_synth_fill": [_p, _p, _i64, ctypes.c_uint64, ctypes.c_uint64, _int, _d],
     "spx_check_bounds": [_p, _p, _p, _d, _d, _i64, ctypes.POINTER(_int)],
     "spx_build_mask": [_p, _p, _i64, _p, _i64],

@@ -369,3 +369,36 @@ SPX_EXPORT int spx_debug_peek(spx_ctx* ctx, int which, size_t offset, size_t nby
   return SPX_OK;
 }
 #endif
+
+// ---------------------------------------------------------------------------------------------
+// Strided views (the reference accepts `view(y, 1:2:10)` as xk: test/runtests.jl:196-209).  The kernels take unit-stride
+// vectors; a host binding keeps a packed copy of a strided xk, refreshes it with this copy before a call and writes through
+// it after shift!.  dst[i * dst_stride] = src[i * src_stride], i < n; strides in ELEMENTS (>= 1), elem_bytes 4 or 8.
+// ---------------------------------------------------------------------------------------------
+template <class W>
+__global__ __launch_bounds__(256) void k_copy_strided(W* __restrict__ dst, int64_t ds, const W* __restrict__ src, int64_t ss,
+                                                       int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i * ds] = src[i * ss];
+}
+SPX_EXPORT int spx_copy_strided(spx_ctx* ctx, void* dst, int64_t dst_stride, const void* src, int64_t src_stride, int64_t n,
+                                int elem_bytes) {
+  SPX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  SPX_REQUIRE(n >= 0 && dst_stride >= 1 && src_stride >= 1, "negative length or non-positive stride");
+  SPX_REQUIRE(elem_bytes == 4 || elem_bytes == 8, "elem_bytes must be 4 or 8");
+  if (n == 0) return SPX_OK;
+  SPX_REQUIRE(dst != nullptr && src != nullptr, "NULL vector with n > 0");
+  SPX_REQUIRE(((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & (uintptr_t)(elem_bytes - 1)) == 0,
+              "vector not aligned to its element size");
+  SPX_ON_DEVICE(ctx);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
+  if (elem_bytes == 8)
+    hipLaunchKernelGGL(k_copy_strided<unsigned long long>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       static_cast<unsigned long long*>(dst), dst_stride, static_cast<const unsigned long long*>(src), src_stride, n);
+  else
+    hipLaunchKernelGGL(k_copy_strided<unsigned int>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       static_cast<unsigned int*>(dst), dst_stride, static_cast<const unsigned int*>(src), src_stride, n);
+  SPX_LAUNCH_CHECK();
+  return SPX_OK;
+}

@@ -128,6 +128,62 @@ def _is_real(v):
 
 
 # ---------------------------------------------------------------------------------------------
+# Strided views as xk (the reference's `x = view(y, 1:2:10)`, test/runtests.jl:196-209).  libspx takes unit-stride vectors:
+# a strided xk is kept as (the caller's view, a packed copy); the copy is refreshed from the view before every call that
+# reads xk (spx_copy_strided: one extra pass over xk) and shift! writes through to the view -- the caller's array stays the
+# storage, as in the reference.  sj, sol, y, q are dense in the reference too (`similar(xk)` is a Vector).
+# ---------------------------------------------------------------------------------------------
+def _stride_of(t):
+    """element stride of a 1-D vector (1 = contiguous), or None if it is not a positive-stride 1-D vector"""
+    if _is_host(t):
+        if t.ndim != 1 or t.itemsize == 0 or t.strides[0] % t.itemsize:
+            return None
+        st = t.strides[0] // t.itemsize
+    else:
+        if not isinstance(t, torch.Tensor) or t.dim() != 1:
+            return None
+        st = t.stride(0)
+    return st if (st >= 1 or _n(t) <= 1) else None
+
+
+class _StridedRef:
+    def __init__(self, view):
+        self.view = view
+        self.stride = _stride_of(view)
+        self.packed = (np.empty(view.shape, dtype=view.dtype) if _is_host(view)
+                       else torch.empty(view.numel(), dtype=view.dtype, device=view.device))
+        self.refresh()
+
+    def _copy(self, dst, ds, src, ss):
+        if _is_host(self.view):
+            np.copyto(dst, src)
+            return
+        n = self.view.numel()
+        _lib.check(_lib.load().spx_copy_strided(_ctx(self.view.device), ctypes.c_void_p(dst.data_ptr()), ds,
+                                                ctypes.c_void_p(src.data_ptr()), ss, n, self.view.element_size()))
+
+    def refresh(self):      # packed <- view
+        self._copy(self.packed, 1, self.view, self.stride)
+
+    def write_through(self):  # view <- packed
+        self._copy(self.view, self.stride, self.packed, 1)
+
+
+def _unstrided(x, name):
+    """(vector to hand to libspx, _StridedRef or None): a strided 1-D view is packed, everything else goes through _vec"""
+    st = _stride_of(x)
+    if st is not None and st > 1 and _n(x) > 1:
+        if _is_host(x):
+            if x.dtype != np.float64:
+                raise TypeError("%s must be float64 (got %s)" % (name, x.dtype))
+        elif not x.is_cuda or x.dtype not in (torch.float64, torch.float32):
+            return x, None   # (_vec raises the right error)
+        ref = _StridedRef(x)
+        return ref.packed, ref
+    return x, None
+
+
+# ---------------------------------------------------------------------------------------------
 # base type                                      src/ShiftedProximalOperators.jl:18,113-121
 # ---------------------------------------------------------------------------------------------
 class ShiftedProximableFunction:
@@ -139,6 +195,11 @@ class ShiftedProximableFunction:
         self.shifted_twice = bool(shifted_twice)
         self.host = _is_host(xk)
         self.f32 = (not self.host) and xk.dtype == torch.float32
+        self._xk_ref = None  # set by shifted() when the caller's xk is a strided view (see _StridedRef)
+
+    def _refresh(self):
+        if self._xk_ref is not None:
+            self._xk_ref.refresh()
 
     def _sym(self, L, name):
         """the entry point `name` of libspx, its host-pointer form for a ψ on host arrays, or its Float32 form"""
@@ -167,6 +228,7 @@ class ShiftedProximableFunction:
         """ψ(y) = h(xk + sj + y) [+ indicator]  (src/ShiftedProximalOperators.jl:51-54 and the Box / BInf methods);
         evaluated on the device, returned as a Python float (synchronises)."""
         _vec(y, "y", _n(self.xk), like=self.xk)
+        self._refresh()
         out = ctypes.c_double(0.0)
         self._obj(_lib.load(), _ctx(_dev(y)), y, ctypes.byref(out))
         # Float32 ψ: the reference returns a Float32 (every term is one; libspx adds them up in Float64): rounded here
@@ -530,17 +592,25 @@ def shifted(h, x, *args):
             raise TypeError("MethodError: shifted(ψ, sj) takes no trust-region arguments")
         ψ, sj = h, _vec(x, "sj", _n(h.xk), like=h.xk)
         if isinstance(ψ, _Boxed):
-            return type(ψ)(ψ.h, ψ.xk, sj, ψ.l, ψ.u, True, ψ.selected, _mask=ψ._mask)
-        if isinstance(ψ, ShiftedIndBallL0BInf):
-            return ShiftedIndBallL0BInf(ψ.h, ψ.xk, sj, ψ.Δ, ψ.χ, True)
-        if isinstance(ψ, ShiftedNormL1B2):
-            return ShiftedNormL1B2(ψ.h, ψ.xk, sj, ψ.Δ, ψ.χ, True)
-        if isinstance(ψ, ShiftedGroupNormL2Binf):
-            return ShiftedGroupNormL2Binf(ψ.h, ψ.xk, sj, ψ.Δ, ψ.χ, True, _layout=ψ._layout)
-        if isinstance(ψ, ShiftedGroupNormL2):
-            return ShiftedGroupNormL2(ψ.h, ψ.xk, sj, True, _layout=ψ._layout)
-        return type(ψ)(ψ.h, ψ.xk, sj, True)
+            ω = type(ψ)(ψ.h, ψ.xk, sj, ψ.l, ψ.u, True, ψ.selected, _mask=ψ._mask)
+        elif isinstance(ψ, ShiftedIndBallL0BInf):
+            ω = ShiftedIndBallL0BInf(ψ.h, ψ.xk, sj, ψ.Δ, ψ.χ, True)
+        elif isinstance(ψ, ShiftedNormL1B2):
+            ω = ShiftedNormL1B2(ψ.h, ψ.xk, sj, ψ.Δ, ψ.χ, True)
+        elif isinstance(ψ, ShiftedGroupNormL2Binf):
+            ω = ShiftedGroupNormL2Binf(ψ.h, ψ.xk, sj, ψ.Δ, ψ.χ, True, _layout=ψ._layout)
+        elif isinstance(ψ, ShiftedGroupNormL2):
+            ω = ShiftedGroupNormL2(ψ.h, ψ.xk, sj, True, _layout=ψ._layout)
+        else:
+            ω = type(ψ)(ψ.h, ψ.xk, sj, True)
+        ω._xk_ref = ψ._xk_ref   # (the packed copy of a strided xk is shared like xk itself)
+        return ω
 
+    x, ref = _unstrided(x, "xk")
+    if ref is not None:
+        ψ = shifted(h, x, *args)
+        ψ._xk_ref = ref
+        return ψ
     xk = _vec(x, "xk")
     zero = lambda: _zeros_like(xk)  # `zero(xk)`
     if isinstance(h, NormL2):  # shiftedGroupNormL2.jl:34-35, shiftedGroupNormL2Binf.jl:48-49
@@ -615,6 +685,7 @@ def _as_shifted(h, x):
 
 def value(h, x):
     """h(x) for an unshifted value type, evaluated on the GPU (device tensor or host array x); a Python float."""
+    x, _ = _unstrided(x, "x")   # (a strided view is evaluated through a packed copy: h only reads x)
     return _as_shifted(h, x)(x)
 
 
@@ -647,6 +718,7 @@ def prox_bang(y, ψ, q, σ=1.0):
     n = _n(ψ.xk)
     _vec(q, "q", n, like=ψ.xk)
     _vec(y, "y", n, like=ψ.xk)
+    ψ._refresh()
     ψ._prox(_lib.load(), _ctx(_dev(y)), y, q, float(σ))
     return y
 
@@ -667,6 +739,7 @@ def prox_value_bang(y, ψ, q, σ, q_scale=1.0):
     n = _n(ψ.xk)
     _vec(q, "q", n, like=ψ.xk)
     _vec(y, "y", n, like=ψ.xk)
+    ψ._refresh()
     L, ctx = _lib.load(), _ctx(_dev(y))
     out = ctypes.c_double(0.0)
     fn = getattr(L, ψ._fn.replace("spx_prox_", "spx_proxval_"))
@@ -697,6 +770,7 @@ def iprox_bang(y, ψ, g, d, check=True):
     _vec(g, "g", n, like=ψ.xk)
     _vec(d, "d", n, like=ψ.xk)
     _vec(y, "y", n, like=ψ.xk)
+    ψ._refresh()
     ψ._iprox(_lib.load(), _ctx(_dev(y)), y, g, d, check)
     return y
 
@@ -711,6 +785,8 @@ def shift_bang(ψ, shift):
     (src/ShiftedProximalOperators.jl:72-79)."""
     _vec(shift, "shift", _n(ψ.xk), like=ψ.xk)
     _copy_into(ψ.sj if ψ.shifted_twice else ψ.xk, shift)
+    if not ψ.shifted_twice and ψ._xk_ref is not None:
+        ψ._xk_ref.write_through()   # ψ.xk IS the caller's strided view in the reference: `ψ.xk .= shift` lands there
     return ψ
 
 

@@ -221,13 +221,10 @@ def test_f32_objective_every_operator(s, n):
 
 def test_f32_reference_type_block(s):
     """The "test different types" block the reference runs for every shifted operator: h = Op(Float32(1.2)), x Float32,
-    psi = shifted(h, x); psi.lambda == h.lambda; psi(zeros(Float32, n)) == h(x).  (The reference builds x as the strided view
-    y[1:2:10]; libspx takes unit-stride views only: a strided tensor raises TypeError, a packed copy of it works.)"""
+    x = view(y, 1:2:10) -- a STRIDED view --, psi = shifted(h, x); psi.lambda == h.lambda; psi(zeros(Float32, n)) == h(x)."""
     import torch
     base = torch.rand(10, dtype=torch.float32, device="cuda")
-    with pytest.raises(TypeError, match="contiguous"):
-        s.shifted(s.NormL1(1.2), base[0::2])
-    x = base[0::2].contiguous()
+    x = base[0::2]                                  # `x = view(y, 1:2:10)`: a strided view (kept as view + packed copy)
     z = torch.zeros(5, dtype=torch.float32, device="cuda")
     chi = s.NormLinf(1.0)
     for h in (s.NormL0(1.2), s.NormL1(1.2), s.RootNormLhalf(1.2), s.IndBallL0(3), s.GroupNormL2.uniform([1.2], 5)):
@@ -242,3 +239,41 @@ def test_f32_reference_type_block(s):
     for h in (s.IndBallL0(3), s.GroupNormL2.uniform([1.2], 5)):
         psi = s.shifted(h, x, 0.5, chi)                                        # runtests.jl:630-646, 749-
         assert psi(z) == h(x), type(h).__name__
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_strided_xk_views(s, orc, dtype):
+    """xk as a strided view of the caller's array (test/runtests.jl:196-209 builds every operator on `view(y, 1:2:10)`): the
+    mirror keeps the view and a packed copy, refreshed before every call (spx_copy_strided); a change of the caller's array
+    is seen by the next call and shift! writes through to it, as with the reference's SubArray."""
+    import torch
+    td = getattr(torch, dtype)
+    nd = np.float64 if dtype == "float64" else np.float32
+    n, st = 50_001, 3
+    rng = np.random.default_rng(12)
+    base = rng.normal(size=n * st).astype(nd)
+    bd = torch.from_numpy(base).cuda()
+    xv = bd[::st]
+    assert xv.stride(0) == st and xv.numel() == n
+    sj = rng.uniform(-0.5, 0.5, size=n).astype(nd); q = rng.normal(size=n).astype(nd)
+    sd, qd = torch.from_numpy(sj).cuda(), torch.from_numpy(q).cuda()
+    psi = s.shifted(s.shifted(s.NormL1(1.0), xv, 1.0, s.NormLinf(1.0)), sd)
+
+    def expect(xh):
+        if dtype == "float64":
+            return orc.prox_l1_box(q, np.ascontiguousarray(xh), sj, 1.0, 1.0, -1.0, 1.0)
+        return orc.prox_f32("l1_box", q, np.ascontiguousarray(xh), sj, 1.0, 1.0, nd(-1.0), nd(1.0))
+
+    same = lambda a, b: np.array_equal(np.asarray(a).view(np.int64 if dtype == "float64" else np.int32),
+                                       np.asarray(b).view(np.int64 if dtype == "float64" else np.int32))
+    assert same(s.prox(psi, qd, 1.0).cpu().numpy(), expect(base[::st]))
+    bd[::st] += 0.25                                   # the caller changes its array: the next call sees it
+    assert same(s.prox(psi, qd, 1.0).cpu().numpy(), expect(bd[::st].cpu().numpy()))
+    others = bd.clone()
+    parent = s.shifted(s.NormL1(1.0), xv, 1.0, s.NormLinf(1.0))
+    new = torch.from_numpy(rng.normal(size=n).astype(nd)).cuda()
+    s.shift_bang(parent, new)                          # `ψ.xk .= shift`: into the caller's strided storage
+    assert torch.equal(bd[::st], new)
+    mask = torch.ones(n * st, dtype=torch.bool, device="cuda"); mask[::st] = False
+    assert torch.equal(bd[mask], others[mask])         # nothing between the strided elements was touched
+    assert abs(parent(torch.zeros(n, dtype=td, device="cuda")) - float(new.abs().sum())) <= 1e-5 * float(new.abs().sum())

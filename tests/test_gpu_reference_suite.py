@@ -6,7 +6,8 @@ GPU through the spx_host_* forms of the C ABI.
 Differences from the reference that these tests state instead of hide:
   * `ψ(y) == h(x + y)` is exact (==) in the reference because both sides sum sequentially on the CPU; here psi(y) is a
     GPU reduction, so sums compare to VALUE_RTOL; counts (NormL0) and +-Inf are exact.
-  * Float32 / strided views ("test different types") are outside the accelerated path: TypeError.
+  * "test different types": the strided view `view(y, 1:2:10)` is taken (view + packed copy); Float32 host arrays raise
+    TypeError (the Float32 forms exist for device vectors: tests/test_gpu_f32.py runs that block in Float32).
 """
 import numpy as np
 import pytest
@@ -59,11 +60,15 @@ def test_operators_without_trust_region(s, orc, op, shifted_op, kind):  # runtes
     assert _close(phi(np.zeros(3)), _h(orc, kind, psi.xk + sv, 1.2))
     t = rng.random(3)
     assert _close(phi(t), _h(orc, kind, psi.xk + sv + t, 1.2))
-    # "different types": Float32 and strided views are not on the accelerated path
+    # "different types" (runtests.jl:196-209): x = view(y, 1:2:10), psi = shifted(h, x), psi(zeros(5)) == h(x).  The strided view
+    # is kept as view + packed copy; Float32 HOST arrays have no host-pointer form (device Float32: tests/test_gpu_f32.py)
     with pytest.raises(TypeError):
         s.shifted(getattr(s, op)(1.2), np.ones(3, dtype=np.float32))
-    with pytest.raises(TypeError):
-        s.shifted(getattr(s, op)(1.2), rng.random(10)[::2])
+    y10 = rng.random(10)
+    hv = getattr(s, op)(1.2)
+    pv = s.shifted(hv, y10[::2])
+    assert _close(pv(np.zeros(5)), _h(orc, kind, np.ascontiguousarray(y10[::2]), 1.2))
+    assert pv(np.zeros(5)) == hv(y10[::2])
     del x0
 
 

@@ -15,7 +15,17 @@ def test_vector_validation(s):
     with pytest.raises(TypeError):
         s.shifted(s.NormL1(1.0), np.ones(4, dtype=np.float32))          # Float32: not on the accelerated path
     with pytest.raises(TypeError):
-        s.shifted(s.NormL1(1.0), np.ones(8)[::2])                        # strided view
+        s.shifted(s.NormL1(1.0), np.ones(8)[::-1])                       # negative stride: not a view the kernels can take
+    base = np.arange(8.0)
+    pv = s.shifted(s.NormL1(1.0), base[::2])                             # strided view (the reference's `view(y, 1:2:10)`): packed copy
+    assert pv.xk.flags["C_CONTIGUOUS"] and pv.xk.tolist() == [0.0, 2.0, 4.0, 6.0] and pv._xk_ref is not None
+    base[2] = -5.0
+    pv._refresh()                                                        # every call that reads xk starts with this
+    assert pv.xk.tolist() == [0.0, -5.0, 4.0, 6.0]
+    s.shift_bang(pv, np.full(4, 9.0))                                    # `ψ.xk .= shift` lands in the caller's array
+    assert base.tolist() == [9.0, 1.0, 9.0, 3.0, 9.0, 5.0, 9.0, 7.0]
+    om = s.shifted(pv, np.zeros(4))
+    assert om._xk_ref is pv._xk_ref and om.xk is pv.xk
     with pytest.raises(TypeError):
         s.shifted(s.NormL1(1.0), torch.ones(4, dtype=torch.float64))     # CPU torch tensor: never staged silently
     with pytest.raises(TypeError):
