@@ -262,11 +262,7 @@ constexpr size_t kB2SetWords = (size_t)kB2MaxPass * kB2Cols * kB2Words;
 constexpr size_t kB2SyncBytes = 2 * kB2SetWords * sizeof(unsigned long long);   // 2 MiB, behind the select state
 __device__ __forceinline__ void b2_put(unsigned long long* slot, double v) {
   const unsigned long long b = (v != v) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(v);
-#ifdef SPX_B2_PUT_SWAP
-  (void)__hip_atomic_exchange(slot, b + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-  __hip_atomic_store(slot, b + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+  __hip_atomic_store(slot, b + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (an atomic swap instead: no faster)
 }
 __device__ __forceinline__ void b2_block_sum5(double& a, double& b, double& c, double& d, double& e, double (*lds)[16]) {
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d); e = wave_sum(e);
