@@ -88,7 +88,9 @@ int spx_ctx_set_value_target(spx_ctx* ctx, double* device_value);
  * capturing).  Not capturable (SPX_ERR_INVALID_ARG, nothing launched): host-valued results, spx_check_bounds, index-set
  * (gather) group layouts, host-pointer forms, the tuning key 7 = 0 paths.  The first capture puts the context into a
  * graph-safe mode for good: the kernels that synchronise inside one launch are then preceded by a zero-fill of the state
- * they use (in the graph and in eager calls alike), ~2-4 us per such call. */
+ * they use (in the graph and in eager calls alike), ~2-4 us per such call.  Do not replay such a graph while ANOTHER context
+ * runs top-r or ShiftedNormL1B2 calls on the same device: eager calls of different contexts are chained through an event so
+ * that two resident grids never wait for CUs the other holds; a replay is outside that chain. */
 
 /* Strided views (the reference accepts `view(y, 1:2:10)` as xk: test/runtests.jl:196-209).  Every entry point takes
  * unit-stride vectors; a host binding keeps a packed copy of a strided xk, refreshes it with this copy before a call and

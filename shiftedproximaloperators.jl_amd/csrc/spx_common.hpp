@@ -79,6 +79,7 @@ int spx_require_not_capturing(spx_ctx* ctx, const char* what);
 struct SpxCoopLaunchGuard {
   spx_ctx* ctx;
   bool chained;
+  bool capturing;
   explicit SpxCoopLaunchGuard(spx_ctx* c);
   ~SpxCoopLaunchGuard();
 };

@@ -11,14 +11,23 @@ int spx_ctx_count(int device) { return g_ctx_count[device & 63].load(); }
 static std::mutex g_coop_mu;
 static hipEvent_t g_coop_ev[64] = {};
 static const spx_ctx* g_coop_last[64] = {};
-SpxCoopLaunchGuard::SpxCoopLaunchGuard(spx_ctx* c) : ctx(c), chained(false) {
+SpxCoopLaunchGuard::SpxCoopLaunchGuard(spx_ctx* c) : ctx(c), chained(false), capturing(false) {
   g_coop_mu.lock();
   const int d = ctx->device & 63;
+  // While the stream is being captured nothing is chained: an event recorded outside the capture cannot be waited for inside
+  // it (and one recorded inside belongs to the graph).  A graph that holds such launches must not be replayed while another
+  // context runs in-launch synchronised kernels on the same device (include/spx.h, "Stream capture").
+  capturing = spx_capture_check(ctx);
+  if (capturing) return;
   chained = (g_coop_last[d] != nullptr && g_coop_last[d] != ctx);
   if (chained && g_coop_ev[d] != nullptr) (void)hipStreamWaitEvent(ctx->stream, g_coop_ev[d], 0);
 }
 SpxCoopLaunchGuard::~SpxCoopLaunchGuard() {
   const int d = ctx->device & 63;
+  if (capturing) {
+    g_coop_mu.unlock();
+    return;
+  }
   if (chained || g_coop_last[d] == nullptr || spx_ctx_count(ctx->device) > 1) {
     if (g_coop_ev[d] == nullptr) (void)hipEventCreateWithFlags(&g_coop_ev[d], hipEventDisableTiming);
     if (g_coop_ev[d] != nullptr) (void)hipEventRecord(g_coop_ev[d], ctx->stream);
