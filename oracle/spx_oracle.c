@@ -845,7 +845,10 @@ ORC_API void orc_prox_l1_b2(double* y, const double* q, const double* xk, const 
     double eta = a;
     if (fa != 0.0) {
       double b = 2 * a, fb = b2_froot(&c, b);
-      for (int it = 0; it < 2000 && !(fb > 0) && isfinite(b); ++it) { a = b; fa = fb; b = 2 * b; fb = b2_froot(&c, b); }
+      /* (an exact zero at a bracket end IS the root -- find_zero returns it; the loop used to step over froot(b) == 0, doubled
+       *  once more and bisected its way to 2 b: found by tools/fuzz_r2_onelaunch.py on integer lattice data, where the GPU was
+       *  right and this restatement wrong) */
+      for (int it = 0; it < 2000 && !(fb >= 0) && isfinite(b); ++it) { a = b; fa = fb; b = 2 * b; fb = b2_froot(&c, b); }
       if (fb == 0.0) eta = b;
       else {
         for (int it = 0; it < 200; ++it) {

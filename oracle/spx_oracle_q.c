@@ -289,7 +289,7 @@ ORC_API void orcq_prox_l1_b2(double* y, const double* q, const double* xk, const
     Q a = delta, fa = a - qb2_norm(&c, a / c.delta), eta = a;
     if (fa != 0) {
       Q b = 2 * a, fb = b - qb2_norm(&c, b / c.delta);
-      for (int it = 0; it < 20000 && !(fb > 0) && finiteq(b); ++it) { a = b; fa = fb; b = 2 * b; fb = b - qb2_norm(&c, b / c.delta); }
+      for (int it = 0; it < 20000 && !(fb >= 0) && finiteq(b); ++it) { a = b; fa = fb; b = 2 * b; fb = b - qb2_norm(&c, b / c.delta); }  /* (fb == 0: the root, as in spx_oracle.c) */
       if (fb == 0) eta = b;
       else {
         for (int it = 0; it < 240; ++it) {

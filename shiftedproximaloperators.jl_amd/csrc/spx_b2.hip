@@ -524,7 +524,11 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
   const bool store_first = can_spec && !last_scaled;
   pass(1.0, 1.0, true, store_first, eta_s > 0.0 ? eta_s / delta : -1.0, false);
   const double chiy = chil * sqrt(P + C);
-  const bool scaled = delta <= chiy;  // :61
+  // :61 `Delta <= chi(y)`.  With EQUALITY froot(Delta) = Delta - chi(y) is zero: find_zero returns its starting point Delta,
+  // eta / Delta = 1 and the scaled branch reproduces y = ProjB(-xk) -- the unscaled result.  (The bracket below takes
+  // froot(Delta) < 0 for granted: on integer lattice data, where chi(y) == Delta happens, it bisected towards a root it
+  // could never accept and ran out of passes 3e-10 away: tests/test_gpu_stress.py::test_b2_integer_lattices_exact_roots.)
+  const bool scaled = delta < chiy;
   if (blockIdx.x == 0 && t == 0) hdr->b2_last_scaled = scaled ? 1 : 0;
   double eta = delta;
   bool stored = !scaled && store_first;
@@ -566,18 +570,20 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
       if (!(next > lo && (next < hi || (hi_closed && next == hi)))) break;
       const double step = fabs(next - eta) / next;
       if (step <= 4e-16) break;
-      // The piece roots converge quadratically (measured steps 4e-2, 1e-4, 6e-10: error(next) ~ K step^2 with K ~ 0.06), and a
-      // breakpoint between eta and the root changes the root only to second order (the pieces join continuously).  With the
-      // constant measured on the spot, K = step / prev_step^2 (capped at 1e3), `next` is taken without the pass that would only
-      // confirm it as soon as K step^2 <= 2e-13 (a fifth of the 1e-12 bar); without a previous step only below 1e-8.
+      // The piece roots converge quadratically on generic data (measured steps 4e-2, 1e-4, 6e-10: error(next) ~ 0.06 step^2), and
+      // a breakpoint between eta and the root changes the root only to second order (the pieces join continuously).  `next` is
+      // taken without the pass that would only confirm it -- but on the evidence of the more pessimistic LINEAR model: with
+      // rho = step / prev_step the error left after this step is at most rho step / (1 - rho); below 2e-13 (a fifth of the
+      // 1e-12 bar) the iteration ends.  (Round 2 first used the quadratic estimate K step^2, K = step / prev_step^2: one pass
+      // fewer at n = 1e4, 19 vs 23 us, and no failure on record -- but two steps cannot tell the two models apart.)  Without
+      // a previous step there is no estimate at all: only a step at rounding level ends the iteration.
       bool done = false;
       if (exact_step) {
         if (prev_step > 0.0) {
-          double K = step / (prev_step * prev_step);
-          if (!(K < 1e3)) K = 1e3;
-          done = step <= 1e-4 && K * step * step <= 2e-13;
+          const double rho = step / prev_step;
+          done = step <= 1e-4 && rho < 0.5 && rho * step <= 2e-13 * (1.0 - rho);
         } else {
-          done = step <= 1e-8;
+          done = step <= 2e-13;
         }
       }
       if (done) { eta = next; y_eta = -1.0; break; }
@@ -788,12 +794,13 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   rc = b2_sums(ctx, q, xk, sj, n, ls, 1.0, ws, (int)blocks, vec, true, &P, &C, &F, store_first ? y : nullptr, 1.0, head);
   if (rc) return rc;
   const double chiy = chi_lambda * std::sqrt(P + C);
-  ctx->b2_last_scaled = (delta <= chiy) ? 1 : 0;
-  if (!(delta <= chiy) && store_first) return SPX_OK;  // unscaled and already stored
+  // (delta == chiy: froot(Delta) == 0, find_zero returns Delta, the scaled branch is the unscaled result: see k_b2_coop)
+  ctx->b2_last_scaled = (delta < chiy) ? 1 : 0;
+  if (!(delta < chiy) && store_first) return SPX_OK;  // unscaled and already stored
   int scaled = 0;
   double eta = delta;
   double y_eta = -1.0;  // eta for which a reduction pass has stored y (speculatively), or -1
-  if (delta <= chiy) {  // :61
+  if (delta < chiy) {  // :61 (equality: see above)
     scaled = 1;
     // froot(eta) = eta - chi_lambda sqrt((eta/Delta)^2 P + C); froot(Delta) <= 0 here.  Bracket lo: froot <= 0, hi: froot > 0.
     double lo = delta, hi = INFINITY;

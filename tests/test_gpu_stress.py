@@ -372,3 +372,21 @@ def test_b2_alternating_sizes_share_the_exchange_words(s, orc):
         psi = s.shifted(s.shifted(s.NormL1(1.0), xd, 1.0, s.NormL2(1.0)), sd)
         y = s.prox(psi, qd, 1.0).cpu().numpy()
         assert np.max(np.abs(y - ref)) <= 1e-12 * max(np.linalg.norm(ref), np.linalg.norm(x)), n
+
+
+def test_b2_integer_lattices_exact_roots(s, orc):
+    """Integer data, lambda = sigma = Delta = 1 and friends: froot vanishes exactly at bracket ends and breakpoints (the case
+    that exposed a defect of the ORACLE's bracket search, tools/fuzz_r2_onelaunch.py: GPU right, restatement wrong).  400 small
+    problems through every form the size selects."""
+    import torch
+    rng = np.random.default_rng(82)
+    for rep in range(400):
+        n = int(rng.integers(1, 80))
+        lev = int(rng.choice([1, 1, 2, 4]))
+        x = np.round(rng.normal(size=n) * lev) / lev; sj = np.round(rng.uniform(-0.5, 0.5, size=n) * lev) / lev
+        q = np.round(rng.normal(size=n) * lev) / lev
+        lam, sigma, delta = float(rng.choice([0.5, 1.0, 2.0])), float(rng.choice([0.5, 1.0, 2.0])), float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0]))
+        xd, sd, qd = _dev(x, sj, q)
+        ref = orc.prox_l1_b2(q, x, sj, lam, sigma, delta, 1.0)
+        y = s.prox(s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(1.0)), sd), qd, sigma).cpu().numpy()
+        assert np.max(np.abs(y - ref)) <= 1e-12 * max(np.linalg.norm(ref), np.linalg.norm(x), 1e-300), (rep, n, lev, lam, sigma, delta)

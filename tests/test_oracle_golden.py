@@ -411,3 +411,20 @@ def test_synthetic_generator_twins_agree(orc):
     assert abs(g.mean()) < 1e-2 and abs(g.var() - 1.0) < 2e-2 and np.abs(g).max() <= 6.0
     assert abs(np.corrcoef(g, oracle.synth_fill(n, 1, 1, 1))[0, 1]) < 1e-2
     assert abs(np.corrcoef(g, oracle.synth_fill(n, 2, 0, 1))[0, 1]) < 1e-2
+
+
+def test_l1b2_exact_zero_at_a_bracket_end(orc):
+    """Integer lattice data where froot(eta) = eta - chi(ProjB(-xk eta / Delta)) vanishes EXACTLY at a point the bracket search
+    lands on (eta = 4 = 2^2 Delta): find_zero returns that point.  The restatement used to step over it and returned 2 eta
+    (found by tools/fuzz_r2_onelaunch.py; the GPU had the root).  Checked against the definition: froot(eta) == 0 at the eta
+    the result implies, in Float64 and in the binary128 arbiter."""
+    x = np.array([-2.0, -1.0, -1.0, -1.0, 0.0, 2.0, -2.0, 0.0, -0.0, -0.0, -0.0, -0.0, 1.0, 1.0, -0.0, -0.0, 1.0, 0.0, 2.0])
+    q = np.array([0.0, -0.0, -2.0, -0.0, -3.0, 0.0, -1.0, 1.0, -0.0, 1.0, -1.0, 1.0, 0.0, 0.0, 0.0, -1.0, -1.0, -1.0, -0.0])
+    sj = np.zeros(19)
+    eta = 4.0
+    proj = np.minimum(np.maximum(-x * eta, q - 1.0), q + 1.0)
+    assert eta - np.linalg.norm(proj) == 0.0                      # the root, exactly
+    want = proj / eta - sj
+    got = orc.prox_l1_b2(q, x, sj, 1.0, 1.0, 1.0, 1.0)
+    assert np.array_equal(got, want)
+    assert np.max(np.abs(orc.q_prox_l1_b2(q, x, sj, 1.0, 1.0, 1.0, 1.0) - want)) <= 1e-15
