@@ -87,6 +87,8 @@ struct FastState {
   int overflow;                   // a workgroup or the candidate buffer overflowed
   unsigned int list_count;        // entries appended to the short list by k_s2_compact
   unsigned long long smax;        // largest FINITE sample key (k_s2_sample; zeroed by k_sel_init)
+  int crowded;                    // k_s2_front: a selected sample bucket is still crowded after the last digit, i.e. the band
+  int pad;                        // holds tied keys -- k_s2_main then counts candidate digits in wave-uniform runs
 };
 
 // totals of the main pass: fire-and-forget atomics of its wavefronts, spread over kShards counters (wave w -> shard
@@ -133,6 +135,28 @@ constexpr uint64_t kNanKey = 0x7ff8000000000000ull;
 __device__ __forceinline__ uint64_t key_of(double v) {
   const uint64_t k = (uint64_t)__double_as_longlong(v) & kAbsMask;
   return k > kInfKey ? kNanKey : k;
+}
+
+// Histogram add of a wavefront's digits with the heavy hitters peeled off first: the digit of the first pending lane is added
+// ONCE with its population count (twice over, if the first peel took a good part of the wave), the rest go lane by lane.
+// Tie-heavy data (lattices, many equal entries) sends whole wavefronts to one bin, and atomics on one address are serialised
+// -- in LDS ~1 per clock, in global memory ~12 ns apiece (n = 1e8 integers: 588 ms per top-r call before, ~3 ms after).  Called
+// by whichever lanes are active; `in` = this lane contributes.  Ctr = unsigned int (LDS) or unsigned long long (global).
+template <class Ctr>
+__device__ __forceinline__ void hist_add_agg(Ctr* h, unsigned int digit, bool in) {
+  unsigned long long todo = __ballot(in);
+  if (todo == 0ull) return;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const unsigned int d0 = __shfl(digit, leader, 64);
+    const unsigned long long same = __ballot(in && digit == d0) & todo;
+    if (lane == leader) atomicAdd(&h[d0], (Ctr)__popcll(same));
+    todo &= ~same;
+    if (todo == 0ull || __popcll(same) < 8) break;  // (wave-uniform) no second heavy hitter in sight
+  }
+  if ((todo >> lane) & 1ull) atomicAdd(&h[digit], (Ctr)1);
 }
 
 // exclusive prefix sum over 256 consecutive lanes (4 wavefronts: tt = 0..255); wtot = 4 shared slots of that group
@@ -674,6 +698,7 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
     f.ok = 0;
     f.key_passes = 0;
     f.overflow = 0;
+    f.crowded = 0;
     f.list_count = 0;
     // (the shard counters are zeroed below by lanes 0..kShards-1)
     // digit machinery of the candidate selection: everything that depends on the band only (the counts -- verdict,
@@ -753,11 +778,18 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
   constexpr int UNROLL = kMainUnroll;
   __shared__ __attribute__((aligned(16))) char dma[4 * 3 * UNROLL * 1024];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // A band the front kernel already knows to be hopeless (its own samples put more of the vector into it than the candidate
+  // regions hold: tie-heavy data -- a band of ONE key with a third of the vector in it) is not walked at all: the verdict is
+  // negative whatever this pass does and the exact select recomputes everything.  (580 ms of serialised per-candidate
+  // atomics on n = 1e8 integers before.)  Written by the previous launch: a plain, cached load, the same in every wave.
+  const int hopeless = ws->fs.overflow;   // (tested once the staging loads have landed: a test up here would hold every
+  const bool crowded = ws->fs.crowded != 0;  // wave's loads back behind its scalar loads -- measured: 5 % of the pass)
   const int64_t gwave = (int64_t)blockIdx.x * 4 + wave;
   const int64_t rbase = gwave * kWaveSlots;  // this wave's candidate region
   const unsigned long long lt_mask = (1ull << lane) - 1;
   unsigned int above = 0;   // per lane
   unsigned int ncand = 0;   // wave-uniform
+  unsigned int run_digit = 0xffffffffu, run_count = 0;  // wave-uniform: the run of index digits being counted (ties, see visit)
   // Called by all 64 lanes together (the ballot needs them); returns the value stored speculatively (WRITE).
   auto visit = [&](bool valid, double v, int64_t i, double x, double s) -> double {
     const uint64_t key = key_of(v);
@@ -782,11 +814,34 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
         cand[rbase + pos].idx = i;
         if constexpr (WRITE) cand[rbase + pos].val = kept;
       }
-      if (in_band) {
-        if (d_phase == 0) {  // every band key is inside the first digit's interval (base = t_lo)
-          atomicAdd(&ws->hist[key_pos(key, t_lo, d_shift, d_width, d_clamp).digit], 1ull);
-        } else if (key == d_teq && (((uint64_t)i) >> d_hs) == d_prefix) {
-          atomicAdd(&ws->hist[(((uint64_t)i) >> d_shift) & d_mask], 1ull);
+      if (ncand <= (unsigned)kWaveSlots) {  // (a wave that has overflowed has decided the verdict: its digits are not needed)
+        // Ties (FastState::crowded, decided by the front kernel from its sample): the candidates of a wave share ONE digit
+        // -- the same key, or neighbouring indices of a one-key band -- and 1.7e6 of them at n = 1e8 were 1.7e6 atomics on
+        // one address, 10.7 ms.  The digit of the first candidate lane is then counted in a wave-uniform RUN, added when the
+        // run's digit changes or the wave ends; other digits of the same visit go lane by lane.
+        bool cnt = in_band;
+        unsigned int dg = 0;
+        if (in_band) {
+          if (d_phase == 0) {  // key digits; every band key is inside the first digit's interval (base = t_lo)
+            dg = key_pos(key, t_lo, d_shift, d_width, d_clamp).digit;
+          } else {             // index digits of a one-key band
+            cnt = key == d_teq && (((uint64_t)i) >> d_hs) == d_prefix;
+            dg = (unsigned int)((((uint64_t)i) >> d_shift) & d_mask);
+          }
+        }
+        if (!crowded) {  // generic data: one candidate per visit, every visit another digit
+          if (cnt) atomicAdd(&ws->hist[dg], 1ull);
+        } else if (const unsigned long long cm = __ballot(cnt)) {
+          const int leader = __ffsll((long long)cm) - 1;
+          const unsigned int d0 = __shfl(dg, leader, 64);
+          const unsigned long long same = __ballot(cnt && dg == d0);
+          if (d0 != run_digit) {
+            if (run_count && lane == 0) atomicAdd(&ws->hist[run_digit], (unsigned long long)run_count);
+            run_digit = d0;
+            run_count = 0;
+          }
+          run_count += (unsigned int)__popcll(same);
+          if (cnt && dg != d0) atomicAdd(&ws->hist[dg], 1ull);
         }
       }
       ncand += (unsigned int)__popcll(m);
@@ -807,6 +862,7 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
     __builtin_amdgcn_global_load_lds((const void*)(sj + i), (lds_void*)(wl + (2 * UNROLL + k) * 1024), 16, 0, 2);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (hopeless) return;
 #pragma unroll
   for (int k = 0; k < UNROLL; ++k) {
     const int64_t i = wbase + k * 64;
@@ -836,6 +892,7 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
   }
   for (int off = 32; off >= 1; off >>= 1) above += __shfl_xor(above, off, 64);
   if (lane == 0) {
+    if (run_count) atomicAdd(&ws->hist[run_digit], (unsigned long long)run_count);
     counts[gwave] = WaveCount{ncand, above};
     if constexpr (SHARD) {
       const int shard = (int)(gwave % kShards) * kShardStride;
@@ -1223,16 +1280,21 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
     const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
     auto visit = [&](double vv, int64_t i) {
       const uint64_t key = key_of(vv);
+      bool in = true;
+      unsigned int dg;
       if (st.phase == 0) {
         if (st.pad == 1) {
-          atomicAdd(&sh.lh[fold_digit(key)], 1u);
+          dg = fold_digit(key);
         } else {
           const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
-          if (kp.in) atomicAdd(&sh.lh[kp.digit], 1u);
+          in = kp.in;
+          dg = kp.digit;
         }
-      } else if (key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix) {
-        atomicAdd(&sh.lh[(((uint64_t)i) >> st.shift) & dmask], 1u);
+      } else {
+        in = key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix;
+        dg = (unsigned int)((((uint64_t)i) >> st.shift) & dmask);
       }
+      hist_add_agg(sh.lh, dg, in);
     };
     if constexpr (REG) {
 #pragma unroll
@@ -1444,12 +1506,14 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
   for (int digit = 1; digit < kPickDigits; ++digit) {
     if (digit == 2 && bucket[0] <= kPickFine && bucket[1] <= kPickFine) break;  // uniform: same histograms everywhere
     const int hs = shift + kDigitBits;
+    // (wave-aggregated: on tie-heavy data every sample of the selected bucket carries the same digit -- 262 144 global
+    //  atomics on one address were 3.3 ms)
 #pragma unroll
     for (int sidx = 0; sidx < kFrontSpl; ++sidx) {
       const uint64_t top = keys[sidx] >> hs;
       const unsigned d = (unsigned)((keys[sidx] >> shift) & (kBins - 1));
-      if (active[0] && top == pre[0]) atomicAdd(&ss->fhist2[digit - 1][0][d], 1ull);
-      if (active[1] && top == pre[1]) atomicAdd(&ss->fhist2[digit - 1][1][d], 1ull);
+      hist_add_agg(ss->fhist2[digit - 1][0], d, active[0] && top == pre[0]);
+      hist_add_agg(ss->fhist2[digit - 1][1], d, active[1] && top == pre[1]);
     }
     SEL_STAMP(2 + 2 * digit);
     spx_grid_barrier(bar, (++nbar) * gridDim.x, &ss->hdr.timed_out);
@@ -1457,6 +1521,26 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     scan_both(ss->fhist2[digit - 1][0], ss->fhist2[digit - 1][1]);
     ndig = digit + 1;
     shift -= kDigitBits;
+  }
+  // workgroup 0: how many of ITS samples (1024 kFrontSpl, spread over the whole vector) fall into the band?  More than the
+  // candidate regions could hold of a wave's elements (64 of 768) -> the main pass is told not to bother (see k_s2_main)
+  int hopeless = 0;
+  if (c == 0) {
+    const int low = 64 - ndig * kDigitBits;
+    const uint64_t b_hi = active[0] ? ((pre[0] << low) | (((uint64_t)1 << low) - 1)) : ~0ull;
+    const uint64_t b_lo = active[1] ? (pre[1] << low) : 0ull;
+    int mine = 0;
+#pragma unroll
+    for (int sidx = 0; sidx < kFrontSpl; ++sidx) mine += (keys[sidx] >= b_lo && keys[sidx] <= b_hi) ? 1 : 0;
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    __syncthreads();   // (scan_both is done with `part`)
+    if ((t & 63) == 0) part[(t >> 6) >> 2][(t >> 6) & 3] = (unsigned long long)mine;
+    __syncthreads();
+    if (t == 0) {
+      unsigned long long tot = 0;
+      for (int k = 0; k < 16; ++k) tot += part[k >> 2][k & 3];
+      hopeless = tot * 768ull > 48ull * (unsigned long long)(1024 * kFrontSpl) ? 1 : 0;  // > 48 of 768: 6 %
+    }
   }
   if (c == 0 && t == 0) {
     FastState& f = ws->fs;
@@ -1467,7 +1551,8 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     f.cand_count = 0;
     f.ok = 0;
     f.key_passes = 0;
-    f.overflow = 0;
+    f.overflow = hopeless;
+    f.crowded = (bucket[0] > 64u || bucket[1] > 64u) ? 1 : 0;  // (generic data ends on <= kPickFine samples per bucket)
     f.list_count = 0;
     SelState& s = ws->st;
     sel_state_init(s, n, r);
