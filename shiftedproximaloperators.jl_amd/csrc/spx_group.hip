@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(256) void k_gather_owner(int* owner, const int64_t*
     if (lo < 0 || hi > nnz || lo > hi) { if (lane == 0) atomicOr(flag, 2); continue; }
     for (int64_t p = lo + lane; p < hi; p += 64) {
       const int64_t j = index[p];
-      if (j < 0 || j >= n) atomicOr(flag, 1);
+      if ((j < 0 || j >= n) && (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) == 0) atomicOr(flag, 1);
       else atomicMax(owner + j, (int)g);
     }
   }

@@ -259,7 +259,8 @@ struct OpIproxL1 {  // src/shiftedNormL1.jl:60-75
   static constexpr int kNIn = 4;
   static constexpr bool kObj = false;
   __device__ __forceinline__ double call4(double g, double d, double x, double s, double, double, bool) const {
-    if (!(d > 0.0)) atomicOr(flag, 1);
+    // (raised once: a d that is wrong everywhere must not queue 1e8 atomics on one address -- 12 ns apiece)
+    if (!(d > 0.0) && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(flag, 1);
     const double t = (-x) - s;                                                       // :67
     return jl_min(jl_max(t, -g / d - lambda / d), -g / d + lambda / d);              // :71
   }
@@ -272,7 +273,8 @@ struct OpIproxL0 {  // src/shiftedNormL0.jl:61-80
   static constexpr int kNIn = 4;
   static constexpr bool kObj = false;
   __device__ __forceinline__ double call4(double g, double d, double x, double s, double, double, bool) const {
-    if (!(d > 0.0)) atomicOr(flag, 1);
+    // (raised once: a d that is wrong everywhere must not queue 1e8 atomics on one address -- 12 ns apiece)
+    if (!(d > 0.0) && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(flag, 1);
     const double ci = sqrt(2 * lambda * d);                                          // :71
     const double xps = x + s;
     return (fabs(d * xps - g) <= ci) ? -xps : (-g / d);                              // :73-77
