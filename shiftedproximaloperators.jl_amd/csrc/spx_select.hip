@@ -902,7 +902,8 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
       if (above) atomicAdd(&ws->shard_above[shard], (unsigned long long)above);
       if (ncand) atomicAdd(&ws->shard_cand[shard], (unsigned long long)ncand);
     }
-    if (ncand > (unsigned)kWaveSlots) atomicExch(&ws->fs.overflow, 1);
+    if (ncand > (unsigned)kWaveSlots && __hip_atomic_load(&ws->fs.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+      atomicExch(&ws->fs.overflow, 1);  // (raised once, not by every overflowing wave in turn)
   }
 }
 
