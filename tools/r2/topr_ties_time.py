@@ -14,6 +14,9 @@ for kind in os.environ.get("SPX_KINDS", "continuous,lattice 1/4,lattice 1,two va
     elif kind == "lattice 1/4": q = torch.round(q0 * 4) / 4
     elif kind == "lattice 1": q = torch.round(q0)
     elif kind == "two values": q = torch.where(q0 > 0.5, torch.full_like(q0, 1.5), torch.full_like(q0, -0.75))
+    elif kind == "sorted": q = torch.sort(q0)[0]
+    elif kind == "sorted |v|": q = q0[torch.argsort(q0.abs())]
+    elif kind == "blocks": q = q0 * (1.0 + 4.0 * ((torch.arange(n, device=q0.device) // 1_000_000) % 2 == 0))
     else: q = torch.full_like(q0, 2.0)
     for r in [int(v) for v in os.environ.get("SPX_RS", "%d,%d" % (n // 100, n // 2)).split(",")]:
         psi = s.shifted(s.shifted(s.IndBallL0(r), z, 1.0, s.NormLinf(1.0)), z)
