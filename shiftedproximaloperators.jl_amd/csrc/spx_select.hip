@@ -88,7 +88,9 @@ struct FastState {
   unsigned int list_count;        // entries appended to the short list by k_s2_compact
   unsigned long long smax;        // largest FINITE sample key (k_s2_sample; zeroed by k_sel_init)
   int crowded;                    // k_s2_front: a selected sample bucket is still crowded after the last digit, i.e. the band
-  int pad;                        // holds tied keys -- k_s2_main then counts candidate digits in wave-uniform runs
+                                  // holds tied keys -- k_s2_main then counts candidate digits in wave-uniform runs
+  unsigned int ovf_count;         // candidates a wavefront could not fit into its own region: appended to the shared overflow
+                                  // list behind the regions (sorted / clustered data: the band is contiguous in the vector)
 };
 
 // totals of the main pass: fire-and-forget atomics of its wavefronts, spread over kShards counters (wave w -> shard
@@ -699,6 +701,7 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
     f.key_passes = 0;
     f.overflow = 0;
     f.crowded = 0;
+    f.ovf_count = 0;
     f.list_count = 0;
     // (the shard counters are zeroed below by lanes 0..kShards-1)
     // digit machinery of the candidate selection: everything that depends on the band only (the counts -- verdict,
@@ -760,7 +763,7 @@ __global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n,
 template <bool BINF, bool WRITE, bool SHARD = true>
 __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, const double* xk_, const double* sj_,
                                                   int64_t n, SelWs* ws, Cand* cand, WaveCount* counts, double delta,
-                                                  int ioff) {
+                                                  int ioff, int64_t ovf_base, unsigned int ovf_cap) {
   // ioff = 1: the caller's vectors start 8 bytes off a 16-byte boundary (all four alike); the pointers passed here
   // are the aligned rest (caller's element 1 on), n counts that rest, and the caller's element 0 sits at [-1].
   // Candidate indices are the caller's.
@@ -790,6 +793,7 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
   unsigned int above = 0;   // per lane
   unsigned int ncand = 0;   // wave-uniform
   unsigned int run_digit = 0xffffffffu, run_count = 0;  // wave-uniform: the run of index digits being counted (ties, see visit)
+  bool full = false;        // (per lane) the overflow list had no room for this lane's candidate
   // Called by all 64 lanes together (the ballot needs them); returns the value stored speculatively (WRITE).
   auto visit = [&](bool valid, double v, int64_t i, double x, double s) -> double {
     const uint64_t key = key_of(v);
@@ -814,7 +818,27 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
         cand[rbase + pos].idx = i;
         if constexpr (WRITE) cand[rbase + pos].val = kept;
       }
-      if (ncand <= (unsigned)kWaveSlots) {  // (a wave that has overflowed has decided the verdict: its digits are not needed)
+      // more candidates than the wave's own region holds (sorted or clustered data: the band is contiguous in the vector):
+      // the rest goes to the shared overflow list, one atomic per visit; only a FULL list makes the verdict negative
+      const bool spill = in_band && pos >= (unsigned)kWaveSlots;
+      if (ncand + (unsigned int)__popcll(m) > (unsigned)kWaveSlots) {  // (wave-uniform: only then can a lane spill)
+        const unsigned long long sm = __ballot(spill);
+        const int sl = __ffsll((long long)sm) - 1;
+        unsigned int sbase = 0;
+        if (lane == sl) sbase = atomicAdd(&ws->fs.ovf_count, (unsigned int)__popcll(sm));
+        sbase = __shfl(sbase, sl, 64);
+        const unsigned int slot = sbase + (unsigned int)__popcll(sm & lt_mask);
+        if (spill) {
+          if (slot < ovf_cap) {
+            cand[ovf_base + slot].key = key;
+            cand[ovf_base + slot].idx = i;
+            if constexpr (WRITE) cand[ovf_base + slot].val = kept;
+          } else {
+            full = true;
+          }
+        }
+      }
+      {
         // Ties (FastState::crowded, decided by the front kernel from its sample): the candidates of a wave share ONE digit
         // -- the same key, or neighbouring indices of a one-key band -- and 1.7e6 of them at n = 1e8 were 1.7e6 atomics on
         // one address, 10.7 ms.  The digit of the first candidate lane is then counted in a wave-uniform RUN, added when the
@@ -829,7 +853,7 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
             dg = (unsigned int)((((uint64_t)i) >> d_shift) & d_mask);
           }
         }
-        if (!crowded) {  // generic data: one candidate per visit, every visit another digit
+        if (!crowded && ncand < (unsigned)kWaveSlots) {  // generic data: one candidate per visit, every visit another digit
           if (cnt) atomicAdd(&ws->hist[dg], 1ull);
         } else if (const unsigned long long cm = __ballot(cnt)) {
           const int leader = __ffsll((long long)cm) - 1;
@@ -891,6 +915,8 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
     }
   }
   for (int off = 32; off >= 1; off >>= 1) above += __shfl_xor(above, off, 64);
+  if (__any(full) && lane == 0 && __hip_atomic_load(&ws->fs.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+    atomicExch(&ws->fs.overflow, 1);  // (raised once, not by every wave that found the list full)
   if (lane == 0) {
     if (run_count) atomicAdd(&ws->hist[run_digit], (unsigned long long)run_count);
     counts[gwave] = WaveCount{ncand, above};
@@ -902,8 +928,7 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
       if (above) atomicAdd(&ws->shard_above[shard], (unsigned long long)above);
       if (ncand) atomicAdd(&ws->shard_cand[shard], (unsigned long long)ncand);
     }
-    if (ncand > (unsigned)kWaveSlots && __hip_atomic_load(&ws->fs.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-      atomicExch(&ws->fs.overflow, 1);  // (raised once, not by every overflowing wave in turn)
+
   }
 }
 
@@ -911,7 +936,12 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
 // steps through its few entries (4 loads in flight per lane), so the count words are read coalesced and no lane waits
 // on a chain of dependent loads.  f(key, index, value) is called for every valid entry.
 template <class F>
-__device__ __forceinline__ void for_each_candidate(const WaveCount* counts, int64_t nregions, const Cand* cand, F&& f) {
+__device__ __forceinline__ void for_each_candidate(const WaveCount* counts, int64_t nregions, const Cand* cand, int64_t novf, F&& f) {
+  {  // the shared overflow list behind the regions (usually empty)
+    const Cand* ov = cand + nregions * kWaveSlots;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < novf; e += nthreads) f(ov[e].key, ov[e].idx, ov[e].val);
+  }
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -985,12 +1015,13 @@ __global__ __launch_bounds__(256) void k_s2_scan_verify(SelWs* ws, int64_t r) {
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_s2_compact(double* y, const Cand* cand, SelWs* ws, uint64_t* list_key,
                                                      int64_t* list_idx, double* list_val, const WaveCount* counts,
-                                                     int64_t nregions) {
+                                                     int64_t nregions, unsigned int ovf_cap) {
   const SelState st = ws->st;
   if (!ws->fs.ok) return;
   if (!WRITE && st.phase == 2) return;
   const int hs = st.shift + st.width;
-  for_each_candidate(counts, nregions, cand, [&](uint64_t key, int64_t i, double val) {
+  const unsigned int novf = ws->fs.ovf_count < ovf_cap ? ws->fs.ovf_count : ovf_cap;
+  for_each_candidate(counts, nregions, cand, (int64_t)novf, [&](uint64_t key, int64_t i, double val) {
     bool in = false, keep = false;
     if (st.phase == 2) {  // resolved by the first digit already
       keep = (key >= st.t_ge) || (key == st.t_eq && i <= st.icut);
@@ -1400,6 +1431,7 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
   __shared__ unsigned long long part[4][4];  // per 256-lane group
   __shared__ unsigned long long pre[2];
   __shared__ long long quo[2];
+  __shared__ long long rank0[2];   // the two sample ranks as first computed (quo is consumed by the scans)
   __shared__ int active[2];
   __shared__ unsigned int bucket[2];
   const int t = threadIdx.x, c = blockIdx.x;
@@ -1426,18 +1458,23 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     active[1] = rank_lo <= kFrontSample;
     quo[0] = rank_hi;
     quo[1] = rank_lo;
+    rank0[0] = rank_hi;
+    rank0[1] = rank_lo;
   }
   __syncthreads();
-  // 256 kFrontSpl chunks of 256 consecutive elements, spread evenly over the vector: sample s of lane t of workgroup c comes
-  // from chunk (s * 64 + c) * 4 + (t >> 8)
-  constexpr int kChunks = kFrontBlocks * 4 * kFrontSpl;
+  // 2048 kFrontSpl chunks of 32 consecutive elements (256 bytes: two full lines per vector), spread evenly over the vector:
+  // sample s of lane t of workgroup c comes from chunk (s * 64 + c) * 32 + (t >> 5).  (Chunks of 256 elements, the first
+  // layout, left 1024 chunks at n = 1e8 -- on SORTED input, where a chunk is 256 nearly equal values, the sample quantiles
+  // then moved in steps as large as the band's whole margin and the verdict failed: 2.0 ms per call instead of 0.55.)
+  constexpr int kChunkLen = 32;
+  constexpr int kChunks = kFrontBlocks * (1024 / kChunkLen) * kFrontSpl;
   uint64_t keys[kFrontSpl];
   unsigned long long m = 0ull;
 #pragma unroll
   for (int sidx = 0; sidx < kFrontSpl; ++sidx) {
-    const int chunk = (sidx * kFrontBlocks + c) * 4 + (t >> 8);
-    const int64_t start = (int64_t)((double)chunk * (double)(n - 256) / (double)(kChunks - 1));
-    const int64_t i = start + (t & 255);
+    const int chunk = (sidx * kFrontBlocks + c) * (1024 / kChunkLen) + (t / kChunkLen);
+    const int64_t start = (int64_t)((double)chunk * (double)(n - kChunkLen) / (double)(kChunks - 1));
+    const int64_t i = start + (t % kChunkLen);
     keys[sidx] = key_of(fabs((xk[i] + sj[i]) + q[i]));
   }
 #pragma unroll
@@ -1523,25 +1560,16 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     ndig = digit + 1;
     shift -= kDigitBits;
   }
-  // workgroup 0: how many of ITS samples (1024 kFrontSpl, spread over the whole vector) fall into the band?  More than the
-  // candidate regions could hold of a wave's elements (64 of 768) -> the main pass is told not to bother (see k_s2_main)
+  // How much of the SAMPLE lies in the band?  Exactly known from the scans: ranks above the upper bucket = rank_hi - quo[0],
+  // ranks down to the low end of the lower bucket = rank_lo - quo[1] + bucket[1].  More than the candidate storage could
+  // take of the vector (6 %: ties -- a bucket that holds per cents of the sample) -> the main pass is told not to bother.
+  // (A count over one workgroup's own samples misfires on SORTED input, whose band is contiguous: 256 samples of a chunk.)
   int hopeless = 0;
-  if (c == 0) {
-    const int low = 64 - ndig * kDigitBits;
-    const uint64_t b_hi = active[0] ? ((pre[0] << low) | (((uint64_t)1 << low) - 1)) : ~0ull;
-    const uint64_t b_lo = active[1] ? (pre[1] << low) : 0ull;
-    int mine = 0;
-#pragma unroll
-    for (int sidx = 0; sidx < kFrontSpl; ++sidx) mine += (keys[sidx] >= b_lo && keys[sidx] <= b_hi) ? 1 : 0;
-    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
-    __syncthreads();   // (scan_both is done with `part`)
-    if ((t & 63) == 0) part[(t >> 6) >> 2][(t >> 6) & 3] = (unsigned long long)mine;
-    __syncthreads();
-    if (t == 0) {
-      unsigned long long tot = 0;
-      for (int k = 0; k < 16; ++k) tot += part[k >> 2][k & 3];
-      hopeless = tot * 768ull > 48ull * (unsigned long long)(1024 * kFrontSpl) ? 1 : 0;  // > 48 of 768: 6 %
-    }
+  if (c == 0 && t == 0) {
+    const long long top = active[0] ? (rank0[0] - quo[0]) : 0;
+    const long long bot = active[1] ? (rank0[1] - quo[1] + (long long)bucket[1]) : (long long)(kFrontBlocks * 1024 * kFrontSpl);
+    const long long in_band = bot - top;
+    hopeless = (in_band * 768ll > 48ll * (long long)(kFrontBlocks * 1024 * kFrontSpl)) ? 1 : 0;
   }
   if (c == 0 && t == 0) {
     FastState& f = ws->fs;
@@ -1553,6 +1581,7 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     f.ok = 0;
     f.key_passes = 0;
     f.overflow = hopeless;
+    f.ovf_count = 0;
     f.crowded = (bucket[0] > 64u || bucket[1] > 64u) ? 1 : 0;  // (generic data ends on <= kPickFine samples per bucket)
     f.list_count = 0;
     SelState& s = ws->st;
@@ -1673,10 +1702,13 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   const int64_t mblocks = (n2 + kMainTilePairs - 1) / kMainTilePairs;
   const int64_t nregions = try_fast ? mblocks * 4 : 0;
   const int64_t ccap = nregions * kWaveSlots;
+  // the shared overflow list behind the per-wave regions: room for a band that is contiguous in the vector (sorted input)
+  const int64_t ovf_cap64 = try_fast ? ((n / 64 > 65536) ? n / 64 : 65536) : 0;
+  const unsigned int ovf_cap = (unsigned int)(ovf_cap64 > 0x7fffffff ? 0x7fffffff : ovf_cap64);
   const size_t off_samp = (sizeof(SelWs) + 255) & ~(size_t)255;
   const size_t off_cnt = off_samp + (size_t)kSample * sizeof(double);
   const size_t off_ckey = (off_cnt + (size_t)nregions * sizeof(WaveCount) + 255) & ~(size_t)255;
-  const size_t off_lkey = off_ckey + (size_t)ccap * sizeof(Cand);
+  const size_t off_lkey = off_ckey + ((size_t)ccap + (size_t)ovf_cap) * sizeof(Cand);
   const size_t off_lidx = off_lkey + (size_t)kShortList * sizeof(uint64_t);
   const size_t off_lval = off_lidx + (size_t)kShortList * sizeof(int64_t);
   rc = spx_ws_reserve(ctx, off_lval + (size_t)kShortList * sizeof(double) + 256);
@@ -1721,22 +1753,22 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
         ctx->coop_parity ^= 1;
         if (write)
           hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,
-                             sj + ioff, n - ioff, sws, cand, counts, delta, ioff);
+                             sj + ioff, n - ioff, sws, cand, counts, delta, ioff, ccap, ovf_cap);
         else
           hipLaunchKernelGGL((k_s2_main<BINF, false>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,
-                             sj + ioff, n - ioff, sws, cand, counts, delta, ioff);
+                             sj + ioff, n - ioff, sws, cand, counts, delta, ioff, ccap, ovf_cap);
         // (tried: verdict + first digit redone by every workgroup of the candidate walk instead of the one-workgroup launch in
         //  front of it -- 598 vs 571 us per call at n = 1e8: 512 workgroups x 64 KiB of L2 reads and the scan chain cost more
         //  than the launch they save)
         hipLaunchKernelGGL(k_s2_scan_verify, dim3(1), dim3(256), 0, ctx->stream, sws, r);
         if (write) {
           hipLaunchKernelGGL((k_s2_compact<true>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, sws, lkey, lidx,
-                             lval, (const WaveCount*)counts, nregions);
+                             lval, (const WaveCount*)counts, nregions, ovf_cap);
           hipLaunchKernelGGL((k_s2_finish<true>), dim3(1), dim3(1024), 0, ctx->stream, y, sws, (const uint64_t*)lkey,
                              (const int64_t*)lidx, (const double*)lval);
         } else {
           hipLaunchKernelGGL((k_s2_compact<false>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, sws, lkey, lidx,
-                             lval, (const WaveCount*)counts, nregions);
+                             lval, (const WaveCount*)counts, nregions, ovf_cap);
           hipLaunchKernelGGL((k_s2_finish<false>), dim3(1), dim3(1024), 0, ctx->stream, y, sws, (const uint64_t*)lkey,
                              (const int64_t*)lidx, (const double*)lval);
         }
@@ -1755,21 +1787,21 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     hipLaunchKernelGGL(k_s2_pick, dim3(1), dim3(1024), 0, ctx->stream, (const double*)samp, n, r, ws);
     if (write)
       hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,
-                         sj + ioff, n - ioff, ws, cand, counts, delta, ioff);
+                         sj + ioff, n - ioff, ws, cand, counts, delta, ioff, ccap, ovf_cap);
     else
       hipLaunchKernelGGL((k_s2_main<BINF, false>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,
-                         sj + ioff, n - ioff, ws, cand, counts, delta, ioff);
+                         sj + ioff, n - ioff, ws, cand, counts, delta, ioff, ccap, ovf_cap);
     // the main pass has already histogrammed the first candidate digit: verdict + first scan step, survivors ->
     // short list, the rest of the selection in one workgroup
     hipLaunchKernelGGL(k_s2_scan_verify, dim3(1), dim3(256), 0, ctx->stream, ws, r);
     if (write) {
       hipLaunchKernelGGL((k_s2_compact<true>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, ws, lkey, lidx,
-                         lval, (const WaveCount*)counts, nregions);
+                         lval, (const WaveCount*)counts, nregions, ovf_cap);
       hipLaunchKernelGGL((k_s2_finish<true>), dim3(1), dim3(1024), 0, ctx->stream, y, ws, (const uint64_t*)lkey,
                          (const int64_t*)lidx, (const double*)lval);
     } else {
       hipLaunchKernelGGL((k_s2_compact<false>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, ws, lkey, lidx,
-                         lval, (const WaveCount*)counts, nregions);
+                         lval, (const WaveCount*)counts, nregions, ovf_cap);
       hipLaunchKernelGGL((k_s2_finish<false>), dim3(1), dim3(1024), 0, ctx->stream, y, ws, (const uint64_t*)lkey,
                          (const int64_t*)lidx, (const double*)lval);
       hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1535) / 1536)), dim3(256), 0, ctx->stream,
