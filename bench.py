@@ -329,14 +329,14 @@ def _extra(s, L, ctx, dev, n, torch):
     line("ShiftedIndBallL0BInf_r=n/2", s.shifted(s.shifted(s.IndBallL0(max(1, n // 2)), xk, 1.0, chi), sj), 32, n, y, q, TOPR)
     # the same operator on TIE-HEAVY data (q rounded to multiples of 1/4: the r-th largest |v| is shared by ~1 % of the vector):
     # the sample-predicted band cannot separate equal keys, the exact select behind it does the work (index tie-break)
-    q4 = torch.round(q * 4.0) / 4.0
-    psi_t = s.shifted(s.shifted(s.IndBallL0(r), xk, 1.0, chi), sj)
+    psi_t = s.shifted(s.shifted(s.IndBallL0(r), torch.zeros_like(xk), 1.0, chi), torch.zeros_like(sj))
+    q4 = torch.round(q * 4.0) / 4.0                             # (with xk = sj = 0 the lattice is exact)
     s.prox_bang(y, psi_t, q4, 1.0)
     ms = _time_op(s, L, ctx, lambda: s.prox_bang(y, psi_t, q4, 1.0), iters=5, rounds=3)
     res["ShiftedIndBallL0BInf_r=n/100_ties"] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4),
                                                 "kernel": "k_sel_coop<true,false> (exact select; + k_s2_front, k_s2_main)",
-                                                "note": "q on a 1/4 lattice: ties at the threshold; round 2 before the fix: 14-590 ms"}
-    del q4
+                                                "note": "xk = sj = 0, q on a 1/4 lattice: ties at the threshold; round 2 before the fix: 14-590 ms"}
+    del q4, psi_t
     # per-call latency at solver-iteration sizes: the two operators with a data-dependent scalar (r-th largest, trust-region
     # root) run as ONE launch with in-launch rendezvous, nothing read back (us per call, HIP events over 50 back-to-back calls)
     for nn in (1_000_000, 10_000):
