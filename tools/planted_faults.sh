@@ -14,7 +14,7 @@ FAULTS=(
  "5|spx_select.hip|s/} else if (!catch_all) {  /} else if (true) {  /|tests/test_gpu_stress.py::test_topr_folded_first_digit"
  "6|spx_b2.hip|s/clear_rows\[pass_i \* kB2Cols \* kB2Words + rem\] = 0ull;/(void)rem;/|tests/test_gpu_stress.py::test_b2_alternating_sizes_share_the_exchange_words tests/test_gpu_stress.py::test_b2_one_launch_forms_at_their_boundaries"
  "7|spx_select.hip|s/rc = spx_zero_async(ctx, &ss->chist\[0\]\[0\]\[0\], sizeof(ss->chist\[0\]));/rc = 0;/|tests/test_gpu_graph.py::test_iteration_in_a_graph_replays_on_new_data"
- "8|spx_select.hip|s/    if (run_count) atomicAdd(&ws->hist\[run_digit\], (unsigned long long)run_count);/    (void)run_count;/|tests/test_gpu_parity.py::test_indball_l0_front_sample_sizes tests/test_gpu_fullsize.py"
+ "8|spx_select.hip|s/      if (run_count\[k\]) atomicAdd(&ws->hist\[run_digit\[k\]\], (unsigned long long)run_count\[k\]);/      (void)run_count[k];/|tests/test_gpu_parity.py::test_indball_l0_front_sample_sizes tests/test_gpu_fullsize.py"
  "4|spx_group.hip|s/if (sb == 0.0) {/if (false) {/;s/for (int k = 0; k < 64; ++k) {/for (int k = 0; k < 12; ++k) { piece_ok = true;/|tests/test_gpu_parity.py::test_group_binf_many_small_groups tests/test_gpu_parity.py::test_group_binf_zero_groups_strong_lambda"
 )
 case "${1:-}" in

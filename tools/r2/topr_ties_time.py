@@ -6,7 +6,7 @@ import torch
 import __graft_entry__ as ge
 s = ge.build(); L = s._lib.load(); ctx = s.context("cuda:0")
 n = 100_000_000
-g = torch.Generator(device="cuda:0").manual_seed(1)
+g = torch.Generator(device="cuda:0").manual_seed(int(os.environ.get("SPX_SEED", "1")))
 q0 = torch.randn(n, dtype=torch.float64, device="cuda:0", generator=g)
 z = torch.zeros(n, dtype=torch.float64, device="cuda:0"); y = torch.empty_like(q0)
 for kind in os.environ.get("SPX_KINDS", "continuous,lattice 1/4,lattice 1,two values,constant").split(","):
