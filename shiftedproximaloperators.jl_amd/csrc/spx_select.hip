@@ -1559,8 +1559,14 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
   int ndig = 1;
   int shift = 64 - 2 * kDigitBits;
   for (int digit = 1; digit < kPickDigits; ++digit) {
-    if (digit == 2 && bucket[0] <= kPickFine && bucket[1] <= kPickFine) break;  // uniform: same histograms everywhere
+    // (uniform: same histograms everywhere.  The resolution asked of the band's ends is a share of the VECTOR: 16 samples of
+    //  65 536, i.e. 16 kFrontSpl of this sample: the third digit -- a barrier and a scan, 10 us -- is then skipped at r = n/2
+    //  as it always was at r = n/100)
+    if (digit == 2 && bucket[0] <= kPickFine * kFrontSpl && bucket[1] <= kPickFine * kFrontSpl) break;
     const int hs = shift + kDigitBits;
+    // both ranks in the same bucket so far (the usual case: the band is narrow): ONE histogram serves both selections -- half
+    // the global atomics of this phase (the barrier behind it waits for them: 9 us)
+    const bool shared = active[0] && active[1] && pre[0] == pre[1];
     // (wave-aggregated: on tie-heavy data every sample of the selected bucket carries the same digit -- 262 144 global
     //  atomics on one address were 3.3 ms)
 #pragma unroll
@@ -1568,12 +1574,12 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
       const uint64_t top = keys[sidx] >> hs;
       const unsigned d = (unsigned)((keys[sidx] >> shift) & (kBins - 1));
       hist_add_agg(ss->fhist2[digit - 1][0], d, active[0] && top == pre[0]);
-      hist_add_agg(ss->fhist2[digit - 1][1], d, active[1] && top == pre[1]);
+      if (!shared) hist_add_agg(ss->fhist2[digit - 1][1], d, active[1] && top == pre[1]);
     }
     SEL_STAMP(2 + 2 * digit);
     spx_grid_barrier(bar, (++nbar) * gridDim.x, &ss->hdr.timed_out);
     SEL_STAMP(3 + 2 * digit);
-    scan_both(ss->fhist2[digit - 1][0], ss->fhist2[digit - 1][1]);
+    scan_both(ss->fhist2[digit - 1][0], ss->fhist2[digit - 1][shared ? 0 : 1]);
     ndig = digit + 1;
     shift -= kDigitBits;
   }
@@ -1599,7 +1605,8 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     f.key_passes = 0;
     f.overflow = hopeless;
     f.ovf_count = 0;
-    f.crowded = (bucket[0] > 64u || bucket[1] > 64u) ? 1 : 0;  // (generic data ends on <= kPickFine samples per bucket)
+    // (generic data ends on <= kPickFine kFrontSpl samples per bucket, or far fewer after a third digit)
+    f.crowded = (bucket[0] > 4u * kPickFine * kFrontSpl || bucket[1] > 4u * kPickFine * kFrontSpl) ? 1 : 0;
     f.list_count = 0;
     SelState& s = ws->st;
     sel_state_init(s, n, r);
