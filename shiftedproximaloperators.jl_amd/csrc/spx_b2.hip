@@ -332,15 +332,17 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
     }
   }
   B2_STAMP();  // (register-resident form: the vectors are in)
-  // the sample (streaming form only): one element per lane of the grid -- chunk c = 4 * workgroup + (t >> 8) of 4 G chunks
-  // of 256 consecutive elements, element t & 255 of it (262 144 elements on 256 CUs: statistical error of its root ~2e-3)
-  const int kChunks = 4 * G;
-  const int chunk = (int)blockIdx.x * 4 + (t >> 8);
-  const int64_t nsample = (int64_t)kChunks * 256;
+  // the sample (streaming form only): one element per lane of the grid -- chunk c = 32 * workgroup + (t >> 5) of 32 G chunks
+  // of 32 consecutive elements (256 bytes), element t & 31 of it (262 144 elements on 256 CUs: statistical error of its root
+  // ~2e-3).  (Chunks of 256 elements at first: on SORTED input a chunk is 256 nearly equal values and the sample's root was
+  // off by more than the second trial can absorb -- a fourth pass, 1.68 instead of 1.36 ms, tools/r2/b2_sorted_time.py.)
+  const int kChunks = 32 * G;
+  const int chunk = (int)blockIdx.x * 32 + (t >> 5);
+  const int64_t nsample = (int64_t)kChunks * 32;
   const bool has_sample = !REG && n >= 4 * nsample;
   double sx = 0.0, ss = 0.0, ssq = 0.0;
   if (has_sample) {
-    const int64_t i = (int64_t)((double)chunk * (double)(n - 256) / (double)(kChunks - 1)) + (t & 255);
+    const int64_t i = (int64_t)((double)chunk * (double)(n - 32) / (double)(kChunks - 1)) + (t & 31);
     sx = xk[i]; ss = sj[i]; ssq = ss + q[i];
   }
   const f64x2* q2 = reinterpret_cast<const f64x2*>(q);
