@@ -288,7 +288,7 @@ int spx_obj_group_l2_binf(spx_ctx* ctx, const double* y, const double* xk, const
  * The result never depends on the route taken, the time does: beyond 2^21 elements a sample predicts a band around the r-th
  * largest magnitude and one streaming pass settles everything outside it (n = 1e8: 0.57 ms, sorted input included); when
  * the keys at the threshold are shared by per cents of the vector (lattice data, constants) the band cannot separate them
- * and the exact radix select behind it does the work (3-5 ms at n = 1e8).  Nothing is read back by either route. */
+ * and the exact radix select behind it does the work (2.6-6.5 ms at n = 1e8).  Nothing is read back by either route. */
 int spx_prox_indball_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
                         int64_t n, int64_t r);
 /* ShiftedIndBallL0BInf.prox! src/shiftedIndBallL0BInf.jl:73-95 : as above, then clamp y to [-delta, delta]. */

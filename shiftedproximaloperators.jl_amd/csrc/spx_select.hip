@@ -1303,6 +1303,9 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
   const int t = threadIdx.x;
   const int64_t NT = (int64_t)gridDim.x * blockDim.x;
   const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + t;
+  // (form that parks v in y: 16-byte accesses when all four vectors allow them -- the exact select behind a failed prediction)
+  const bool vec2 = !REG && n >= 2 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(q) |
+                                        reinterpret_cast<uintptr_t>(xk) | reinterpret_cast<uintptr_t>(sj)) & 15u) == 0;
   double v[REG ? kCoopEpl : 1];
   if constexpr (REG) {
 #pragma unroll
@@ -1351,6 +1354,34 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
         const int64_t i = gtid + (int64_t)k * NT;
         if (i < n) visit(v[k], i);
       }
+    } else if (vec2) {
+      // 16-byte accesses (all four vectors 16-byte aligned): lane (block, t) owns the pairs gtid, gtid + NT, ... in every pass
+      const int64_t n2 = n >> 1;
+      f64x2* y2 = reinterpret_cast<f64x2*>(y);
+      if (p == 0) {
+        const f64x2* q2 = reinterpret_cast<const f64x2*>(q);
+        const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
+        const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
+        for (int64_t pr = gtid; pr < n2; pr += NT) {
+          const f64x2 a = q2[pr], b = x2[pr], c = s2[pr];
+          const f64x2 vv = f64x2{(b.x + c.x) + a.x, (b.y + c.y) + a.y};
+          y2[pr] = vv;
+          visit(vv.x, 2 * pr);
+          visit(vv.y, 2 * pr + 1);
+        }
+        if ((n & 1) && gtid == 0) {
+          const double vv = (xk[n - 1] + sj[n - 1]) + q[n - 1];
+          y[n - 1] = vv;
+          visit(vv, n - 1);
+        }
+      } else {
+        for (int64_t pr = gtid; pr < n2; pr += NT) {
+          const f64x2 vv = y2[pr];
+          visit(vv.x, 2 * pr);
+          visit(vv.y, 2 * pr + 1);
+        }
+        if ((n & 1) && gtid == 0) visit(y[n - 1], n - 1);
+      }
     } else {
       if (p == 0) {
         for (int64_t i = gtid; i < n; i += NT) {
@@ -1383,6 +1414,16 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
       const int64_t i = gtid + (int64_t)k * NT;
       if (i < n) y[i] = sel_out<BINF>(v[k], i, xk[i], sj[i], fin, delta);
     }
+  } else if (vec2 && p != 0) {
+    const int64_t n2 = n >> 1;
+    f64x2* y2 = reinterpret_cast<f64x2*>(y);
+    const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
+    const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
+    for (int64_t pr = gtid; pr < n2; pr += NT) {
+      const f64x2 vv = y2[pr], b = x2[pr], c = s2[pr];
+      y2[pr] = f64x2{sel_out<BINF>(vv.x, 2 * pr, b.x, c.x, fin, delta), sel_out<BINF>(vv.y, 2 * pr + 1, b.y, c.y, fin, delta)};
+    }
+    if ((n & 1) && gtid == 0) y[n - 1] = sel_out<BINF>(y[n - 1], n - 1, xk[n - 1], sj[n - 1], fin, delta);
   } else {
     if (p == 0) {  // resolved before any pass (r <= 0 or r >= n): v was never parked in y
       for (int64_t i = gtid; i < n; i += NT) y[i] = sel_out<BINF>((xk[i] + sj[i]) + q[i], i, xk[i], sj[i], fin, delta);
