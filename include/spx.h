@@ -55,9 +55,14 @@ typedef enum spx_status {
   SPX_ERR_ALLOC = 4,       /* workspace allocation failed                                         */
   SPX_ERR_NO_DEVICE = 5,   /* no usable gfx950 device                                             */
   SPX_ERR_ASSERT = 6,      /* the reference's `@assert d[i] > 0` failed (unboxed iprox!)           */
-  SPX_ERR_INTERNAL = 7     /* spx_sync: a kernel that synchronises inside one launch gave up waiting for its own
-                              workgroups (corrupt synchronisation state, e.g. a context shared by two threads); the
-                              results of that context since the previous spx_sync are undefined              */
+  SPX_ERR_INTERNAL = 7     /* the device side of the context has reported a failure: a kernel that synchronises inside one
+                              launch gave up waiting for its own workgroups (they were not all resident: another process or
+                              a graph replay held the CUs; or a context shared by two threads), or library-owned device
+                              state was found outside its layout.  The kernel raises a status word in host-mapped memory;
+                              EVERY entry point looks at it before it enqueues anything, so the first libspx call after
+                              the failure -- whichever it is, no spx_sync needed -- returns this code, and so does every
+                              later one until spx_sync has reported it (spx_sync resets the state: the context is usable
+                              again).  The failing kernel stores NaN, never a plausible wrong result.                   */
 } spx_status;
 
 typedef struct spx_ctx spx_ctx; /* opaque: device id, HIP stream, library-owned scratch */
@@ -86,11 +91,15 @@ int spx_ctx_set_value_target(spx_ctx* ctx, double* device_value);
  * prox / iprox (check = 0) / objective / prox-value entry point on device pointers, provided values go to a device double
  * (spx_ctx_set_value_target) and the same call has run once before on this context (workspaces do not grow while
  * capturing).  Not capturable (SPX_ERR_INVALID_ARG, nothing launched): host-valued results, spx_check_bounds, index-set
- * (gather) group layouts, host-pointer forms, the tuning key 7 = 0 paths.  The first capture puts the context into a
- * graph-safe mode for good: the kernels that synchronise inside one launch are then preceded by a zero-fill of the state
- * they use (in the graph and in eager calls alike), ~2-4 us per such call.  Do not replay such a graph while ANOTHER context
- * runs top-r or ShiftedNormL1B2 calls on the same device: eager calls of different contexts are chained through an event so
- * that two resident grids never wait for CUs the other holds; a replay is outside that chain. */
+ * (gather) group layouts, host-pointer forms, ShiftedNormL1B2 on vectors of mixed alignment.  The first capture puts the
+ * context into a graph-safe mode for good: the kernels that synchronise inside one launch are then preceded by a zero-fill of
+ * the state they use (in the graph and in eager calls alike), ~2-4 us per such call, and a workspace that a LATER, larger
+ * eager call outgrows is retired, not freed, until spx_ctx_destroy -- a captured graph keeps pointing at the block it was
+ * captured with, so replaying it after such a call is safe (at most 64 such growths per context, then SPX_ERR_INVALID_ARG).
+ * Do not replay such a graph while ANOTHER context runs top-r or ShiftedNormL1B2 calls on the same device: eager calls of
+ * different contexts are chained through an event so that two resident grids never wait for CUs the other holds; a replay
+ * is outside that chain.  If it happens anyway the waiting kernels give up after a bounded number of polls, store NaN and
+ * the next call on the context returns SPX_ERR_INTERNAL (see spx_status) -- an error, never a silent wrong result. */
 
 /* Strided views (the reference accepts `view(y, 1:2:10)` as xk: test/runtests.jl:196-209).  Every entry point takes
  * unit-stride vectors; a host binding keeps a packed copy of a strided xk, refreshes it with this copy before a call and
@@ -114,8 +123,15 @@ int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms); /* records stop, waits, ret
  * full-vector radix select (0), key 3 = LDS-staged (1, default) or register-staged (0) separable skeleton, key 4 =
  * single-pass form of the top-r path when y overlaps no input (1, default) or always the two-pass form (0), key 5 =
  * XCD-contiguous tile ranges in the LDS-staged skeleton (0, default: tile = workgroup id), key 6 = one-workgroup top-r
- * kernel for n <= 8192 (n <= 65536 under key 7 = 0) (1, default), key 7 = top-r / ShiftedNormL1B2 kernels that
- * synchronise inside one launch (1, default) or the multi-launch pipeline (0).  Contexts are independent; a context is used by one thread at a time. */
+ * kernel for n <= 8192 (1, default), key 8 = pretend that at most this many workgroups of a kernel that synchronises inside
+ * one launch can be resident at once (0, default: what hipOccupancyMaxActiveBlocksPerMultiprocessor says; the grids of
+ * top-r and ShiftedNormL1B2 are sized by it and fall back to their any-grid forms -- this key lets a test force that).
+ * (Key 7, round 2's switch to the multi-launch pipelines, is gone with those pipelines.)
+ * Key 9 DOES change results, within the stated tolerance: ShiftedGroupNormL2Binf, 0 (default) = the closed form at the root
+ * (within ~1e-15 of the exact value of the reference's formula everywhere), 1 = groups whose root sits next to the pole of
+ * step(n) (u < n / 1000) are evaluated literally, operation by operation as src/shiftedGroupNormL2Binf.jl:87-113 with
+ * Roots-style bisection -- the reference's own Float64 value there, which is up to 4.5e-9 of the scale off its formula.
+ * For callers who must reproduce a reference run.  Contexts are independent; a context is used by one thread at a time. */
 int spx_ctx_set_tuning(spx_ctx* ctx, int key, int value);
 
 /* ---- construction-time helpers (the reference's constructors) ---------------------------- */

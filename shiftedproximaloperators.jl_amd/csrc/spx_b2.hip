@@ -477,7 +477,7 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
             w4 = __hip_atomic_load(theirs + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           if (w0 && w1 && w2 && w3 && w4) break;
-          if (spx_wait_expired(spins, &hdr->timed_out)) break;  // (the sums come out as garbage / NaN: see kSpxPollLimit)
+          if (spx_wait_expired(spins, hdr)) break;  // (the sums come out as garbage / NaN: see kSpxPollLimit)
           __builtin_amdgcn_s_sleep(1);
         }
         pp = __longlong_as_double((long long)(w0 - 1ull));
@@ -724,12 +724,17 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   B2Ws* ws = reinterpret_cast<B2Ws*>(ctx->ws);
   const double ls = lambda * sigma;  // `psi.lambda * sigma`, :56
   bool vec = n >= 2 && spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj);
-  if (ctx->tune_sel_coop && ctx->num_cu >= 32 &&
-      (vec || n <= (int64_t)kB2RegBlock * (ctx->num_cu < kB2Cols ? ctx->num_cu : kB2Cols))) {
+  // Residency (spx_resident_cap): the grid of a launch that synchronises inside itself never exceeds what can be resident
+  // at once; the streaming form works with any grid >= 1, the register-resident one needs ceil(n / 8192) workgroups.
+  const int64_t cap_reg = spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_b2_coop<true, kB2Epl, kB2RegThreads>), kB2RegThreads, 0);
+  const int64_t cap_mem = spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_b2_coop<false, 1, 1024>), 1024, 0);
+  if (cap_mem < 1) return SPX_ERR_INTERNAL;  // (message set by spx_resident_cap)
+  const int64_t gmax_reg = cap_reg < kB2Cols ? cap_reg : kB2Cols;
+  const int64_t gmax_mem = cap_mem < kB2Cols ? cap_mem : kB2Cols;
+  if (vec || n <= (int64_t)kB2RegBlock * gmax_reg) {
     // one launch, no read-back (see k_b2_coop)
-    const int64_t gmax = ctx->num_cu < kB2Cols ? ctx->num_cu : kB2Cols;
-    const bool reg = n <= (int64_t)kB2RegBlock * gmax;
-    int64_t g = reg ? (n + kB2RegBlock - 1) / kB2RegBlock : gmax;
+    const bool reg = n <= (int64_t)kB2RegBlock * gmax_reg;
+    int64_t g = reg ? (n + kB2RegBlock - 1) / kB2RegBlock : gmax_mem;
     if (g < 1) g = 1;
     rc = spx_sync_reserve(ctx, kSpxSyncSelBytes + kB2SyncBytes);
     if (rc) return rc;

@@ -54,14 +54,42 @@ struct spx_ctx {
   int tune_sep_lds = 1;            // key 3: LDS-staged separable skeleton
   int tune_sel_spec = 1;           // key 4: single-pass (speculative store) form of the top-r fast path
   int tune_sep_xcd = 0;            // key 5: XCD-contiguous tile ranges (experiment)
-  int tune_sel_small = 1;          // key 6: one-workgroup top-r for n <= 65536
-  int tune_sel_coop = 1;           // key 7: in-launch synchronised top-r kernels (0 = the multi-launch pipeline of round 1)
+  int tune_sel_small = 1;          // key 6: one-workgroup top-r for n <= 8192
+  int tune_coop_cap = 0;           // key 8: pretend that only this many workgroups of an in-launch synchronised kernel are
+                                   //        resident at once (0 = what the occupancy query says): exercises the smaller-grid paths
+  int tune_binf_literal = 0;       // key 9: GroupNormL2Binf groups whose root sits next to the pole of step(n) (u < n/1000) take
+                                   //        the reference's literal Float64 evaluation (reproduces a reference run bit pattern
+                                   //        by bit pattern where the default is the more accurate side: include/spx.h)
+  // Device-side status word in host-mapped pinned memory (spx_ctx.hip): a kernel that gives up waiting for the other
+  // workgroups of its launch, or finds library-owned state outside its layout, stores a non-zero code here (system-scope
+  // store); every entry point looks at it before it enqueues anything (SPX_ON_DEVICE) and fails with SPX_ERR_INTERNAL from
+  // then on, until spx_sync has reported it.  No stream synchronisation and no read-back is involved.
+  volatile int* status_host = nullptr;
+  int* status_dev = nullptr;
+  // Blocks that a captured graph may still reference (graph_safe): never freed before the context is destroyed.
+  void* retired[64] = {};
+  int nretired = 0;
+  // resident workgroups per CU of the in-launch synchronised kernels (hipOccupancyMaxActiveBlocksPerMultiprocessor),
+  // queried once per kernel and context: spx_resident_cap
+  const void* occ_fn[32] = {};
+  int occ_blocks[32] = {};
+  int nocc = 0;
 };
+
+// codes of spx_ctx::status_host (bits)
+constexpr int kSpxStatusTimeout = 1;    // an in-launch synchronised kernel gave up waiting for its own workgroups
+constexpr int kSpxStatusCorrupt = 2;    // library-owned device state outside its layout (deferred-group list)
 
 void spx_set_error(const char* fmt, ...);
 int spx_ws_reserve(spx_ctx* ctx, size_t bytes);
 int spx_sync_reserve(spx_ctx* ctx, size_t bytes);  // persistent, zero-initialised (see spx_ctx::sync)
 int spx_ctx_count(int device);                     // live contexts on a device
+// How many workgroups of `fn` (block_threads lanes, dyn_lds bytes of dynamic LDS) can be resident at once on the context's
+// device: occupancy query x number of CUs, cached per kernel; spx_ctx_set_tuning key 8 lowers it (tests).  Every launch that
+// synchronises inside itself sizes its grid with this and takes a smaller-grid form when the grid it wants does not fit --
+// a workgroup must never wait for one that cannot be placed.  0 with an error set if the kernel cannot run at all.
+int64_t spx_resident_cap(spx_ctx* ctx, const void* fn, int block_threads, size_t dyn_lds);
+int spx_status_report(spx_ctx* ctx);               // SPX_ERR_INTERNAL + message for a non-zero device status word
 // Is ctx's stream being captured into a graph?  Sets spx_ctx::graph_safe (sticky) when it is.  Calls that would have to
 // synchronise the stream or (re)allocate refuse to run while capturing (SPX_ERR_INVALID_ARG, spx_require_not_capturing).
 // Zero-fill on the context's stream by a KERNEL (4-byte words): used instead of hipMemsetAsync / hipMemset2DAsync wherever
@@ -107,9 +135,13 @@ struct SpxDeviceGuard {
     if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
   }
 };
-#define SPX_ON_DEVICE(ctx)                      \
+#define SPX_ON_DEVICE_RAW(ctx)                  \
   SpxDeviceGuard spx_device_guard((ctx)->device); \
   SPX_HIP(spx_device_guard.err)
+// ... and refuse to enqueue anything on a context whose device side has reported a failure (spx_ctx::status_host)
+#define SPX_ON_DEVICE(ctx)                                                       \
+  if ((ctx)->status_host != nullptr && *(ctx)->status_host != 0) return spx_status_report(ctx); \
+  SPX_ON_DEVICE_RAW(ctx)
 
 #define SPX_REQUIRE(cond, msg)                 \
   do {                                         \
@@ -169,27 +201,46 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // spx_ctx::sync: [0, kSpxSyncSelBytes) belongs to spx_select.hip (SelSync, whose head is the SpxSyncHeader below), the
 // partial-sum words of spx_b2.hip follow.  Zero-filled when (re)allocated; the host-side flags are reset with it.
-constexpr size_t kSpxSyncSelBytes = (size_t)3 << 19;  // 1.5 MiB >= sizeof(SelSync) (static_assert in spx_select.hip)
+constexpr size_t kSpxSyncSelBytes = (size_t)2 << 20;  // 2 MiB >= sizeof(SelSync) (static_assert in spx_select.hip)
 
 // Head of spx_ctx::sync, shared by every kernel that synchronises inside one launch.
 struct SpxSyncHeader {
   unsigned int bar[2][32];  // grid-barrier counters, one 128-byte line each: a launch uses [parity] and clears [parity ^ 1]
   int b2_last_scaled;       // ShiftedNormL1B2: did the previous call on this context find the trust region active?
-  int timed_out;            // sticky: a workgroup gave up waiting for the others (kSpxPollLimit); reported by spx_sync
-  int pad[30];
+  int timed_out;            // sticky: a workgroup gave up waiting for the others (kSpxPollLimit); no workgroup waits any more
+  int* status;              // device view of spx_ctx::status_host (host-mapped): the failure is reported by the NEXT libspx call
+  int pad[28];
 };
+static_assert(sizeof(SpxSyncHeader) == 2 * 32 * 4 + 128, "SpxSyncHeader layout");
 
 // Every wait of one workgroup for others is bounded: kSpxPollLimit polls (each a memory round trip plus a short sleep: a few
 // seconds in all, against microseconds of legitimate waiting).  A workgroup that gives up sets SpxSyncHeader::timed_out,
-// after which no workgroup of that context waits any more: the grid drains with undefined results instead of hanging the
-// device, and spx_sync reports SPX_ERR_INTERNAL.  It can only happen when the synchronisation state is corrupt (a context
-// shared by two threads, device memory overwritten) -- or in tools/planted_faults.sh.
-constexpr unsigned int kSpxPollLimit = 1u << 22;
-__device__ __forceinline__ bool spx_wait_expired(unsigned int& spins, int* timed_out) {
+// after which no workgroup of that context waits any more -- the grid drains instead of hanging the device, the kernels
+// that store a result store NaN (spx_poisoned) -- and raises the context's host-mapped status word, which makes the next
+// libspx call on the context (any entry point, not only spx_sync) fail with SPX_ERR_INTERNAL.  It happens when the
+// workgroups of the launch are not all resident (a grid of another process or of a graph replay holding the CUs: the
+// in-process cases are excluded by spx_resident_cap and SpxCoopLaunchGuard), when the synchronisation state is corrupt (a
+// context shared by two threads, device memory overwritten) -- or in tools/planted_faults.sh.
+#ifndef SPX_POLL_LIMIT_LOG2
+#define SPX_POLL_LIMIT_LOG2 22
+#endif
+constexpr unsigned int kSpxPollLimit = 1u << SPX_POLL_LIMIT_LOG2;
+__device__ __forceinline__ void spx_raise_status(int* status, int code) {
+  if (status != nullptr) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool spx_wait_expired(unsigned int& spins, SpxSyncHeader* hdr) {
   if (++spins < 64u) return false;                       // (cheap path: the flag is not even read for short waits)
   if ((spins & 63u) != 0u && spins < kSpxPollLimit) return false;
-  if (spins >= kSpxPollLimit) { __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
-  return __hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  if (spins >= kSpxPollLimit) {
+    __hip_atomic_store(&hdr->timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    spx_raise_status(hdr->status, kSpxStatusTimeout);
+    return true;
+  }
+  return __hip_atomic_load(&hdr->timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+// Has any workgroup of this context given up?  Asked once, before the result of an in-launch synchronised kernel is stored.
+__device__ __forceinline__ bool spx_poisoned(SpxSyncHeader* hdr) {
+  return __hip_atomic_load(&hdr->timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -200,7 +251,7 @@ __device__ __forceinline__ bool spx_wait_expired(unsigned int& spins, int* timed
 // `target` = (number of barriers passed so far in this launch + 1) * gridDim.x.  Every workgroup of the grid must call
 // it the same number of times (the exit condition every wave reaches: no early return between barriers).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void spx_grid_barrier(unsigned int* counter, unsigned int target, int* timed_out) {
+__device__ __forceinline__ void spx_grid_barrier(unsigned int* counter, unsigned int target, SpxSyncHeader* hdr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -209,7 +260,7 @@ __device__ __forceinline__ void spx_grid_barrier(unsigned int* counter, unsigned
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned int spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (spx_wait_expired(spins, timed_out)) break;
+      if (spx_wait_expired(spins, hdr)) break;
       __builtin_amdgcn_s_sleep(2);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -222,14 +273,14 @@ __device__ __forceinline__ void spx_grid_barrier(unsigned int* counter, unsigned
 // with agent-scope atomics (spx_atomic_store_f64 / spx_atomic_load_f64 below: `sc1` accesses that bypass the non-coherent
 // caches).  The release / acquire fences are most of a barrier's cost when few workgroups meet (3.5 of ~4 us).
 // ONE lane per workgroup must have issued all of the workgroup's atomic stores before it calls this.
-__device__ __forceinline__ void spx_grid_rendezvous(unsigned int* counter, unsigned int target, int* timed_out) {
+__device__ __forceinline__ void spx_grid_rendezvous(unsigned int* counter, unsigned int target, SpxSyncHeader* hdr) {
   __syncthreads();
   if (threadIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's atomic stores have left
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned int spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (spx_wait_expired(spins, timed_out)) break;
+      if (spx_wait_expired(spins, hdr)) break;
       __builtin_amdgcn_s_sleep(1);
     }
   }

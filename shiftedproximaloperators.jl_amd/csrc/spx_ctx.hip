@@ -28,10 +28,10 @@ SpxCoopLaunchGuard::~SpxCoopLaunchGuard() {
     g_coop_mu.unlock();
     return;
   }
-  if (chained || g_coop_last[d] == nullptr || spx_ctx_count(ctx->device) > 1) {
-    if (g_coop_ev[d] == nullptr) (void)hipEventCreateWithFlags(&g_coop_ev[d], hipEventDisableTiming);
-    if (g_coop_ev[d] != nullptr) (void)hipEventRecord(g_coop_ev[d], ctx->stream);
-  }
+  // recorded after EVERY guarded eager launch (~1 us): a context created later, while this one's launch is still in flight,
+  // then waits for this launch and not for some earlier one (round 2 recorded only when a second context already existed)
+  if (g_coop_ev[d] == nullptr) (void)hipEventCreateWithFlags(&g_coop_ev[d], hipEventDisableTiming);
+  if (g_coop_ev[d] != nullptr) (void)hipEventRecord(g_coop_ev[d], ctx->stream);
   g_coop_last[d] = ctx;
   g_coop_mu.unlock();
 }
@@ -84,6 +84,22 @@ static int ctx_create_impl(int device, bool borrow, void* stream, spx_ctx** out)
     delete c;
     return SPX_ERR_HIP;
   }
+  {  // the device-side status word: host-mapped pinned memory, so that the host sees a kernel's report without any copy
+    void* hp = nullptr;
+    void* dp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+      spx_set_error("hipHostMalloc(mapped) for the status word failed");
+      if (hp) (void)hipHostFree(hp);
+      (void)hipEventDestroy(c->ev_start);
+      (void)hipEventDestroy(c->ev_stop);
+      if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+      delete c;
+      return SPX_ERR_ALLOC;
+    }
+    std::memset(hp, 0, 64);
+    c->status_host = static_cast<volatile int*>(hp);
+    c->status_dev = static_cast<int*>(dp);
+  }
   g_ctx_count[device & 63].fetch_add(1);
   *out = c;
   return SPX_OK;
@@ -101,6 +117,8 @@ SPX_EXPORT int spx_ctx_destroy(spx_ctx* ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->sync) (void)hipFree(ctx->sync);
   if (ctx->stage) (void)hipFree(ctx->stage);
+  for (int k = 0; k < ctx->nretired; ++k) (void)hipFree(ctx->retired[k]);
+  if (ctx->status_host) (void)hipHostFree(const_cast<int*>(ctx->status_host));
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -125,7 +143,8 @@ SPX_EXPORT int spx_ctx_set_tuning(spx_ctx* ctx, int key, int value) {
     case 4: ctx->tune_sel_spec = value ? 1 : 0; return SPX_OK;
     case 5: ctx->tune_sep_xcd = value ? 1 : 0; return SPX_OK;
     case 6: ctx->tune_sel_small = value ? 1 : 0; return SPX_OK;
-    case 7: ctx->tune_sel_coop = value ? 1 : 0; return SPX_OK;
+    case 8: if (value < 0) break; ctx->tune_coop_cap = value; return SPX_OK;
+    case 9: ctx->tune_binf_literal = value ? 1 : 0; return SPX_OK;
     default: break;
   }
   spx_set_error("invalid argument: unknown tuning key/value");
@@ -138,21 +157,62 @@ SPX_EXPORT int spx_ctx_set_value_target(spx_ctx* ctx, double* device_value) {
   return SPX_OK;
 }
 
+// The message for a raised status word; the word stays raised (every entry point keeps failing) until spx_sync has run.
+int spx_status_report(spx_ctx* ctx) {
+  const int code = ctx->status_host ? *ctx->status_host : 0;
+  if (code & kSpxStatusTimeout)
+    spx_set_error("internal error: a kernel that synchronises inside one launch timed out waiting for its own workgroups (are "
+                  "two processes, or a graph replay and an eager call, running such kernels on this GPU at once? is the "
+                  "context shared by two threads?); the results of this context since the failing call are undefined (the "
+                  "failing kernel stored NaN); call spx_sync to acknowledge and reset");
+  else
+    spx_set_error("internal error: library-owned device state was found outside its layout (status %d: deferred-group list); "
+                  "the results of this context since the failing call are undefined; call spx_sync to acknowledge and reset", code);
+  return SPX_ERR_INTERNAL;
+}
+
 SPX_EXPORT int spx_sync(spx_ctx* ctx) {
   SPX_REQUIRE(ctx != nullptr, "ctx is NULL");
   SPX_HIP(hipStreamSynchronize(ctx->stream));
-  if (ctx->sync && ctx->sync_bytes >= sizeof(SpxSyncHeader)) {  // did a workgroup give up waiting (kSpxPollLimit)?
-    SPX_ON_DEVICE(ctx);
-    int flag = 0;
-    SPX_HIP(hipMemcpy(&flag, &reinterpret_cast<const SpxSyncHeader*>(ctx->sync)->timed_out, sizeof(int), hipMemcpyDeviceToHost));
-    if (flag) {
-      SPX_HIP(hipMemset(&reinterpret_cast<SpxSyncHeader*>(ctx->sync)->timed_out, 0, sizeof(int)));  // reported once
-      spx_set_error("internal error: a kernel that synchronises inside one launch timed out waiting for its own workgroups; "
-                    "results of this context since the last spx_sync are undefined (was the context used by two threads?)");
-      return SPX_ERR_INTERNAL;
+  if (ctx->status_host != nullptr && *ctx->status_host != 0) {  // reported here once, then the context is usable again
+    const int rc = spx_status_report(ctx);
+    SPX_ON_DEVICE_RAW(ctx);
+    if (ctx->sync) {  // counters, histograms and exchange words of an abandoned launch: back to the initial state
+      SPX_HIP(hipMemset(ctx->sync, 0, ctx->sync_bytes));
+      SPX_HIP(hipMemcpy(&reinterpret_cast<SpxSyncHeader*>(ctx->sync)->status, &ctx->status_dev, sizeof(int*), hipMemcpyHostToDevice));
+      ctx->coop_parity = 0;
+      ctx->b2_set = 0;
+      ctx->b2_dirty_g[0] = ctx->b2_dirty_g[1] = 0;
+      ctx->sel_hist_next = 0;
+      ctx->sel_hist_dirty[0] = ctx->sel_hist_dirty[1] = 0;
     }
+    *ctx->status_host = 0;
+    return rc;
   }
   return SPX_OK;
+}
+
+int64_t spx_resident_cap(spx_ctx* ctx, const void* fn, int block_threads, size_t dyn_lds) {
+  int per_cu = -1;
+  for (int k = 0; k < ctx->nocc; ++k)
+    if (ctx->occ_fn[k] == fn) per_cu = ctx->occ_blocks[k];
+  if (per_cu < 0) {
+    int nb = 0;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, block_threads, dyn_lds);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      spx_set_error("hipOccupancyMaxActiveBlocksPerMultiprocessor failed: %s", hipGetErrorString(e));
+      return 0;
+    }
+    per_cu = nb;
+    if (ctx->nocc < 32) { ctx->occ_fn[ctx->nocc] = fn; ctx->occ_blocks[ctx->nocc] = nb; ++ctx->nocc; }
+  }
+  // The algorithms never want more than one workgroup per CU, and the query is known to promise one block per CU too many
+  // for some register counts (MI355X_MICROARCH.md, "Residency and cooperative launch"): count ONE per CU, or none.
+  int64_t cap = per_cu >= 1 ? (int64_t)ctx->num_cu : 0;
+  if (ctx->tune_coop_cap > 0 && cap > ctx->tune_coop_cap) cap = ctx->tune_coop_cap;
+  if (cap <= 0) spx_set_error("internal error: an in-launch synchronised kernel cannot be resident on this device (occupancy 0)");
+  return cap;
 }
 
 SPX_EXPORT int spx_timer_start(spx_ctx* ctx) {
@@ -179,6 +239,11 @@ int spx_zero2d_async(spx_ctx* ctx, void* ptr, size_t pitch_bytes, size_t width_b
               width_bytes <= pitch_bytes, "spx_zero2d_async: unaligned range");
   const size_t total = (width_bytes / 4) * rows;
   if (total == 0) return SPX_OK;
+#ifdef SPX_GRAPH_MEMSET_NODES  // diagnostic builds only (tools/r3/graph_fault_probe.py): the runtime's memset nodes, as in round 2
+  if (rows == 1 || width_bytes == pitch_bytes) SPX_HIP(hipMemsetAsync(ptr, 0, pitch_bytes * (rows - 1) + width_bytes, ctx->stream));
+  else SPX_HIP(hipMemset2DAsync(ptr, pitch_bytes, 0, width_bytes, rows, ctx->stream));
+  return SPX_OK;
+#endif
   size_t blocks = (total + 255) / 256;
   if (blocks > (size_t)ctx->num_cu * 8) blocks = (size_t)ctx->num_cu * 8;
   hipLaunchKernelGGL(k_zero_words, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, static_cast<unsigned int*>(ptr),
@@ -209,9 +274,23 @@ int spx_require_not_capturing(spx_ctx* ctx, const char* what) {
 int spx_ws_reserve(spx_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return SPX_OK;
   { const int rc = spx_require_not_capturing(ctx, "growing the workspace"); if (rc) return rc; }
-  SPX_ON_DEVICE(ctx);
+  SPX_ON_DEVICE_RAW(ctx);
   SPX_HIP(hipStreamSynchronize(ctx->stream));
-  if (ctx->ws) SPX_HIP(hipFree(ctx->ws));
+  if (ctx->ws) {
+    // A graph captured from this context holds the old block's address in its kernel nodes: once the context has seen a
+    // capture (graph_safe, sticky) old blocks are kept until spx_ctx_destroy, so that a replay after this call still
+    // finds its own scratch (it never needed more than the old size).
+    if (ctx->graph_safe) {
+      if (ctx->nretired >= 64) {
+        spx_set_error("invalid argument: the workspace of a context that has been captured into a graph cannot grow any further "
+                      "(64 retired blocks); create a new context for the larger problem");
+        return SPX_ERR_INVALID_ARG;
+      }
+      ctx->retired[ctx->nretired++] = ctx->ws;
+    } else {
+      SPX_HIP(hipFree(ctx->ws));
+    }
+  }
   ctx->ws = nullptr;
   ctx->ws_bytes = 0;
   hipError_t e = hipMalloc(&ctx->ws, bytes);
@@ -228,9 +307,19 @@ int spx_ws_reserve(spx_ctx* ctx, size_t bytes) {
 int spx_sync_reserve(spx_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->sync_bytes) return SPX_OK;
   { const int rc = spx_require_not_capturing(ctx, "growing the synchronisation state"); if (rc) return rc; }
-  SPX_ON_DEVICE(ctx);
+  SPX_ON_DEVICE_RAW(ctx);
   SPX_HIP(hipStreamSynchronize(ctx->stream));
-  if (ctx->sync) SPX_HIP(hipFree(ctx->sync));
+  if (ctx->sync) {
+    if (ctx->graph_safe) {  // (as spx_ws_reserve: a captured graph may still point into the old block)
+      if (ctx->nretired >= 64) {
+        spx_set_error("invalid argument: the synchronisation state of a captured context cannot grow any further");
+        return SPX_ERR_INVALID_ARG;
+      }
+      ctx->retired[ctx->nretired++] = ctx->sync;
+    } else {
+      SPX_HIP(hipFree(ctx->sync));
+    }
+  }
   ctx->sync = nullptr;
   ctx->sync_bytes = 0;
   hipError_t e = hipMalloc(&ctx->sync, bytes);
@@ -239,6 +328,7 @@ int spx_sync_reserve(spx_ctx* ctx, size_t bytes) {
     return SPX_ERR_ALLOC;
   }
   SPX_HIP(hipMemsetAsync(ctx->sync, 0, bytes, ctx->stream));
+  SPX_HIP(hipMemcpyAsync(&reinterpret_cast<SpxSyncHeader*>(ctx->sync)->status, &ctx->status_dev, sizeof(int*), hipMemcpyHostToDevice, ctx->stream));
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   ctx->sync_bytes = bytes;
   ctx->coop_parity = 0;
@@ -275,7 +365,9 @@ SPX_EXPORT int spx_check_bounds(spx_ctx* ctx, const double* l_vec, const double*
     return SPX_OK;
   }
   if (n == 0) return SPX_OK;
-  int rc = spx_ws_reserve(ctx, 256);
+  int rc = spx_require_not_capturing(ctx, "spx_check_bounds (synchronous)");  // (before anything is enqueued)
+  if (rc) return rc;
+  rc = spx_ws_reserve(ctx, 256);
   if (rc) return rc;
   SPX_ON_DEVICE(ctx);
   int* flag = reinterpret_cast<int*>(ctx->ws);
@@ -285,7 +377,6 @@ SPX_EXPORT int spx_check_bounds(spx_ctx* ctx, const double* l_vec, const double*
   hipLaunchKernelGGL(k_check_bounds, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, l_vec, u_vec, l_scalar,
                      u_scalar, n, flag);
   SPX_LAUNCH_CHECK();
-  { const int rcc = spx_require_not_capturing(ctx, "spx_check_bounds (synchronous)"); if (rcc) return rcc; }
   SPX_HIP(hipMemcpyAsync(any_l_gt_u, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   return SPX_OK;
@@ -372,7 +463,7 @@ SPX_EXPORT int spx_debug_peek(spx_ctx* ctx, int which, size_t offset, size_t nby
   const char* base = static_cast<const char*>(which ? ctx->sync : ctx->ws);
   const size_t cap = which ? ctx->sync_bytes : ctx->ws_bytes;
   SPX_REQUIRE(base != nullptr && offset + nbytes <= cap, "range outside the buffer");
-  SPX_ON_DEVICE(ctx);
+  SPX_ON_DEVICE_RAW(ctx);
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   SPX_HIP(hipMemcpy(out, base + offset, nbytes, hipMemcpyDeviceToHost));
   return SPX_OK;

@@ -17,6 +17,21 @@
 
 #include "spx_common.hpp"
 
+#ifdef SPX_DEBUG_PEEK  // diagnostic builds only: [0] last raw count the LIT launch read, [1] LIT launches that read a count
+                       // outside [0, ngroups], [2] LIT launches, [3] count at the entry of the last main launch, [4] main
+                       // launches, [5] main launches that found the count outside [0, ngroups] on entry
+__device__ long long g_group_dbg[8];
+extern "C" __attribute__((visibility("default"))) int spx_debug_group_words(long long* out8, int reset) {
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_group_dbg), sizeof(g_group_dbg));
+  if (e == hipSuccess && reset) {
+    long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_group_dbg), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // team reductions: TEAM lanes (8, 16, 32, 64: aligned lane ranges of one wave; 256: the workgroup)
 // ---------------------------------------------------------------------------------------------
@@ -734,7 +749,8 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
                                                     int64_t ngroups, int gsize, const double* __restrict__ lambda,
                                                     double sigma, double delta,
                                                     long long* deferred /* [0] = count, [1..] = groups */,
-                                                    const int64_t* __restrict__ offsets /* !PAIRS only: ragged groups */) {
+                                                    const int64_t* __restrict__ offsets /* !PAIRS only: ragged groups */,
+                                                    int* status /* spx_ctx::status_dev */) {
   static_assert((EPL % 2) == 0, "EPL must be even (16-byte pairs)");
   const int64_t GS = gsize;  // <= LPG * EPL
   constexpr int GPW = 64 / LPG;  // groups per wave
@@ -748,16 +764,36 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
   constexpr bool kDma = !BINF && PAIRS;
   __shared__ __attribute__((aligned(16))) char dma_lds[kDma ? 4 * 3 * (EPL / 2) * 1024 : 16];
   const int npairs = gsize >> 1;
-  // (the list can hold at most every group once: a count outside [0, ngroups] is never followed into memory)
+  // (the list can hold at most every group once: a count outside [0, ngroups] is never followed into memory -- and never
+  //  skipped silently either: the context's status word is raised and every later call fails, spx_common.hpp)
   const int64_t nlist = LIT ? (int64_t)deferred[0] : 0;
-  const int64_t ntodo = LIT ? ((nlist < 0 || nlist > ngroups) ? 0 : nlist) : ngroups;
+  const bool bad_count = LIT && (nlist < 0 || nlist > ngroups);
+  if (bad_count && blockIdx.x == 0 && threadIdx.x == 0) spx_raise_status(status, kSpxStatusCorrupt);
+  const int64_t ntodo = LIT ? (bad_count ? 0 : nlist) : ngroups;
+#ifdef SPX_DEBUG_PEEK  // diagnostic builds (tools/r3/graph_fault_probe.py): what the count word held when a launch read it
+  if (deferred != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    if constexpr (LIT) {
+      g_group_dbg[0] = nlist;
+      if (nlist < 0 || nlist > ngroups) g_group_dbg[1] += 1;
+      g_group_dbg[2] += 1;
+    } else {
+      g_group_dbg[3] = (long long)__hip_atomic_load(deferred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g_group_dbg[3] < 0 || g_group_dbg[3] > ngroups) g_group_dbg[5] += 1;
+      g_group_dbg[4] += 1;
+    }
+  }
+#endif
   for (int64_t g0 = wave * GPW; g0 < ntodo; g0 += nwaves * GPW) {  // wave-uniform trip count
     bool valid = (g0 + slot) < ntodo;
     const int64_t gi = valid ? (g0 + slot) : (ntodo - 1);  // idle slots shadow the last group, no store
     int64_t g = gi;
     if constexpr (LIT) {
       g = (int64_t)deferred[1 + gi];
-      if (g < 0 || g >= ngroups) { g = 0; valid = false; }  // (never an id from outside the layout)
+      if (g < 0 || g >= ngroups) {  // (never an id from outside the layout; reported, not skipped silently)
+        if (valid && j == 0) spx_raise_status(status, kSpxStatusCorrupt);
+        g = 0;
+        valid = false;
+      }
     }
     int64_t base = g * GS;
     int gs = gsize;  // this group's size (row-uniform)
@@ -969,17 +1005,23 @@ template <int TEAM, bool BINF>
 __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, const double* xk, const double* sj,
                                                     int64_t n, const int64_t* __restrict__ offsets, int64_t gsize,
                                                     int64_t ngroups, const double* __restrict__ lambda, double sigma,
-                                                    double delta, const long long* list /* NULL, or [0] = count, [1..] */) {
+                                                    double delta, const long long* list /* NULL, or [0] = count, [1..] */,
+                                                    int* status /* spx_ctx::status_dev */) {
   __shared__ double lds[8];
   constexpr int TPB = 256 / TEAM;  // teams per block
   const int lane = threadIdx.x % TEAM;
   const int64_t team = (int64_t)blockIdx.x * TPB + threadIdx.x / TEAM;
   const int64_t nteams = (int64_t)gridDim.x * TPB;
   const int64_t nlist = list ? (int64_t)list[0] : 0;
-  const int64_t ntodo = list ? ((nlist < 0 || nlist > ngroups) ? 0 : nlist) : ngroups;
+  const bool bad_count = list && (nlist < 0 || nlist > ngroups);  // (as k_group_reg: reported through the status word)
+  if (bad_count && blockIdx.x == 0 && threadIdx.x == 0) spx_raise_status(status, kSpxStatusCorrupt);
+  const int64_t ntodo = list ? (bad_count ? 0 : nlist) : ngroups;
   for (int64_t t = team; t < ntodo; t += nteams) {  // for TEAM == 256 the trip count is block-uniform
     const int64_t g = list ? (int64_t)list[1 + t] : t;
-    if (g < 0 || g >= ngroups) continue;  // (never an id from outside the layout; block-uniform for TEAM == 256)
+    if (g < 0 || g >= ngroups) {  // (never an id from outside the layout; block-uniform for TEAM == 256)
+      if (lane == 0) spx_raise_status(status, kSpxStatusCorrupt);
+      continue;
+    }
     int64_t lo, hi;
     if (offsets) { lo = offsets[g]; hi = offsets[g + 1]; }
     else { lo = g * gsize; hi = lo + gsize; }
@@ -1196,13 +1238,13 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   do {                                                                                                              \
     if (pairs && gsize == (LPG) * (EPL))                                                                            \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, true, false, true>), grid, block, 0, ctx->stream, y, q, xk, sj, \
-                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr);             \
+                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev); \
     else if (pairs)                                                                                                 \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, true>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,   \
-                         (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr);                      \
+                         (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev);    \
     else                                                                                                            \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, false>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,  \
-                         (int)gsize, lambda, sigma, delta, deferred, ragged_reg ? offsets : (const int64_t*)nullptr); \
+                         (int)gsize, lambda, sigma, delta, deferred, ragged_reg ? offsets : (const int64_t*)nullptr, ctx->status_dev); \
   } while (0)
     if (lpg == 4 && epl == 4) { if constexpr (BINF) SPX_LAUNCH_REG(4, 4); }
     else if (lpg == 4 && epl == 8) { if constexpr (BINF) SPX_LAUNCH_REG(4, 8); }
@@ -1226,10 +1268,10 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   do {                                                                                                               \
     if (pairs)                                                                                                       \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, true, true, true>), lgrid, block, 0, ctx->stream, y, q, xk, sj,      \
-                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr);              \
+                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev); \
     else                                                                                                             \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, true, false, true>), lgrid, block, 0, ctx->stream, y, q, xk, sj,     \
-                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr);              \
+                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev); \
   } while (0)
         if (lpg == 4 && epl == 4) SPX_LAUNCH_LIT(4, 4);
         else if (lpg == 4) SPX_LAUNCH_LIT(4, 8);
@@ -1245,7 +1287,7 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     if (BINF || ragged_reg) {  // usually an empty list: the kernel returns at once
       hipLaunchKernelGGL((k_group_mem<64, BINF>), dim3((unsigned)(ctx->num_cu * 2)), dim3(256), 0, ctx->stream, y, q, xk,
                          sj, n, ragged_reg ? offsets : (const int64_t*)nullptr, gsize, ngroups, lambda, sigma, delta,
-                         (const long long*)deferred);
+                         (const long long*)deferred, ctx->status_dev);
     }
     SPX_LAUNCH_CHECK();
     return SPX_OK;
@@ -1274,11 +1316,11 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     int64_t blocks = (ngroups + 3) / 4;
     if (blocks > cap_blocks) blocks = cap_blocks;
     hipLaunchKernelGGL((k_group_mem<64, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n,
-                       offsets, gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr);
+                       offsets, gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr, ctx->status_dev);
   } else {
     int64_t blocks = ngroups < cap_blocks ? ngroups : cap_blocks;
     hipLaunchKernelGGL((k_group_mem<256, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n,
-                       offsets, gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr);
+                       offsets, gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr, ctx->status_dev);
   }
   SPX_LAUNCH_CHECK();
   return SPX_OK;
@@ -1310,6 +1352,10 @@ static int run_group_gather(spx_ctx* ctx, double* y, const double* q, const doub
   if (n == 0) return SPX_OK;
   if (ngroups > 0) SPX_REQUIRE(ptr != nullptr && lambda != nullptr, "group_ptr or lambda_vec is NULL");
   if (nnz > 0) SPX_REQUIRE(index != nullptr, "group_index is NULL");
+  if (ngroups > 0) {  // (the index-set validation below reads a flag back: refused before anything is enqueued)
+    const int rcc = spx_require_not_capturing(ctx, "validating a group layout");
+    if (rcc) return rcc;
+  }
   SPX_ON_DEVICE(ctx);
   // workspace: flag (256 B) | sol (n doubles) | owner (n ints)
   const size_t sol_off = 256, own_off = sol_off + (size_t)n * sizeof(double);
@@ -1331,7 +1377,6 @@ static int run_group_gather(spx_ctx* ctx, double* y, const double* q, const doub
                        flag);
     SPX_LAUNCH_CHECK();
     int hflag = 0;  // the reference throws BoundsError before touching y: check before the stores
-    { const int rcc = spx_require_not_capturing(ctx, "validating a group layout"); if (rcc) return rcc; }
     SPX_HIP(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SPX_HIP(hipStreamSynchronize(ctx->stream));
     if (hflag & 2) { spx_set_error("invalid argument: group_ptr is not a non-decreasing sequence inside [0, nnz]"); return SPX_ERR_INVALID_ARG; }

@@ -5,22 +5,13 @@
 // src/shiftedIndBallL0BInf.jl:87) -- a STABLE permutation, i.e. descending |v|, ties in ascending index.
 // Only the set of the first r entries matters, so this is an exact top-r SELECTION with the composite
 // order (|v| descending, index ascending).  For finite doubles |v| is ordered like the 63-bit integer
-// bits(v) & 0x7ff..f, so the selection is an MSD radix select on that integer key:
-//
-//   pass 0      v -> y (y is the reference's scratch too, :66), LDS histogram of key digit 0 (12 bits)
-//   scan        one workgroup walks the 4096 bins from the top, finds the bin holding the r-th largest,
-//               updates (base, quota) in device memory -- base = low end of the bin, the undecided part of key
-//               space is [base, base + 2^(shift + width)) -- no host round trip
-//   pass 1..5   re-read y (8 B/element), histogram the next digit of key - base for the keys inside that interval
-//   tie passes  only if the threshold key T is shared by more elements than the remaining quota:
-//               the same machinery over the index digits of {i : key_i == T}, ascending
-//   final       y[i] = (keep_i ? v_i : 0) - (xk[i] + sj[i])   [clamped for BInf]
-//               keep_i = key_i >= t_ge || (key_i == t_eq && i <= icut)
-//
-// Every pass after the one that resolves the selection returns immediately (phase flag in device
-// memory), so the usual cost is pass 0 (24 B read + 8 B write per element), 2-3 key passes (8 B) and the
-// final pass (24 B read + 8 B write).  y may alias q: pass 0 reads q[i] before it writes y[i] and q is
-// not needed afterwards.
+// bits(v) & 0x7ff..f, so the selection is an MSD radix select on that integer key (12-bit digits of key - base, then --
+// only if the threshold key T is shared by more elements than the remaining quota -- the index digits of {i : key_i == T}):
+//     keep_i = key_i >= t_ge || (key_i == t_eq && i <= icut)
+//     y[i] = (keep_i ? v_i : 0) - (xk[i] + sj[i])   [clamped for BInf]
+// Three forms, by size (run_select): one workgroup (k_sel_small), one launch of a resident grid that synchronises inside
+// itself (k_sel_coop), and the sample-predicted single streaming pass (k_s2_front / k_s2_main / candidate kernels) with
+// k_sel_coop queued behind it as the exact fallback.  (Round 1's multi-launch pipelines, which read a verdict back, are gone.)
 #include "spx_common.hpp"
 
 namespace {
@@ -91,7 +82,22 @@ struct FastState {
                                   // holds tied keys -- k_s2_main then counts candidate digits in wave-uniform runs
   unsigned int ovf_count;         // candidates a wavefront could not fit into its own region: appended to the shared overflow
                                   // list behind the regions (sorted / clustered data: the band is contiguous in the vector)
+  // Tie mode (round 3).  A sample bucket that is still crowded after 36 key bits is a key shared by >= 0.1 % of the vector
+  // (lattice data, a constant, a sparse vector's zeros): the front kernel then resolves BOTH sample ranks to the full 64 bits,
+  // t_hi / t_lo are exact keys, and the elements EQUAL to them (classes "hi" / "lo") are counted per wavefront in index
+  // order (ClassCount) instead of being recorded as candidates -- a class can be the whole vector.  Only keys strictly
+  // between the ends remain candidates.  If the cut falls inside a class the index of its quota-th member comes from a
+  // prefix sum over the per-wave counts (k_s2_tail), and y is written by one more streaming pass: 56 B/element in all,
+  // against ~12 passes of the exact radix select (2.6-5.8 ms at n = 1e8 in round 2).
+  int tie;
+  int has_hi, has_lo;             // which ends are classes (no upper end for tiny r, no lower end for r ~ n; one class if t_hi == t_lo)
+  unsigned long long cls_hi, cls_lo;  // class totals (k_s2_scan_verify)
+  int todo;                       // what k_s2_tail still has to do: kTodo* bits (k_s2_scan_verify, k_s2_finish)
+  int tie_class;                  // kTodoTieScan: the class that holds the cut (0 = hi, 1 = lo); quota in SelState
 };
+constexpr int kTodoCandSelect = 1;  // the bucket of the first candidate digit overflows the short list: radix select over the candidates
+constexpr int kTodoTieScan = 2;     // the cut lies inside a class: find the index of its quota-th member
+constexpr int kTodoFinal = 4;       // tie mode: y is (re)written from q, xk, sj and the final thresholds by a streaming pass
 
 // totals of the main pass: fire-and-forget atomics of its wavefronts, spread over kShards counters (wave w -> shard
 // w % kShards) so that no single address serialises them; k_s2_scan_verify adds the shards up.  Round 2: 2048 shards
@@ -107,6 +113,8 @@ struct SelWs {
   unsigned long long hist[kBins];
   unsigned long long shard_above[kShards * kShardStride];
   unsigned long long shard_cand[kShards * kShardStride];
+  unsigned long long shard_hi[kShards * kShardStride];   // tie mode: class totals
+  unsigned long long shard_lo[kShards * kShardStride];
 };
 
 // Candidates of the main pass: every WAVEFRONT of its grid owns a fixed region of kWaveSlots entries and one count
@@ -115,6 +123,11 @@ struct SelWs {
 constexpr int kWaveSlots = 64;
 struct WaveCount {
   unsigned int cand, above;
+};
+// Tie mode: members of the two classes per wavefront of the main pass, in index order: slot 0 = the caller's element 0 of an
+// 8-byte-misaligned view, slot 1 + w = wave w (elements ioff + 768 w .. ioff + 768 w + 767), last slot = the odd last element.
+struct ClassCount {
+  unsigned int hi, lo;
 };
 // One candidate: key, index and (single-pass form) the value y[index] gets if the entry makes the cut.  An array of
 // structs: the handful of entries a region holds then shares one or two cache lines, instead of one line in each of
@@ -125,7 +138,6 @@ struct Cand {
   double val;
 };
 
-constexpr int kSample = 65536;        // sample size (256 chunks of 256 consecutive elements)
 constexpr int kMainUnroll = 6;        // KiB per wave and vector in the main pass (as k_sep_lds)
 constexpr int kMainTilePairs = 256 * kMainUnroll;  // 16-byte pairs per workgroup of the main pass
 constexpr int kShortList = 4096;      // candidates left after the first digit that k_s2_finish resolves in LDS
@@ -175,121 +187,6 @@ __device__ __forceinline__ unsigned long long scan256_exclusive(unsigned long lo
   unsigned long long base = 0;
   for (int k = 0; k < w; ++k) base += wtot[k];
   return base + inc - v;
-}
-
-__global__ void k_sel_init(SelWs* ws, int64_t n, int64_t r) {
-  const int t = threadIdx.x;
-  for (int b = t; b < kBins; b += blockDim.x) ws->hist[b] = 0ull;
-  if (t == 0) {
-    SelState& s = ws->st;
-    int bits = 0;
-    while (bits < 63 && ((int64_t)1 << bits) < n) ++bits;
-    s.idx_bits = bits;
-    s.prefix = 0;
-    s.icut = -1;
-    s.t_eq = ~0ull;
-    s.pad = s.pad2 = s.pad3 = 0;
-    s.t_floor = 0;
-    s.base = 0;
-    s.clamp = 0;
-    ws->fs.smax = 0ull;
-    if (r <= 0) {            // nothing kept
-      s.phase = 2; s.t_ge = ~0ull; s.quota = 0; s.shift = 0; s.width = 0;
-    } else if (r >= n) {     // everything kept
-      s.phase = 2; s.t_ge = 0ull; s.quota = 0; s.shift = 0; s.width = 0;
-    } else {
-      s.phase = 0; s.shift = 64 - kDigitBits; s.width = kDigitBits; s.quota = r; s.t_ge = ~0ull;
-    }
-  }
-}
-
-// flush a workgroup's LDS histogram to the global one
-__device__ __forceinline__ void flush_hist(unsigned int* lh, unsigned long long* gh) {
-  __syncthreads();
-  for (int b = threadIdx.x; b < kBins; b += blockDim.x) {
-    unsigned int c = lh[b];
-    if (c) atomicAdd(&gh[b], (unsigned long long)c);
-  }
-}
-
-// pass 0: v = (xk + sj) + q -> y; histogram of the top key digit.  Runs even when the selection is
-// already resolved (r <= 0 or r >= n) because the final pass reads v from y.
-__global__ __launch_bounds__(256) void k_sel_pass0(double* y, const double* q, const double* xk, const double* sj,
-                                                    int64_t n, int vec, SelWs* ws) {
-  __shared__ unsigned int lh[kBins];
-  for (int b = threadIdx.x; b < kBins; b += blockDim.x) lh[b] = 0u;
-  __syncthreads();
-  const bool count = (ws->st.phase == 0);
-  const int shift = 64 - kDigitBits;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  if (vec) {
-    const int64_t n2 = n >> 1;
-    const f64x2* q2 = reinterpret_cast<const f64x2*>(q);
-    const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
-    const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
-    f64x2* y2 = reinterpret_cast<f64x2*>(y);
-    for (int64_t i = tid; i < n2; i += stride) {
-      f64x2 a = q2[i], b = x2[i], c = s2[i];
-      f64x2 v;
-      v.x = (b.x + c.x) + a.x;  // shiftedIndBallL0.jl:66  y .= xk .+ sj .+ q
-      v.y = (b.y + c.y) + a.y;
-      y2[i] = v;
-      if (count) {
-        atomicAdd(&lh[key_of(v.x) >> shift], 1u);
-        atomicAdd(&lh[key_of(v.y) >> shift], 1u);
-      }
-    }
-    if ((n & 1) && tid == 0) {
-      const int64_t i = n - 1;
-      double v = (xk[i] + sj[i]) + q[i];
-      y[i] = v;
-      if (count) atomicAdd(&lh[key_of(v) >> shift], 1u);
-    }
-  } else {
-    for (int64_t i = tid; i < n; i += stride) {
-      double v = (xk[i] + sj[i]) + q[i];
-      y[i] = v;
-      if (count) atomicAdd(&lh[key_of(v) >> shift], 1u);
-    }
-  }
-  if (count) flush_hist(lh, ws->hist);
-}
-
-// passes >= 1: histogram the current digit of the elements still undecided (SelState::base).
-__global__ __launch_bounds__(256) void k_sel_hist(const double* y, int64_t n, int vec, SelWs* ws) {
-  const SelState st = ws->st;
-  if (st.phase == 2) return;
-  __shared__ unsigned int lh[kBins];
-  for (int b = threadIdx.x; b < kBins; b += blockDim.x) lh[b] = 0u;
-  __syncthreads();
-  const int shift = st.shift;
-  const int hs = st.shift + st.width;  // bits above the current digit
-  const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  auto visit = [&](double v, int64_t i) {
-    const uint64_t key = key_of(v);
-    if (st.phase == 0) {
-      const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
-      if (kp.in) atomicAdd(&lh[kp.digit], 1u);
-    } else {
-      if (key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix) atomicAdd(&lh[(((uint64_t)i) >> shift) & dmask], 1u);
-    }
-  };
-  if (vec) {
-    const int64_t n2 = n >> 1;
-    const f64x2* y2 = reinterpret_cast<const f64x2*>(y);
-    for (int64_t i = tid; i < n2; i += stride) {
-      f64x2 v = y2[i];
-      visit(v.x, 2 * i);
-      visit(v.y, 2 * i + 1);
-    }
-    if ((n & 1) && tid == 0) visit(y[n - 1], n - 1);
-  } else {
-    for (int64_t i = tid; i < n; i += stride) visit(y[i], i);
-  }
-  flush_hist(lh, ws->hist);
 }
 
 // Locates the bucket that holds the quota-th element (from the top for keys, from the bottom for indices) in a
@@ -416,16 +313,6 @@ __device__ __forceinline__ void sel_scan_step(const Hist& hist, const SelState s
   if (t == 0) *out = sel_advance(st, found[0], found[1], found[2]);
 }
 
-// One workgroup: scan step on the global histogram, then clear it for the next pass.
-__global__ __launch_bounds__(256) void k_sel_scan(SelWs* ws) {
-  __shared__ unsigned long long scratch[8];
-  const SelState st = ws->st;
-  if (st.phase == 2) return;
-  sel_scan_step(ws->hist, st, &ws->st, scratch);
-  __syncthreads();  // every lane has read its bins (inside the step) before they are cleared
-  for (int b = threadIdx.x; b < kBins; b += blockDim.x) ws->hist[b] = 0ull;
-}
-
 template <bool BINF>
 __device__ __forceinline__ double sel_out(double v, int64_t i, double x, double s, const SelState& st, double delta) {
   const uint64_t key = key_of(v);
@@ -436,30 +323,6 @@ __device__ __forceinline__ double sel_out(double v, int64_t i, double x, double 
   else return t;
 }
 
-template <bool BINF>
-__global__ __launch_bounds__(256) void k_sel_final(double* y, const double* xk, const double* sj, int64_t n, int vec,
-                                                    const SelWs* ws, double delta) {
-  const SelState st = ws->st;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  if (vec) {
-    const int64_t n2 = n >> 1;
-    f64x2* y2 = reinterpret_cast<f64x2*>(y);
-    const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
-    const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
-    for (int64_t i = tid; i < n2; i += stride) {
-      f64x2 v = y2[i], b = x2[i], c = s2[i];
-      f64x2 r;
-      r.x = sel_out<BINF>(v.x, 2 * i, b.x, c.x, st, delta);
-      r.y = sel_out<BINF>(v.y, 2 * i + 1, b.y, c.y, st, delta);
-      y2[i] = r;
-    }
-    if ((n & 1) && tid == 0) y[n - 1] = sel_out<BINF>(y[n - 1], n - 1, xk[n - 1], sj[n - 1], st, delta);
-  } else {
-    for (int64_t i = tid; i < n; i += stride) y[i] = sel_out<BINF>(y[i], i, xk[i], sj[i], st, delta);
-  }
-}
-
 // =============================================================================================
 // Small n (<= kSmallN): the whole selection in ONE workgroup and one launch.  The multi-launch path above costs 65-70 us
 // at any small size (18-20 dependent launches); here a single CU streams the vectors (L2-resident after the first
@@ -467,8 +330,7 @@ __global__ __launch_bounds__(256) void k_sel_final(double* y, const double* xk, 
 // exponent bins for the LDS atomics), index digits for ties, final pass.  Lane t owns elements t, t + 1024, ... in
 // every pass, so y needs no fence between passes.
 // =============================================================================================
-constexpr int64_t kSmallN = 1 << 16;
-constexpr int64_t kSmallNCoop = 1 << 13;  // ... when k_sel_coop serves the sizes above (see run_select)
+constexpr int64_t kSmallNCoop = 1 << 13;  // k_sel_coop serves the sizes above (see run_select)
 template <bool BINF>
 __global__ __launch_bounds__(1024) void k_sel_small(double* y, const double* q, const double* xk, const double* sj, int64_t n,
                                                      int64_t r, double delta) {
@@ -582,188 +444,18 @@ __global__ __launch_bounds__(1024) void k_sel_small(double* y, const double* q, 
 // the last kernel has been queued (steps 5a/5b return at once if the verdict is negative).
 // In the aliased case y is not touched before step 5b and step 5b reads q[i] before writing y[i].
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_s2_sample(const double* q, const double* xk, const double* sj, int64_t n,
-                                                    double* samp, SelWs* ws) {
-  // also histograms the top key digit of the sample into ws->hist (zeroed by k_sel_init): that digit is
-  // mostly exponent bits, a handful of hot bins, which would serialise a single workgroup's LDS atomics
-  __shared__ unsigned int lh[kBins];
-  for (int b = threadIdx.x; b < kBins; b += blockDim.x) lh[b] = 0u;
-  __syncthreads();
-  const int c = blockIdx.x;  // chunk
-  const int64_t start = (int64_t)((double)c * (double)(n - 256) / 255.0);
-  const int64_t i = start + threadIdx.x;
-  const double a = fabs((xk[i] + sj[i]) + q[i]);
-  samp[c * 256 + threadIdx.x] = a;
-  const uint64_t key = key_of(a);
-  atomicAdd(&lh[key >> (64 - kDigitBits)], 1u);
-  // largest finite sample key: scales the first candidate digit when the band has no upper end (k_s2_pick)
-  unsigned long long m = key < kInfKey ? key : 0ull;
-  for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned long long o = __shfl_xor(m, off, 64);
-    m = o > m ? o : m;
-  }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(&ws->fs.smax, m);
-  flush_hist(lh, ws->hist);
-}
-
-// One workgroup of 1024 lanes: brackets the sample's rank_hi-th and rank_lo-th largest keys to 36 bits
-// (three 12-bit digits; the first comes from the histogram k_s2_sample built) and writes the band.
-constexpr int kPickDigits = 3;
-constexpr unsigned int kPickFine = 16;  // samples per selected bucket below which no further digit is resolved
-__global__ __launch_bounds__(1024) void k_s2_pick(const double* samp, int64_t n, int64_t r, SelWs* ws) {
-  __shared__ unsigned int h[2][kBins];
-  __shared__ unsigned long long part[4][4];  // per 256-lane group
-  __shared__ unsigned long long pre[2];
-  __shared__ long long quo[2];
-  __shared__ int active[2];
-  __shared__ unsigned int bucket[2];  // samples in the bucket each selection sits in after the last digit
-  const int t = threadIdx.x;
-  if (t == 0) {
-    bucket[0] = bucket[1] = 0u;
-    const double M = (double)kSample;
-    const double p = (double)r / (double)n;
-    const double k = p * M;
-    const double margin = 6.0 * sqrt(M * p * (1.0 - p)) + 16.0;
-    const long long rank_hi = (long long)floor(k - margin);  // 1-based from the largest
-    const long long rank_lo = (long long)ceil(k + margin);
-    pre[0] = pre[1] = 0;
-    active[0] = rank_hi >= 1;
-    active[1] = rank_lo <= kSample;
-    quo[0] = rank_hi;
-    quo[1] = rank_lo;
-  }
-  int shift = 64 - kDigitBits;
-  const int width = kDigitBits;
-  int ndig = 0;
-  for (int digit = 0; digit < kPickDigits; ++digit) {
-    __syncthreads();
-    // a third digit only when the second still leaves a crowd in a selected bucket (data packed into a narrow relative
-    // range): two digits are 2^-12 relative, far below the +-6 sigma width of the band itself
-    if (digit == 2 && bucket[0] <= kPickFine && bucket[1] <= kPickFine) break;
-    ndig = digit + 1;
-    if (digit == 0) {
-      for (int b = t; b < kBins; b += 1024) { const unsigned int c = (unsigned int)ws->hist[b]; h[0][b] = c; h[1][b] = c; }
-    } else {
-      for (int b = t; b < 2 * kBins; b += 1024) (&h[0][0])[b] = 0u;
-      __syncthreads();
-      const int hs = shift + width;
-      const uint64_t p0 = pre[0], p1 = pre[1];
-      const bool a0 = active[0], a1 = active[1];
-      for (int i0 = t; i0 < kSample; i0 += 1024 * 8) {  // 8 independent loads in flight per lane
-        double sv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sv[k] = samp[i0 + 1024 * k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const uint64_t key = key_of(sv[k]);
-          const uint64_t top = key >> hs;
-          const unsigned d = (unsigned)((key >> shift) & (kBins - 1));
-          if (a0 && top == p0) atomicAdd(&h[0][d], 1u);
-          if (a1 && top == p1) atomicAdd(&h[1][d], 1u);
-        }
-      }
-    }
-    __syncthreads();
-    // scan from the top: lanes 0..255 serve selection 0, lanes 256..511 selection 1
-    constexpr int PER = kBins / 256;
-    const int sel = (t >> 8) & 1, tt = t & 255, grp256 = t >> 8;
-    unsigned long long loc[PER], sum = 0;
-    if (t < 512) {
-#pragma unroll
-      for (int k = 0; k < PER; ++k) { loc[k] = h[sel][kBins - 1 - (tt * PER + k)]; sum += loc[k]; }
-    }
-    const unsigned long long run0 = scan256_exclusive(sum, tt, part[grp256]);  // every 256-lane group has its own slots
-    if (t < 512 && active[sel]) {
-      unsigned long long run = run0;
-      const unsigned long long quota = (unsigned long long)quo[sel];
-#pragma unroll
-      for (int k = 0; k < PER; ++k) {
-        if (run < quota && run + loc[k] >= quota) {
-          pre[sel] = (pre[sel] << width) | (uint64_t)(kBins - 1 - (tt * PER + k));
-          quo[sel] = (long long)(quota - run);
-          bucket[sel] = (unsigned int)loc[k];
-        }
-        run += loc[k];
-      }
-    }
-    shift -= width;
-  }
-  __syncthreads();
-  for (int b = t; b < kBins; b += 1024) ws->hist[b] = 0ull;  // clean for the candidate passes
-  if (t == 0) {
-    FastState& f = ws->fs;
-    const int low = 64 - ndig * kDigitBits;  // undecided low bits: take the whole bucket
-    f.t_hi = active[0] ? ((pre[0] << low) | (((uint64_t)1 << low) - 1)) : ~0ull;  // nothing is above all-ones
-    f.t_lo = active[1] ? (pre[1] << low) : 0ull;
-    f.cnt_above = 0;
-    f.cand_count = 0;
-    f.ok = 0;
-    f.key_passes = 0;
-    f.overflow = 0;
-    f.crowded = 0;
-    f.ovf_count = 0;
-    f.list_count = 0;
-    // (the shard counters are zeroed below by lanes 0..kShards-1)
-    // digit machinery of the candidate selection: everything that depends on the band only (the counts -- verdict,
-    // quota -- are filled in by k_s2_scan_verify).  The first digit spreads the band's SPAN over the bins (SelState::base).
-    SelState& s = ws->st;
-    s.t_floor = f.t_lo;
-    s.t_eq = ~0ull;
-    s.icut = -1;
-    s.t_ge = ~0ull;
-    s.quota = 0;
-    s.prefix = 0;
-    s.base = f.t_lo;
-    s.clamp = 0;
-    if (!active[0]) {
-      // no upper end (r is small against the sample's resolution): bins sized so that the largest finite sample sits
-      // in bin 512..1023 and the last bin (open above) starts 4-8x as far from the band's low end; whatever lies beyond
-      // (outliers, Inf, NaN) shares that last bin and is resolved on the short list
-      const uint64_t smax = f.smax > f.t_lo ? f.smax : f.t_lo;
-      const uint64_t dist = (smax - f.t_lo) | 1ull;
-      const int bits = 64 - __clzll((long long)dist);
-      int shift = bits - 10;
-      if (shift < 0) shift = 0;
-      if (shift > 51) shift = 51;  // t_lo + (4095 << 51) < 2^64
-      s.phase = 0;
-      s.shift = shift;
-      s.width = kDigitBits;
-      s.clamp = 1;
-      f.key_passes = 6;
-    } else if (f.t_lo == f.t_hi) {  // one key value in the band: straight to the index tie-break
-      s.t_ge = f.t_lo + 1;
-      s.t_eq = f.t_lo;
-      s.phase = 1;
-      const int idx_bits = s.idx_bits;
-      const int w = idx_bits % kDigitBits ? idx_bits % kDigitBits : kDigitBits;
-      s.shift = idx_bits - w;
-      s.width = w;
-    } else {
-      const uint64_t span = f.t_hi - f.t_lo;      // > 0
-      const int bits = 64 - __clzll((long long)span);  // span < 2^bits: every band key is inside [base, base + 2^bits)
-      const int width = bits < kDigitBits ? bits : kDigitBits;
-      f.key_passes = (bits + kDigitBits - 1) / kDigitBits;
-      s.phase = 0;
-      s.shift = bits - width;
-      s.width = width;
-    }
-  }
-  for (int k = t; k < kShards; k += 1024) { ws->shard_above[k * kShardStride] = 0ull; ws->shard_cand[k * kShardStride] = 0ull; }
-}
-
 // Main pass: one tile per workgroup, waves fully independent (no barrier, no atomics).  Counts the elements above the
 // band and appends the band's elements to the wave's own candidate region.
 // WRITE (y overlaps none of the inputs): the pass also stores y, speculatively -- entries above the band as kept,
 // entries below it and inside it as dropped; the kept value of a band entry travels with the candidate and
 // k_s2_compact / k_s2_finish store it once the cut is known.  The call then moves the algorithmic 32 B/element plus the ~0.5 % of
 // candidates, instead of 56 B/element with the separate final pass (k_sel_final_q, used when y aliases an input).
-// SHARD: the wave totals also go into the sharded counters of SelWs (multi-launch pipeline: k_s2_scan_verify adds 64
-// shards up).  !SHARD (in-launch synchronised pipeline): k_s2_tail sums the per-wave count words itself with its whole
-// grid, so the pass issues no atomics besides the per-candidate histogram ones.
-template <bool BINF, bool WRITE, bool SHARD = true>
+// The wave totals also go into the sharded counters of SelWs (k_s2_scan_verify adds the shards up).
+template <bool BINF, bool WRITE>
 __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, const double* xk_, const double* sj_,
                                                   int64_t n, SelWs* ws, Cand* cand, WaveCount* counts, double delta,
-                                                  int ioff, int64_t ovf_base, unsigned int ovf_cap) {
+                                                  int ioff, int64_t ovf_base, unsigned int ovf_cap, ClassCount* cls,
+                                                  int64_t nwaves_total) {
   // ioff = 1: the caller's vectors start 8 bytes off a 16-byte boundary (all four alike); the pointers passed here
   // are the aligned rest (caller's element 1 on), n counts that rest, and the caller's element 0 sits at [-1].
   // Candidate indices are the caller's.
@@ -787,6 +479,12 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
   // atomics on n = 1e8 integers before.)  Written by the previous launch: a plain, cached load, the same in every wave.
   const int hopeless = ws->fs.overflow;   // (tested once the staging loads have landed: a test up here would hold every
   const bool crowded = ws->fs.crowded != 0;  // wave's loads back behind its scalar loads -- measured: 5 % of the pass)
+  // tie mode (FastState::tie): t_hi / t_lo are exact keys; their elements are counted (eq_hi / eq_lo), not recorded, and y is
+  // written by the streaming pass that follows the resolution (k_s2_tail / k_sel_final_q), not here
+  const bool tie = ws->fs.tie != 0;
+  const bool has_hi = ws->fs.has_hi != 0, has_lo = ws->fs.has_lo != 0;
+  unsigned int eq_hi = 0, eq_lo = 0;      // per lane
+  unsigned int seq_hi[2] = {0u, 0u}, seq_lo[2] = {0u, 0u};  // the stragglers wave 0 takes along: [0] head element, [1] odd last element
   const int64_t gwave = (int64_t)blockIdx.x * 4 + wave;
   const int64_t rbase = gwave * kWaveSlots;  // this wave's candidate region
   const unsigned long long lt_mask = (1ull << lane) - 1;
@@ -797,7 +495,7 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
   int run_next = 0;
   bool full = false;        // (per lane) the overflow list had no room for this lane's candidate
   // Called by all 64 lanes together (the ballot needs them); returns the value stored speculatively (WRITE).
-  auto visit = [&](bool valid, double v, int64_t i, double x, double s) -> double {
+  auto visit = [&](bool valid, double v, int64_t i, double x, double s, int straggler = -1) -> double {
     const uint64_t key = key_of(v);
     double kept = 0.0, dropped = 0.0;
     if constexpr (WRITE) {
@@ -810,8 +508,15 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
       }
     }
     const bool is_above = valid && key > t_hi;
-    const bool in_band = valid && !is_above && key >= t_lo;
+    bool in_band = valid && !is_above && key >= t_lo;
     above += is_above ? 1u : 0u;
+    if (tie) {  // (wave-uniform) members of the classes are counted in index order, never recorded
+      const bool c_hi = in_band && has_hi && key == t_hi;
+      const bool c_lo = in_band && has_lo && key == t_lo;
+      if (straggler < 0) { eq_hi += c_hi ? 1u : 0u; eq_lo += c_lo ? 1u : 0u; }
+      else { seq_hi[straggler & 1] += c_hi ? 1u : 0u; seq_lo[straggler & 1] += c_lo ? 1u : 0u; }
+      in_band = in_band && !c_hi && !c_lo;
+    }
     const unsigned long long m = __ballot(in_band);
     if (m) {
       const unsigned int pos = ncand + (unsigned int)__popcll(m & lt_mask);
@@ -913,20 +618,36 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
     o.x = visit(valid, (b.x + c.x) + a.x, 2 * i + ioff, b.x, c.x);      // shiftedIndBallL0.jl:66  xk .+ sj .+ q
     o.y = visit(valid, (b.y + c.y) + a.y, 2 * i + 1 + ioff, b.y, c.y);
     if constexpr (WRITE) {
-      if (valid) __builtin_nontemporal_store(o, y2 + i);
+      if (valid && !tie) __builtin_nontemporal_store(o, y2 + i);
     }
   }
   if ((n & 1) && gwave == 0) {  // the odd last element rides with wave 0 (all of its lanes call visit)
     const int64_t i = n - 1;
-    const double o = visit(lane == 0, (xk_[i] + sj_[i]) + q_[i], i + ioff, xk_[i], sj_[i]);
+    const double o = visit(lane == 0, (xk_[i] + sj_[i]) + q_[i], i + ioff, xk_[i], sj_[i], 1);
     if constexpr (WRITE) {
-      if (lane == 0) y_[i] = o;
+      if (lane == 0 && !tie) y_[i] = o;
     }
   }
   if (ioff && gwave == 0) {  // and so does the caller's element 0 of an 8-byte-misaligned view
-    const double o = visit(lane == 0, (xk_[-1] + sj_[-1]) + q_[-1], 0, xk_[-1], sj_[-1]);
+    const double o = visit(lane == 0, (xk_[-1] + sj_[-1]) + q_[-1], 0, xk_[-1], sj_[-1], 0);
     if constexpr (WRITE) {
-      if (lane == 0) y_[-1] = o;
+      if (lane == 0 && !tie) y_[-1] = o;
+    }
+  }
+  if (tie) {
+    for (int off = 32; off >= 1; off >>= 1) { eq_hi += __shfl_xor(eq_hi, off, 64); eq_lo += __shfl_xor(eq_lo, off, 64); }
+    if (lane == 0) {
+      cls[1 + gwave] = ClassCount{eq_hi, eq_lo};
+      unsigned int th = eq_hi, tl = eq_lo;
+      if (gwave == 0) {  // (only lane 0 of wave 0 visited the stragglers)
+        cls[0] = ClassCount{seq_hi[0], seq_lo[0]};
+        cls[1 + nwaves_total] = ClassCount{seq_hi[1], seq_lo[1]};
+        th += seq_hi[0] + seq_hi[1];
+        tl += seq_lo[0] + seq_lo[1];
+      }
+      const int shard = (int)(gwave % kShards) * kShardStride;
+      if (th) atomicAdd(&ws->shard_hi[shard], (unsigned long long)th);
+      if (tl) atomicAdd(&ws->shard_lo[shard], (unsigned long long)tl);
     }
   }
   for (int off = 32; off >= 1; off >>= 1) above += __shfl_xor(above, off, 64);
@@ -937,7 +658,7 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
     for (int k = 0; k < 4; ++k)
       if (run_count[k]) atomicAdd(&ws->hist[run_digit[k]], (unsigned long long)run_count[k]);
     counts[gwave] = WaveCount{ncand, above};
-    if constexpr (SHARD) {
+    {
       const int shard = (int)(gwave % kShards) * kShardStride;
       // (measured on one box, interleaved: these two atomics per wave cost ~13 us of the pass; packing both totals into
       //  ONE 64-bit atomic per wave was slower still, 0.645 vs 0.622 ms per call; the per-candidate histogram atomics
@@ -982,42 +703,75 @@ __device__ __forceinline__ void for_each_candidate(const WaveCount* counts, int6
 }
 
 // One workgroup: the verdict (is the r-th largest provably inside the band?), then the first scan step.
+// Tie mode: the order is  above | class hi (one key) | candidates strictly between | class lo (one key) | below; the cut
+// falls into one of the three middle parts.  Inside a class: all of it kept (resolved), or FastState::todo |= kTodoTieScan
+// with the quota in SelState::quota and (t_eq, t_ge) set -- k_s2_tail finds icut.  Among the candidates: as without ties.
 __global__ __launch_bounds__(256) void k_s2_scan_verify(SelWs* ws, int64_t r) {
   __shared__ unsigned long long scratch[8];
   __shared__ int sok;
   __shared__ SelState sst;
-  unsigned long long above = 0, cand = 0;
+  unsigned long long above = 0, cand = 0, chi = 0, clo = 0;
   {  // the 256 lanes add up the shards of the main pass
-    __shared__ unsigned long long red[2][4];
+    __shared__ unsigned long long red[4][4];
+    const bool tie = ws->fs.tie != 0;
     for (int k = threadIdx.x; k < kShards; k += 256) {
       above += ws->shard_above[k * kShardStride];
       cand += ws->shard_cand[k * kShardStride];
+      if (tie) { chi += ws->shard_hi[k * kShardStride]; clo += ws->shard_lo[k * kShardStride]; }
     }
     for (int off = 32; off >= 1; off >>= 1) {
       above += __shfl_xor(above, off, 64);
       cand += __shfl_xor(cand, off, 64);
+      chi += __shfl_xor(chi, off, 64);
+      clo += __shfl_xor(clo, off, 64);
     }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = above; red[1][threadIdx.x >> 6] = cand; }
+    if ((threadIdx.x & 63) == 0) {
+      red[0][threadIdx.x >> 6] = above; red[1][threadIdx.x >> 6] = cand;
+      red[2][threadIdx.x >> 6] = chi; red[3][threadIdx.x >> 6] = clo;
+    }
     __syncthreads();
     above = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     cand = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    chi = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    clo = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
   }
   if (threadIdx.x == 0) {
     FastState& f = ws->fs;
     SelState& s = ws->st;
+    const unsigned long long ur = (unsigned long long)r;
     f.cnt_above = above;
     f.cand_count = cand;
-    const bool ok = !f.overflow && above < (unsigned long long)r && (unsigned long long)r <= above + cand;
-    f.ok = ok ? 1 : 0;
-    if (ok) {
-      s.quota = (int64_t)((unsigned long long)r - above);
+    f.cls_hi = chi;
+    f.cls_lo = clo;
+    bool ok = !f.overflow && above < ur && ur <= above + chi + cand + clo;
+    bool scan = false;  // the cut lies among the candidates: first scan step below
+    if (ok && f.tie) {
+      f.todo = kTodoFinal;
+      if (ur <= above + chi) {               // inside class hi
+        s.quota = (int64_t)(ur - above);
+        s.phase = 2;
+        if ((unsigned long long)s.quota == chi) { s.t_ge = f.t_hi; s.t_eq = ~0ull; s.icut = -1; }
+        else { s.t_ge = f.t_hi + 1; s.t_eq = f.t_hi; s.icut = -1; f.todo |= kTodoTieScan; f.tie_class = 0; }
+      } else if (ur <= above + chi + cand) {  // among the candidates (class hi kept, class lo dropped: t_floor = t_lo + 1)
+        s.quota = (int64_t)(ur - above - chi);
+        scan = true;
+      } else {                               // inside class lo (everything above it is kept)
+        s.quota = (int64_t)(ur - above - chi - cand);
+        s.phase = 2;
+        if ((unsigned long long)s.quota == clo) { s.t_ge = f.t_lo; s.t_eq = ~0ull; s.icut = -1; }
+        else { s.t_ge = f.t_lo + 1; s.t_eq = f.t_lo; s.icut = -1; f.todo |= kTodoTieScan; f.tie_class = 1; }
+      }
+    } else if (ok) {
+      s.quota = (int64_t)(ur - above);
+      scan = true;
       if (f.t_lo == f.t_hi && (unsigned long long)s.quota == cand) {  // a one-key band, all of it kept
         s.phase = 2;
         s.t_ge = f.t_lo;
         s.t_eq = ~0ull;
       }
     }
-    sok = ok ? 1 : 0;
+    f.ok = ok ? 1 : 0;
+    sok = (ok && scan) ? 1 : 0;
     sst = s;
   }
   __syncthreads();
@@ -1035,7 +789,8 @@ __global__ __launch_bounds__(256) void k_s2_compact(double* y, const Cand* cand,
                                                      int64_t nregions, unsigned int ovf_cap) {
   const SelState st = ws->st;
   if (!ws->fs.ok) return;
-  if (!WRITE && st.phase == 2) return;
+  const bool wr = WRITE && !ws->fs.tie;  // (tie mode: y is written by the final streaming pass, from the thresholds alone)
+  if (!wr && st.phase == 2) return;
   const int hs = st.shift + st.width;
   const unsigned int novf = ws->fs.ovf_count < ovf_cap ? ws->fs.ovf_count : ovf_cap;
   for_each_candidate(counts, nregions, cand, (int64_t)novf, [&](uint64_t key, int64_t i, double val) {
@@ -1067,7 +822,7 @@ __global__ __launch_bounds__(256) void k_s2_compact(double* y, const Cand* cand,
       }
     }
     if constexpr (WRITE) {
-      if (keep) y[i] = val;
+      if (keep && wr) y[i] = val;
     }
   });
 }
@@ -1087,8 +842,10 @@ __global__ __launch_bounds__(1024) void k_s2_finish(double* y, SelWs* ws, const 
   __syncthreads();
   if (sst.phase == 2) return;
   const unsigned int m = ws->fs.list_count;
-  if (m > (unsigned)kShortList) {  // too many survivors (heavy ties): let the full-vector path do it
-    if (t == 0) ws->fs.ok = 0;
+  if (m > (unsigned)kShortList) {
+    // too many survivors for LDS (a key shared by thousands of candidates: moderately tie-heavy data).  The state after the
+    // first digit stays in ws->st; k_s2_tail continues the radix select over the candidate regions with its whole grid.
+    if (t == 0) ws->fs.todo |= kTodoCandSelect;
     return;
   }
   for (unsigned int e = t; e < m; e += 1024) { lk[e] = list_key[e]; li[e] = list_idx[e]; }
@@ -1115,7 +872,7 @@ __global__ __launch_bounds__(1024) void k_s2_finish(double* y, SelWs* ws, const 
   }
   __syncthreads();
   if (t == 0) ws->st = sst;
-  if constexpr (WRITE) {  // the short-list entries that made the cut (everything above it was stored by k_s2_compact)
+  if (WRITE && !ws->fs.tie) {  // the short-list entries that made the cut (everything above it was stored by k_s2_compact)
     const SelState fin = sst;
     for (unsigned int e = t; e < m; e += 1024) {
       const uint64_t key = lk[e];
@@ -1212,8 +969,12 @@ struct SelSync {
   // fallback inside k_s2_tail, which clears it itself (one more barrier on a path that is rare and slow anyway).
   unsigned long long chist[3][kCoopMaxPass][kBins];
   unsigned long long fhist1[kBins];        // k_s2_front: top digit of the sample keys            (cleared by the fallback launch)
-  unsigned long long fhist2[2][2][kBins];  // k_s2_front: digits 2, 3 of the two rank selections  (cleared by the fallback launch)
+  unsigned long long fhist2[5][2][kBins];  // k_s2_front: digits 2..6 of the two rank selections   (cleared by the fallback launch)
   SelWs ws;                                // st, fs, hist, shards (cleared by k_s2_front; fs.smax by the fallback launch)
+  // k_s2_tail, tie scan: class members per workgroup slice and the cut found by the slice that holds it -- words that are
+  // their own ready flag (value + 1, zero = not yet written; cleared by the launch itself after its last reader)
+  unsigned long long tie_part[256];
+  unsigned long long tie_cut;
 };
 
 static_assert(sizeof(SelSync) <= kSpxSyncSelBytes, "SelSync outgrew its share of spx_ctx::sync");
@@ -1299,7 +1060,7 @@ __device__ __forceinline__ void sel_state_init(SelState& s, int64_t n, int64_t r
 template <bool BINF, bool REG>
 __device__ __forceinline__ void coop_select(double* y, const double* q, const double* xk, const double* sj, int64_t n,
                                             int64_t r, double delta, unsigned long long (*hist)[kBins], unsigned int* bar,
-                                            unsigned int& nbar, CoopShared& sh, int* timed_out) {
+                                            unsigned int& nbar, CoopShared& sh, SpxSyncHeader* hdr) {
   const int t = threadIdx.x;
   const int64_t NT = (int64_t)gridDim.x * blockDim.x;
   const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + t;
@@ -1401,18 +1162,22 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
     SEL_STAMP(33 + 3 * p);
     // the histogram atomics of every wave have been performed (vmcnt) before its workgroup arrives; nothing else is exchanged
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    spx_grid_rendezvous(bar, (++nbar) * gridDim.x, timed_out);
+    spx_grid_rendezvous(bar, (++nbar) * gridDim.x, hdr);
     SEL_STAMP(34 + 3 * p);
     coop_scan_step(hist[p], st, &sh.sst, sh.scratch);
     SEL_STAMP(35 + 3 * p);
   }
   __syncthreads();
-  const SelState fin = sh.sst;
+  SelState fin = sh.sst;
+  // A workgroup of this context gave up waiting (spx_wait_expired): the thresholds are not to be trusted.  Every element is
+  // then stored as NaN (t_ge above every key, v replaced below) and the next libspx call reports the failure.
+  const bool poisoned = spx_poisoned(hdr);
+  auto P = [&](double val) -> double { return poisoned ? __longlong_as_double(0x7ff8000000000000ll) : val; };  // (a select: -0.0 stays -0.0)
   if constexpr (REG) {
 #pragma unroll
     for (int k = 0; k < kCoopEpl; ++k) {
       const int64_t i = gtid + (int64_t)k * NT;
-      if (i < n) y[i] = sel_out<BINF>(v[k], i, xk[i], sj[i], fin, delta);
+      if (i < n) y[i] = P(sel_out<BINF>(v[k], i, xk[i], sj[i], fin, delta));
     }
   } else if (vec2 && p != 0) {
     const int64_t n2 = n >> 1;
@@ -1421,14 +1186,14 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
     const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
     for (int64_t pr = gtid; pr < n2; pr += NT) {
       const f64x2 vv = y2[pr], b = x2[pr], c = s2[pr];
-      y2[pr] = f64x2{sel_out<BINF>(vv.x, 2 * pr, b.x, c.x, fin, delta), sel_out<BINF>(vv.y, 2 * pr + 1, b.y, c.y, fin, delta)};
+      y2[pr] = f64x2{P(sel_out<BINF>(vv.x, 2 * pr, b.x, c.x, fin, delta)), P(sel_out<BINF>(vv.y, 2 * pr + 1, b.y, c.y, fin, delta))};
     }
-    if ((n & 1) && gtid == 0) y[n - 1] = sel_out<BINF>(y[n - 1], n - 1, xk[n - 1], sj[n - 1], fin, delta);
+    if ((n & 1) && gtid == 0) y[n - 1] = P(sel_out<BINF>(y[n - 1], n - 1, xk[n - 1], sj[n - 1], fin, delta));
   } else {
     if (p == 0) {  // resolved before any pass (r <= 0 or r >= n): v was never parked in y
-      for (int64_t i = gtid; i < n; i += NT) y[i] = sel_out<BINF>((xk[i] + sj[i]) + q[i], i, xk[i], sj[i], fin, delta);
+      for (int64_t i = gtid; i < n; i += NT) y[i] = P(sel_out<BINF>((xk[i] + sj[i]) + q[i], i, xk[i], sj[i], fin, delta));
     } else {
-      for (int64_t i = gtid; i < n; i += NT) y[i] = sel_out<BINF>(y[i], i, xk[i], sj[i], fin, delta);
+      for (int64_t i = gtid; i < n; i += NT) y[i] = P(sel_out<BINF>(y[i], i, xk[i], sj[i], fin, delta));
     }
   }
   SEL_STAMP(63);
@@ -1449,7 +1214,7 @@ __global__ __launch_bounds__(1024) void k_sel_coop(double* y, const double* q, c
     unsigned long long* z1 = ss->fhist1;
     unsigned long long* z2 = &ss->fhist2[0][0][0];
     for (int64_t b = gt; b < kBins; b += nt) z1[b] = 0ull;
-    for (int64_t b = gt; b < 4 * kBins; b += nt) z2[b] = 0ull;
+    for (int64_t b = gt; b < 10 * kBins; b += nt) z2[b] = 0ull;
     if (gt == 0) ss->ws.fs.smax = 0ull;
     if (ss->ws.fs.ok) return;
   }
@@ -1462,9 +1227,257 @@ __global__ __launch_bounds__(1024) void k_sel_coop(double* y, const double* q, c
   if (fallback) {
     unsigned long long* z = &ss->chist[use_set][0][0];
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total; b += (int64_t)gridDim.x * blockDim.x) z[b] = 0ull;
-    spx_grid_barrier(ss->hdr.bar[parity], (++nbar) * gridDim.x, &ss->hdr.timed_out);
+    spx_grid_barrier(ss->hdr.bar[parity], (++nbar) * gridDim.x, &ss->hdr);
   }
-  coop_select<BINF, REG>(y, q, xk, sj, n, r, delta, ss->chist[use_set], ss->hdr.bar[parity], nbar, sh, &ss->hdr.timed_out);
+  coop_select<BINF, REG>(y, q, xk, sj, n, r, delta, ss->chist[use_set], ss->hdr.bar[parity], nbar, sh, &ss->hdr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_s2_tail: the last launch of a sample-predicted call, queued unconditionally (nothing is read back): as many 1024-lane
+// workgroups as are resident at once.  Returns at once when the candidate kernels have finished the job (generic data: ~5 us).
+// Otherwise, with its whole grid and in-launch rendezvous:
+//   kTodoCandSelect  the first candidate digit left more survivors than the one-workgroup short list holds (a key shared by
+//                    thousands of elements): the radix select continues over the candidate regions -- the loop of
+//                    coop_select, fed from the records instead of the vector (12 us per digit at n = 1e8)
+//   kTodoTieScan     tie mode, the cut lies inside a class: prefix sum over the per-wave member counts (index order) ->
+//                    the wave that holds the quota-th member -> its 768 elements are re-read -> icut
+//   kTodoFinal       tie mode: y = sel_out(v) for every element, one streaming pass (24 B read + 8 B written per element)
+//   verdict negative the exact select over the whole vector (coop_select, v parked in y)
+// ---------------------------------------------------------------------------------------------
+// exclusive prefix sum over the 1024 lanes of a workgroup; *total = the sum.  lds = 17 words.
+__device__ __forceinline__ unsigned long long scan1024_exclusive(unsigned long long v, unsigned long long* total, unsigned long long* lds) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  unsigned long long inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long up = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += up;
+  }
+  __syncthreads();  // (lds may still be read by the previous call's lanes)
+  if (lane == 63) lds[w] = inc;
+  __syncthreads();
+  unsigned long long base = 0, all = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const unsigned long long x = lds[k];
+    base += (k < w) ? x : 0ull;
+    all += x;
+  }
+  *total = all;
+  return base + inc - v;
+}
+
+template <bool BINF>
+__global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                                   int64_t r, double delta, SelSync* ss, int parity, const Cand* cand,
+                                                   const WaveCount* counts, int64_t nregions, unsigned int ovf_cap,
+                                                   const ClassCount* cls, int ioff, int write) {
+  __shared__ CoopShared sh;
+  __shared__ unsigned long long tl[20];
+  __shared__ unsigned long long tparts[256];
+  const int t = threadIdx.x, G = (int)gridDim.x, b = (int)blockIdx.x;
+  const int64_t gt = (int64_t)b * blockDim.x + t, nt = (int64_t)G * blockDim.x;
+  SpxSyncHeader* hdr = &ss->hdr;
+  unsigned int* bar = hdr->bar[parity];
+  unsigned int nbar = 0;
+  if (b == 0 && t == 0) hdr->bar[parity ^ 1][0] = 0u;
+  {  // clean slates for the next call's k_s2_front
+    unsigned long long* z1 = ss->fhist1;
+    unsigned long long* z2 = &ss->fhist2[0][0][0];
+    for (int64_t k = gt; k < kBins; k += nt) z1[k] = 0ull;
+    for (int64_t k = gt; k < 10 * kBins; k += nt) z2[k] = 0ull;
+    if (gt == 0) ss->ws.fs.smax = 0ull;
+  }
+  // written by earlier launches: the same values in every workgroup
+  const int ok = ss->ws.fs.ok, todo = ss->ws.fs.todo, tie = ss->ws.fs.tie;
+  if (ok && todo == 0) return;
+  if (t == 0) { sh.sst = ss->ws.st; tl[17] = ~0ull; tl[18] = 0ull; tl[19] = ~0ull; }
+  const int64_t total_hist = (int64_t)kCoopMaxPass * kBins;
+  if (!ok || (todo & kTodoCandSelect)) {  // histogram set 2 belongs to this launch: cleared here, one barrier
+    unsigned long long* z = &ss->chist[2][0][0];
+    for (int64_t k = gt; k < total_hist; k += nt) z[k] = 0ull;
+    spx_grid_barrier(bar, (++nbar) * G, hdr);
+  }
+  if (!ok) {  // prediction not verified: exact select over the whole vector (recomputes everything from q, xk, sj)
+    coop_select<BINF, false>(y, q, xk, sj, n, r, delta, ss->chist[2], bar, nbar, sh, hdr);
+    return;
+  }
+  const unsigned int novf = ss->ws.fs.ovf_count < ovf_cap ? ss->ws.fs.ovf_count : ovf_cap;
+  if (todo & kTodoCandSelect) {
+    int p = 0;
+    for (; p < kCoopMaxPass; ++p) {
+      __syncthreads();
+      const SelState st = sh.sst;
+      if (st.phase == 2) break;  // the same in every workgroup: they all computed it from the same histograms
+      for (int k = t; k < kBins; k += 1024) sh.lh[k] = 0u;
+      __syncthreads();
+      const int hs = st.shift + st.width;
+      const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
+      for_each_candidate(counts, nregions, cand, (int64_t)novf, [&](uint64_t key, int64_t i, double) {
+        bool in;
+        unsigned int dg;
+        if (st.phase == 0) {
+          const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
+          in = kp.in;
+          dg = kp.digit;
+        } else {
+          in = key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix;
+          dg = (unsigned int)((((uint64_t)i) >> st.shift) & dmask);
+        }
+        hist_add_agg(sh.lh, dg, in);
+      });
+      __syncthreads();
+      for (int k = t; k < kBins; k += 1024) {
+        const unsigned int c = sh.lh[k];
+        if (c) atomicAdd(&ss->chist[2][p][k], (unsigned long long)c);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      spx_grid_rendezvous(bar, (++nbar) * G, hdr);
+      coop_scan_step(ss->chist[2][p], st, &sh.sst, sh.scratch);
+    }
+    __syncthreads();
+    const SelState fin = sh.sst;
+    if (b == 0 && t == 0) ss->ws.st = fin;  // (every workgroup read the old state before the first rendezvous above)
+    if (write && !tie && !spx_poisoned(hdr)) {
+      // the candidates that make the cut (k_s2_compact stored those above the first digit's bucket; storing them again is harmless)
+      for_each_candidate(counts, nregions, cand, (int64_t)novf, [&](uint64_t key, int64_t i, double val) {
+        if ((key >= fin.t_ge) || (key == fin.t_eq && i <= fin.icut)) y[i] = val;
+      });
+    }
+  }
+  if (todo & kTodoTieScan) {
+    // members of the class (key == t_eq) per slot, slots in index order (ClassCount); keep the first `quota` of them
+    const int which = ss->ws.fs.tie_class;
+    const int64_t nslots = nregions + 2;
+    const int64_t S = (nslots + G - 1) / G, lo = (int64_t)b * S, hi = (lo + S < nslots) ? lo + S : nslots;
+    auto members = [&](int64_t w) -> unsigned long long { return which ? (unsigned long long)cls[w].lo : (unsigned long long)cls[w].hi; };
+    unsigned long long mine = 0;
+    for (int64_t w = lo + t; w < hi; w += 1024) mine += members(w);
+    unsigned long long tot;
+    (void)scan1024_exclusive(mine, &tot, tl);
+    if (t == 0) __hip_atomic_store(&ss->tie_part[b], tot + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < G) {
+      unsigned long long w0;
+      unsigned int spins = 0;
+      for (;;) {
+        w0 = __hip_atomic_load(&ss->tie_part[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w0) break;
+        if (spx_wait_expired(spins, hdr)) { w0 = 1ull; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      tparts[t] = w0 - 1ull;
+    }
+    __syncthreads();
+    const unsigned long long quota = (unsigned long long)sh.sst.quota;
+    unsigned long long dummy;
+    const unsigned long long before = scan1024_exclusive(t < G ? tparts[t] : 0ull, &dummy, tl);
+    if (t < G && before < quota && quota <= before + tparts[t]) { tl[17] = (unsigned long long)t; tl[18] = quota - before; }
+    __syncthreads();
+    if (b == (int)tl[17]) {  // this slice holds the quota-th member: which slot, which element
+      const unsigned long long qrem = tl[18];
+      unsigned long long running = 0;
+      __syncthreads();
+      if (t == 0) tl[19] = ~0ull;
+      for (int64_t base = lo; base < hi; base += 1024) {
+        const int64_t w = base + t;
+        const unsigned long long c = (w < hi) ? members(w) : 0ull;
+        unsigned long long chunk;
+        const unsigned long long ex = scan1024_exclusive(c, &chunk, tl);
+        if (c && running + ex < qrem && qrem <= running + ex + c) { tl[19] = (unsigned long long)w; tl[18] = qrem - running - ex; }
+        running += chunk;
+        __syncthreads();
+        if (tl[19] != ~0ull) break;
+      }
+      const int64_t wstar = (int64_t)tl[19];
+      const unsigned long long rho = tl[18];  // the rho-th member of slot wstar, in index order
+      const uint64_t t_eq = sh.sst.t_eq;
+      // (q, xk, sj are the caller's pointers; the aligned rest starts at ioff; the last slot is the odd last element of the rest)
+      const int64_t nrest = n - ioff, npairs2 = (nrest >> 1) << 1;
+      unsigned long long icut = ~0ull;
+      if (wstar == 0) {
+        icut = 0ull;
+      } else if (wstar == nslots - 1) {
+        icut = (unsigned long long)(n - 1);
+      } else if (wstar > 0) {
+        const int64_t e = (wstar - 1) * (64 * kMainUnroll * 2) + t;  // element of the aligned rest
+        const bool valid = t < 64 * kMainUnroll * 2 && e < npairs2;
+        bool match = false;
+        if (valid) {
+          const int64_t i = e + ioff;
+          match = key_of((xk[i] + sj[i]) + q[i]) == t_eq;
+        }
+        unsigned long long cnt;
+        const unsigned long long ex = scan1024_exclusive(match ? 1ull : 0ull, &cnt, tl);
+        if (match && ex + 1ull == rho) tl[19] = (unsigned long long)(e + ioff);
+        __syncthreads();
+        icut = tl[19];
+      }
+      if (t == 0) __hip_atomic_store(&ss->tie_cut, icut + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t == 0) {
+      unsigned long long w0;
+      unsigned int spins = 0;
+      for (;;) {
+        w0 = __hip_atomic_load(&ss->tie_cut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w0) break;
+        if (spx_wait_expired(spins, hdr)) { w0 = 1ull; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      sh.sst.icut = (int64_t)(w0 - 1ull);
+    }
+    // everybody has read the exchange words: the first workgroup clears them for the next call and publishes the state
+    spx_grid_rendezvous(bar, (++nbar) * G, hdr);
+    if (b == 0) {
+      if (t < 256) ss->tie_part[t] = 0ull;
+      if (t == 0) { ss->tie_cut = 0ull; ss->ws.st = sh.sst; }
+    }
+  }
+  __syncthreads();
+  if ((todo & kTodoFinal) && write) {
+    // y from q, xk, sj and the final thresholds; 16-byte pairs of the aligned rest, 4 in flight per lane and vector
+    SelState fin = sh.sst;
+    const bool poisoned = spx_poisoned(hdr);
+    auto P = [&](double val) -> double { return poisoned ? __longlong_as_double(0x7ff8000000000000ll) : val; };
+    const double* qa = q + ioff; const double* xa = xk + ioff; const double* sa = sj + ioff; double* ya = y + ioff;
+    const int64_t nrest = n - ioff, n2 = nrest >> 1;
+    const bool vec2 = ((reinterpret_cast<uintptr_t>(ya) | reinterpret_cast<uintptr_t>(qa) | reinterpret_cast<uintptr_t>(xa) |
+                        reinterpret_cast<uintptr_t>(sa)) & 15u) == 0;
+    if (vec2) {
+      const f64x2* q2 = reinterpret_cast<const f64x2*>(qa);
+      const f64x2* x2 = reinterpret_cast<const f64x2*>(xa);
+      const f64x2* s2 = reinterpret_cast<const f64x2*>(sa);
+      f64x2* y2 = reinterpret_cast<f64x2*>(ya);
+      constexpr int KP = 4;
+      const int64_t ntiles = (n2 + 1024 * KP - 1) / (1024 * KP);
+      for (int64_t tile = b; tile < ntiles; tile += G) {
+        f64x2 a[KP], bb[KP], c[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+          int64_t i = tile * (1024 * KP) + k * 1024 + t;
+          if (i >= n2) i = n2 - 1;
+          a[k] = __builtin_nontemporal_load(q2 + i);
+          bb[k] = __builtin_nontemporal_load(x2 + i);
+          c[k] = __builtin_nontemporal_load(s2 + i);
+        }
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+          const int64_t i = tile * (1024 * KP) + k * 1024 + t;
+          if (i < n2) {
+            f64x2 o;
+            o.x = P(sel_out<BINF>((bb[k].x + c[k].x) + a[k].x, 2 * i + ioff, bb[k].x, c[k].x, fin, delta));
+            o.y = P(sel_out<BINF>((bb[k].y + c[k].y) + a[k].y, 2 * i + 1 + ioff, bb[k].y, c[k].y, fin, delta));
+            __builtin_nontemporal_store(o, y2 + i);
+          }
+        }
+      }
+      if (gt == 0) {
+        if (nrest & 1) { const int64_t i = n - 1; y[i] = P(sel_out<BINF>((xk[i] + sj[i]) + q[i], i, xk[i], sj[i], fin, delta)); }
+        if (ioff) y[0] = P(sel_out<BINF>((xk[0] + sj[0]) + q[0], 0, xk[0], sj[0], fin, delta));
+      }
+    } else {
+      for (int64_t i = gt; i < n; i += nt) y[i] = P(sel_out<BINF>((xk[i] + sj[i]) + q[i], i, xk[i], sj[i], fin, delta));
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1482,6 +1495,8 @@ __global__ __launch_bounds__(1024) void k_sel_coop(double* y, const double* q, c
 // saves while the sample is a sizeable part of the vector (n = 3e6: 63 -> 70 us): 1 below 2^23, 2 below 2^25, 4 from there on
 // (tools/r2/topr_big.py).
 constexpr int kFrontBlocks = 64;
+constexpr int kFrontMaxDigits = 6;      // the sample ranks are bracketed to 2-3 x 12 key bits; to all 64 in tie mode
+constexpr unsigned int kPickFine = 16;  // samples per selected bucket below which no further digit is resolved
 template <int kFrontSpl>
 __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double* xk, const double* sj, int64_t n, int64_t r,
                                                     SelSync* ss, int parity) {
@@ -1501,7 +1516,10 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
   for (int b = t; b < kBins; b += 1024) lh[b] = 0u;
   // clean slates for the main pass (it runs in a later launch)
   for (int b = c * 1024 + t; b < kBins; b += 1024 * (int)gridDim.x) ws->hist[b] = 0ull;
-  for (int b = c * 1024 + t; b < kShards; b += 1024 * (int)gridDim.x) { ws->shard_above[b * kShardStride] = 0ull; ws->shard_cand[b * kShardStride] = 0ull; }
+  for (int b = c * 1024 + t; b < kShards; b += 1024 * (int)gridDim.x) {
+    ws->shard_above[b * kShardStride] = 0ull; ws->shard_cand[b * kShardStride] = 0ull;
+    ws->shard_hi[b * kShardStride] = 0ull; ws->shard_lo[b * kShardStride] = 0ull;
+  }
   if (t == 0) {
     bucket[0] = bucket[1] = 0u;
     constexpr int kFrontSample = kFrontBlocks * 1024 * kFrontSpl;
@@ -1561,11 +1579,11 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     if (cnt) atomicAdd(&ss->fhist1[b], (unsigned long long)cnt);
   }
   SEL_STAMP(1);
-  spx_grid_barrier(bar, (++nbar) * gridDim.x, &ss->hdr.timed_out);
+  spx_grid_barrier(bar, (++nbar) * gridDim.x, &ss->hdr);
   SEL_STAMP(2);
   // scan of a 4096-bin histogram from the top: lanes 0..255 serve selection 0, lanes 256..511 selection 1 (as k_s2_pick)
   constexpr int PER = kBins / 256;
-  auto scan_both = [&](const unsigned long long* h0, const unsigned long long* h1) {
+  auto scan_both = [&](const unsigned long long* h0, const unsigned long long* h1, int width) {
     const int sel = (t >> 8) & 1, tt = t & 255, grp256 = t >> 8;
     const unsigned long long* h = sel ? h1 : h0;
     unsigned long long loc[PER], sum = 0;
@@ -1583,7 +1601,7 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
 #pragma unroll
       for (int k = 0; k < PER; ++k) {
         if (run < quota && run + loc[k] >= quota) {
-          npre = (pre[sel] << kDigitBits) | (uint64_t)(kBins - 1 - (tt * PER + k));
+          npre = (pre[sel] << width) | (uint64_t)(kBins - 1 - (tt * PER + k));
           nquo = quota - run;
           nb = (unsigned int)loc[k];
           hit = true;
@@ -1595,16 +1613,25 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     if (hit) { pre[sel] = npre; quo[sel] = (long long)nquo; bucket[sel] = nb; }
     __syncthreads();
   };
-  scan_both(ss->fhist1, ss->fhist1);
+  scan_both(ss->fhist1, ss->fhist1, kDigitBits);
   SEL_STAMP(3);
-  int ndig = 1;
-  int shift = 64 - 2 * kDigitBits;
-  for (int digit = 1; digit < kPickDigits; ++digit) {
+  // Further digits.  2 and 3 as round 2: bits 51..40, then 39..28 only if a selected bucket still holds more than a handful of
+  // samples.  4..6 (bits 27..16, 15..4, 3..0): TIE MODE -- a bucket that is still crowded after 36 bits is one key (or keys 2^-24
+  // apart) shared by >= 0.1 % of the vector; both ranks are then resolved to the full key (see FastState::tie).
+  int bits_done = kDigitBits;  // key bits resolved so far (from the top)
+  int tie = 0;
+  for (int digit = 1; digit < kFrontMaxDigits; ++digit) {
     // (uniform: same histograms everywhere.  The resolution asked of the band's ends is a share of the VECTOR: 16 samples of
     //  65 536, i.e. 16 kFrontSpl of this sample: the third digit -- a barrier and a scan, 10 us -- is then skipped at r = n/2
     //  as it always was at r = n/100)
     if (digit == 2 && bucket[0] <= kPickFine * kFrontSpl && bucket[1] <= kPickFine * kFrontSpl) break;
-    const int hs = shift + kDigitBits;
+    if (digit == 3) {
+      tie = (bucket[0] > 4u * kPickFine * kFrontSpl || bucket[1] > 4u * kPickFine * kFrontSpl) ? 1 : 0;
+      if (!tie) break;
+    }
+    const int width = (64 - bits_done) < kDigitBits ? (64 - bits_done) : kDigitBits;
+    const int shift = 64 - bits_done - width;
+    const int hs = shift + width;
     // both ranks in the same bucket so far (the usual case: the band is narrow): ONE histogram serves both selections -- half
     // the global atomics of this phase (the barrier behind it waits for them: 9 us)
     const bool shared = active[0] && active[1] && pre[0] == pre[1];
@@ -1613,32 +1640,38 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
 #pragma unroll
     for (int sidx = 0; sidx < kFrontSpl; ++sidx) {
       const uint64_t top = keys[sidx] >> hs;
-      const unsigned d = (unsigned)((keys[sidx] >> shift) & (kBins - 1));
+      const unsigned d = (unsigned)((keys[sidx] >> shift) & (((uint64_t)1 << width) - 1));
       hist_add_agg(ss->fhist2[digit - 1][0], d, active[0] && top == pre[0]);
       if (!shared) hist_add_agg(ss->fhist2[digit - 1][1], d, active[1] && top == pre[1]);
     }
     SEL_STAMP(2 + 2 * digit);
-    spx_grid_barrier(bar, (++nbar) * gridDim.x, &ss->hdr.timed_out);
+    spx_grid_barrier(bar, (++nbar) * gridDim.x, &ss->hdr);
     SEL_STAMP(3 + 2 * digit);
-    scan_both(ss->fhist2[digit - 1][0], ss->fhist2[digit - 1][shared ? 0 : 1]);
-    ndig = digit + 1;
-    shift -= kDigitBits;
+    scan_both(ss->fhist2[digit - 1][0], ss->fhist2[digit - 1][shared ? 0 : 1], width);
+    bits_done += width;
   }
-  // How much of the SAMPLE lies in the band?  Exactly known from the scans: ranks above the upper bucket = rank_hi - quo[0],
-  // ranks down to the low end of the lower bucket = rank_lo - quo[1] + bucket[1].  More than the candidate storage could
-  // take of the vector (6 %: ties -- a bucket that holds per cents of the sample) -> the main pass is told not to bother.
-  // (A count over one workgroup's own samples misfires on SORTED input, whose band is contiguous: 256 samples of a chunk.)
+  // How much of the SAMPLE lies in the band (tie mode: strictly between its ends)?  Exactly known from the scans: ranks above
+  // the upper bucket = rank_hi - quo[0], ranks down to the low end of the lower bucket = rank_lo - quo[1] + bucket[1].  More
+  // than the candidate storage could take of the vector (6 %) -> the main pass is told not to bother.  With the heavy keys
+  // counted as classes this cannot happen any more for a band of +-6 sigma (at most 2.6 % of the smallest sample); kept as
+  // a guard.  (A count over one workgroup's own samples misfires on SORTED input, whose band is contiguous.)
   int hopeless = 0;
   if (c == 0 && t == 0) {
-    const long long top = active[0] ? (rank0[0] - quo[0]) : 0;
-    const long long bot = active[1] ? (rank0[1] - quo[1] + (long long)bucket[1]) : (long long)(kFrontBlocks * 1024 * kFrontSpl);
-    const long long in_band = bot - top;
-    hopeless = (in_band * 768ll > 48ll * (long long)(kFrontBlocks * 1024 * kFrontSpl)) ? 1 : 0;
+    const long long nsamp = (long long)(kFrontBlocks * 1024 * kFrontSpl);
+    long long top = active[0] ? (rank0[0] - quo[0]) : 0;                                   // samples above the upper bucket
+    long long bot = active[1] ? (rank0[1] - quo[1] + (long long)bucket[1]) : nsamp;          // samples down to the lower bucket's low end
+    if (tie) {  // the buckets are single keys now, counted as classes
+      if (active[0]) top += (long long)bucket[0];
+      if (active[1] && !(active[0] && pre[0] == pre[1])) bot -= (long long)bucket[1];
+    }
+    const long long in_band = bot > top ? bot - top : 0;
+    hopeless = (in_band * 768ll > 48ll * nsamp) ? 1 : 0;
   }
   if (c == 0 && t == 0) {
     FastState& f = ws->fs;
-    const int low = 64 - ndig * kDigitBits;  // undecided low bits: take the whole bucket
-    f.t_hi = active[0] ? ((pre[0] << low) | (((uint64_t)1 << low) - 1)) : ~0ull;  // nothing is above all-ones
+    const int low = 64 - bits_done;  // undecided low bits: take the whole bucket (0 in tie mode)
+    const uint64_t lowmask = low > 0 ? (((uint64_t)1 << low) - 1) : 0ull;
+    f.t_hi = active[0] ? ((pre[0] << low) | lowmask) : ~0ull;  // nothing is above all-ones
     f.t_lo = active[1] ? (pre[1] << low) : 0ull;
     f.cnt_above = 0;
     f.cand_count = 0;
@@ -1646,34 +1679,50 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     f.key_passes = 0;
     f.overflow = hopeless;
     f.ovf_count = 0;
-    // (generic data ends on <= kPickFine kFrontSpl samples per bucket, or far fewer after a third digit)
-    f.crowded = (bucket[0] > 4u * kPickFine * kFrontSpl || bucket[1] > 4u * kPickFine * kFrontSpl) ? 1 : 0;
+    f.tie = tie;
+    f.has_hi = (tie && active[0]) ? 1 : 0;
+    f.has_lo = (tie && active[1] && !(active[0] && f.t_hi == f.t_lo)) ? 1 : 0;
+    f.cls_hi = f.cls_lo = 0ull;
+    f.todo = 0;
+    f.tie_class = 0;
+    // (generic data ends on <= kPickFine kFrontSpl samples per bucket, or far fewer after a third digit; in tie mode the keys
+    //  BETWEEN the ends may be shared by many elements too: their digits are counted in runs as well)
+    f.crowded = (tie || bucket[0] > 4u * kPickFine * kFrontSpl || bucket[1] > 4u * kPickFine * kFrontSpl) ? 1 : 0;
     f.list_count = 0;
     SelState& s = ws->st;
     sel_state_init(s, n, r);
-    s.t_floor = f.t_lo;
+    s.t_floor = f.has_lo ? f.t_lo + 1 : f.t_lo;  // (a class "lo" is not kept when the cut lies among the candidates above it)
     s.quota = 0;
     s.base = f.t_lo;
-    if (!active[0]) {  // no upper end: bins scaled by the largest finite sample, last bin open above (see k_s2_pick)
+    if (!active[0]) {  // no upper end: bins scaled by the largest finite sample, last bin open above
+      // (r is small against the sample's resolution): bins sized so that the largest finite sample sits in bin 512..1023 and
+      // the last bin (open above) starts 4-8x as far from the band's low end; whatever lies beyond (outliers, Inf, NaN) shares
+      // that last bin and is resolved on the short list
       const uint64_t smax = f.smax > f.t_lo ? f.smax : f.t_lo;
       const uint64_t dist = (smax - f.t_lo) | 1ull;
       const int bits = 64 - __clzll((long long)dist);
       int sh = bits - 10;
       if (sh < 0) sh = 0;
-      if (sh > 51) sh = 51;
+      if (sh > 51) sh = 51;  // t_lo + (4095 << 51) < 2^64
       s.phase = 0;
       s.shift = sh;
       s.width = kDigitBits;
       s.clamp = 1;
       f.key_passes = 6;
-    } else if (f.t_lo == f.t_hi) {  // one key value in the band: straight to the index tie-break
-      s.t_ge = f.t_lo + 1;
-      s.t_eq = f.t_lo;
-      s.phase = 1;
-      const int idx_bits = s.idx_bits;
-      const int w = idx_bits % kDigitBits ? idx_bits % kDigitBits : kDigitBits;
-      s.shift = idx_bits - w;
-      s.width = w;
+    } else if (f.t_lo == f.t_hi) {
+      if (tie) {  // one class, no candidates at all: the state is filled in by k_s2_scan_verify
+        s.phase = 0;
+        s.shift = 0;
+        s.width = 1;
+      } else {    // one key value in the band: straight to the index tie-break
+        s.t_ge = f.t_lo + 1;
+        s.t_eq = f.t_lo;
+        s.phase = 1;
+        const int idx_bits = s.idx_bits;
+        const int w = idx_bits % kDigitBits ? idx_bits % kDigitBits : kDigitBits;
+        s.shift = idx_bits - w;
+        s.width = w;
+      }
     } else {
       const uint64_t span = f.t_hi - f.t_lo;  // > 0
       const int bits = 64 - __clzll((long long)span);
@@ -1684,12 +1733,9 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
       s.width = width;
     }
   }
-  SEL_STAMP(9);
+  SEL_STAMP(15);
 }
 
-#ifndef SPX_SEL_FAST_MIN_LOG2
-#define SPX_SEL_FAST_MIN_LOG2 20  // smallest n (log2) on the sample-predicted path: 83-98 us vs 100-123 us for the full-vector path at 2^20, behind it below (tools/exp/topr_threshold.py)
-#endif
 #ifndef SPX_SEL_REG_MAX_LOG2
 #define SPX_SEL_REG_MAX_LOG2 21  // largest n (log2) on the register-resident one-launch select = what 256 CUs hold at 8 elements per lane (n = 2e6: 37 us vs 57 us for the sample-predicted pipeline; beyond it the one-launch form parks v in y and is no faster: tools/r2/topr_midn.py)
 #endif
@@ -1701,10 +1747,9 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   if (rc) return rc;
   if (n == 0) return SPX_OK;
   SPX_ON_DEVICE(ctx);
-  // one workgroup, one launch, no scratch -- up to 8192 elements when the register-resident grid-wide select is there to take
-  // over (n = 16 384: 32 us in one workgroup, 21 us on two; n = 65 536: 84 vs 19 us -- tools/r2/topr_small.py)
-  const int64_t small_max = (ctx->tune_sel_coop && ctx->num_cu >= 32) ? kSmallNCoop : kSmallN;
-  if (n <= small_max && ctx->tune_sel_small) {
+  // one workgroup, one launch, no scratch -- up to 8192 elements (n = 16 384: 32 us in one workgroup, 21 us on two;
+  // n = 65 536: 84 vs 19 us -- tools/r2/topr_small.py)
+  if (n <= kSmallNCoop && ctx->tune_sel_small) {
     hipLaunchKernelGGL((k_sel_small<BINF>), dim3(1), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta);
     SPX_LAUNCH_CHECK();
     return SPX_OK;
@@ -1714,24 +1759,32 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   // runs on the aligned rest and its wave 0 takes element 0 along (ioff = 1)
   auto off8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 8u; };
   const int ioff = (!vec && off8(y) && off8(q) && off8(xk) && off8(sj)) ? 1 : 0;
-  const bool coop = ctx->tune_sel_coop && ctx->num_cu >= 32;
-  const int64_t reg_cap = (int64_t)kCoopEpl * 1024 * ctx->num_cu;  // (2 Mi elements on 256 CUs)
-  const int64_t fast_min = coop ? ((int64_t)1 << SPX_SEL_REG_MAX_LOG2) + 1 : ((int64_t)1 << SPX_SEL_FAST_MIN_LOG2);
-  const bool try_fast = ctx->tune_sel_fast && (vec || ioff) && (n - ioff) >= fast_min && r > 0 && r < n;
-  SelSync* ss = nullptr;
-  if (coop) {
-    rc = spx_sync_reserve(ctx, sizeof(SelSync));
-    if (rc) return rc;
-    ss = reinterpret_cast<SelSync*>(ctx->sync);
-  }
-  const bool graph_safe = coop && (spx_capture_check(ctx) || ctx->graph_safe);  // (see spx_ctx::graph_safe)
-  if (coop && !try_fast) {
-    // exact select in ONE launch: register-resident up to 8 Ki elements per CU, v parked in y beyond that
+  // Residency of the kernels that synchronise inside one launch: a grid never exceeds what the occupancy query says can be
+  // resident at once (spx_resident_cap); a form whose grid does not fit hands over to the one that works with any grid.
+  const int64_t cap_reg = spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_sel_coop<BINF, true>), 1024, 0);
+  const int64_t cap_mem = spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_sel_coop<BINF, false>), 1024, 0);
+  if (cap_mem < 1) return SPX_ERR_INTERNAL;  // (message set by spx_resident_cap)
+  const void* front_fn = n >= ((int64_t)1 << 25) ? reinterpret_cast<const void*>(&k_s2_front<4>)
+                       : n >= ((int64_t)1 << 23) ? reinterpret_cast<const void*>(&k_s2_front<2>)
+                                                 : reinterpret_cast<const void*>(&k_s2_front<1>);
+  const int64_t cap_front = spx_resident_cap(ctx, front_fn, 1024, 0);
+  const int64_t reg_cap = (int64_t)kCoopEpl * 1024 * (cap_reg < ctx->num_cu ? cap_reg : ctx->num_cu);  // (2 Mi elements on 256 CUs)
+  const int64_t fast_min = ((int64_t)1 << SPX_SEL_REG_MAX_LOG2) + 1;
+  const bool try_fast = ctx->tune_sel_fast && (vec || ioff) && (n - ioff) >= fast_min && r > 0 && r < n &&
+                        cap_front >= kFrontBlocks;  // (the front kernel's sample layout is tied to its grid)
+  rc = spx_sync_reserve(ctx, sizeof(SelSync));
+  if (rc) return rc;
+  SelSync* ss = reinterpret_cast<SelSync*>(ctx->sync);
+  const bool graph_safe = spx_capture_check(ctx) || ctx->graph_safe;  // (see spx_ctx::graph_safe)
+  const int64_t g_mem = cap_mem < ctx->num_cu ? cap_mem : ctx->num_cu;  // grid of the form that parks v in y: any size >= 1 works
+  const int64_t cap_tail = spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_s2_tail<BINF>), 1024, 0);
+  if (cap_tail < 1) return SPX_ERR_INTERNAL;
+  const int64_t g_tail = cap_tail < 256 ? (cap_tail < ctx->num_cu ? cap_tail : ctx->num_cu) : (ctx->num_cu < 256 ? ctx->num_cu : 256);  // (<= 256: SelSync::tie_part)
+  if (!try_fast) {
+    // exact select in ONE launch: register-resident up to 8 Ki elements per resident workgroup, v parked in y beyond that
     const bool reg = n <= reg_cap;
     // as few workgroups as hold the vector at 8 elements per lane: a grid barrier costs ~2 us with 64 arrivers, ~7 us with 256
-    int64_t g = reg ? (n + (int64_t)kCoopEpl * 1024 - 1) / ((int64_t)kCoopEpl * 1024) : ctx->num_cu;
-    if (g > ctx->num_cu) g = ctx->num_cu;
-    if (g < 1) g = 1;
+    const int64_t g = reg ? (n + (int64_t)kCoopEpl * 1024 - 1) / ((int64_t)kCoopEpl * 1024) : g_mem;
     int use_set = ctx->sel_hist_next, other = use_set ^ 1;
     int clear_set = ctx->sel_hist_dirty[other] ? other : -1;
     int parity = ctx->coop_parity;
@@ -1765,143 +1818,83 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   // fast path scratch: one candidate region + count word per wavefront of the main pass
   const int64_t n2 = (n - ioff) >> 1;
   const int64_t mblocks = (n2 + kMainTilePairs - 1) / kMainTilePairs;
-  const int64_t nregions = try_fast ? mblocks * 4 : 0;
+  const int64_t nregions = mblocks * 4;
   const int64_t ccap = nregions * kWaveSlots;
   // the shared overflow list behind the per-wave regions: room for a band that is contiguous in the vector (sorted input)
-  const int64_t ovf_cap64 = try_fast ? ((n / 64 > 65536) ? n / 64 : 65536) : 0;
+  const int64_t ovf_cap64 = (n / 64 > 65536) ? n / 64 : 65536;
   const unsigned int ovf_cap = (unsigned int)(ovf_cap64 > 0x7fffffff ? 0x7fffffff : ovf_cap64);
-  const size_t off_samp = (sizeof(SelWs) + 255) & ~(size_t)255;
-  const size_t off_cnt = off_samp + (size_t)kSample * sizeof(double);
-  const size_t off_ckey = (off_cnt + (size_t)nregions * sizeof(WaveCount) + 255) & ~(size_t)255;
+  const size_t off_cnt = 256;
+  const size_t off_cls = (off_cnt + (size_t)nregions * sizeof(WaveCount) + 255) & ~(size_t)255;   // tie mode: class members per slot
+  const size_t off_ckey = (off_cls + (size_t)(nregions + 2) * sizeof(ClassCount) + 255) & ~(size_t)255;
   const size_t off_lkey = off_ckey + ((size_t)ccap + (size_t)ovf_cap) * sizeof(Cand);
   const size_t off_lidx = off_lkey + (size_t)kShortList * sizeof(uint64_t);
   const size_t off_lval = off_lidx + (size_t)kShortList * sizeof(int64_t);
   rc = spx_ws_reserve(ctx, off_lval + (size_t)kShortList * sizeof(double) + 256);
   if (rc) return rc;
-  SelWs* ws = reinterpret_cast<SelWs*>(ctx->ws);
-  if (try_fast) {
-    char* wsb = reinterpret_cast<char*>(ctx->ws);
-    double* samp = reinterpret_cast<double*>(wsb + off_samp);
-    WaveCount* counts = reinterpret_cast<WaveCount*>(wsb + off_cnt);
-    Cand* cand = reinterpret_cast<Cand*>(wsb + off_ckey);
-    // single-pass form when y overlaps none of the inputs (a failed prediction recomputes everything from them)
-    auto disjoint = [&](const double* a) { return (y + n <= a) || (a + n <= y); };
-    const bool write = ctx->tune_sel_spec && disjoint(q) && disjoint(xk) && disjoint(sj);
-    uint64_t* lkey = reinterpret_cast<uint64_t*>(wsb + off_lkey);
-    int64_t* lidx = reinterpret_cast<int64_t*>(wsb + off_lidx);
-    double* lval = reinterpret_cast<double*>(wsb + off_lval);
-    const dim3 mgrid((unsigned)mblocks);
-    if (coop) {
-      // front (sample + band, one in-launch synchronised kernel) -> main pass -> verdict / candidates -> fallback (exact
-      // select; returns at once when the verdict is positive).  Nothing is read back.
-      SelWs* sws = &ss->ws;
-      if (graph_safe) {
-        // counters, the front kernel's histograms and the pipeline's workspace header, zeroed by nodes in front of the
-        // launches (in eager mode the previous call's last launch leaves them clean); parities 0 / 1 fixed
-        rc = spx_zero_async(ctx, &ss->hdr, sizeof(ss->hdr.bar));
-        if (rc) return rc;
-        rc = spx_zero_async(ctx, &ss->fhist1[0], sizeof(SelSync) - offsetof(SelSync, fhist1));
-        if (rc) return rc;
-        ctx->coop_parity = 0;
-      }
-      {
-        SpxCoopLaunchGuard guard(ctx);
-        if (n >= ((int64_t)1 << 25))
-          hipLaunchKernelGGL(k_s2_front<4>, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
-                             n - ioff, r, ss, ctx->coop_parity);
-        else if (n >= ((int64_t)1 << 23))
-          hipLaunchKernelGGL(k_s2_front<2>, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
-                             n - ioff, r, ss, ctx->coop_parity);
-        else
-          hipLaunchKernelGGL(k_s2_front<1>, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
-                             n - ioff, r, ss, ctx->coop_parity);
-        ctx->coop_parity ^= 1;
-        if (write)
-          hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,
-                             sj + ioff, n - ioff, sws, cand, counts, delta, ioff, ccap, ovf_cap);
-        else
-          hipLaunchKernelGGL((k_s2_main<BINF, false>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,
-                             sj + ioff, n - ioff, sws, cand, counts, delta, ioff, ccap, ovf_cap);
-        // (tried: verdict + first digit redone by every workgroup of the candidate walk instead of the one-workgroup launch in
-        //  front of it -- 598 vs 571 us per call at n = 1e8: 512 workgroups x 64 KiB of L2 reads and the scan chain cost more
-        //  than the launch they save)
-        hipLaunchKernelGGL(k_s2_scan_verify, dim3(1), dim3(256), 0, ctx->stream, sws, r);
-        if (write) {
-          hipLaunchKernelGGL((k_s2_compact<true>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, sws, lkey, lidx,
-                             lval, (const WaveCount*)counts, nregions, ovf_cap);
-          hipLaunchKernelGGL((k_s2_finish<true>), dim3(1), dim3(1024), 0, ctx->stream, y, sws, (const uint64_t*)lkey,
-                             (const int64_t*)lidx, (const double*)lval);
-        } else {
-          hipLaunchKernelGGL((k_s2_compact<false>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, sws, lkey, lidx,
-                             lval, (const WaveCount*)counts, nregions, ovf_cap);
-          hipLaunchKernelGGL((k_s2_finish<false>), dim3(1), dim3(1024), 0, ctx->stream, y, sws, (const uint64_t*)lkey,
-                             (const int64_t*)lidx, (const double*)lval);
-        }
-        hipLaunchKernelGGL((k_sel_coop<BINF, false>), dim3((unsigned)ctx->num_cu), dim3(1024), 0, ctx->stream, y, q, xk, sj, n,
-                           r, delta, ss, ctx->coop_parity, 2, -1, 1);
-        ctx->coop_parity ^= 1;
-      }
-      if (!write)
-        hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1535) / 1536)), dim3(256), 0, ctx->stream,
-                           y + ioff, q + ioff, xk + ioff, sj + ioff, n - ioff, (const SelWs*)sws, delta, ioff);
-      SPX_LAUNCH_CHECK();
-      return SPX_OK;
-    }
-    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, ctx->stream, ws, n, r);
-    hipLaunchKernelGGL(k_s2_sample, dim3(256), dim3(256), 0, ctx->stream, q, xk, sj, n, samp, ws);
-    hipLaunchKernelGGL(k_s2_pick, dim3(1), dim3(1024), 0, ctx->stream, (const double*)samp, n, r, ws);
+  char* wsb = reinterpret_cast<char*>(ctx->ws);
+  WaveCount* counts = reinterpret_cast<WaveCount*>(wsb + off_cnt);
+  ClassCount* cls = reinterpret_cast<ClassCount*>(wsb + off_cls);
+  Cand* cand = reinterpret_cast<Cand*>(wsb + off_ckey);
+  // single-pass form when y overlaps none of the inputs (a failed prediction recomputes everything from them)
+  auto disjoint = [&](const double* a) { return (y + n <= a) || (a + n <= y); };
+  const bool write = ctx->tune_sel_spec && disjoint(q) && disjoint(xk) && disjoint(sj);
+  uint64_t* lkey = reinterpret_cast<uint64_t*>(wsb + off_lkey);
+  int64_t* lidx = reinterpret_cast<int64_t*>(wsb + off_lidx);
+  double* lval = reinterpret_cast<double*>(wsb + off_lval);
+  const dim3 mgrid((unsigned)mblocks);
+  // front (sample + band, one in-launch synchronised kernel) -> main pass -> verdict / candidates -> fallback (exact
+  // select; returns at once when the verdict is positive).  Nothing is read back.
+  SelWs* sws = &ss->ws;
+  if (graph_safe) {
+    // counters, the front kernel's histograms and the pipeline's workspace header, zeroed by nodes in front of the
+    // launches (in eager mode the previous call's last launch leaves them clean); parities 0 / 1 fixed
+    rc = spx_zero_async(ctx, &ss->hdr, sizeof(ss->hdr.bar));
+    if (rc) return rc;
+    rc = spx_zero_async(ctx, &ss->fhist1[0], sizeof(SelSync) - offsetof(SelSync, fhist1));
+    if (rc) return rc;
+    ctx->coop_parity = 0;
+  }
+  {
+    SpxCoopLaunchGuard guard(ctx);
+    if (n >= ((int64_t)1 << 25))
+      hipLaunchKernelGGL(k_s2_front<4>, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
+                         n - ioff, r, ss, ctx->coop_parity);
+    else if (n >= ((int64_t)1 << 23))
+      hipLaunchKernelGGL(k_s2_front<2>, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
+                         n - ioff, r, ss, ctx->coop_parity);
+    else
+      hipLaunchKernelGGL(k_s2_front<1>, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
+                         n - ioff, r, ss, ctx->coop_parity);
+    ctx->coop_parity ^= 1;
     if (write)
       hipLaunchKernelGGL((k_s2_main<BINF, true>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,
-                         sj + ioff, n - ioff, ws, cand, counts, delta, ioff, ccap, ovf_cap);
+                         sj + ioff, n - ioff, sws, cand, counts, delta, ioff, ccap, ovf_cap, cls, nregions);
     else
       hipLaunchKernelGGL((k_s2_main<BINF, false>), mgrid, dim3(256), 0, ctx->stream, y + ioff, q + ioff, xk + ioff,
-                         sj + ioff, n - ioff, ws, cand, counts, delta, ioff, ccap, ovf_cap);
-    // the main pass has already histogrammed the first candidate digit: verdict + first scan step, survivors ->
-    // short list, the rest of the selection in one workgroup
-    hipLaunchKernelGGL(k_s2_scan_verify, dim3(1), dim3(256), 0, ctx->stream, ws, r);
+                         sj + ioff, n - ioff, sws, cand, counts, delta, ioff, ccap, ovf_cap, cls, nregions);
+    // (tried: verdict + first digit redone by every workgroup of the candidate walk instead of the one-workgroup launch in
+    //  front of it -- 598 vs 571 us per call at n = 1e8: 512 workgroups x 64 KiB of L2 reads and the scan chain cost more
+    //  than the launch they save)
+    hipLaunchKernelGGL(k_s2_scan_verify, dim3(1), dim3(256), 0, ctx->stream, sws, r);
     if (write) {
-      hipLaunchKernelGGL((k_s2_compact<true>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, ws, lkey, lidx,
+      hipLaunchKernelGGL((k_s2_compact<true>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, sws, lkey, lidx,
                          lval, (const WaveCount*)counts, nregions, ovf_cap);
-      hipLaunchKernelGGL((k_s2_finish<true>), dim3(1), dim3(1024), 0, ctx->stream, y, ws, (const uint64_t*)lkey,
+      hipLaunchKernelGGL((k_s2_finish<true>), dim3(1), dim3(1024), 0, ctx->stream, y, sws, (const uint64_t*)lkey,
                          (const int64_t*)lidx, (const double*)lval);
     } else {
-      hipLaunchKernelGGL((k_s2_compact<false>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, ws, lkey, lidx,
+      hipLaunchKernelGGL((k_s2_compact<false>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, sws, lkey, lidx,
                          lval, (const WaveCount*)counts, nregions, ovf_cap);
-      hipLaunchKernelGGL((k_s2_finish<false>), dim3(1), dim3(1024), 0, ctx->stream, y, ws, (const uint64_t*)lkey,
+      hipLaunchKernelGGL((k_s2_finish<false>), dim3(1), dim3(1024), 0, ctx->stream, y, sws, (const uint64_t*)lkey,
                          (const int64_t*)lidx, (const double*)lval);
-      hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1535) / 1536)), dim3(256), 0, ctx->stream,
-                         y + ioff, q + ioff, xk + ioff, sj + ioff, n - ioff, (const SelWs*)ws, delta, ioff);
     }
-    SPX_LAUNCH_CHECK();
-    // the verdict is read back AFTER the speculative final pass has been queued: the GPU never idles on the host
-    rc = spx_require_not_capturing(ctx, "the multi-launch top-r path (spx_ctx_set_tuning key 7 = 0), which reads its verdict back,");
-    if (rc) return rc;
-    int ok = 0;
-    SPX_HIP(hipMemcpyAsync(&ok, &ws->fs.ok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    SPX_HIP(hipStreamSynchronize(ctx->stream));
-    if (ok) return SPX_OK;
-    // prediction failed: exact full-vector path below
+    hipLaunchKernelGGL((k_s2_tail<BINF>), dim3((unsigned)g_tail), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta, ss,
+                       ctx->coop_parity, (const Cand*)cand, (const WaveCount*)counts, nregions, ovf_cap,
+                       (const ClassCount*)cls, ioff, write ? 1 : 0);
+    ctx->coop_parity ^= 1;
   }
-  const int64_t work = vec ? (n + 1) / 2 : n;
-  int64_t blocks = (work + 255) / 256;
-  const int64_t cap = (int64_t)ctx->num_cu * 8;
-  if (blocks > cap) blocks = cap;
-  if (blocks < 1) blocks = 1;
-  dim3 grid((unsigned)blocks), block(256);
-  hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, ctx->stream, ws, n, r);
-  hipLaunchKernelGGL(k_sel_pass0, grid, block, 0, ctx->stream, y, q, xk, sj, n, vec, ws);
-  hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(256), 0, ctx->stream, ws);
-  // remaining key digits (5 after the first 12 of 64 bits) + index digits of a possible tie
-  int idx_bits = 0;
-  while (idx_bits < 63 && ((int64_t)1 << idx_bits) < n) ++idx_bits;
-  const int passes = (64 - kDigitBits + kDigitBits - 1) / kDigitBits + (idx_bits + kDigitBits - 1) / kDigitBits;
-  if (r > 0 && r < n) {
-    for (int p = 0; p < passes; ++p) {
-      hipLaunchKernelGGL(k_sel_hist, grid, block, 0, ctx->stream, (const double*)y, n, vec, ws);
-      hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(256), 0, ctx->stream, ws);
-    }
-  }
-  hipLaunchKernelGGL((k_sel_final<BINF>), grid, block, 0, ctx->stream, y, xk, sj, n, vec, (const SelWs*)ws, delta);
+  if (!write)
+    hipLaunchKernelGGL((k_sel_final_q<BINF>), dim3((unsigned)((n2 + 1535) / 1536)), dim3(256), 0, ctx->stream,
+                       y + ioff, q + ioff, xk + ioff, sj + ioff, n - ioff, (const SelWs*)sws, delta, ioff);
   SPX_LAUNCH_CHECK();
   return SPX_OK;
 }

@@ -197,14 +197,14 @@ def test_indball_fast_path_and_fallback(s, orc, case):
     L = s._lib.load()
     for r in (1, 7, n // 1000, n // 3, n - 5):
         ref = orc.prox_indball_l0_binf(q, x, sj, r, 1.0)
-        # (fast, spec, coop): single-pass speculative form (default), two-pass form, exact select only -- each through the
-        # in-launch synchronised kernels (coop = 1, default: no verdict read back, fallback queued unconditionally) and
-        # through the multi-launch pipeline of round 1 (coop = 0)
+        # (fast, spec, cap): single-pass speculative form (default), two-pass form, exact select only -- and the same with the
+        # resident grid of the in-launch synchronised kernels capped (key 8) at 40 workgroups (the front kernel needs 64: the
+        # call takes the exact select on a 40-workgroup grid) and at 3 (every kernel on a grid far below the CU count)
         ctx = s.context("cuda:0")
-        for fast, spec, coop in ((1, 1, 1), (1, 0, 1), (0, 1, 1), (1, 1, 0), (1, 0, 0), (0, 1, 0)):
+        for fast, spec, coop in ((1, 1, 0), (1, 0, 0), (0, 1, 0), (1, 1, 40), (0, 1, 3), (1, 1, 100)):
             s._lib.check(L.spx_ctx_set_tuning(ctx, 2, fast))
             s._lib.check(L.spx_ctx_set_tuning(ctx, 4, spec))
-            s._lib.check(L.spx_ctx_set_tuning(ctx, 7, coop))
+            s._lib.check(L.spx_ctx_set_tuning(ctx, 8, coop))
             try:
                 psi = s.shifted(s.shifted(s.IndBallL0(r), xd, 1.0, s.NormLinf(1.0)), sd)
                 psi.sol.fill_(float("nan"))  # every entry must be written
@@ -212,7 +212,7 @@ def test_indball_fast_path_and_fallback(s, orc, case):
             finally:
                 s._lib.check(L.spx_ctx_set_tuning(ctx, 2, 1))
                 s._lib.check(L.spx_ctx_set_tuning(ctx, 4, 1))
-                s._lib.check(L.spx_ctx_set_tuning(ctx, 7, 1))
+                s._lib.check(L.spx_ctx_set_tuning(ctx, 8, 0))
             assert _bits_equal(y, ref), (case, r, fast, spec, coop)
     # plain IndBallL0 (no clamp) through the single-pass form
     ref = orc.prox_indball_l0(q, x, sj, n // 50)

@@ -248,15 +248,15 @@ def test_indball_l0(s, orc, n, quant):
 
 
 def test_indball_l0_small_n_both_kernels(s, orc):
-    """n <= 8192 (65536 without the in-launch kernels) runs in one workgroup (k_sel_small); key 6 = 0 sends the same sizes through the
-    kernels larger vectors use: the register-resident one-launch select (key 7 = 1, default) or the multi-launch radix
-    select of round 1 (key 7 = 0).  All three must give the oracle's bits, ties and NaN included."""
+    """n <= 8192 runs in one workgroup (k_sel_small); key 6 = 0 sends the same sizes through the kernel larger vectors use, the
+    register-resident one-launch select -- and, with the resident grid capped at 2 workgroups (key 8), through the form that
+    parks v in y.  All three must give the oracle's bits, ties and NaN included."""
     L = s._lib.load()
     rng = np.random.default_rng(6)
     try:
-        for mode, coop in ((1, 1), (0, 1), (0, 0)):
+        for mode, coop in ((1, 0), (0, 0), (0, 2)):
             L.spx_ctx_set_tuning(s.context("cuda:0"), 6, mode)
-            L.spx_ctx_set_tuning(s.context("cuda:0"), 7, coop)
+            L.spx_ctx_set_tuning(s.context("cuda:0"), 8, coop)
             for n in (1, 2, 63, 1024, 1025, 5000, 8192, 8193, 65536):
                 x, sj, q = _data(n, 700 + n, 8)
                 if n >= 63:
@@ -277,7 +277,7 @@ def test_indball_l0_small_n_both_kernels(s, orc):
                 assert _bits_equal(y, orc.prox_indball_l0(q, x, sj, r)), (mode, r)
     finally:
         L.spx_ctx_set_tuning(s.context("cuda:0"), 6, 1)
-        L.spx_ctx_set_tuning(s.context("cuda:0"), 7, 1)
+        L.spx_ctx_set_tuning(s.context("cuda:0"), 8, 0)
 
 
 def test_indball_l0_ties_and_kats(s, orc, kats):
