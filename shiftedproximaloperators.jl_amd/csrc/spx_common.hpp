@@ -60,6 +60,8 @@ struct spx_ctx {
   int tune_binf_literal = 0;       // key 9: GroupNormL2Binf groups whose root sits next to the pole of step(n) (u < n/1000) take
                                    //        the reference's literal Float64 evaluation (reproduces a reference run bit pattern
                                    //        by bit pattern where the default is the more accurate side: include/spx.h)
+  int tune_force_grid = 0;         // key 100, test builds only (-DSPX_TEST_HOOKS): launch the one-launch top-r with THIS many workgroups,
+                                   //          residency or not -- the planted fault behind tests/test_gpu_robustness.py
   // Device-side status word in host-mapped pinned memory (spx_ctx.hip): a kernel that gives up waiting for the other
   // workgroups of its launch, or finds library-owned state outside its layout, stores a non-zero code here (system-scope
   // store); every entry point looks at it before it enqueues anything (SPX_ON_DEVICE) and fails with SPX_ERR_INTERNAL from

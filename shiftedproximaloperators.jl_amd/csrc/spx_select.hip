@@ -1784,7 +1784,10 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     // exact select in ONE launch: register-resident up to 8 Ki elements per resident workgroup, v parked in y beyond that
     const bool reg = n <= reg_cap;
     // as few workgroups as hold the vector at 8 elements per lane: a grid barrier costs ~2 us with 64 arrivers, ~7 us with 256
-    const int64_t g = reg ? (n + (int64_t)kCoopEpl * 1024 - 1) / ((int64_t)kCoopEpl * 1024) : g_mem;
+    int64_t g = reg ? (n + (int64_t)kCoopEpl * 1024 - 1) / ((int64_t)kCoopEpl * 1024) : g_mem;
+#ifdef SPX_TEST_HOOKS  // the planted fault of tests/test_gpu_robustness.py: a grid that cannot be resident
+    if (!reg && ctx->tune_force_grid > 0) g = ctx->tune_force_grid;
+#endif
     int use_set = ctx->sel_hist_next, other = use_set ^ 1;
     int clear_set = ctx->sel_hist_dirty[other] ? other : -1;
     int parity = ctx->coop_parity;
