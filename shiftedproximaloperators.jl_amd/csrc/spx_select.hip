@@ -87,17 +87,26 @@ struct FastState {
   // t_hi / t_lo are exact keys, and the elements EQUAL to them (classes "hi" / "lo") are counted per wavefront in index
   // order (ClassCount) instead of being recorded as candidates -- a class can be the whole vector.  Only keys strictly
   // between the ends remain candidates.  If the cut falls inside a class the index of its quota-th member comes from a
-  // prefix sum over the per-wave counts (k_s2_tail), and y is written by one more streaming pass: 56 B/element in all,
-  // against ~12 passes of the exact radix select (2.6-5.8 ms at n = 1e8 in round 2).
+  // prefix sum over the per-wave counts (k_s2_tail).  y: speculative stores in the main pass (spec_hi / spec_lo below) and a
+  // rewrite of the index range where the speculation was wrong; a full second streaming pass (56 B/element in all) when y
+  // aliases an input -- against ~12 passes of the exact radix select (2.6-5.8 ms at n = 1e8 in round 2).
   int tie;
   int has_hi, has_lo;             // which ends are classes (no upper end for tiny r, no lower end for r ~ n; one class if t_hi == t_lo)
   unsigned long long cls_hi, cls_lo;  // class totals (k_s2_scan_verify)
   int todo;                       // what k_s2_tail still has to do: kTodo* bits (k_s2_scan_verify, k_s2_finish)
   int tie_class;                  // kTodoTieScan: the class that holds the cut (0 = hi, 1 = lo); quota in SelState
+  // Speculative stores of the class members in the single-pass form (y disjoint from the inputs): what the SAMPLE says about
+  // the cut -- 0: the class is dropped, 1: kept, 2: the cut lies inside it, its members are kept up to index spec_cut
+  // (= the sample's share of the class above the cut, times n: exact for ties spread evenly over the vector).  Once the true
+  // cut is known k_s2_tail rewrites the index range in which the guess was wrong (a per cent of the vector on random data,
+  // everything at worst): the call moves 32 B/element plus that range instead of 56.
+  int spec_hi, spec_lo;
+  long long spec_cut;
 };
 constexpr int kTodoCandSelect = 1;  // the bucket of the first candidate digit overflows the short list: radix select over the candidates
 constexpr int kTodoTieScan = 2;     // the cut lies inside a class: find the index of its quota-th member
-constexpr int kTodoFinal = 4;       // tie mode: y is (re)written from q, xk, sj and the final thresholds by a streaming pass
+constexpr int kTodoFinal = 4;       // tie mode: y is (re)written from q, xk, sj and the final thresholds -- where the speculative
+                                    // stores of the class members were wrong (single-pass form), everywhere (y aliases an input)
 
 // totals of the main pass: fire-and-forget atomics of its wavefronts, spread over kShards counters (wave w -> shard
 // w % kShards) so that no single address serialises them; k_s2_scan_verify adds the shards up.  Round 2: 2048 shards
@@ -479,10 +488,12 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
   // atomics on n = 1e8 integers before.)  Written by the previous launch: a plain, cached load, the same in every wave.
   const int hopeless = ws->fs.overflow;   // (tested once the staging loads have landed: a test up here would hold every
   const bool crowded = ws->fs.crowded != 0;  // wave's loads back behind its scalar loads -- measured: 5 % of the pass)
-  // tie mode (FastState::tie): t_hi / t_lo are exact keys; their elements are counted (eq_hi / eq_lo), not recorded, and y is
-  // written by the streaming pass that follows the resolution (k_s2_tail / k_sel_final_q), not here
+  // tie mode (FastState::tie): t_hi / t_lo are exact keys; their elements are counted (eq_hi / eq_lo), not recorded, and
+  // stored on the sample's guess of the cut (FastState::spec_*); k_s2_tail rewrites the range where the guess was wrong
   const bool tie = ws->fs.tie != 0;
   const bool has_hi = ws->fs.has_hi != 0, has_lo = ws->fs.has_lo != 0;
+  const int spec_hi = ws->fs.spec_hi, spec_lo = ws->fs.spec_lo;
+  const int64_t spec_cut = ws->fs.spec_cut;
   unsigned int eq_hi = 0, eq_lo = 0;      // per lane
   unsigned int seq_hi[2] = {0u, 0u}, seq_lo[2] = {0u, 0u};  // the stragglers wave 0 takes along: [0] head element, [1] odd last element
   const int64_t gwave = (int64_t)blockIdx.x * 4 + wave;
@@ -510,12 +521,15 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
     const bool is_above = valid && key > t_hi;
     bool in_band = valid && !is_above && key >= t_lo;
     above += is_above ? 1u : 0u;
+    bool spec_kept = is_above;  // what the speculative store assumes about this element
     if (tie) {  // (wave-uniform) members of the classes are counted in index order, never recorded
       const bool c_hi = in_band && has_hi && key == t_hi;
       const bool c_lo = in_band && has_lo && key == t_lo;
       if (straggler < 0) { eq_hi += c_hi ? 1u : 0u; eq_lo += c_lo ? 1u : 0u; }
       else { seq_hi[straggler & 1] += c_hi ? 1u : 0u; seq_lo[straggler & 1] += c_lo ? 1u : 0u; }
       in_band = in_band && !c_hi && !c_lo;
+      if (c_hi) spec_kept = spec_hi == 1 || (spec_hi == 2 && i <= spec_cut);
+      if (c_lo) spec_kept = spec_lo == 1 || (spec_lo == 2 && i <= spec_cut);
     }
     const unsigned long long m = __ballot(in_band);
     if (m) {
@@ -560,7 +574,11 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
             dg = (unsigned int)((((uint64_t)i) >> d_shift) & d_mask);
           }
         }
-        if (!crowded && ncand < (unsigned)kWaveSlots) {  // generic data: one candidate per visit, every visit another digit
+        if (crowded) {
+          // tie mode: the keys between the band's ends may be shared by per cents of the vector too (a lattice: eight keys
+          // holding 2.4 % of n = 1e8 were 1e6 run flushes onto eight addresses, 12 ns apiece: 1.7 ms).  Nothing is histogrammed
+          // here; the radix select over the candidate records (k_s2_tail, LDS histograms per workgroup) does every digit.
+        } else if (ncand < (unsigned)kWaveSlots) {  // generic data: one candidate per visit, every visit another digit
           if (cnt) atomicAdd(&ws->hist[dg], 1ull);
         } else if (const unsigned long long cm = __ballot(cnt)) {
           const int leader = __ffsll((long long)cm) - 1;
@@ -590,7 +608,7 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
       }
       ncand += (unsigned int)__popcll(m);
     }
-    return is_above ? kept : dropped;
+    return spec_kept ? kept : dropped;
   };
   // each wave moves kMainUnroll KiB per vector through LDS (global_load_lds nt), waits once and reads back its own
   // 16-byte slots -- the staging of the separable skeleton (spx_separable.hip)
@@ -618,20 +636,20 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
     o.x = visit(valid, (b.x + c.x) + a.x, 2 * i + ioff, b.x, c.x);      // shiftedIndBallL0.jl:66  xk .+ sj .+ q
     o.y = visit(valid, (b.y + c.y) + a.y, 2 * i + 1 + ioff, b.y, c.y);
     if constexpr (WRITE) {
-      if (valid && !tie) __builtin_nontemporal_store(o, y2 + i);
+      if (valid) __builtin_nontemporal_store(o, y2 + i);
     }
   }
   if ((n & 1) && gwave == 0) {  // the odd last element rides with wave 0 (all of its lanes call visit)
     const int64_t i = n - 1;
     const double o = visit(lane == 0, (xk_[i] + sj_[i]) + q_[i], i + ioff, xk_[i], sj_[i], 1);
     if constexpr (WRITE) {
-      if (lane == 0 && !tie) y_[i] = o;
+      if (lane == 0) y_[i] = o;
     }
   }
   if (ioff && gwave == 0) {  // and so does the caller's element 0 of an 8-byte-misaligned view
     const double o = visit(lane == 0, (xk_[-1] + sj_[-1]) + q_[-1], 0, xk_[-1], sj_[-1], 0);
     if constexpr (WRITE) {
-      if (lane == 0 && !tie) y_[-1] = o;
+      if (lane == 0) y_[-1] = o;
     }
   }
   if (tie) {
@@ -770,6 +788,10 @@ __global__ __launch_bounds__(256) void k_s2_scan_verify(SelWs* ws, int64_t r) {
         s.t_eq = ~0ull;
       }
     }
+    if (ok && scan && f.crowded && s.phase != 2) {  // no digit was histogrammed by the main pass (see there): k_s2_tail does them all
+      f.todo |= kTodoCandSelect;
+      scan = false;
+    }
     f.ok = ok ? 1 : 0;
     sok = (ok && scan) ? 1 : 0;
     sst = s;
@@ -788,8 +810,8 @@ __global__ __launch_bounds__(256) void k_s2_compact(double* y, const Cand* cand,
                                                      int64_t* list_idx, double* list_val, const WaveCount* counts,
                                                      int64_t nregions, unsigned int ovf_cap) {
   const SelState st = ws->st;
-  if (!ws->fs.ok) return;
-  const bool wr = WRITE && !ws->fs.tie;  // (tie mode: y is written by the final streaming pass, from the thresholds alone)
+  if (!ws->fs.ok || (ws->fs.todo & kTodoCandSelect)) return;
+  const bool wr = WRITE;
   if (!wr && st.phase == 2) return;
   const int hs = st.shift + st.width;
   const unsigned int novf = ws->fs.ovf_count < ovf_cap ? ws->fs.ovf_count : ovf_cap;
@@ -837,7 +859,7 @@ __global__ __launch_bounds__(1024) void k_s2_finish(double* y, SelWs* ws, const 
   __shared__ unsigned long long scratch[8];
   __shared__ SelState sst;
   const int t = threadIdx.x;
-  if (!ws->fs.ok) return;
+  if (!ws->fs.ok || (ws->fs.todo & kTodoCandSelect)) return;
   if (t == 0) sst = ws->st;
   __syncthreads();
   if (sst.phase == 2) return;
@@ -872,7 +894,7 @@ __global__ __launch_bounds__(1024) void k_s2_finish(double* y, SelWs* ws, const 
   }
   __syncthreads();
   if (t == 0) ws->st = sst;
-  if (WRITE && !ws->fs.tie) {  // the short-list entries that made the cut (everything above it was stored by k_s2_compact)
+  if (WRITE) {  // the short-list entries that made the cut (everything above it was stored by k_s2_compact)
     const SelState fin = sst;
     for (unsigned int e = t; e < m; e += 1024) {
       const uint64_t key = lk[e];
@@ -1338,7 +1360,7 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
     __syncthreads();
     const SelState fin = sh.sst;
     if (b == 0 && t == 0) ss->ws.st = fin;  // (every workgroup read the old state before the first rendezvous above)
-    if (write && !tie && !spx_poisoned(hdr)) {
+    if (write && !spx_poisoned(hdr)) {
       // the candidates that make the cut (k_s2_compact stored those above the first digit's bucket; storing them again is harmless)
       for_each_candidate(counts, nregions, cand, (int64_t)novf, [&](uint64_t key, int64_t i, double val) {
         if ((key >= fin.t_ge) || (key == fin.t_eq && i <= fin.icut)) y[i] = val;
@@ -1434,48 +1456,71 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
   }
   __syncthreads();
   if ((todo & kTodoFinal) && write) {
-    // y from q, xk, sj and the final thresholds; 16-byte pairs of the aligned rest, 4 in flight per lane and vector
-    SelState fin = sh.sst;
+    // The main pass stored the class members on the sample's guess of the cut (FastState::spec_*); now the cut is known.
+    // Both rules are "kept up to an index c" per class (c = -1: none, n - 1: all): the guess was wrong on (min(c_spec,
+    // c_true), max(..)] -- that index range is rewritten from q, xk, sj and the final thresholds, every element of it (the
+    // candidates in it get the value the candidate kernels gave them).  Evenly spread ties: ~1 % of the vector.
+    const SelState fin = sh.sst;
     const bool poisoned = spx_poisoned(hdr);
     auto P = [&](double val) -> double { return poisoned ? __longlong_as_double(0x7ff8000000000000ll) : val; };
-    const double* qa = q + ioff; const double* xa = xk + ioff; const double* sa = sj + ioff; double* ya = y + ioff;
-    const int64_t nrest = n - ioff, n2 = nrest >> 1;
-    const bool vec2 = ((reinterpret_cast<uintptr_t>(ya) | reinterpret_cast<uintptr_t>(qa) | reinterpret_cast<uintptr_t>(xa) |
-                        reinterpret_cast<uintptr_t>(sa)) & 15u) == 0;
-    if (vec2) {
-      const f64x2* q2 = reinterpret_cast<const f64x2*>(qa);
-      const f64x2* x2 = reinterpret_cast<const f64x2*>(xa);
-      const f64x2* s2 = reinterpret_cast<const f64x2*>(sa);
-      f64x2* y2 = reinterpret_cast<f64x2*>(ya);
-      constexpr int KP = 4;
-      const int64_t ntiles = (n2 + 1024 * KP - 1) / (1024 * KP);
-      for (int64_t tile = b; tile < ntiles; tile += G) {
-        f64x2 a[KP], bb[KP], c[KP];
+    int64_t flo = n, fhi = -1;  // caller's indices, inclusive
+    auto mismatch = [&](int has, uint64_t key, int spec) {
+      if (!has) return;
+      const int64_t ca = key >= fin.t_ge ? n - 1 : (key == fin.t_eq ? fin.icut : (int64_t)-1);
+      int64_t cs = spec == 1 ? n - 1 : (spec == 2 ? (int64_t)ss->ws.fs.spec_cut : (int64_t)-1);
+      cs = cs < -1 ? -1 : (cs > n - 1 ? n - 1 : cs);
+      if (ca == cs) return;
+      const int64_t lo = (ca < cs ? ca : cs) + 1, hi = ca < cs ? cs : ca;
+      flo = lo < flo ? lo : flo;
+      fhi = hi > fhi ? hi : fhi;
+    };
+    mismatch(ss->ws.fs.has_hi, ss->ws.fs.t_hi, ss->ws.fs.spec_hi);
+    mismatch(ss->ws.fs.has_lo, ss->ws.fs.t_lo, ss->ws.fs.spec_lo);
+    if (poisoned) { flo = 0; fhi = n - 1; }
+    if (fhi >= flo) {
+      const double* qa = q + ioff; const double* xa = xk + ioff; const double* sa = sj + ioff; double* ya = y + ioff;
+      const int64_t nrest = n - ioff, n2 = nrest >> 1;
+      // pairs of the aligned rest that overlap [flo, fhi]: elements 2p + ioff, 2p + 1 + ioff
+      const int64_t e0 = flo - ioff < 0 ? 0 : flo - ioff, e1 = fhi - ioff;
+      const int64_t plo = e0 >> 1, phi = (e1 >> 1) < n2 - 1 ? (e1 >> 1) : n2 - 1;
+      const bool vec2 = ((reinterpret_cast<uintptr_t>(ya) | reinterpret_cast<uintptr_t>(qa) | reinterpret_cast<uintptr_t>(xa) |
+                          reinterpret_cast<uintptr_t>(sa)) & 15u) == 0;
+      if (vec2 && e1 >= 0 && phi >= plo) {
+        const f64x2* q2 = reinterpret_cast<const f64x2*>(qa);
+        const f64x2* x2 = reinterpret_cast<const f64x2*>(xa);
+        const f64x2* s2 = reinterpret_cast<const f64x2*>(sa);
+        f64x2* y2 = reinterpret_cast<f64x2*>(ya);
+        constexpr int KP = 4;
+        const int64_t np = phi - plo + 1;
+        const int64_t ntiles = (np + 1024 * KP - 1) / (1024 * KP);
+        for (int64_t tile = b; tile < ntiles; tile += G) {
+          f64x2 a[KP], bb[KP], c[KP];
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-          int64_t i = tile * (1024 * KP) + k * 1024 + t;
-          if (i >= n2) i = n2 - 1;
-          a[k] = __builtin_nontemporal_load(q2 + i);
-          bb[k] = __builtin_nontemporal_load(x2 + i);
-          c[k] = __builtin_nontemporal_load(s2 + i);
-        }
+          for (int k = 0; k < KP; ++k) {
+            int64_t i = plo + tile * (1024 * KP) + k * 1024 + t;
+            if (i > phi) i = phi;
+            a[k] = __builtin_nontemporal_load(q2 + i);
+            bb[k] = __builtin_nontemporal_load(x2 + i);
+            c[k] = __builtin_nontemporal_load(s2 + i);
+          }
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-          const int64_t i = tile * (1024 * KP) + k * 1024 + t;
-          if (i < n2) {
-            f64x2 o;
-            o.x = P(sel_out<BINF>((bb[k].x + c[k].x) + a[k].x, 2 * i + ioff, bb[k].x, c[k].x, fin, delta));
-            o.y = P(sel_out<BINF>((bb[k].y + c[k].y) + a[k].y, 2 * i + 1 + ioff, bb[k].y, c[k].y, fin, delta));
-            __builtin_nontemporal_store(o, y2 + i);
+          for (int k = 0; k < KP; ++k) {
+            const int64_t i = plo + tile * (1024 * KP) + k * 1024 + t;
+            if (i <= phi) {
+              f64x2 o;
+              o.x = P(sel_out<BINF>((bb[k].x + c[k].x) + a[k].x, 2 * i + ioff, bb[k].x, c[k].x, fin, delta));
+              o.y = P(sel_out<BINF>((bb[k].y + c[k].y) + a[k].y, 2 * i + 1 + ioff, bb[k].y, c[k].y, fin, delta));
+              __builtin_nontemporal_store(o, y2 + i);
+            }
           }
         }
+      } else if (!vec2) {  // (the pipeline only runs on aligned vectors; kept for safety)
+        for (int64_t i = flo + gt; i <= fhi; i += nt) y[i] = P(sel_out<BINF>((xk[i] + sj[i]) + q[i], i, xk[i], sj[i], fin, delta));
       }
-      if (gt == 0) {
-        if (nrest & 1) { const int64_t i = n - 1; y[i] = P(sel_out<BINF>((xk[i] + sj[i]) + q[i], i, xk[i], sj[i], fin, delta)); }
-        if (ioff) y[0] = P(sel_out<BINF>((xk[0] + sj[0]) + q[0], 0, xk[0], sj[0], fin, delta));
+      if (gt == 0) {  // the stragglers wave 0 of the main pass took along
+        if ((nrest & 1) && fhi == n - 1) { const int64_t i = n - 1; y[i] = P(sel_out<BINF>((xk[i] + sj[i]) + q[i], i, xk[i], sj[i], fin, delta)); }
+        if (ioff && flo == 0) y[0] = P(sel_out<BINF>((xk[0] + sj[0]) + q[0], 0, xk[0], sj[0], fin, delta));
       }
-    } else {
-      for (int64_t i = gt; i < n; i += nt) y[i] = P(sel_out<BINF>((xk[i] + sj[i]) + q[i], i, xk[i], sj[i], fin, delta));
     }
   }
 }
@@ -1501,6 +1546,7 @@ template <int kFrontSpl>
 __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double* xk, const double* sj, int64_t n, int64_t r,
                                                     SelSync* ss, int parity) {
   __shared__ unsigned int lh[kBins];
+  __shared__ unsigned int lh1[kBins];        // (digits 2..: the second rank's histogram)
   __shared__ unsigned long long part[4][4];  // per 256-lane group
   __shared__ unsigned long long pre[2];
   __shared__ long long quo[2];
@@ -1635,14 +1681,24 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     // both ranks in the same bucket so far (the usual case: the band is narrow): ONE histogram serves both selections -- half
     // the global atomics of this phase (the barrier behind it waits for them: 9 us)
     const bool shared = active[0] && active[1] && pre[0] == pre[1];
-    // (wave-aggregated: on tie-heavy data every sample of the selected bucket carries the same digit -- 262 144 global
-    //  atomics on one address were 3.3 ms)
+    // (aggregated per WORKGROUP in LDS before they reach the global histogram: on tie-heavy data every sample of the selected
+    //  bucket carries the same digit -- 262 144 global atomics on one address were 3.3 ms in round 2, one per wavefront still
+    //  50 us per digit: atomics on one address retire ~12 ns apart; now 64 per address)
+    __syncthreads();
+    for (int bb = t; bb < kBins; bb += 1024) { lh[bb] = 0u; lh1[bb] = 0u; }
+    __syncthreads();
 #pragma unroll
     for (int sidx = 0; sidx < kFrontSpl; ++sidx) {
       const uint64_t top = keys[sidx] >> hs;
       const unsigned d = (unsigned)((keys[sidx] >> shift) & (((uint64_t)1 << width) - 1));
-      hist_add_agg(ss->fhist2[digit - 1][0], d, active[0] && top == pre[0]);
-      if (!shared) hist_add_agg(ss->fhist2[digit - 1][1], d, active[1] && top == pre[1]);
+      hist_add_agg(lh, d, active[0] && top == pre[0]);
+      if (!shared) hist_add_agg(lh1, d, active[1] && top == pre[1]);
+    }
+    __syncthreads();
+    for (int bb = t; bb < kBins; bb += 1024) {
+      const unsigned int c0 = lh[bb], c1 = lh1[bb];
+      if (c0) atomicAdd(&ss->fhist2[digit - 1][0][bb], (unsigned long long)c0);
+      if (c1) atomicAdd(&ss->fhist2[digit - 1][1][bb], (unsigned long long)c1);
     }
     SEL_STAMP(2 + 2 * digit);
     spx_grid_barrier(bar, (++nbar) * gridDim.x, &ss->hdr);
@@ -1685,9 +1741,24 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     f.cls_hi = f.cls_lo = 0ull;
     f.todo = 0;
     f.tie_class = 0;
+    f.spec_hi = 1;   // (without a cut inside it, class hi lies above the cut and class lo below)
+    f.spec_lo = 0;
+    f.spec_cut = -1;
+    if (tie) {
+      // where the sample puts the cut: its rank in the sample is p M; `sabove` samples lie above a class of `m` samples
+      const double M = (double)(kFrontBlocks * 1024 * kFrontSpl);
+      const double kcut = (double)r / (double)n * M;
+      auto guess = [&](double sabove, double m, int& spec) {
+        if (kcut <= sabove) spec = 0;
+        else if (kcut >= sabove + m) spec = 1;
+        else { spec = 2; f.spec_cut = (long long)((kcut - sabove) / m * (double)n); }
+      };
+      if (f.has_hi) guess((double)(rank0[0] - quo[0]), (double)bucket[0], f.spec_hi);
+      if (f.has_lo) guess((double)(rank0[1] - quo[1]), (double)bucket[1], f.spec_lo);
+    }
     // (generic data ends on <= kPickFine kFrontSpl samples per bucket, or far fewer after a third digit; in tie mode the keys
     //  BETWEEN the ends may be shared by many elements too: their digits are counted in runs as well)
-    f.crowded = (tie || bucket[0] > 4u * kPickFine * kFrontSpl || bucket[1] > 4u * kPickFine * kFrontSpl) ? 1 : 0;
+    f.crowded = tie;
     f.list_count = 0;
     SelState& s = ws->st;
     sel_state_init(s, n, r);

@@ -10,7 +10,7 @@ s = ge.build(); L = s._lib.load(); ctx = s.context("cuda:0")
 n = int(float(os.environ.get("SPX_N", "1e8")))
 g = torch.Generator(device="cuda:0").manual_seed(int(os.environ.get("SPX_SEED", "1")))
 q0 = torch.randn(n, dtype=torch.float64, device="cuda:0", generator=g)
-z = torch.zeros(n, dtype=torch.float64, device="cuda:0"); y = torch.empty_like(q0); yref = torch.empty_like(q0)
+z = torch.zeros(n, dtype=torch.float64, device="cuda:0"); z2 = torch.zeros_like(z); y = torch.empty_like(q0); yref = torch.empty_like(q0)
 kinds = os.environ.get("SPX_KINDS", "continuous,lattice 1/4,lattice 1,lattice 2^-8,two values,constant,90% zeros,sorted lattice").split(",")
 for kind in kinds:
     if kind == "continuous": q = q0
@@ -24,7 +24,7 @@ for kind in kinds:
     else: q = torch.full_like(q0, 2.0)
     rs = [int(float(v)) for v in os.environ.get("SPX_RS", "%d,%d,%d" % (n // 100, n // 2, n - n // 20)).split(",")]
     for r in rs:
-        psi = s.shifted(s.shifted(s.IndBallL0(r), z, 1.0, s.NormLinf(1.0)), z)
+        psi = s.shifted(s.shifted(s.IndBallL0(r), z, 1.0, s.NormLinf(1.0)), z2)   # (xk and sj in buffers of their own: honest traffic)
         L.spx_ctx_set_tuning(ctx, 2, 0)
         s.prox_bang(yref, psi, q, 1.0)
         L.spx_ctx_set_tuning(ctx, 2, 1)
