@@ -503,7 +503,7 @@ enum { BINF_ZERO = 0, BINF_ROOT = 1, BINF_LITERAL = 2 };
 // (:102-103);  BINF_LITERAL: degenerate bracket / exact zero at an end / NaN -> the caller must run binf_literal_root.
 template <int TEAM, class G>
 __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma, double delta, double* lds,
-                                         double& root_u) {
+                                         double& root_u, bool pole_lit) {
   const double eps = 2.220446049250313e-16;
   const double sl = lam * sigma;          // :85
   const double lmin = sl * (1 + eps);     // :94
@@ -716,6 +716,11 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
 #endif
   }
   root_u = fmin(fmax(u, ul), lmax - sl);  // inside the reference's bracket [lmin, lmax]
+  // spx_ctx_set_tuning key 9 (pole_lit): a root next to the pole of step(n) (u < n / 1000) is where the reference's own
+  // Float64 evaluation is up to 4.5e-9 of the scale off its formula (n - sigma lambda and 1 - sigma lambda / ||w|| cancel);
+  // the closed form above is the accurate side, the literal evaluation reproduces the reference's doubles -- for callers
+  // who must reproduce a reference run (src/shiftedGroupNormL2Binf.jl:105-113)
+  if (pole_lit && root_u * 1000.0 < sl + root_u) return BINF_LITERAL;
   return BINF_ROOT;
 }
 
@@ -750,7 +755,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
                                                     double sigma, double delta,
                                                     long long* deferred /* [0] = count, [1..] = groups */,
                                                     const int64_t* __restrict__ offsets /* !PAIRS only: ragged groups */,
-                                                    int* status /* spx_ctx::status_dev */) {
+                                                    int* status /* spx_ctx::status_dev */, int pole_lit /* tuning key 9 */) {
   static_assert((EPL % 2) == 0, "EPL must be even (16-byte pairs)");
   const int64_t GS = gsize;  // <= LPG * EPL
   constexpr int GPW = 64 / LPG;  // groups per wave
@@ -886,7 +891,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
       for (int k = 0; k < EPL; ++k) out[k] = out[k] - grp.XS[k];  // :116
     } else {
       double ru;
-      const int status = binf_root<LPG>(grp, lam, sigma, delta, nullptr, ru);
+      const int status = binf_root<LPG>(grp, lam, sigma, delta, nullptr, ru, pole_lit != 0);
       const double sl = lam * sigma;
       if (status == BINF_LITERAL) {
         // rare (degenerate bracket / exact zero / NaN): handed to k_group_list, which evaluates the reference's
@@ -963,7 +968,7 @@ struct GatherGroup {
 
 template <int TEAM, bool BINF, class GRP>
 __device__ __forceinline__ void group_body(const GRP& grp, double* y, double lam, double sigma, double delta, double* lds,
-                                           bool literal_only) {
+                                           bool literal_only, bool pole_lit) {
   if constexpr (!BINF) {
     double ss = 0.0;
     grp.for_each([&](double S, double) { ss += S * S; });
@@ -972,7 +977,7 @@ __device__ __forceinline__ void group_body(const GRP& grp, double* y, double lam
     grp.store(y, [&](double S, double) { return (snorm == 0.0) ? 0.0 : alpha * S; });
   } else {
     double root, ru = 0.0;
-    int status = literal_only ? BINF_LITERAL : binf_root<TEAM>(grp, lam, sigma, delta, lds, ru);
+    int status = literal_only ? BINF_LITERAL : binf_root<TEAM>(grp, lam, sigma, delta, lds, ru, pole_lit);
     const double sl = lam * sigma;
     if (status == BINF_LITERAL) {
       // the reference, literally, including its last step (:106-113) -- the root may lie below sl here
@@ -1006,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, c
                                                     int64_t n, const int64_t* __restrict__ offsets, int64_t gsize,
                                                     int64_t ngroups, const double* __restrict__ lambda, double sigma,
                                                     double delta, const long long* list /* NULL, or [0] = count, [1..] */,
-                                                    int* status /* spx_ctx::status_dev */) {
+                                                    int* status /* spx_ctx::status_dev */, int pole_lit) {
   __shared__ double lds[8];
   constexpr int TPB = 256 / TEAM;  // teams per block
   const int lane = threadIdx.x % TEAM;
@@ -1028,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, c
     if (lo < 0) lo = 0;
     if (hi > n) hi = n;
     MemGroup<TEAM> grp{q, xk, sj, lo, hi, lane};
-    group_body<TEAM, BINF>(grp, y, lambda[g], sigma, delta, lds, list != nullptr);
+    group_body<TEAM, BINF>(grp, y, lambda[g], sigma, delta, lds, list != nullptr, pole_lit != 0);
     if constexpr (TEAM == 256) __syncthreads();
   }
 }
@@ -1067,7 +1072,7 @@ __global__ __launch_bounds__(256) void k_group_lds(double* y, const double* q, c
                                                     int64_t n, const int64_t* __restrict__ offsets /* NULL: uniform */,
                                                     int64_t gsize /* group size, or the bound on it with offsets */,
                                                     int64_t ngroups, const double* __restrict__ lambda, double sigma,
-                                                    double delta) {
+                                                    double delta, int pole_lit) {
   extern __shared__ __attribute__((aligned(16))) double dyn[];  // S[gsize] | X[gsize]
   __shared__ double lds[8];
   double* S = dyn;
@@ -1083,7 +1088,7 @@ __global__ __launch_bounds__(256) void k_group_lds(double* y, const double* q, c
       sz = hi > lo ? hi - lo : 0;
       if (sz > gsize) {  // the caller's bound was wrong for this group: straight from memory, as the general kernel
         MemGroup<256> big{q, xk, sj, lo, hi, tid};
-        group_body<256, BINF>(big, y, lambda[g], sigma, delta, lds, false);
+        group_body<256, BINF>(big, y, lambda[g], sigma, delta, lds, false, pole_lit != 0);
         __syncthreads();
         continue;
       }
@@ -1096,7 +1101,7 @@ __global__ __launch_bounds__(256) void k_group_lds(double* y, const double* q, c
     }
     __syncthreads();  // the group is staged (and q fully read: y may alias q)
     LdsGroup grp{S, X, sj + lo, lo, m, tid};
-    group_body<256, BINF>(grp, y, lambda[g], sigma, delta, lds, false);
+    group_body<256, BINF>(grp, y, lambda[g], sigma, delta, lds, false, pole_lit != 0);
     __syncthreads();  // all reads of S / X done before the next group overwrites them
   }
 }
@@ -1150,7 +1155,8 @@ template <int TEAM, bool BINF>
 __global__ __launch_bounds__(256) void k_group_gather(double* y, const double* sol, const double* xk, const double* sj,
                                                        const int* owner, const int64_t* __restrict__ ptr,
                                                        const int64_t* __restrict__ index, int64_t ngroups,
-                                                       const double* __restrict__ lambda, double sigma, double delta) {
+                                                       const double* __restrict__ lambda, double sigma, double delta,
+                                                       int pole_lit) {
   __shared__ double lds[8];
   constexpr int TPB = 256 / TEAM;
   const int lane = threadIdx.x % TEAM;
@@ -1158,7 +1164,7 @@ __global__ __launch_bounds__(256) void k_group_gather(double* y, const double* s
   const int64_t nteams = (int64_t)gridDim.x * TPB;
   for (int64_t g = team; g < ngroups; g += nteams) {
     GatherGroup<TEAM> grp{sol, xk, sj, index, owner, ptr[g], ptr[g + 1], lane, (int)g};
-    group_body<TEAM, BINF>(grp, y, lambda[g], sigma, delta, lds, false);
+    group_body<TEAM, BINF>(grp, y, lambda[g], sigma, delta, lds, false, pole_lit != 0);
     if constexpr (TEAM == 256) __syncthreads();
   }
 }
@@ -1238,13 +1244,13 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   do {                                                                                                              \
     if (pairs && gsize == (LPG) * (EPL))                                                                            \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, true, false, true>), grid, block, 0, ctx->stream, y, q, xk, sj, \
-                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev); \
+                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal); \
     else if (pairs)                                                                                                 \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, true>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,   \
-                         (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev);    \
+                         (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal);    \
     else                                                                                                            \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, false>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,  \
-                         (int)gsize, lambda, sigma, delta, deferred, ragged_reg ? offsets : (const int64_t*)nullptr, ctx->status_dev); \
+                         (int)gsize, lambda, sigma, delta, deferred, ragged_reg ? offsets : (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal); \
   } while (0)
     if (lpg == 4 && epl == 4) { if constexpr (BINF) SPX_LAUNCH_REG(4, 4); }
     else if (lpg == 4 && epl == 8) { if constexpr (BINF) SPX_LAUNCH_REG(4, 8); }
@@ -1268,10 +1274,10 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   do {                                                                                                               \
     if (pairs)                                                                                                       \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, true, true, true>), lgrid, block, 0, ctx->stream, y, q, xk, sj,      \
-                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev); \
+                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal); \
     else                                                                                                             \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, true, false, true>), lgrid, block, 0, ctx->stream, y, q, xk, sj,     \
-                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev); \
+                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal); \
   } while (0)
         if (lpg == 4 && epl == 4) SPX_LAUNCH_LIT(4, 4);
         else if (lpg == 4) SPX_LAUNCH_LIT(4, 8);
@@ -1287,7 +1293,7 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     if (BINF || ragged_reg) {  // usually an empty list: the kernel returns at once
       hipLaunchKernelGGL((k_group_mem<64, BINF>), dim3((unsigned)(ctx->num_cu * 2)), dim3(256), 0, ctx->stream, y, q, xk,
                          sj, n, ragged_reg ? offsets : (const int64_t*)nullptr, gsize, ngroups, lambda, sigma, delta,
-                         (const long long*)deferred, ctx->status_dev);
+                         (const long long*)deferred, ctx->status_dev, ctx->tune_binf_literal);
     }
     SPX_LAUNCH_CHECK();
     return SPX_OK;
@@ -1305,7 +1311,7 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsGroupMax * 2 * (int)sizeof(double)));
     int64_t blocks = ngroups < cap_blocks ? ngroups : cap_blocks;
     hipLaunchKernelGGL((k_group_lds<BINF>), dim3((unsigned)blocks), dim3(256), dyn, ctx->stream, y, q, xk, sj, n, offsets,
-                       gsize, ngroups, lambda, sigma, delta);
+                       gsize, ngroups, lambda, sigma, delta, ctx->tune_binf_literal);
     SPX_LAUNCH_CHECK();
     return SPX_OK;
   }
@@ -1316,11 +1322,11 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     int64_t blocks = (ngroups + 3) / 4;
     if (blocks > cap_blocks) blocks = cap_blocks;
     hipLaunchKernelGGL((k_group_mem<64, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n,
-                       offsets, gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr, ctx->status_dev);
+                       offsets, gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr, ctx->status_dev, ctx->tune_binf_literal);
   } else {
     int64_t blocks = ngroups < cap_blocks ? ngroups : cap_blocks;
     hipLaunchKernelGGL((k_group_mem<256, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n,
-                       offsets, gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr, ctx->status_dev);
+                       offsets, gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr, ctx->status_dev, ctx->tune_binf_literal);
   }
   SPX_LAUNCH_CHECK();
   return SPX_OK;
@@ -1384,11 +1390,11 @@ static int run_group_gather(spx_ctx* ctx, double* y, const double* q, const doub
     const double avg = (double)nnz / (double)ngroups;
     if (avg <= 2048.0) {
       hipLaunchKernelGGL((k_group_gather<64, BINF>), dim3((unsigned)gb), dim3(256), 0, ctx->stream, y, sol, xk, sj, owner,
-                         ptr, index, ngroups, lambda, sigma, delta);
+                         ptr, index, ngroups, lambda, sigma, delta, ctx->tune_binf_literal);
     } else {
       int64_t blocks = ngroups < cap_blocks ? ngroups : cap_blocks;
       hipLaunchKernelGGL((k_group_gather<256, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, sol, xk, sj,
-                         owner, ptr, index, ngroups, lambda, sigma, delta);
+                         owner, ptr, index, ngroups, lambda, sigma, delta, ctx->tune_binf_literal);
     }
   }
   // :77 subtracts the shift at EVERY index; the Binf form does so per group (:116) and leaves the rest of y alone
