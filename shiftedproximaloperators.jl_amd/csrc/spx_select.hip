@@ -12,6 +12,8 @@
 // Three forms, by size (run_select): one workgroup (k_sel_small), one launch of a resident grid that synchronises inside
 // itself (k_sel_coop), and the sample-predicted single streaming pass (k_s2_front / k_s2_main / candidate kernels) with
 // k_sel_coop queued behind it as the exact fallback.  (Round 1's multi-launch pipelines, which read a verdict back, are gone.)
+#include <type_traits>
+
 #include "spx_common.hpp"
 
 namespace {
@@ -489,16 +491,36 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
   const int hopeless = ws->fs.overflow;   // (tested once the staging loads have landed: a test up here would hold every
   const bool crowded = ws->fs.crowded != 0;  // wave's loads back behind its scalar loads -- measured: 5 % of the pass)
   // tie mode (FastState::tie): t_hi / t_lo are exact keys; their elements are counted (eq_hi / eq_lo), not recorded, and
-  // stored on the sample's guess of the cut (FastState::spec_*); k_s2_tail rewrites the range where the guess was wrong
-  const bool tie = ws->fs.tie != 0;
+  // stored on the sample's guess of the cut (FastState::spec_*); k_s2_tail rewrites the range where the guess was wrong.
+  // The processing part below exists TWICE in this kernel, with the tie code compiled in and out (body(tag)), behind one
+  // wave-uniform branch taken after the staging loads have landed: as a run-time `if (tie)` inside the per-element code
+  // it cost the generic path 12-25 us of the pass (measured A/B: r = n/100 0.600 -> 0.588 ms, r = n/2 0.661 -> 0.636).
+  const bool tie_mode = ws->fs.tie != 0;
   const bool has_hi = ws->fs.has_hi != 0, has_lo = ws->fs.has_lo != 0;
   const int spec_hi = ws->fs.spec_hi, spec_lo = ws->fs.spec_lo;
   const int64_t spec_cut = ws->fs.spec_cut;
-  unsigned int eq_hi = 0, eq_lo = 0;      // per lane
-  unsigned int seq_hi[2] = {0u, 0u}, seq_lo[2] = {0u, 0u};  // the stragglers wave 0 takes along: [0] head element, [1] odd last element
   const int64_t gwave = (int64_t)blockIdx.x * 4 + wave;
   const int64_t rbase = gwave * kWaveSlots;  // this wave's candidate region
   const unsigned long long lt_mask = (1ull << lane) - 1;
+  // each wave moves kMainUnroll KiB per vector through LDS (global_load_lds nt), waits once and reads back its own
+  // 16-byte slots -- the staging of the separable skeleton (spx_separable.hip)
+  char* wl = dma + wave * (3 * UNROLL * 1024);
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int64_t wbase = gwave * (64 * UNROLL) + lane;
+#pragma unroll
+  for (int k = 0; k < UNROLL; ++k) {
+    int64_t i = wbase + k * 64;
+    if (i >= n2) i = n2 - 1;
+    __builtin_amdgcn_global_load_lds((const void*)(q + i), (lds_void*)(wl + (0 * UNROLL + k) * 1024), 16, 0, 2);
+    __builtin_amdgcn_global_load_lds((const void*)(xk + i), (lds_void*)(wl + (1 * UNROLL + k) * 1024), 16, 0, 2);
+    __builtin_amdgcn_global_load_lds((const void*)(sj + i), (lds_void*)(wl + (2 * UNROLL + k) * 1024), 16, 0, 2);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (hopeless) return;
+  auto body = [&](auto tie_tag) {
+  constexpr bool tie = decltype(tie_tag)::value;
+  unsigned int eq_hi = 0, eq_lo = 0;      // per lane
+  unsigned int seq_hi[2] = {0u, 0u}, seq_lo[2] = {0u, 0u};  // the stragglers wave 0 takes along: [0] head element, [1] odd last element
   unsigned int above = 0;   // per lane
   unsigned int ncand = 0;   // wave-uniform
   // wave-uniform: the runs of candidate digits being counted (ties, see visit)
@@ -522,7 +544,7 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
     bool in_band = valid && !is_above && key >= t_lo;
     above += is_above ? 1u : 0u;
     bool spec_kept = is_above;  // what the speculative store assumes about this element
-    if (tie) {  // (wave-uniform) members of the classes are counted in index order, never recorded
+    if constexpr (tie) {  // members of the classes are counted in index order, never recorded
       const bool c_hi = in_band && has_hi && key == t_hi;
       const bool c_lo = in_band && has_lo && key == t_lo;
       if (straggler < 0) { eq_hi += c_hi ? 1u : 0u; eq_lo += c_lo ? 1u : 0u; }
@@ -574,7 +596,7 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
             dg = (unsigned int)((((uint64_t)i) >> d_shift) & d_mask);
           }
         }
-        if (crowded) {
+        if (tie || crowded) {
           // tie mode: the keys between the band's ends may be shared by per cents of the vector too (a lattice: eight keys
           // holding 2.4 % of n = 1e8 were 1e6 run flushes onto eight addresses, 12 ns apiece: 1.7 ms).  Nothing is histogrammed
           // here; the radix select over the candidate records (k_s2_tail, LDS histograms per workgroup) does every digit.
@@ -610,21 +632,6 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
     }
     return spec_kept ? kept : dropped;
   };
-  // each wave moves kMainUnroll KiB per vector through LDS (global_load_lds nt), waits once and reads back its own
-  // 16-byte slots -- the staging of the separable skeleton (spx_separable.hip)
-  char* wl = dma + wave * (3 * UNROLL * 1024);
-  typedef __attribute__((address_space(3))) void lds_void;
-  const int64_t wbase = gwave * (64 * UNROLL) + lane;
-#pragma unroll
-  for (int k = 0; k < UNROLL; ++k) {
-    int64_t i = wbase + k * 64;
-    if (i >= n2) i = n2 - 1;
-    __builtin_amdgcn_global_load_lds((const void*)(q + i), (lds_void*)(wl + (0 * UNROLL + k) * 1024), 16, 0, 2);
-    __builtin_amdgcn_global_load_lds((const void*)(xk + i), (lds_void*)(wl + (1 * UNROLL + k) * 1024), 16, 0, 2);
-    __builtin_amdgcn_global_load_lds((const void*)(sj + i), (lds_void*)(wl + (2 * UNROLL + k) * 1024), 16, 0, 2);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (hopeless) return;
 #pragma unroll
   for (int k = 0; k < UNROLL; ++k) {
     const int64_t i = wbase + k * 64;
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
       if (lane == 0) y_[-1] = o;
     }
   }
-  if (tie) {
+  if constexpr (tie) {
     for (int off = 32; off >= 1; off >>= 1) { eq_hi += __shfl_xor(eq_hi, off, 64); eq_lo += __shfl_xor(eq_lo, off, 64); }
     if (lane == 0) {
       cls[1 + gwave] = ClassCount{eq_hi, eq_lo};
@@ -684,8 +691,10 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
       if (above) atomicAdd(&ws->shard_above[shard], (unsigned long long)above);
       if (ncand) atomicAdd(&ws->shard_cand[shard], (unsigned long long)ncand);
     }
-
   }
+  };  // body
+  if (tie_mode) body(std::true_type{});
+  else body(std::false_type{});
 }
 
 // Candidate kernels walk the regions TRANSPOSED: a wavefront takes 64 regions at a time, lane l owns region w0 + l and

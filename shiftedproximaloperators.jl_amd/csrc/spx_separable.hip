@@ -420,8 +420,19 @@ __device__ __forceinline__ double block_sum4(double v, double* lds4) {  // 256-l
 __global__ __launch_bounds__(1024) void k_value_reduce(const double* partials, int64_t count, double* out, double scale,
                                                         double* target) {
   __shared__ double lds[16];
-  double acc = 0.0;
-  for (int64_t i = threadIdx.x; i < count; i += 1024) acc += partials[i];
+  // eight independent loads in flight per lane, added in a fixed order (reproducible run to run)
+  double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int64_t i0 = threadIdx.x; i0 < count; i0 += 8 * 1024) {
+    double v8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t i = i0 + (int64_t)k * 1024;
+      v8[k] = (i < count) ? partials[i < count ? i : 0] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a8[k] += v8[k];
+  }
+  double acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -573,7 +584,12 @@ __global__ __launch_bounds__(256) void k_sep_lds(double* y_, const double* q_, c
   int64_t bid = blockIdx.x;
   if (xcd_chunk > 0) {
     bid = (int64_t)(blockIdx.x & 7) * xcd_chunk + (blockIdx.x >> 3);
-    if (bid * (256 * UNROLL) >= n2) return;
+    if (bid * (256 * UNROLL) >= n2) {
+      if constexpr (Op::kObj) {
+        if (threadIdx.x == 0) op.partials[bid] = 0.0;  // (a slot of its own: every slot the host counts is written)
+      }
+      return;
+    }
   }
   const int64_t base = (bid * 4 + wave) * (64 * UNROLL) + lane;  // this lane's first pair
   double hacc = 0.0;
@@ -617,8 +633,17 @@ __global__ __launch_bounds__(256) void k_sep_lds(double* y_, const double* q_, c
     if (i < n2) __builtin_nontemporal_store(r, y + i);
   }
   if constexpr (Op::kObj) {
+    // one partial per WORKGROUP (round 3; round 2 wrote one per wavefront: 130 208 of them at n = 1e8, and the ordered
+    // reduction behind the pass cost ~25 us of the fused call).  The wave's staging area has been consumed: its first 8 bytes
+    // carry the wave's sum to lane 0 of the workgroup, which adds the four in a fixed order.
     const double t = wave_sum(hacc);
-    if (lane == 0) op.partials[bid * 4 + wave] = t;  // every wave of the grid writes its slot (0 for an idle tail wave)
+    if (lane == 0) *reinterpret_cast<double*>(wl) = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double* w0 = reinterpret_cast<const double*>(lds);
+      constexpr int stride = NARR * UNROLL * 1024 / 8;
+      op.partials[bid] = (w0[0] + w0[stride]) + (w0[2 * stride] + w0[3 * stride]);
+    }
   }
 }
 
@@ -664,12 +689,12 @@ static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d,
     // 3 input vectors: 6 KiB per wave and vector -> 72 KiB per workgroup; 5 vectors (vector bounds): 3 KiB -> 60 KiB
     constexpr int U = (VECB && Op::kBox) ? (Op::kLdsKiB > SPX_VECB_KIB ? SPX_VECB_KIB : Op::kLdsKiB) : Op::kLdsKiB;  // <= 72 KiB per workgroup
     int64_t blocks = (n2 + 256 * U - 1) / (256 * U);
-    *value_slots = blocks * 4;  // one per wavefront
     int64_t xcd_chunk = 0;
     if (ctx->tune_sep_xcd) {
       xcd_chunk = (blocks + 7) / 8;
       blocks = xcd_chunk * 8;
     }
+    *value_slots = blocks;  // one per workgroup (idle workgroups of the XCD-contiguous experiment write a zero)
     hipLaunchKernelGGL((k_sep_lds<Op, U, VECB, MASK>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, d, xk,
                        sj, l, u, mask, ls, us, n2, op, xcd_chunk);
     SPX_LAUNCH_CHECK();

@@ -253,3 +253,104 @@ def test_beyond_int32_indexing(s):
         assert bool(torch.equal(y[lo:hi], want)), lo
         del xs, xsq, t, want
     assert float(psi(y)) > 0.0  # the objective kernel indexes the same range
+
+
+def _fill_chunks(n, seed):
+    import torch
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    x = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    sj = torch.empty_like(x)
+    q = torch.empty_like(x)
+    step = 1 << 28
+    for lo in range(0, n, step):  # fill in chunks: the RNG kernels need not handle 2^31 elements at once
+        hi = min(n, lo + step)
+        x[lo:hi].normal_(generator=g)
+        sj[lo:hi].uniform_(-0.5, 0.5, generator=g)
+        q[lo:hi].normal_(generator=g)
+    return x, sj, q, step
+
+
+def test_beyond_int32_indexing_topr(s):
+    """ShiftedIndBallL0 at n > 2^31 through the sample-predicted pipeline: candidate indices, per-wave regions (n / 768 of them),
+    the overflow list and the count words are all addressed with 64-bit arithmetic.  Continuous data (no ties): exactly r entries
+    are kept, every kept magnitude is >= every dropped one, and y is (kept ? v : 0) - (xk + sj) bit for bit -- evaluated by torch
+    on the same device, chunk by chunk (test plumbing)."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    n = (1 << 31) + 4099
+    if free < 4 * n * 8 + (24 << 30):
+        pytest.skip("not enough free HBM for a 2^31-element top-r run")
+    x, sj, q, step = _fill_chunks(n, 11)
+    y = torch.empty_like(q)
+    r = n // 64 + 7
+    psi = s.shifted(s.shifted(s.IndBallL0(r), x), sj)
+    s.prox_bang(y, psi, q, 1.0)
+    torch.cuda.synchronize()
+    kept_total, min_kept, max_drop = 0, float("inf"), 0.0
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        xs = x[lo:hi] + sj[lo:hi]
+        v = xs + q[lo:hi]
+        kept = y[lo:hi] != (0.0 - xs)
+        kept_total += int(kept.sum())
+        a = v.abs()
+        if bool(kept.any()):
+            min_kept = min(min_kept, float(a[kept].min()))
+        if bool((~kept).any()):
+            max_drop = max(max_drop, float(a[~kept].max()))
+        del xs, v, kept, a
+    assert kept_total == r, (kept_total, r)
+    assert min_kept >= max_drop, (min_kept, max_drop)
+    for lo in list(range(0, n, step))[::3] + [n - 5000]:
+        hi = min(n, lo + step)
+        xs = x[lo:hi] + sj[lo:hi]
+        v = xs + q[lo:hi]
+        want = torch.where(v.abs() >= min_kept, v, torch.zeros_like(v)) - xs
+        assert bool(torch.equal(y[lo:hi].view(torch.int64), want.view(torch.int64))), lo
+        del xs, v, want
+    assert s._lib.load().spx_sync(s.context("cuda:0")) == 0
+
+
+def test_beyond_int32_indexing_groups(s, orc):
+    """Uniform groups of 128 over more than 2^31 elements (2^24 + 33 groups): the register-tile kernels of ShiftedGroupNormL2 and
+    ShiftedGroupNormL2Binf index `g * gsize` in 64 bits.  Plain: the closed form evaluated by torch, a third of the chunks and the
+    tail.  Binf: the last 32 groups (all of their indices are beyond 2^31) against the oracle, and ||sj + y||_inf <= Delta on
+    the chunks."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    gs, ng = 128, (1 << 24) + 33
+    n = gs * ng
+    assert n > (1 << 31)
+    if free < 4 * n * 8 + (12 << 30):
+        pytest.skip("not enough free HBM for a 2^31-element group run")
+    x, sj, q, step = _fill_chunks(n, 13)
+    lam = torch.rand(ng, dtype=torch.float64, device="cuda:0") + 0.5
+    y = torch.empty_like(q)
+    h = s.GroupNormL2.uniform(lam, gs)
+    sigma = 0.9
+    s.prox_bang(y, s.shifted(s.shifted(h, x), sj), q, sigma)
+    torch.cuda.synchronize()
+    for lo in list(range(0, n, step))[::3] + [n - gs * 4096]:
+        hi = min(n, lo + step)
+        S = ((q[lo:hi] + x[lo:hi]) + sj[lo:hi]).view(-1, gs)
+        nrm = torch.linalg.vector_norm(S, dim=1, keepdim=True)
+        alpha = torch.clamp(1.0 - sigma * lam[lo // gs:hi // gs].view(-1, 1) / nrm, min=0.0)
+        want = (alpha * S).view(-1) - (x[lo:hi] + sj[lo:hi])
+        scale = torch.maximum(torch.maximum(want.abs(), (x[lo:hi] + sj[lo:hi]).abs()), nrm.expand(-1, gs).reshape(-1))
+        assert bool(((y[lo:hi] - want).abs() <= 1e-12 * scale).all()), lo
+        del S, nrm, alpha, want, scale
+    delta = 1.0
+    s.prox_bang(y, s.shifted(s.shifted(h, x, delta, s.NormLinf(1.0)), sj), q, sigma)
+    torch.cuda.synchronize()
+    for lo in list(range(0, n, step))[::3]:
+        hi = min(n, lo + step)
+        assert float((sj[lo:hi] + y[lo:hi]).abs().max()) <= delta * (1.0 + 1e-12), lo
+    lo = n - gs * 32
+    assert lo > (1 << 31)
+    xh, sh, qh, lh = (t.cpu().numpy() for t in (x[lo:], sj[lo:], q[lo:], lam[ng - 32:]))
+    ref = orc.prox_group_l2_binf(qh, xh, sh, lh, sigma, delta, gsize=gs)
+    got = y[lo:].cpu().numpy()
+    nrmS = np.repeat(np.linalg.norm(((qh + xh) + sh).reshape(-1, gs), axis=1), gs)
+    scale = np.maximum(np.maximum(np.abs(ref), np.abs(xh + sh)), nrmS)
+    assert np.all(np.abs(got - ref) <= 1e-12 * scale), float(np.max(np.abs(got - ref) / scale))
+    assert s._lib.load().spx_sync(s.context("cuda:0")) == 0

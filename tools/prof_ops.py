@@ -6,7 +6,7 @@ import __graft_entry__ as ge
 s = ge.build()
 dev = torch.device("cuda:0")
 n = int(os.environ.get("SPX_N", "100000000"))
-which = os.environ.get("SPX_OPS", "l1box,l0box,lhalf,lhalfbox,indball,iprox,objective,b2,f32,group,binf").split(",")
+which = os.environ.get("SPX_OPS", "l1box,l1,l0,l0box,vecbounds,lhalf,lhalfbox,indball,indball_ties,small,iprox,objective,proxvalue,b2,f32,group,binf").split(",")
 g = torch.Generator(device=dev).manual_seed(1)
 chi = s.NormLinf(1.0)
 def vecs(m):
@@ -17,6 +17,24 @@ xk, sj, q = vecs(n); y = torch.empty_like(q)
 if "l1box" in which:
     psi = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj)
     for _ in range(5): s.prox_bang(y, psi, q, 1.0)
+if "l1" in which:
+    psi = s.shifted(s.shifted(s.NormL1(1.0), xk), sj)
+    for _ in range(5): s.prox_bang(y, psi, q, 1.0)
+if "l0" in which:
+    psi = s.shifted(s.shifted(s.NormL0(1.0), xk), sj)
+    for _ in range(5): s.prox_bang(y, psi, q, 1.0)
+if "vecbounds" in which:
+    lv = -1.0 - 0.1 * torch.rand(n, dtype=torch.float64, device=dev, generator=g)
+    uv = 1.0 + 0.1 * torch.rand(n, dtype=torch.float64, device=dev, generator=g)
+    psi = s.shifted(s.shifted(s.NormL1(1.0), xk, lv, uv), sj)
+    for _ in range(5): s.prox_bang(y, psi, q, 1.0)
+    del lv, uv, psi
+if "small" in which:   # solver-iteration sizes: the one-launch forms
+    for nn in (1_000_000, 10_000):
+        if nn <= n:
+            for psi in (s.shifted(s.shifted(s.IndBallL0(max(1, nn // 100)), xk[:nn], 1.0, chi), sj[:nn]),
+                        s.shifted(s.shifted(s.NormL1(1.0), xk[:nn], 1.0, s.NormL2(1.0)), sj[:nn])):
+                for _ in range(5): s.prox_bang(y[:nn], psi, q[:nn], 1.0)
 if "l0box" in which:
     psi = s.shifted(s.shifted(s.NormL0(1.0), xk, 1.0, chi), sj)
     for _ in range(5): s.prox_bang(y, psi, q, 1.0)
@@ -43,6 +61,18 @@ if "b2" in which:
 if "indball" in which:
     psi = s.shifted(s.shifted(s.IndBallL0(n // 100), xk, 1.0, chi), sj)
     for _ in range(5): s.prox_bang(y, psi, q, 1.0)
+if "indball_ties" in which:   # (round 3) tie mode of the top-r pipeline: q on a 1/4 lattice, xk = sj = 0 in buffers of their own
+    z1, z2 = torch.zeros_like(xk), torch.zeros_like(sj)
+    q4 = torch.round(q * 4.0) / 4.0
+    for r in (n // 100, n // 2):
+        psi = s.shifted(s.shifted(s.IndBallL0(r), z1, 1.0, chi), z2)
+        for _ in range(5): s.prox_bang(y, psi, q4, 1.0)
+    del z1, z2, q4
+if "proxvalue" in which:
+    psi = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, chi), sj)
+    vout = torch.zeros(1, dtype=torch.float64, device=dev)
+    with s.device_values(vout):
+        for _ in range(5): s.prox_value_bang(y, psi, q, 1.0)
 if "lhalfbox" in which:
     psi = s.shifted(s.shifted(s.RootNormLhalf(1.0), xk, 1.0, chi), sj)
     for _ in range(5): s.prox_bang(y, psi, q, 1.0)
