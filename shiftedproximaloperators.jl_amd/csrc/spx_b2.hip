@@ -172,6 +172,7 @@ __device__ __forceinline__ void b2_st(double* v, int64_t p, f64x2 o) {
   else { __builtin_nontemporal_store(o.x, v + 2 * p); __builtin_nontemporal_store(o.y, v + 2 * p + 1); }
 }
 
+constexpr int kB2DmaKiB = 3;            // KiB per wavefront, vector and tile of the LDS-DMA staged streaming passes (16 waves: 144 KiB)
 constexpr double kB2Bracket = 1.5e-2;   // half-width of the bracket around the sample's root (its statistical error: ~2e-3)
 
 template <bool REG, int EPL, int THREADS, bool VEC>
@@ -315,10 +316,44 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
   // current one is evaluated (ping-pong register sets; a persistent lane otherwise serialises load latency and arithmetic).
   // The SAME element -> lane mapping in every pass: two stores to one address are ordered only when the same lane issues
   // them (no cache maintenance between the passes; seen: 256 stale elements at n = 2.3e6 with differing tile shapes).
-  constexpr int KP = 2;
-  constexpr int64_t kTilePairs = (int64_t)THREADS * KP;
+  // VEC: LDS-DMA staging as in the separable skeleton (global_load_lds ... nt: no VGPR destination, 1 KiB per wave instruction):
+  // every wavefront owns 3 KiB per vector and tile, issues its nine loads, waits once, reads its own 16-byte slots back and
+  // loops -- 144 KiB in flight per CU without holding registers (the register ping-pong of round 2 streamed at 5.8 TB/s, the
+  // skeleton at 6.3).  !VEC (views of mixed alignment): 8-byte register loads, ping-pong.
+  constexpr int KP = (VEC && !REG) ? kB2DmaKiB : 2;
+  constexpr int64_t kTilePairs = (VEC && !REG) ? (int64_t)(THREADS / 64) * 64 * kB2DmaKiB : (int64_t)THREADS * KP;
   const int64_t ntiles = (n2 + kTilePairs - 1) / kTilePairs;
+  __shared__ __attribute__((aligned(16))) char dma[(VEC && !REG) ? (THREADS / 64) * 3 * kB2DmaKiB * 1024 : 16];
   auto stream = [&](auto&& visit_pair) {  // visit_pair(valid, pair index, q pair, xk pair, sj pair), called by every lane
+    if constexpr (VEC && !REG) {
+      typedef __attribute__((address_space(3))) void lds_void;
+      const int wave = t >> 6, lane = t & 63;
+      char* wl = dma + wave * (3 * kB2DmaKiB * 1024);
+      const f64x2* q2 = reinterpret_cast<const f64x2*>(q);
+      const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
+      const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
+      for (int64_t tile = blockIdx.x; tile < ntiles; tile += G) {
+        const int64_t base = tile * kTilePairs + (int64_t)wave * (64 * kB2DmaKiB) + lane;
+#pragma unroll
+        for (int k = 0; k < kB2DmaKiB; ++k) {
+          int64_t i = base + k * 64;
+          if (i >= n2) i = n2 - 1;
+          __builtin_amdgcn_global_load_lds((const void*)(q2 + i), (lds_void*)(wl + (0 * kB2DmaKiB + k) * 1024), 16, 0, 2);
+          __builtin_amdgcn_global_load_lds((const void*)(x2 + i), (lds_void*)(wl + (1 * kB2DmaKiB + k) * 1024), 16, 0, 2);
+          __builtin_amdgcn_global_load_lds((const void*)(s2 + i), (lds_void*)(wl + (2 * kB2DmaKiB + k) * 1024), 16, 0, 2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < kB2DmaKiB; ++k) {
+          const int64_t i = base + k * 64;
+          const f64x2 a = *reinterpret_cast<const f64x2*>(wl + (0 * kB2DmaKiB + k) * 1024 + lane * 16);
+          const f64x2 b = *reinterpret_cast<const f64x2*>(wl + (1 * kB2DmaKiB + k) * 1024 + lane * 16);
+          const f64x2 d = *reinterpret_cast<const f64x2*>(wl + (2 * kB2DmaKiB + k) * 1024 + lane * 16);
+          visit_pair(i < n2, i, a, b, d);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's LDS reads are done before the next tile's loads are issued
+      }
+    } else {
     auto ld = [&](int64_t tile, f64x2* a, f64x2* b, f64x2* d) {
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
@@ -349,6 +384,7 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
         comp(t1, a1, b1, d1);
       }
       tile = t2;
+    }
     }
   };
   // the storing pass: y = ProjB((-xk) r) rinv - sj
@@ -502,19 +538,26 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
   }
   const unsigned int ncand_mine = ncand < cand_cap ? ncand : cand_cap;
   // sums over this wavefront's candidates at scale r, added to the fixed part: the exact (P, C) of the whole vector at any
-  // eta inside the bracket, for one reduction of a few per cent of the data
-  auto pass_cand = [&](double r) {
+  // eta inside the bracket, for one reduction of a few per cent of the data.  Up to three scales per sweep (the bracket's two
+  // ends and the sample's root in ONE reduction: r[k] <= 0 = unused); totals in Pm[k], Cm[k], the first also in P, C.
+  double Pm[3] = {0.0, 0.0, 0.0}, Cm[3] = {0.0, 0.0, 0.0};
+  auto pass_cand = [&](double r0, double r1, double r2) {
     double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     bad = false;
     if constexpr (!REG) {
       for (unsigned int e = (unsigned int)(t & 63); e < ncand_mine; e += 64) {
         const f64x2 rec = myreg[e];
-        acc(rec.y - ls, rec.y + ls, rec.x, r, v[0], v[1]);
+        const double lo = rec.y - ls, hi = rec.y + ls;
+        acc(lo, hi, rec.x, r0, v[0], v[1]);
+        if (r1 > 0.0) acc(lo, hi, rec.x, r1, v[2], v[3]);
+        if (r2 > 0.0) acc(lo, hi, rec.x, r2, v[4], v[5]);
       }
     }
-    if (bad) v[0] = __longlong_as_double(0x7ff8000000000000ll);
-    reduce(v, 3u);
-    P = Pf + v[0]; C = Cf + v[1];
+    if (bad) v[0] = v[2] = v[4] = __longlong_as_double(0x7ff8000000000000ll);
+    reduce(v, r2 > 0.0 ? 63u : (r1 > 0.0 ? 15u : 3u));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { Pm[k] = Pf + v[2 * k]; Cm[k] = Cf + v[2 * k + 1]; }
+    P = Pm[0]; C = Cm[0];
     B2_STAMP();
   };
   const double chiy = chil * sqrt(P + C);
@@ -536,21 +579,22 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
     bool have_eval = false;
     const double P1 = P, C1 = C;  // (the sums at r = 1)
     if (have_bracket) {
-      // does the bracket hold the root?  froot at both ends, exact on aggregate + candidates
-      pass_cand(eta_a / delta);
-      const double fa = eta_a - chil * sqrt((eta_a / delta) * (eta_a / delta) * P + C);
-      const double Pa = P, Ca = C;
-      pass_cand(eta_b / delta);
-      const double fb = eta_b - chil * sqrt((eta_b / delta) * (eta_b / delta) * P + C);
+      // does the bracket hold the root?  froot at both ends and at the sample's root, exact on aggregate + candidates, one sweep
+      const double eta_c = (eta_s > eta_a && eta_s < eta_b) ? eta_s : 0.5 * (eta_a + eta_b);
+      pass_cand(eta_a / delta, eta_b / delta, eta_c / delta);
+      auto fr = [&](double e, double Pe, double Ce) { return e - chil * sqrt((e / delta) * (e / delta) * Pe + Ce); };
+      const double fa = fr(eta_a, Pm[0], Cm[0]), fb = fr(eta_b, Pm[1], Cm[1]), fc = fr(eta_c, Pm[2], Cm[2]);
       if (fa <= 0.0 && fb >= 0.0) {
         in_bracket = true;
-        lo = eta_a; hi = eta_b;
-        eta = eta_b; have_eval = true;   // (P, C) are those of eta_b: the piece roots approach the root from above
-        if (fa == 0.0) { eta = eta_a; P = Pa; C = Ca; }
+        have_eval = true;
+        // start from the evaluated point nearest the root: the sample's (2e-3 away; the piece roots converge quadratically)
+        if (fa == 0.0) { lo = hi = eta_a; eta = eta_a; P = Pm[0]; C = Cm[0]; }
+        else if (fc < 0.0) { lo = eta_c; hi = eta_b; eta = eta_c; P = Pm[2]; C = Cm[2]; }
+        else { lo = eta_a; hi = eta_c; eta = eta_c; P = Pm[2]; C = Cm[2]; }
+      // (a miss -- the sample misled by more than 1.5 % -- costs this one cheap reduction and then the plain iteration)
       } else {
         P = P1; C = C1;
       }
-      // (a miss -- the sample misled by more than 1.5 % -- costs these two cheap reductions and then the plain iteration)
     }
     if (!have_eval && ub_ok) {
       eta = eta_ub;
@@ -575,7 +619,7 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
         // a reduction over the candidates costs microseconds: iterate until the piece is confirmed (P, C identical) -- the
         // exact fixed point, no stopping rule
         pP = P; pC = C; eta = next;
-        pass_cand(eta / delta);
+        pass_cand(eta / delta, -1.0, -1.0);
         continue;
       }
       // Reductions over the VECTORS (register-resident form; streaming form without a usable bracket).  The piece roots converge
