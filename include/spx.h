@@ -22,6 +22,8 @@
  *     spx_proxval_* unless the context has a device value target (spx_ctx_set_value_target), the unboxed
  *     spx_iprox_* with check_d != 0, the gather-index group forms (index validation) and every spx_host_* form.
  *     (Since round 2 the top-r operators and spx_prox_l1_b2 read nothing back.)
+ *     Failures of the device side (spx_status SPX_ERR_INTERNAL) are reported by the NEXT call on the context, whichever
+ *     entry point it is -- see spx_status.
  *     A context is not re-entrant (neither is a reference psi: shared scratch sol/xsy/p).
  *   - Return value: 0 = SPX_OK, else an spx_status; spx_last_error() gives a thread-local message.
  *   - Indices handed over in arrays (selected sets, group offsets) are 0-BASED int64.
@@ -194,6 +196,20 @@ int spx_prox_l0_box_f32(spx_ctx* ctx, float* y, const float* q, const float* xk,
                         float sigma, const float* l_vec, const float* u_vec, float l_scalar, float u_scalar,
                         const uint8_t* sel_mask);
 
+/* iprox! on Float32 vectors (round 3): the reference's methods are generic in R here too (src/shiftedNormL1.jl:60-75,
+ * shiftedNormL0.jl:61-80, shiftedNormL1Box.jl:131-225, shiftedNormL0Box.jl:137-231; thresholds eps(R) = eps(Float32), unselected
+ * entries iprox_zero, src/ShiftedProximalOperators.jl:217-236).  Bit for bit in fp32; arguments as the Float64 forms; 20 B/element. */
+int spx_iprox_l1_f32(spx_ctx* ctx, float* y, const float* g, const float* d, const float* xk, const float* sj, int64_t n,
+                     float lambda, int check_d);
+int spx_iprox_l0_f32(spx_ctx* ctx, float* y, const float* g, const float* d, const float* xk, const float* sj, int64_t n,
+                     float lambda, int check_d);
+int spx_iprox_l1_box_f32(spx_ctx* ctx, float* y, const float* g, const float* d, const float* xk, const float* sj, int64_t n,
+                         float lambda, const float* l_vec, const float* u_vec, float l_scalar, float u_scalar,
+                         const uint8_t* sel_mask);
+int spx_iprox_l0_box_f32(spx_ctx* ctx, float* y, const float* g, const float* d, const float* xk, const float* sj, int64_t n,
+                         float lambda, const float* l_vec, const float* u_vec, float l_scalar, float u_scalar,
+                         const uint8_t* sel_mask);
+
 /* psi(y) on Float32 vectors, for every operator (the reference's tests evaluate each shifted operator built on Float32
  * data: test/runtests.jl:196-209, 268-282, 346-360, 397-412, 524-550, 630-646).  Every element operation is a Float32
  * operation as in the reference ((xk + sj) + y, sj + y, the box ends -+ sqrt(eps(Float32)), each square root); `1.1 * Delta`
@@ -302,9 +318,11 @@ int spx_obj_group_l2_binf(spx_ctx* ctx, const double* y, const double* xk, const
 /* ShiftedIndBallL0.prox!     src/shiftedIndBallL0.jl:54-72 : keep the r entries of (xk+sj)+q largest in
  * magnitude (ties: lowest index first, = stable sortperm), zero the rest, subtract xk+sj.
  * The result never depends on the route taken, the time does: beyond 2^21 elements a sample predicts a band around the r-th
- * largest magnitude and one streaming pass settles everything outside it (n = 1e8: 0.57 ms, sorted input included); when
- * the keys at the threshold are shared by per cents of the vector (lattice data, constants) the band cannot separate them
- * and the exact radix select behind it does the work (2.6-6.5 ms at n = 1e8).  Nothing is read back by either route. */
+ * largest magnitude and one streaming pass settles everything outside it (n = 1e8: 0.57-0.66 ms, sorted input included).
+ * Keys at the threshold that are shared by per cents of the vector (lattice data, constants, a sparse vector's zeros) are
+ * counted per wavefront instead of recorded, and the index tie-break (lowest index first) comes from a prefix sum over those
+ * counts: 0.59-0.85 ms at n = 1e8 (round 2: 2.6-6.5 ms).  If the sample misleads, the exact radix select queued behind the
+ * pass recomputes everything.  Nothing is read back by any route. */
 int spx_prox_indball_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
                         int64_t n, int64_t r);
 /* ShiftedIndBallL0BInf.prox! src/shiftedIndBallL0BInf.jl:73-95 : as above, then clamp y to [-delta, delta]. */
@@ -313,7 +331,9 @@ int spx_prox_indball_l0_binf(spx_ctx* ctx, double* y, const double* q, const dou
 
 /* ---- l1 norm + l2-ball trust region ------------------------------------------------------ */
 /* ShiftedNormL1B2.prox!  src/shiftedNormL1B2.jl:50-67 (chi = NormL2(chi_lambda)).  All elements are coupled through
- * one scalar root (find_zero, :62): the call runs a few global reduction passes and synchronises after each. */
+ * one scalar root (find_zero, :62).  One launch, asynchronous, nothing read back: register-resident up to 2^21 elements;
+ * beyond, two streaming passes (56 B/element) -- the first classifies every element against a bracket around a sample's
+ * root, the root is found on the aggregate sums + the few per cent of candidates, the second stores y. */
 int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
                    int64_t n, double lambda, double sigma, double delta, double chi_lambda);
 /* psi(y) of ShiftedNormL1B2, src/shiftedNormL1B2.jl:32: lambda ||xk + sj + y||_1 + IndBallL2(Delta)(sj + y); the value is

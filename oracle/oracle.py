@@ -471,7 +471,8 @@ def lib32():
     global _lib32
     if _lib32 is None:
         src = os.path.join(_HERE, "spx_oracle_f32.c")
-        if not os.path.exists(_SO32) or os.path.getmtime(_SO32) < os.path.getmtime(src):
+        src64 = os.path.join(_HERE, "spx_oracle.c")   # (the iprox! block is generated from it)
+        if not os.path.exists(_SO32) or os.path.getmtime(_SO32) < max(os.path.getmtime(src), os.path.getmtime(src64)):
             subprocess.check_call(["make", "-C", _HERE, "-s", "libspx_oracle_f32.so"])
         L = ctypes.CDLL(_SO32)
         f, i64, fp, up = ctypes.c_float, ctypes.c_int64, _c_float_p, _c_uint8_p
@@ -481,6 +482,12 @@ def lib32():
         L.orc32_prox_l0_box.argtypes = [fp, fp, fp, fp, i64, f, f, fp, fp, f, f, up]
         for name in ("orc32_prox_l1", "orc32_prox_l0", "orc32_prox_l1_box", "orc32_prox_l0_box"):
             getattr(L, name).restype = None
+        L.orc32_iprox_l1.argtypes = [fp, fp, fp, fp, fp, i64, f]
+        L.orc32_iprox_l0.argtypes = [fp, fp, fp, fp, fp, i64, f]
+        L.orc32_iprox_l1.restype = L.orc32_iprox_l0.restype = i64
+        L.orc32_iprox_l1_box.argtypes = [fp, fp, fp, fp, fp, i64, f, fp, fp, f, f, up]
+        L.orc32_iprox_l0_box.argtypes = [fp, fp, fp, fp, fp, i64, f, fp, fp, f, f, up]
+        L.orc32_iprox_l1_box.restype = L.orc32_iprox_l0_box.restype = None
         _lib32 = L
     return _lib32
 
@@ -512,4 +519,25 @@ def prox_f32(op, q, xk, sj, lam, sigma, l=None, u=None, mask=None, aliased=False
     else: uv = _f32(u)
     m, mp = _mask(mask, n)
     getattr(lib32(), "orc32_prox_" + op)(_fp(y), _fp(qq), _fp(xk), _fp(sj), n, lam, sigma, _fp(lv), _fp(uv), ls, us, mp)
+    return y
+
+
+def iprox_f32(op, g, d, xk, sj, lam, l=None, u=None, mask=None):
+    """iprox! with R = Float32 (oracle/_gen/iprox_f32.inc); op in {"l1", "l0", "l1_box", "l0_box"}.  The unboxed forms return
+    (y, first index with d <= 0 or -1) like their Float64 twins."""
+    g, d, xk, sj = _f32(g), _f32(d), _f32(xk), _f32(sj)
+    n = g.shape[0]
+    y = np.empty(n, dtype=np.float32)
+    lam = np.float32(lam)
+    if op in ("l1", "l0"):
+        bad = getattr(lib32(), "orc32_iprox_" + op)(_fp(y), _fp(g), _fp(d), _fp(xk), _fp(sj), n, lam)
+        return y, int(bad)
+    lv = uv = None
+    ls = us = np.float32(0)
+    if np.ndim(l) == 0: ls = np.float32(l)
+    else: lv = _f32(l)
+    if np.ndim(u) == 0: us = np.float32(u)
+    else: uv = _f32(u)
+    m, mp = _mask(mask, n)
+    getattr(lib32(), "orc32_iprox_" + op)(_fp(y), _fp(g), _fp(d), _fp(xk), _fp(sj), n, lam, _fp(lv), _fp(uv), ls, us, mp)
     return y

@@ -106,3 +106,10 @@ ORC_API void orc32_prox_l0_box(float* y, const float* q, const float* xk, const 
     }
   }
 }
+
+/* ==========================================================================================
+ * iprox! with R = Float32 (round 3): the Float64 block of spx_oracle.c, type-substituted by the Makefile
+ * (src/shiftedNormL1.jl:60-75, shiftedNormL0.jl:61-80, shiftedNormL1Box.jl:131-225, shiftedNormL0Box.jl:137-231,
+ * ShiftedProximalOperators.jl:217-236; thresholds eps(R) = eps(Float32)).
+ * ========================================================================================== */
+#include "_gen/iprox_f32.inc"

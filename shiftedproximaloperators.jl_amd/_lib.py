@@ -36,6 +36,10 @@ SIGNATURES = {
     "spx_prox_l0_f32": [_p, _p, _p, _p, _p, _i64, _f, _f],
     "spx_prox_l1_box_f32": [_p, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _f, _f, _p],
     "spx_prox_l0_box_f32": [_p, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _f, _f, _p],
+    "spx_iprox_l1_f32": [_p, _p, _p, _p, _p, _p, _i64, _f, _int],
+    "spx_iprox_l0_f32": [_p, _p, _p, _p, _p, _p, _i64, _f, _int],
+    "spx_iprox_l1_box_f32": [_p, _p, _p, _p, _p, _p, _i64, _f, _p, _p, _f, _f, _p],
+    "spx_iprox_l0_box_f32": [_p, _p, _p, _p, _p, _p, _i64, _f, _p, _p, _f, _f, _p],
     "spx_proxval_l1": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, ctypes.POINTER(_d)],
     "spx_proxval_l0": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, ctypes.POINTER(_d)],
     "spx_proxval_lhalf": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, ctypes.POINTER(_d)],

@@ -277,3 +277,53 @@ def test_strided_xk_views(s, orc, dtype):
     mask = torch.ones(n * st, dtype=torch.bool, device="cuda"); mask[::st] = False
     assert torch.equal(bd[mask], others[mask])         # nothing between the strided elements was touched
     assert abs(parent(torch.zeros(n, dtype=td, device="cuda")) - float(new.abs().sum())) <= 1e-5 * float(new.abs().sum())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# iprox! in Float32 (round 3): the reference's iprox! methods are generic in R too; thresholds eps(Float32)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 1023, 4097, 300_001])
+def test_f32_iprox_bit_exact(s, orc, n):
+    import torch
+    rng = np.random.default_rng(70 + n)
+    x, sj, g = _data(n, 70 + n, quant=8 if n % 2 else None)
+    dpos = rng.uniform(0.3, 2.0, size=n).astype(np.float32)
+    # Box forms take any sign of d, exact zeros and values at +-eps(Float32)
+    dany = np.resize(np.array([1.0, -1.0, 0.0, -0.0, 2.0, 1e-8, -1e-8, 1.1920929e-07, -1.1920929e-07, 0.5, -3.0], dtype=np.float32), n)
+    dany = (dany * rng.uniform(0.5, 1.5, size=n).astype(np.float32)).astype(np.float32)
+    lam = np.float32(0.7)
+    xd, sd, gd = _dev(x, sj, g)
+    for op, H in (("l1", s.NormL1), ("l0", s.NormL0)):
+        psi = s.shifted(s.shifted(H(float(lam)), xd), sd)
+        dd = _dev(dpos)[0]
+        y = s.iprox(psi, gd, dd).cpu().numpy()
+        ref, bad = orc.iprox_f32(op, g, dpos, x, sj, lam)
+        assert bad == -1 and _bits(y, ref), (op, n)
+    lo_v = (-0.9 - 0.2 * rng.random(n)).astype(np.float32)
+    up_v = (0.9 + 0.2 * rng.random(n)).astype(np.float32)
+    sel = np.flatnonzero(rng.random(n) < 0.8)
+    mask = np.zeros(n, dtype=np.uint8); mask[sel] = 1
+    for op, H in (("l1_box", s.NormL1), ("l0_box", s.NormL0)):
+        for dv in (dpos, dany):
+            dd = _dev(dv)[0]
+            psi = s.shifted(s.shifted(H(float(lam)), xd, -0.9, 0.9), sd)
+            assert _bits(s.iprox(psi, gd, dd).cpu().numpy(), orc.iprox_f32(op, g, dv, x, sj, lam, np.float32(-0.9), np.float32(0.9))), (op, n)
+            lod, upd = _dev(lo_v, up_v)
+            psi = s.shifted(s.shifted(H(float(lam)), xd, lod, upd, torch.from_numpy(sel).cuda()), sd)
+            assert _bits(s.iprox(psi, gd, dd).cpu().numpy(), orc.iprox_f32(op, g, dv, x, sj, lam, lo_v, up_v, mask=mask)), (op, n, "vector bounds + mask")
+
+
+def test_f32_iprox_asserts_d_positive_and_views(s, orc):
+    """unboxed forms: `@assert d[i] > 0` (check=True raises AssertionError); views from any element"""
+    n = 10_001
+    x, sj, g = _data(n, 5)
+    d = np.random.default_rng(6).uniform(0.3, 2.0, size=n).astype(np.float32)
+    for off in (1, 2, 3):
+        xd, sd, gd, dd = _dev(x, sj, g, d, off=off)
+        psi = s.shifted(s.shifted(s.NormL1(0.4), xd), sd)
+        y = s.iprox(psi, gd, dd).cpu().numpy()
+        assert _bits(y, orc.iprox_f32("l1", g, d, x, sj, np.float32(0.4))[0]), off
+    d2 = d.copy(); d2[777] = 0.0
+    xd, sd, gd, dd = _dev(x, sj, g, d2)
+    with pytest.raises(AssertionError):
+        s.iprox(s.shifted(s.shifted(s.NormL0(0.4), xd), sd), gd, dd)

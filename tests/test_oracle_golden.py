@@ -392,6 +392,40 @@ def test_f32_oracle_agrees_with_f64_on_dyadic_data(orc):
     assert np.array_equal(a.astype(np.float64), (-x) - sj)
 
 
+def test_f32_iprox_oracle_agrees_with_f64_on_dyadic_data(orc):
+    """The Float32 iprox! restatement (generated from the Float64 block, oracle/Makefile) against the Float64 one where both are
+    exact: dyadic data, d in {1/2, 1, 2, 4} (every quotient and product representable in both formats), and the d = 0 /
+    d < 0 branches of the Box forms.  lambda = 2 d for the L0 forms (sqrt(2 lambda d) exact)."""
+    rng = np.random.default_rng(12)
+    n = 20_000
+    x = rng.integers(-64, 65, size=n) / 16.0
+    sj = rng.integers(-16, 17, size=n) / 16.0
+    g = rng.integers(-96, 97, size=n) / 16.0
+    l = -(rng.integers(8, 33, size=n) / 16.0)
+    u = rng.integers(8, 33, size=n) / 16.0
+    mask = (rng.random(n) < 0.7).astype(np.uint8)
+    d = rng.choice([0.5, 1.0, 2.0, 4.0], size=n)
+    a, bad = orc.iprox_f32("l1", g, d, x, sj, 0.5)
+    b = orc.iprox_l1(g, d, x, sj, 0.5)
+    assert bad == -1 and np.array_equal(a.astype(np.float64), b)
+    d1 = np.full(n, 2.0)
+    a, _ = orc.iprox_f32("l0", g, d1, x, sj, 4.0)       # sqrt(2 * 4 * 2) = 4
+    b = orc.iprox_l0(g, d1, x, sj, 4.0)
+    assert np.array_equal(a.astype(np.float64), b)
+    dsg = rng.choice([0.5, 1.0, 2.0, -0.5, -1.0, -2.0, 0.0], size=n)
+    for op in ("l1_box", "l0_box"):
+        for lo, uo, m in ((-1.0, 1.0, None), (l, u, None), (l, u, mask)):
+            a = orc.iprox_f32(op, g, dsg, x, sj, 0.5, lo, uo, mask=m)
+            b = getattr(orc, "iprox_" + op)(g, dsg, x, sj, 0.5, lo, uo, mask=m)
+            assert np.array_equal(a.astype(np.float64), b), op
+    # the first d <= 0 is reported at the same index
+    d2 = d.copy(); d2[123] = 0.0
+    assert orc.iprox_f32("l1", g, d2, x, sj, 0.5)[1] == 123
+    with pytest.raises(orc.AssertionErrorAt) as e:
+        orc.iprox_l1(g, d2, x, sj, 0.5)
+    assert e.value.index == 123
+
+
 def test_synthetic_generator_twins_agree(orc):
     """SURVEY 8d's shared generator: the C host twin (oracle.synth_fill) and the numpy one (oracle/synth.py) give the same
     bits; the draws have the advertised moments; streams and seeds are independent of each other."""
