@@ -20,7 +20,12 @@ import ShiftedProximalOperators: prox!, iprox!
 using AMDGPU  # ROCArray, AMDGPU.stream(), AMDGPU.device_id
 
 const libspx = get(ENV, "LIBSPX", "libspx.so")
-const DVec = ROCVector{Float64}
+# Device vectors the C ABI takes as they are: a ROCVector, or a UNIT-STRIDE view of one (`view(x, 2:n)`: the reference builds
+# operators on views, test/runtests.jl:196-209).  `pointer(v)` of such a view is the base pointer advanced by the offset
+# (round 3: by pointer arithmetic, no copy, no CPU fallback); libspx handles vectors that start at any element (8-byte
+# aligned: the kernels peel to the 16-byte boundary or take 8-byte accesses).  Strided views (`1:2:10`) still fall through to
+# the reference's own method.
+const DVec = Union{ROCVector{Float64}, SubArray{Float64, 1, <:ROCVector{Float64}, <:Tuple{AbstractUnitRange}, true}}
 
 # ---------------------------------------------------------------------------------------------
 # context: one per (device, HIP stream); enqueue on AMDGPU.jl's current stream so prox! is ordered with
@@ -28,6 +33,10 @@ const DVec = ROCVector{Float64}
 # ---------------------------------------------------------------------------------------------
 const CTX = Dict{Tuple{Int, Ptr{Cvoid}}, Ptr{Cvoid}}()
 
+# Status 7 (SPX_ERR_INTERNAL) is the device side reporting a failure of an EARLIER asynchronous call on this context (a kernel
+# that synchronises inside one launch gave up waiting: another process or a graph replay held the CUs) -- libspx raises it on
+# the next call, whichever it is; the results since then are NaN.  `ccall((:spx_sync, libspx), Cint, (Ptr{Cvoid},), ctx())`
+# acknowledges it and resets the context.
 function check(status::Cint)
   status == 0 && return
   msg = unsafe_string(ccall((:spx_last_error, libspx), Cstring, ()))
@@ -368,6 +377,36 @@ for (T, sym) in ((:ShiftedNormL1Box, :spx_prox_l1_box_f32), (:ShiftedNormL0Box, 
                 (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cfloat, Cfloat,
                  Ptr{Cfloat}, Ptr{Cfloat}, Cfloat, Cfloat, Ptr{UInt8}),
                 ctx(), dptr32(y), dptr32(q), dptr32(ψ.xk), dptr32(ψ.sj), n, ψ.λ, σ,
+                dptr32(vec32_or_nothing(ψ.l)), dptr32(vec32_or_nothing(ψ.u)), scal32(ψ.l), scal32(ψ.u), mptr(m)))
+    return y
+  end
+end
+
+# iprox! on Float32 vectors (round 3: spx_iprox_*_f32; src/shiftedNormL1.jl:60-75, shiftedNormL0.jl:61-80, shiftedNormL1Box.jl:131-225,
+# shiftedNormL0Box.jl:137-231).  check_d = 1: the reference's `@assert d[i] > 0` (status 6 -> AssertionError).
+for (T, sym) in ((:ShiftedNormL1, :spx_iprox_l1_f32), (:ShiftedNormL0, :spx_iprox_l0_f32))
+  @eval function iprox!(y::DVec32, ψ::$T{Float32, <:DVec32, <:DVec32, <:DVec32}, g::DVec32, d::DVec32)
+    n = length(ψ.xk)
+    (length(y) == n && length(g) == n && length(d) == n) || throw(BoundsError())
+    st = ccall(($(QuoteNode(sym)), libspx), Cint,
+               (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cfloat, Cint),
+               ctx(), dptr32(y), dptr32(g), dptr32(d), dptr32(ψ.xk), dptr32(ψ.sj), n, ψ.λ, 1)
+    st == 6 && throw(AssertionError("d[i] > 0"))
+    check(st)
+    return y
+  end
+end
+for (T, sym) in ((:ShiftedNormL1Box, :spx_iprox_l1_box_f32), (:ShiftedNormL0Box, :spx_iprox_l0_box_f32))
+  @eval function iprox!(y::DVec32, ψ::$T{Float32, <:DVec32, <:DVec32, <:DVec32}, g::DVec32, d::DVec32)
+    n = length(ψ.xk)
+    (length(y) == n && length(g) == n && length(d) == n) || throw(BoundsError())
+    (ψ.l isa Real || ψ.l isa DVec32) && (ψ.u isa Real || ψ.u isa DVec32) ||
+      return invoke(iprox!, Tuple{AbstractVector{Float32}, $T{Float32}, AbstractVector{Float32}, AbstractVector{Float32}}, y, ψ, g, d)
+    m = mask_for(ψ)
+    check(ccall(($(QuoteNode(sym)), libspx), Cint,
+                (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cfloat,
+                 Ptr{Cfloat}, Ptr{Cfloat}, Cfloat, Cfloat, Ptr{UInt8}),
+                ctx(), dptr32(y), dptr32(g), dptr32(d), dptr32(ψ.xk), dptr32(ψ.sj), n, ψ.λ,
                 dptr32(vec32_or_nothing(ψ.l)), dptr32(vec32_or_nothing(ψ.u)), scal32(ψ.l), scal32(ψ.u), mptr(m)))
     return y
   end
