@@ -329,6 +329,14 @@ int spx_prox_indball_l0(spx_ctx* ctx, double* y, const double* q, const double* 
 int spx_prox_indball_l0_binf(spx_ctx* ctx, double* y, const double* q, const double* xk,
                              const double* sj, int64_t n, int64_t r, double delta);
 
+/* The same operators on Float32 vectors (round 3; the reference's methods are generic in R, src/shiftedIndBallL0.jl:54-59):
+ * v = (xk + sj) + q, the magnitude order and the final subtraction / clamp are Float32 operations -- bit-exact in fp32, ties by
+ * lowest index, NaN largest.  Exact select in one launch (one workgroup / register-resident / v parked in y); the
+ * sample-predicted single pass is Float64 only. */
+int spx_prox_indball_l0_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, const float* sj, int64_t n, int64_t r);
+int spx_prox_indball_l0_binf_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, const float* sj, int64_t n,
+                                 int64_t r, float delta);
+
 /* ---- l1 norm + l2-ball trust region ------------------------------------------------------ */
 /* ShiftedNormL1B2.prox!  src/shiftedNormL1B2.jl:50-67 (chi = NormL2(chi_lambda)).  All elements are coupled through
  * one scalar root (find_zero, :62).  One launch, asynchronous, nothing read back: register-resident up to 2^21 elements;

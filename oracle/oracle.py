@@ -541,3 +541,24 @@ def iprox_f32(op, g, d, xk, sj, lam, l=None, u=None, mask=None):
     m, mp = _mask(mask, n)
     getattr(lib32(), "orc32_iprox_" + op)(_fp(y), _fp(g), _fp(d), _fp(xk), _fp(sj), n, lam, _fp(lv), _fp(uv), ls, us, mp)
     return y
+
+
+def prox_indball_l0_f32(q, xk, sj, r, delta=None):
+    """ShiftedIndBallL0(BInf).prox! with R = Float32 (src/shiftedIndBallL0.jl:54-72, shiftedIndBallL0BInf.jl:73-95), restated in
+    numpy: v = (xk + sj) + q in Float32, stable descending sort by |v| (isless order: NaN largest, all NaNs tie; ties by
+    ascending index), zero all but the first r, subtract xk + sj, clamp to +-delta.  Small cases only (a full argsort)."""
+    q, xk, sj = _f32(q), _f32(xk), _f32(sj)
+    n = q.shape[0]
+    xs = (xk + sj).astype(np.float32)
+    v = (xs + q).astype(np.float32)
+    key = (v.view(np.uint32) & np.uint32(0x7fffffff)).astype(np.int64)
+    key = np.where(key > 0x7f800000, 0x7fc00000, key)
+    order = np.argsort(-key, kind="stable")
+    kept = v.copy()
+    kept[order[max(int(r), 0):]] = np.float32(0)
+    y = (kept - xs).astype(np.float32)
+    if delta is not None:
+        d = np.float32(delta)
+        # Julia min / max: NaN propagates (a NaN entry stays NaN); -0.0 < +0.0 is irrelevant for a clamp at +-delta != 0
+        y = np.where(np.isnan(y), y, np.minimum(np.maximum(y, -d), d)).astype(np.float32)
+    return y

@@ -72,6 +72,8 @@ SIGNATURES = {
     "spx_obj_group_l2_binf_f32": [_p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _f, ctypes.POINTER(_d)],
     "spx_prox_indball_l0": [_p, _p, _p, _p, _p, _i64, _i64],
     "spx_prox_indball_l0_binf": [_p, _p, _p, _p, _p, _i64, _i64, _d],
+    "spx_prox_indball_l0_f32": [_p, _p, _p, _p, _p, _i64, _i64],
+    "spx_prox_indball_l0_binf_f32": [_p, _p, _p, _p, _p, _i64, _i64, _f],
     "spx_prox_l1_b2": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d],
     "spx_obj_l1_b2": [_p, _p, _p, _p, _i64, _d, _d, ctypes.POINTER(_d)],
     "spx_prox_group_l2": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _d],

@@ -189,6 +189,18 @@ __device__ __forceinline__ double jl_max(double x, double y) {
   double a = (__double_as_longlong(d) < 0) ? y : x;
   return (x != x || y != y) ? d : a;
 }
+// the same on Float32 (overloads in the SAME scope as the Float64 forms: a float overload declared in an inner namespace would
+// hide these and silently round every double argument to float)
+__device__ __forceinline__ float jl_min(float x, float y) {
+  const float d = x - y;
+  const float a = (__float_as_int(d) < 0) ? x : y;
+  return (x != x || y != y) ? d : a;
+}
+__device__ __forceinline__ float jl_max(float x, float y) {
+  const float d = x - y;
+  const float a = (__float_as_int(d) < 0) ? y : x;
+  return (x != x || y != y) ? d : a;
+}
 // Base.sign: +-1.0, or x itself for +-0.0 / NaN
 __device__ __forceinline__ double jl_sign(double x) { return (x > 0.0) ? 1.0 : (x < 0.0) ? -1.0 : x; }
 // prox_zero(q, l, u) = min(max(q, l), u)   src/ShiftedProximalOperators.jl:203

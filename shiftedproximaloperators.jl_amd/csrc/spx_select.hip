@@ -324,12 +324,19 @@ __device__ __forceinline__ void sel_scan_step(const Hist& hist, const SelState s
   if (t == 0) *out = sel_advance(st, found[0], found[1], found[2]);
 }
 
-template <bool BINF>
-__device__ __forceinline__ double sel_out(double v, int64_t i, double x, double s, const SelState& st, double delta) {
+// Float32 vectors (round 3; the reference's methods are generic in R, src/shiftedIndBallL0.jl:54-59): bits(|v|) of a Float32 moved
+// into the top half of the 64-bit key -- monotone, so every digit / scan / tie-break routine below serves both element types
+// (the low 32 key bits are zero: the digits there resolve at once).  All NaNs are one key above Inf, as for Float64.
+__device__ __forceinline__ uint64_t key_of(float v) {
+  const uint32_t k = (uint32_t)__float_as_int(v) & 0x7fffffffu;
+  return (uint64_t)(k > 0x7f800000u ? 0x7fc00000u : k) << 32;
+}
+template <bool BINF, class T>
+__device__ __forceinline__ T sel_out(T v, int64_t i, T x, T s, const SelState& st, T delta) {
   const uint64_t key = key_of(v);
   const bool keep = (key >= st.t_ge) || (key == st.t_eq && i <= st.icut);
-  const double kept = keep ? v : 0.0;               // shiftedIndBallL0.jl:69  y[p[r+1:end]] .= 0
-  const double t = kept - (x + s);                  // :70
+  const T kept = keep ? v : (T)0;                   // shiftedIndBallL0.jl:69  y[p[r+1:end]] .= 0
+  const T t = kept - (x + s);                       // :70
   if constexpr (BINF) return jl_min(jl_max(t, -delta), delta);  // shiftedIndBallL0BInf.jl:91
   else return t;
 }
@@ -342,9 +349,9 @@ __device__ __forceinline__ double sel_out(double v, int64_t i, double x, double 
 // every pass, so y needs no fence between passes.
 // =============================================================================================
 constexpr int64_t kSmallNCoop = 1 << 13;  // k_sel_coop serves the sizes above (see run_select)
-template <bool BINF>
-__global__ __launch_bounds__(1024) void k_sel_small(double* y, const double* q, const double* xk, const double* sj, int64_t n,
-                                                     int64_t r, double delta) {
+template <bool BINF, class T = double>
+__global__ __launch_bounds__(1024) void k_sel_small(T* y, const T* q, const T* xk, const T* sj, int64_t n,
+                                                     int64_t r, T delta) {
   __shared__ unsigned int h[kBins];
   __shared__ unsigned long long scratch[8];
   __shared__ unsigned long long kmm[2];
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(1024) void k_sel_small(double* y, const double* q, 
   __syncthreads();
   uint64_t kmin = ~0ull, kmax = 0ull;
   for (int64_t i = t; i < n; i += 1024) {
-    const double v = (xk[i] + sj[i]) + q[i];  // shiftedIndBallL0.jl:66
+    const T v = (xk[i] + sj[i]) + q[i];  // shiftedIndBallL0.jl:66
     y[i] = v;
     const uint64_t k = key_of(v);
     kmin = k < kmin ? k : kmin;
@@ -1088,29 +1095,30 @@ __device__ __forceinline__ void sel_state_init(SelState& s, int64_t n, int64_t r
 // The exact selection, executed by every workgroup of a resident grid of 1024-lane workgroups.  hist[p] must be zero on
 // entry for every pass p that runs.  Lane (block, t) owns the elements gtid, gtid + NT, ... in every pass (so v parked in
 // y needs no fence between passes, and y may alias q: q[i] is read before y[i] is written by the same lane).
-template <bool BINF, bool REG>
-__device__ __forceinline__ void coop_select(double* y, const double* q, const double* xk, const double* sj, int64_t n,
-                                            int64_t r, double delta, unsigned long long (*hist)[kBins], unsigned int* bar,
+template <bool BINF, bool REG, class T = double>
+__device__ __forceinline__ void coop_select(T* y, const T* q, const T* xk, const T* sj, int64_t n,
+                                            int64_t r, T delta, unsigned long long (*hist)[kBins], unsigned int* bar,
                                             unsigned int& nbar, CoopShared& sh, SpxSyncHeader* hdr) {
   const int t = threadIdx.x;
   const int64_t NT = (int64_t)gridDim.x * blockDim.x;
   const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + t;
   // (form that parks v in y: 16-byte accesses when all four vectors allow them -- the exact select behind a failed prediction)
-  const bool vec2 = !REG && n >= 2 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(q) |
+  constexpr bool kF64 = std::is_same<T, double>::value;
+  const bool vec2 = kF64 && !REG && n >= 2 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(q) |
                                         reinterpret_cast<uintptr_t>(xk) | reinterpret_cast<uintptr_t>(sj)) & 15u) == 0;
-  double v[REG ? kCoopEpl : 1];
+  T v[REG ? kCoopEpl : 1];
   if constexpr (REG) {
 #pragma unroll
     for (int k = 0; k < kCoopEpl; ++k) {
       const int64_t i = gtid + (int64_t)k * NT;
       const int64_t ic = i < n ? i : n - 1;            // clamped, unconditional: all the loads in flight at once
-      const double xv = xk[ic], sv = sj[ic], qv = q[ic];
-      v[k] = (i < n) ? (xv + sv) + qv : 0.0;           // shiftedIndBallL0.jl:66
+      const T xv = xk[ic], sv = sj[ic], qv = q[ic];
+      v[k] = (i < n) ? (xv + sv) + qv : (T)0;          // shiftedIndBallL0.jl:66
     }
   }
   if (t == 0) {
     sel_state_init(sh.sst, n, r);
-    if (sh.sst.phase == 0 && kCoopFold) sh.sst.pad = 1;  // first digit: fold_digit
+    if (sh.sst.phase == 0 && kCoopFold && kF64) sh.sst.pad = 1;  // first digit: fold_digit (binades of a Float64)
   }
   SEL_STAMP(32);
   int p = 0;
@@ -1122,7 +1130,7 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
     __syncthreads();
     const int hs = st.shift + st.width;
     const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
-    auto visit = [&](double vv, int64_t i) {
+    auto visit = [&](T vv, int64_t i) {
       const uint64_t key = key_of(vv);
       bool in = true;
       unsigned int dg;
@@ -1147,6 +1155,7 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
         if (i < n) visit(v[k], i);
       }
     } else if (vec2) {
+      if constexpr (kF64) {
       // 16-byte accesses (all four vectors 16-byte aligned): lane (block, t) owns the pairs gtid, gtid + NT, ... in every pass
       const int64_t n2 = n >> 1;
       f64x2* y2 = reinterpret_cast<f64x2*>(y);
@@ -1174,10 +1183,11 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
         }
         if ((n & 1) && gtid == 0) visit(y[n - 1], n - 1);
       }
+      }
     } else {
       if (p == 0) {
         for (int64_t i = gtid; i < n; i += NT) {
-          const double vv = (xk[i] + sj[i]) + q[i];
+          const T vv = (xk[i] + sj[i]) + q[i];
           y[i] = vv;
           visit(vv, i);
         }
@@ -1203,7 +1213,7 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
   // A workgroup of this context gave up waiting (spx_wait_expired): the thresholds are not to be trusted.  Every element is
   // then stored as NaN (t_ge above every key, v replaced below) and the next libspx call reports the failure.
   const bool poisoned = spx_poisoned(hdr);
-  auto P = [&](double val) -> double { return poisoned ? __longlong_as_double(0x7ff8000000000000ll) : val; };  // (a select: -0.0 stays -0.0)
+  auto P = [&](T val) -> T { return poisoned ? (T)__longlong_as_double(0x7ff8000000000000ll) : val; };  // (a select: -0.0 stays -0.0)
   if constexpr (REG) {
 #pragma unroll
     for (int k = 0; k < kCoopEpl; ++k) {
@@ -1211,6 +1221,7 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
       if (i < n) y[i] = P(sel_out<BINF>(v[k], i, xk[i], sj[i], fin, delta));
     }
   } else if (vec2 && p != 0) {
+    if constexpr (kF64) {
     const int64_t n2 = n >> 1;
     f64x2* y2 = reinterpret_cast<f64x2*>(y);
     const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
@@ -1220,6 +1231,7 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
       y2[pr] = f64x2{P(sel_out<BINF>(vv.x, 2 * pr, b.x, c.x, fin, delta)), P(sel_out<BINF>(vv.y, 2 * pr + 1, b.y, c.y, fin, delta))};
     }
     if ((n & 1) && gtid == 0) y[n - 1] = P(sel_out<BINF>(y[n - 1], n - 1, xk[n - 1], sj[n - 1], fin, delta));
+    }
   } else {
     if (p == 0) {  // resolved before any pass (r <= 0 or r >= n): v was never parked in y
       for (int64_t i = gtid; i < n; i += NT) y[i] = P(sel_out<BINF>((xk[i] + sj[i]) + q[i], i, xk[i], sj[i], fin, delta));
@@ -1231,36 +1243,19 @@ __device__ __forceinline__ void coop_select(double* y, const double* q, const do
 }
 
 // use_set: the histogram set of this launch; clear_set >= 0: the set to zero for a later launch (never use_set).
-// fallback != 0: the launch that follows k_s2_tail -- returns at once if the prediction was verified (the flag was
-// written by an earlier launch: the same value in every workgroup), otherwise clears its own set (2) first, one more
-// barrier on a path that is rare and slow anyway.
-template <bool BINF, bool REG>
-__global__ __launch_bounds__(1024) void k_sel_coop(double* y, const double* q, const double* xk, const double* sj, int64_t n,
-                                                    int64_t r, double delta, SelSync* ss, int parity, int use_set,
-                                                    int clear_set, int fallback) {
+template <bool BINF, bool REG, class T = double>
+__global__ __launch_bounds__(1024) void k_sel_coop(T* y, const T* q, const T* xk, const T* sj, int64_t n,
+                                                    int64_t r, T delta, SelSync* ss, int parity, int use_set,
+                                                    int clear_set) {
   __shared__ CoopShared sh;
   if (blockIdx.x == 0 && threadIdx.x == 0) ss->hdr.bar[parity ^ 1][0] = 0u;
-  if (fallback) {  // last launch of a sample-predicted call: clean slates for the next call's k_s2_front
-    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
-    unsigned long long* z1 = ss->fhist1;
-    unsigned long long* z2 = &ss->fhist2[0][0][0];
-    for (int64_t b = gt; b < kBins; b += nt) z1[b] = 0ull;
-    for (int64_t b = gt; b < 10 * kBins; b += nt) z2[b] = 0ull;
-    if (gt == 0) ss->ws.fs.smax = 0ull;
-    if (ss->ws.fs.ok) return;
-  }
   const int64_t total = (int64_t)kCoopMaxPass * kBins;
   unsigned int nbar = 0;
   if (clear_set >= 0) {
     unsigned long long* z = &ss->chist[clear_set][0][0];
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total; b += (int64_t)gridDim.x * blockDim.x) z[b] = 0ull;
   }
-  if (fallback) {
-    unsigned long long* z = &ss->chist[use_set][0][0];
-    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total; b += (int64_t)gridDim.x * blockDim.x) z[b] = 0ull;
-    spx_grid_barrier(ss->hdr.bar[parity], (++nbar) * gridDim.x, &ss->hdr);
-  }
-  coop_select<BINF, REG>(y, q, xk, sj, n, r, delta, ss->chist[use_set], ss->hdr.bar[parity], nbar, sh, &ss->hdr);
+  coop_select<BINF, REG, T>(y, q, xk, sj, n, r, delta, ss->chist[use_set], ss->hdr.bar[parity], nbar, sh, &ss->hdr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1882,10 +1877,10 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
       SpxCoopLaunchGuard guard(ctx);
       if (reg)
         hipLaunchKernelGGL((k_sel_coop<BINF, true>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r,
-                           delta, ss, parity, use_set, clear_set, 0);
+                           delta, ss, parity, use_set, clear_set);
       else
         hipLaunchKernelGGL((k_sel_coop<BINF, false>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r,
-                           delta, ss, parity, use_set, clear_set, 0);
+                           delta, ss, parity, use_set, clear_set);
     }
     if (graph_safe) {  // whatever the host believed about the sets no longer holds: both count as used
       ctx->sel_hist_dirty[0] = ctx->sel_hist_dirty[1] = 1;
@@ -1982,7 +1977,72 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   return SPX_OK;
 }
 
+// Float32 vectors (round 3): the exact select in one launch, on the same kernels -- one workgroup up to 8192 elements,
+// register-resident up to 8 Ki elements per resident workgroup, v parked in y beyond.  (The sample-predicted single pass is
+// Float64 only: ~44 B/element here instead of 16, 0.7 ms at n = 1e8.)  Bit-exact: v = (xk + sj) + q, the comparisons and the
+// final subtraction are Float32 operations, as in the reference with R = Float32.
+template <bool BINF>
+int run_select_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, const float* sj, int64_t n, int64_t r, float delta) {
+  int rc = spx_check_common(ctx, y, q, xk, sj, n);
+  if (rc) return rc;
+  if (n == 0) return SPX_OK;
+  SPX_ON_DEVICE(ctx);
+  if (n <= kSmallNCoop && ctx->tune_sel_small) {
+    hipLaunchKernelGGL((k_sel_small<BINF, float>), dim3(1), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta);
+    SPX_LAUNCH_CHECK();
+    return SPX_OK;
+  }
+  const int64_t cap_reg = spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_sel_coop<BINF, true, float>), 1024, 0);
+  const int64_t cap_mem = spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_sel_coop<BINF, false, float>), 1024, 0);
+  if (cap_mem < 1) return SPX_ERR_INTERNAL;
+  rc = spx_sync_reserve(ctx, sizeof(SelSync));
+  if (rc) return rc;
+  SelSync* ss = reinterpret_cast<SelSync*>(ctx->sync);
+  const bool graph_safe = spx_capture_check(ctx) || ctx->graph_safe;
+  const int64_t reg_cap = (int64_t)kCoopEpl * 1024 * (cap_reg < ctx->num_cu ? cap_reg : ctx->num_cu);
+  const bool reg = n <= reg_cap;
+  const int64_t g = reg ? (n + (int64_t)kCoopEpl * 1024 - 1) / ((int64_t)kCoopEpl * 1024) : (cap_mem < ctx->num_cu ? cap_mem : ctx->num_cu);
+  int use_set = ctx->sel_hist_next, other = use_set ^ 1;
+  int clear_set = ctx->sel_hist_dirty[other] ? other : -1;
+  int parity = ctx->coop_parity;
+  if (graph_safe) {
+    rc = spx_zero_async(ctx, &ss->hdr, sizeof(ss->hdr.bar));
+    if (rc) return rc;
+    rc = spx_zero_async(ctx, &ss->chist[0][0][0], sizeof(ss->chist[0]));
+    if (rc) return rc;
+    use_set = 0; other = 1; clear_set = -1; parity = 0;
+  }
+  {
+    SpxCoopLaunchGuard guard(ctx);
+    if (reg)
+      hipLaunchKernelGGL((k_sel_coop<BINF, true, float>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta, ss,
+                         parity, use_set, clear_set);
+    else
+      hipLaunchKernelGGL((k_sel_coop<BINF, false, float>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta, ss,
+                         parity, use_set, clear_set);
+  }
+  if (graph_safe) {
+    ctx->sel_hist_dirty[0] = ctx->sel_hist_dirty[1] = 1;
+  } else {
+    ctx->coop_parity ^= 1;
+    ctx->sel_hist_dirty[use_set] = 1;
+    ctx->sel_hist_dirty[other] = 0;
+    ctx->sel_hist_next = other;
+  }
+  SPX_LAUNCH_CHECK();
+  return SPX_OK;
+}
+
 }  // namespace
+
+SPX_EXPORT int spx_prox_indball_l0_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, const float* sj, int64_t n,
+                                       int64_t r) {
+  return run_select_f32<false>(ctx, y, q, xk, sj, n, r, 0.0f);
+}
+SPX_EXPORT int spx_prox_indball_l0_binf_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, const float* sj, int64_t n,
+                                            int64_t r, float delta) {
+  return run_select_f32<true>(ctx, y, q, xk, sj, n, r, delta);
+}
 
 SPX_EXPORT int spx_prox_indball_l0(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
                                    int64_t n, int64_t r) {

@@ -327,3 +327,42 @@ def test_f32_iprox_asserts_d_positive_and_views(s, orc):
     xd, sd, gd, dd = _dev(x, sj, g, d2)
     with pytest.raises(AssertionError):
         s.iprox(s.shifted(s.shifted(s.NormL0(0.4), xd), sd), gd, dd)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ShiftedIndBallL0(BInf) in Float32 (round 3): exact select on Float32 keys, every size class of the one-launch kernels
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 5, 1000, 8192, 8193, 50_001, 1_000_003, 2_500_001])
+def test_f32_topr_bit_exact(s, orc, n):
+    """one workgroup (n <= 8192), register-resident (<= 2^21), v parked in y (beyond): bit for bit against the numpy
+    restatement in Float32 (stable descending sort by |v|): continuous data, a 1/8 lattice (ties: lowest index first), NaN and
+    Inf entries (NaN is the largest magnitude, all NaNs tie), y === q, views from an odd element."""
+    for kind in ("continuous", "lattice", "special"):
+        x, sj, q = _data(n, 300 + n, quant=8 if kind == "lattice" else None)
+        if kind == "special" and n >= 50:
+            rng = np.random.default_rng(n)
+            q[rng.choice(n, size=3, replace=False)] = np.nan
+            q[rng.choice(n, size=2, replace=False)] = np.inf
+            q[rng.choice(n, size=2, replace=False)] = -np.inf
+        xd, sd, qd = _dev(x, sj, q)
+        for r in sorted({1, max(1, n // 100), max(1, n // 2), max(1, n - 1), n, n + 5}):
+            with np.errstate(all="ignore"):
+                ref = orc.prox_indball_l0_f32(q, x, sj, r, 0.75)
+                ref0 = orc.prox_indball_l0_f32(q, x, sj, r)
+            y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.75, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
+            same = (y.view(np.int32) == ref.view(np.int32)) | (np.isnan(y) & np.isnan(ref))
+            assert same.all(), (n, kind, r, int((~same).sum()))
+            y0 = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qd, 1.0).cpu().numpy()
+            same = (y0.view(np.int32) == ref0.view(np.int32)) | (np.isnan(y0) & np.isnan(ref0))
+            assert same.all(), (n, kind, r, "plain", int((~same).sum()))
+        if n >= 5:
+            r = max(1, n // 3)
+            with np.errstate(all="ignore"):
+                ref0 = orc.prox_indball_l0_f32(q, x, sj, r)
+            qa = qd.clone()
+            s.prox_bang(qa, s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qa, 1.0)     # y === q
+            ya = qa.cpu().numpy()
+            assert ((ya.view(np.int32) == ref0.view(np.int32)) | (np.isnan(ya) & np.isnan(ref0))).all(), (n, kind, "aliased")
+            xo, so, qo = _dev(x, sj, q, off=1)
+            yo = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xo), so), qo, 1.0).cpu().numpy()
+            assert ((yo.view(np.int32) == ref0.view(np.int32)) | (np.isnan(yo) & np.isnan(ref0))).all(), (n, kind, "view")

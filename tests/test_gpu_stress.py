@@ -390,3 +390,44 @@ def test_b2_integer_lattices_exact_roots(s, orc):
         ref = orc.prox_l1_b2(q, x, sj, lam, sigma, delta, 1.0)
         y = s.prox(s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(1.0)), sd), qd, sigma).cpu().numpy()
         assert np.max(np.abs(y - ref)) <= 1e-12 * max(np.linalg.norm(ref), np.linalg.norm(x), 1e-300), (rep, n, lev, lam, sigma, delta)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Top-r, tie mode of the sample-predicted pipeline (round 3; csrc/spx_select.hip: FastState::tie, ClassCount, k_s2_tail).  The
+# threshold key is shared by per cents of the vector (or by all of it): its members are counted per wavefront, stored on the
+# sample's guess of the cut, the index cut comes from a prefix sum and the mis-guessed index range is rewritten; moderately
+# tied keys go through the radix select over the candidate records.  Against the CPU oracle (stable sort), bit for bit;
+# odd n and views from an odd element put members of the classes into the stragglers' slots; y === q takes the form
+# without speculative stores.
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["constant", "two values", "lattice 1/4", "lattice 2^-8", "90% zeros", "sorted lattice",
+                                  "lattice + noise on half"])
+def test_topr_tie_mode_against_exact_select(s, orc, kind):
+    import torch
+    rng = np.random.default_rng(sum(map(ord, kind)))
+    n = 2_400_001 + int(rng.integers(0, 7)) * 2          # odd: the last element is a straggler of wave 0
+    g = rng.normal(size=n)
+    if kind == "constant": q = np.full(n, -2.0)
+    elif kind == "two values": q = np.where(g > 0.5, 1.5, -0.75)
+    elif kind == "lattice 1/4": q = np.round(g * 4) / 4
+    elif kind == "lattice 2^-8": q = np.round(g * 256) / 256
+    elif kind == "90% zeros": q = np.where(rng.random(n) < 0.9, 0.0, g)
+    elif kind == "sorted lattice": q = np.sort(np.round(g * 4) / 4)
+    else: q = np.where(np.arange(n) % 2 == 0, np.round(g * 2) / 2, g)
+    x = np.zeros(n); sj = np.zeros(n)
+    for head in (0, 1):                                   # head = 1: views from an odd element (8 bytes off a 16-byte boundary)
+        mk = (lambda a: torch.cat([torch.zeros(1, dtype=torch.float64), torch.from_numpy(a)]).cuda()[1:]) if head else \
+            (lambda a: torch.from_numpy(a).cuda())
+        xd, sd, qd = mk(x), mk(sj), mk(q)
+        for r in (n // 100, n // 2, n - n // 20, 3):
+            ref = orc.prox_indball_l0_binf(q, x, sj, r, 1.25)
+            y = mk(np.full(n, np.nan))
+            psi = s.shifted(s.shifted(s.IndBallL0(r), xd, 1.25, s.NormLinf(1.0)), sd)
+            s.prox_bang(y, psi, qd, 1.0)
+            got = y.cpu().numpy()
+            assert np.array_equal(got.view(np.int64), ref.view(np.int64)), (kind, head, r, int(np.sum(got.view(np.int64) != ref.view(np.int64))))
+            if r == n // 2:
+                qa = qd.clone() if not head else mk(q.copy())
+                s.prox_bang(qa, psi, qa, 1.0)              # y === q: nothing is stored before the cut is known
+                assert np.array_equal(qa.cpu().numpy().view(np.int64), ref.view(np.int64)), (kind, head, r, "aliased")
+    s._lib.check(s._lib.load().spx_sync(s.context("cuda:0")))

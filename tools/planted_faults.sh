@@ -1,6 +1,6 @@
 #!/bin/bash
 # Confirms that the driver-run stress tests FAIL on planted faults.
-#   tools/planted_faults.sh build     (here, no GPU): patched copies of csrc/ -> lib/libspx_fault<k>.so
+#   tools/planted_faults.sh build [ids]   (here, no GPU): patched copies of csrc/ -> lib/libspx_fault<k>.so (all, or the ids listed)
 #   tools/planted_faults.sh run       (on the GPU box): the named tests against each faulty library; every one must fail
 # Nothing in the product tree is modified: the patches are applied to a scratch copy under /tmp.
 set -uo pipefail
@@ -15,12 +15,18 @@ FAULTS=(
  "6|spx_b2.hip|s/clear_rows\[pass_i \* kB2Cols \* kB2Words + rem\] = 0ull;/(void)rem;/|tests/test_gpu_stress.py::test_b2_alternating_sizes_share_the_exchange_words tests/test_gpu_stress.py::test_b2_one_launch_forms_at_their_boundaries"
  "7|spx_select.hip|s/rc = spx_zero_async(ctx, &ss->chist\[0\]\[0\]\[0\], sizeof(ss->chist\[0\]));/rc = 0;/|tests/test_gpu_graph.py::test_iteration_in_a_graph_replays_on_new_data"
  "8|spx_select.hip|s/      if (run_count\[k\]) atomicAdd(&ws->hist\[run_digit\[k\]\], (unsigned long long)run_count\[k\]);/      (void)run_count[k];/|tests/test_gpu_parity.py::test_indball_l0_front_sample_sizes tests/test_gpu_fullsize.py"
+ "9|spx_select.hip|s/if (match \&\& ex + 1ull == rho) tl\[19\]/if (match \&\& ex == rho) tl[19]/|tests/test_gpu_stress.py::test_topr_tie_mode_against_exact_select tests/test_gpu_fullsize.py::test_indball_fast_path_and_fallback"
+ "10|spx_b2.hip|s/const bool fixp = valid \&\& ua \&\& ub, fixc = valid \&\& !ua \&\& !ub \&\& pa == pb;/const bool fixp = valid \&\& ua \&\& ub, fixc = valid \&\& !ua \&\& !ub;/|tests/test_gpu_stress.py::test_b2_streaming_form_scenarios"
+ "11|spx_select.hip|s/const int64_t lo = (ca < cs ? ca : cs) + 1, hi = ca < cs ? cs : ca;/const int64_t lo = (ca < cs ? ca : cs) + 3, hi = ca < cs ? cs : ca;/|tests/test_gpu_stress.py::test_topr_tie_mode_against_exact_select"
+ "12|spx_select.hip|s/(spec_hi == 2 \&\& i <= spec_cut);/(spec_hi == 2 \&\& i < spec_cut);/|tests/test_gpu_stress.py::test_topr_tie_mode_against_exact_select"
  "4|spx_group.hip|s/if (sb == 0.0) {/if (false) {/;s/for (int k = 0; k < 64; ++k) {/for (int k = 0; k < 12; ++k) { piece_ok = true;/|tests/test_gpu_parity.py::test_group_binf_many_small_groups tests/test_gpu_parity.py::test_group_binf_zero_groups_strong_lambda"
 )
 case "${1:-}" in
 build)
+  only=" ${*:2} "
   for f in "${FAULTS[@]}"; do
     IFS='|' read -r id file expr tests <<< "$f"
+    [ "$only" = "  " ] || [[ "$only" == *" $id "* ]] || continue
     W="/tmp/spx_fault_$id"; rm -rf "$W"; mkdir -p "$W/shiftedproximaloperators.jl_amd" "$W/include"
     cp -r "$CSRC" "$W/shiftedproximaloperators.jl_amd/csrc"; cp "$ROOT/include/spx.h" "$W/include/"
     before=$(md5sum < "$W/shiftedproximaloperators.jl_amd/csrc/$file")
