@@ -368,6 +368,14 @@ int spx_prox_group_l2_binf(spx_ctx* ctx, double* y, const double* q, const doubl
                            int64_t group_size, int64_t ngroups, const double* lambda_vec,
                            double sigma, double delta);
 
+/* ShiftedGroupNormL2.prox! on Float32 vectors (round 3; the method is generic in R, src/shiftedGroupNormL2.jl:52-79): every
+ * elementwise operation in Float32; the group norm is accumulated in Float64 and rounded once (the reference's `norm` is
+ * BLAS / a generic loop: agreement to a few Float32 ulps of the operands, not bits).  Contiguous groups (uniform or CSR).
+ * ShiftedGroupNormL2Binf has no Float32 form. */
+int spx_prox_group_l2_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, const float* sj, int64_t n,
+                          const int64_t* group_offsets, int64_t group_size, int64_t ngroups, const float* lambda_vec,
+                          float sigma);
+
 /* Groups as ARBITRARY index sets -- the reference's `idx::Vector{Vector{Int}}` (src/groupNormL2.jl:30-31,
  * test/runtests.jl:290): group g = group_index[group_ptr[g] .. group_ptr[g+1]) (device int64, 0-based; group_ptr has
  * ngroups+1 entries, group_index nnz).  Literal reference semantics: an index listed by several groups keeps the value

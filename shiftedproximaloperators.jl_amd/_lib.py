@@ -77,6 +77,7 @@ SIGNATURES = {
     "spx_prox_l1_b2": [_p, _p, _p, _p, _p, _i64, _d, _d, _d, _d],
     "spx_obj_l1_b2": [_p, _p, _p, _p, _i64, _d, _d, ctypes.POINTER(_d)],
     "spx_prox_group_l2": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _d],
+    "spx_prox_group_l2_f32": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _f],
     "spx_prox_group_l2_binf": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _d, _d],
     "spx_prox_group_l2_gather": [_p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _d],
     "spx_prox_group_l2_binf_gather": [_p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _d, _d],

@@ -366,3 +366,47 @@ def test_f32_topr_bit_exact(s, orc, n):
             xo, so, qo = _dev(x, sj, q, off=1)
             yo = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xo), so), qo, 1.0).cpu().numpy()
             assert ((yo.view(np.int32) == ref0.view(np.int32)) | (np.isnan(yo) & np.isnan(ref0))).all(), (n, kind, "view")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ShiftedGroupNormL2 in Float32 (round 3): elementwise operations in Float32, the norm to a Float32 ulp
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("gs", [1, 7, 64, 128, 1000])
+def test_f32_group_l2(s, gs):
+    """uniform groups and ragged CSR groups (incl. indices in no group: y - (xk + sj), src/shiftedGroupNormL2.jl:77), y === q.
+    Reference: the method restated in numpy with Float32 operations and the norm formed in Float64 and rounded once (the
+    reference's own `norm` is BLAS / a generic loop: neither pins the last ulp) -- bar 1e-6 of the operands' scale."""
+    import torch
+    rng = np.random.default_rng(500 + gs)
+    ng = 3000
+    n = ng * gs
+    x, sj, q = _data(n, 500 + gs)
+    lam = rng.uniform(0.2, 3.0, size=ng).astype(np.float32)
+    sigma = np.float32(0.8)
+
+    def ref(offs, y_in):
+        S = ((q + x) + sj).astype(np.float32)
+        y = y_in.copy()
+        for g in range(len(offs) - 1):
+            lo, hi = offs[g], offs[g + 1]
+            sn = np.float32(np.sqrt(np.sum(S[lo:hi].astype(np.float64) ** 2)))
+            if sn == 0:
+                y[lo:hi] = 0
+            else:
+                a = np.maximum(np.float32(1) - sigma * lam[g] / sn, np.float32(0))
+                y[lo:hi] = a * S[lo:hi]
+        return (y - (x + sj)).astype(np.float32), S
+
+    xd, sd, qd = _dev(x, sj, q)
+    h = s.GroupNormL2.uniform(torch.from_numpy(lam).cuda(), gs)
+    psi = s.shifted(s.shifted(h, xd), sd)
+    assert psi.f32
+    y = s.prox(psi, qd, float(sigma)).cpu().numpy()
+    offs = np.arange(0, n + 1, gs)
+    want, S = ref(offs, np.zeros(n, dtype=np.float32))
+    nrm = np.repeat(np.sqrt(np.add.reduceat(S.astype(np.float64) ** 2, offs[:-1])), gs)
+    scale = np.maximum(np.maximum(np.abs(want), np.abs(x + sj)), nrm)
+    assert np.all(np.abs(y - want) <= 1e-6 * np.maximum(scale, 1e-30)), float(np.max(np.abs(y - want) / np.maximum(scale, 1e-30)))
+    qa = qd.clone()
+    s.prox_bang(qa, psi, qa, float(sigma))                 # y === q
+    assert np.all(np.abs(qa.cpu().numpy() - want) <= 1e-6 * np.maximum(scale, 1e-30))

@@ -16,7 +16,7 @@ FAULTS=(
  "7|spx_select.hip|s/rc = spx_zero_async(ctx, &ss->chist\[0\]\[0\]\[0\], sizeof(ss->chist\[0\]));/rc = 0;/|tests/test_gpu_graph.py::test_iteration_in_a_graph_replays_on_new_data"
  "8|spx_select.hip|s/      if (run_count\[k\]) atomicAdd(&ws->hist\[run_digit\[k\]\], (unsigned long long)run_count\[k\]);/      (void)run_count[k];/|tests/test_gpu_parity.py::test_indball_l0_front_sample_sizes tests/test_gpu_fullsize.py"
  "9|spx_select.hip|s/if (match \&\& ex + 1ull == rho) tl\[19\]/if (match \&\& ex == rho) tl[19]/|tests/test_gpu_stress.py::test_topr_tie_mode_against_exact_select tests/test_gpu_fullsize.py::test_indball_fast_path_and_fallback"
- "10|spx_b2.hip|s/const bool fixp = valid \&\& ua \&\& ub, fixc = valid \&\& !ua \&\& !ub \&\& pa == pb;/const bool fixp = valid \&\& ua \&\& ub, fixc = valid \&\& !ua \&\& !ub;/|tests/test_gpu_stress.py::test_b2_streaming_form_scenarios"
+ "10|spx_b2.hip|s/for (unsigned int e = (unsigned int)(t \& 63); e < ncand_mine; e += 64) {/for (unsigned int e = (unsigned int)(t \& 63); e + 64 < ncand_mine; e += 64) {/|tests/test_gpu_stress.py::test_b2_streaming_form_scenarios"
  "11|spx_select.hip|s/const int64_t lo = (ca < cs ? ca : cs) + 1, hi = ca < cs ? cs : ca;/const int64_t lo = (ca < cs ? ca : cs) + 3, hi = ca < cs ? cs : ca;/|tests/test_gpu_stress.py::test_topr_tie_mode_against_exact_select"
  "12|spx_select.hip|s/(spec_hi == 2 \&\& i <= spec_cut);/(spec_hi == 2 \&\& i < spec_cut);/|tests/test_gpu_stress.py::test_topr_tie_mode_against_exact_select"
  "4|spx_group.hip|s/if (sb == 0.0) {/if (false) {/;s/for (int k = 0; k < 64; ++k) {/for (int k = 0; k < 12; ++k) { piece_ok = true;/|tests/test_gpu_parity.py::test_group_binf_many_small_groups tests/test_gpu_parity.py::test_group_binf_zero_groups_strong_lambda"
@@ -42,7 +42,9 @@ run)
     IFS='|' read -r id file expr tests <<< "$f"
     SPX_LIB_NAME="libspx_fault$id.so" SPX_NO_BUILD=1 timeout -k 10 300 python -m pytest $tests -m gpu -q -x -p no:cacheprovider > "gpurun_out/fault$id.log" 2>&1
     rc=$?
-    if [ $rc -eq 1 ]; then echo "fault $id: caught ($(grep -c '^FAILED' gpurun_out/fault$id.log) failing test(s), first: $(grep -m1 '^FAILED' gpurun_out/fault$id.log | cut -c1-120))"
+    nfail=$(grep -c '^FAILED' "gpurun_out/fault$id.log"); nerr=$(grep -c '^ERROR' "gpurun_out/fault$id.log")
+    if [ $rc -eq 1 ] && [ "$nfail" -ge 1 ] && [ "$nerr" -eq 0 ]; then echo "fault $id: caught ($nfail failing test(s), first: $(grep -m1 '^FAILED' gpurun_out/fault$id.log | cut -c1-120))"
+    elif [ "$nerr" -ge 1 ]; then echo "fault $id: the test run ERRORED (stale library? rebuild with tools/planted_faults.sh build): $(grep -m1 '^ERROR' gpurun_out/fault$id.log | cut -c1-120)"; bad=1
     else echo "fault $id: NOT CAUGHT (pytest rc $rc)"; bad=1; fi
   done
   exit $bad ;;
