@@ -128,7 +128,8 @@ int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms); /* records stop, waits, ret
  * kernel for n <= 8192 (1, default), key 8 = pretend that at most this many workgroups of a kernel that synchronises inside
  * one launch can be resident at once (0, default: what hipOccupancyMaxActiveBlocksPerMultiprocessor says; the grids of
  * top-r and ShiftedNormL1B2 are sized by it and fall back to their any-grid forms -- this key lets a test force that).
- * (Key 7, round 2's switch to the multi-launch pipelines, is gone with those pipelines.)
+ * Key 10 = samples per lane of the top-r front kernel (0, default: 1 / 2 / 4 by n, 16 for a cut in the bulk of a vector of
+ * >= 2^26 elements; 1, 2, 4, 16 force it).  (Key 7, round 2's switch to the multi-launch pipelines, is gone with those pipelines.)
  * Key 9 DOES change results, within the stated tolerance: ShiftedGroupNormL2Binf, 0 (default) = the closed form at the root
  * (within ~1e-15 of the exact value of the reference's formula everywhere), 1 = groups whose root sits next to the pole of
  * step(n) (u < n / 1000) are evaluated literally, operation by operation as src/shiftedGroupNormL2Binf.jl:87-113 with

@@ -60,6 +60,7 @@ struct spx_ctx {
   int tune_binf_literal = 0;       // key 9: GroupNormL2Binf groups whose root sits next to the pole of step(n) (u < n/1000) take
                                    //        the reference's literal Float64 evaluation (reproduces a reference run bit pattern
                                    //        by bit pattern where the default is the more accurate side: include/spx.h)
+  int tune_front_spl = 0;          // key 10: samples per lane of the top-r front kernel (1, 2, 4, 16; 0 = by n and r / n)
   int tune_force_grid = 0;         // key 100, test builds only (-DSPX_TEST_HOOKS): launch the one-launch top-r with THIS many workgroups,
                                    //          residency or not -- the planted fault behind tests/test_gpu_robustness.py
   // Device-side status word in host-mapped pinned memory (spx_ctx.hip): a kernel that gives up waiting for the other

@@ -1839,9 +1839,17 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   const int64_t cap_reg = spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_sel_coop<BINF, true>), 1024, 0);
   const int64_t cap_mem = spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_sel_coop<BINF, false>), 1024, 0);
   if (cap_mem < 1) return SPX_ERR_INTERNAL;  // (message set by spx_resident_cap)
-  const void* front_fn = n >= ((int64_t)1 << 25) ? reinterpret_cast<const void*>(&k_s2_front<4>)
-                       : n >= ((int64_t)1 << 23) ? reinterpret_cast<const void*>(&k_s2_front<2>)
-                                                 : reinterpret_cast<const void*>(&k_s2_front<1>);
+  // samples per lane of the front kernel: 1 / 2 / 4 by n (see k_s2_front); 16 for a cut in the bulk of a large vector -- the band
+  // is +-6 sigma of the SAMPLE rank, sigma^2 = M p (1 - p): its share of the vector shrinks with sqrt(M), and at r = n/2 the band
+  // of the 4-sample form holds 1.2 % of the vector as candidates (main pass +40 us, compaction +20 us; tuning key 10 overrides)
+  const double pcut = (double)r / (double)n;
+  int spl = n >= ((int64_t)1 << 25) ? 4 : (n >= ((int64_t)1 << 23) ? 2 : 1);
+  if (n >= ((int64_t)1 << 26) && pcut * (1.0 - pcut) > 0.04) spl = 16;
+  if (ctx->tune_front_spl == 1 || ctx->tune_front_spl == 2 || ctx->tune_front_spl == 4 || ctx->tune_front_spl == 16) spl = ctx->tune_front_spl;
+  const void* front_fn = spl == 16 ? reinterpret_cast<const void*>(&k_s2_front<16>)
+                       : spl == 4 ? reinterpret_cast<const void*>(&k_s2_front<4>)
+                       : spl == 2 ? reinterpret_cast<const void*>(&k_s2_front<2>)
+                                  : reinterpret_cast<const void*>(&k_s2_front<1>);
   const int64_t cap_front = spx_resident_cap(ctx, front_fn, 1024, 0);
   const int64_t reg_cap = (int64_t)kCoopEpl * 1024 * (cap_reg < ctx->num_cu ? cap_reg : ctx->num_cu);  // (2 Mi elements on 256 CUs)
   const int64_t fast_min = ((int64_t)1 << SPX_SEL_REG_MAX_LOG2) + 1;
@@ -1934,10 +1942,13 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   }
   {
     SpxCoopLaunchGuard guard(ctx);
-    if (n >= ((int64_t)1 << 25))
+    if (spl == 16)
+      hipLaunchKernelGGL(k_s2_front<16>, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
+                         n - ioff, r, ss, ctx->coop_parity);
+    else if (spl == 4)
       hipLaunchKernelGGL(k_s2_front<4>, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
                          n - ioff, r, ss, ctx->coop_parity);
-    else if (n >= ((int64_t)1 << 23))
+    else if (spl == 2)
       hipLaunchKernelGGL(k_s2_front<2>, dim3(kFrontBlocks), dim3(1024), 0, ctx->stream, q + ioff, xk + ioff, sj + ioff,
                          n - ioff, r, ss, ctx->coop_parity);
     else
