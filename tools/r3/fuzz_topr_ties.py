@@ -1,0 +1,63 @@
+"""Round 3 hunt: the sample-predicted top-r pipeline (generic band, tie mode, candidate select, speculation + range fix-up)
+against the exact select (tuning key 2 = 0), bit for bit, on random instances: n in (2^21, 7e6], data = mixtures of
+continuous values, lattices at random scales, a few heavy values, exact zeros, sorted stretches, NaN / Inf specks; random r
+(tiny, bulk, near n), views from an odd element, y === q.  usage: fuzz_topr_ties.py [instances] [seed]"""
+import os, sys
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, R)
+import numpy as np, torch
+import __graft_entry__ as ge
+s = ge.build(); L = s._lib.load(); ctx = s.context("cuda:0")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+g = torch.Generator(device="cuda:0").manual_seed(seed)
+rng = np.random.default_rng(seed)
+bad = 0
+for it in range(N):
+    n = int(rng.integers((1 << 21) + 2, 7_000_000))
+    base = torch.randn(n + 1, dtype=torch.float64, device="cuda:0", generator=g)
+    kind = int(rng.integers(0, 9))
+    scale = float(2.0 ** rng.integers(-6, 7))
+    if kind == 0: q = base * scale
+    elif kind == 1: q = torch.round(base * scale) / scale                                   # lattice at a random scale
+    elif kind == 2: q = torch.where(base > float(rng.normal()), torch.full_like(base, 1.5), torch.full_like(base, -0.75))
+    elif kind == 3: q = torch.where(torch.rand(n + 1, device="cuda:0", generator=g) < float(rng.uniform(0.05, 0.99)), torch.zeros_like(base), base)
+    elif kind == 4: q = torch.sort(torch.round(base * scale) / scale)[0]
+    elif kind == 5:                                                                          # half lattice, half continuous
+        q = torch.where(torch.arange(n + 1, device="cuda:0") % 2 == 0, torch.round(base * scale) / scale, base)
+    elif kind == 6:                                                                          # three heavy values + noise
+        u = torch.rand(n + 1, device="cuda:0", generator=g)
+        q = torch.where(u < 0.3, torch.full_like(base, 2.0), torch.where(u < 0.5, torch.full_like(base, -2.0), torch.where(u < 0.6, torch.full_like(base, 2.0000000001), base)))
+    elif kind == 7: q = torch.full_like(base, float(rng.normal()))
+    else:
+        q = torch.round(base * 4) / 4
+        idx = torch.randint(0, n + 1, (5,), device="cuda:0", generator=g)
+        q[idx] = float("nan"); q[(idx + 7) % (n + 1)] = float("inf")
+    xscale = float(rng.choice([0.0, 0.0, 1.0, 1e-3]))
+    x = torch.round(torch.randn(n + 1, dtype=torch.float64, device="cuda:0", generator=g) * 8) / 8 * xscale
+    sj = torch.zeros(n + 1, dtype=torch.float64, device="cuda:0")
+    head = int(rng.integers(0, 2))
+    xv, sv, qv = x[head:head + n], sj[head:head + n], q[head:head + n]
+    r = int(rng.choice([1, 3, n // 1000, n // 100, n // 10, n // 3, n // 2, n - n // 10, n - 5, int(rng.integers(1, n))]))
+    delta = float(rng.choice([0.5, 1.0, 1e6]))
+    psi = s.shifted(s.shifted(s.IndBallL0(r), xv, delta, s.NormLinf(1.0)), sv)
+    yref = torch.empty(n + 1, dtype=torch.float64, device="cuda:0")[head:head + n]
+    y = torch.full((n + 1,), float("nan"), dtype=torch.float64, device="cuda:0")[head:head + n]
+    L.spx_ctx_set_tuning(ctx, 2, 0); s.prox_bang(yref, psi, qv, 1.0); L.spx_ctx_set_tuning(ctx, 2, 1)
+    s.prox_bang(y, psi, qv, 1.0)
+    a, b = y.view(torch.int64), yref.view(torch.int64)
+    same = bool(torch.equal(a, b)) or bool(((a == b) | (torch.isnan(y) & torch.isnan(yref))).all())
+    alias_ok = True
+    if it % 3 == 0:
+        qa = q.clone()[head:head + n]
+        s.prox_bang(qa, psi, qa, 1.0)
+        alias_ok = bool(((qa.view(torch.int64) == b) | (torch.isnan(qa) & torch.isnan(yref))).all())
+    rc = L.spx_sync(ctx)
+    if not (same and alias_ok and rc == 0):
+        bad += 1
+        print("MISMATCH it=%d n=%d kind=%d scale=%g xscale=%g head=%d r=%d delta=%g same=%s alias=%s rc=%d ndiff=%d" % (
+            it, n, kind, scale, xscale, head, r, delta, same, alias_ok, rc, int((a != b).sum())), flush=True)
+    if it % 25 == 24:
+        print("... %d instances, %d mismatches" % (it + 1, bad), flush=True)
+print("done: %d instances, %d mismatches" % (N, bad))
+sys.exit(1 if bad else 0)
