@@ -844,7 +844,9 @@ __global__ __launch_bounds__(256) void k_s2_compact(double* y, const Cand* cand,
       in = key == st.t_eq && itop == st.prefix;
       keep = (key >= st.t_ge) || (key == st.t_eq && itop < st.prefix);
     }
-    if (in) {
+    // (a list that has already overflowed is not appended to any more: a bucket of 1e4-1e6 survivors -- moderately tied
+    //  data -- was tens of thousands of atomics on this one counter, 73 us of the walk; k_s2_tail takes over anyway)
+    if (in && __hip_atomic_load(&ws->fs.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= (unsigned)kShortList) {
       // one atomic per wave instruction, not per survivor (they all hit one address: ~12 ns each, serialised)
       const unsigned long long am = __ballot(1);
       const int lane = threadIdx.x & 63;
@@ -1013,6 +1015,9 @@ struct SelSync {
   // their own ready flag (value + 1, zero = not yet written; cleared by the launch itself after its last reader)
   unsigned long long tie_part[256];
   unsigned long long tie_cut;
+  // k_s2_tail, candidate select: smallest / largest key and number of the candidates inside the bucket of each pass (set to
+  // ~0 / 0 / 0 by the launch before its first pass): a bucket of ONE key ends the key digits at once
+  unsigned long long cmin[kCoopMaxPass], cmax[kCoopMaxPass], ccnt[kCoopMaxPass];
 };
 
 static_assert(sizeof(SelSync) <= kSpxSyncSelBytes, "SelSync outgrew its share of spx_ctx::sync");
@@ -1322,6 +1327,7 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
   if (!ok || (todo & kTodoCandSelect)) {  // histogram set 2 belongs to this launch: cleared here, one barrier
     unsigned long long* z = &ss->chist[2][0][0];
     for (int64_t k = gt; k < total_hist; k += nt) z[k] = 0ull;
+    if (gt < kCoopMaxPass) { ss->cmin[gt] = ~0ull; ss->cmax[gt] = 0ull; ss->ccnt[gt] = 0ull; }
     spx_grid_barrier(bar, (++nbar) * G, hdr);
   }
   if (!ok) {  // prediction not verified: exact select over the whole vector (recomputes everything from q, xk, sj)
@@ -1339,6 +1345,7 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
       __syncthreads();
       const int hs = st.shift + st.width;
       const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
+      unsigned long long kmin = ~0ull, kmax = 0ull, kcnt = 0ull;  // (phase 0) keys of this lane's candidates inside the bucket
       for_each_candidate(counts, nregions, cand, (int64_t)novf, [&](uint64_t key, int64_t i, double) {
         bool in;
         unsigned int dg;
@@ -1346,12 +1353,26 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
           const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
           in = kp.in;
           dg = kp.digit;
+          if (in) { kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax; ++kcnt; }
         } else {
           in = key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix;
           dg = (unsigned int)((((uint64_t)i) >> st.shift) & dmask);
         }
         hist_add_agg(sh.lh, dg, in);
       });
+      if (st.phase == 0) {  // one global atomic of each kind per wavefront that saw a candidate of the bucket
+        for (int off = 32; off >= 1; off >>= 1) {
+          const unsigned long long a = __shfl_xor(kmin, off, 64), c = __shfl_xor(kmax, off, 64);
+          kmin = a < kmin ? a : kmin;
+          kmax = c > kmax ? c : kmax;
+          kcnt += __shfl_xor(kcnt, off, 64);
+        }
+        if ((t & 63) == 0 && kcnt) {
+          atomicMin(&ss->cmin[p], kmin);
+          atomicMax(&ss->cmax[p], kmax);
+          atomicAdd(&ss->ccnt[p], kcnt);
+        }
+      }
       __syncthreads();
       for (int k = t; k < kBins; k += 1024) {
         const unsigned int c = sh.lh[k];
@@ -1360,6 +1381,35 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       spx_grid_rendezvous(bar, (++nbar) * G, hdr);
       coop_scan_step(ss->chist[2][p], st, &sh.sst, sh.scratch);
+      if (st.phase == 0) {
+        // A bucket that holds ONE key (lattice data: the usual state after the first digit) needs no further key digits:
+        // all of it kept, or the index tie-break on that key -- the state the remaining digits would arrive at, 2-4 sweeps later.
+        __syncthreads();
+        if (t == 0) {
+          const unsigned long long lo = __hip_atomic_load(&ss->cmin[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long hi = __hip_atomic_load(&ss->cmax[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long cnt = __hip_atomic_load(&ss->ccnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lo == hi && cnt > 0 && (unsigned long long)st.quota <= cnt) {
+            SelState o = st;
+            o.pad = 0;
+            if ((unsigned long long)st.quota == cnt) {   // the whole bucket is kept
+              o.phase = 2;
+              o.t_ge = lo > st.t_floor ? lo : st.t_floor;
+            } else {                                     // more equal keys than quota: ties by ascending index
+              o.t_ge = lo + 1;
+              o.t_eq = lo;
+              o.phase = 1;
+              o.prefix = 0;
+              const int top = st.idx_bits;
+              const int w = top % kDigitBits ? top % kDigitBits : kDigitBits;
+              if (top == 0) { o.phase = 2; o.icut = 0; }
+              o.shift = top - w;
+              o.width = w;
+            }
+            sh.sst = o;
+          }
+        }
+      }
     }
     __syncthreads();
     const SelState fin = sh.sst;
