@@ -129,7 +129,9 @@ int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms); /* records stop, waits, ret
  * one launch can be resident at once (0, default: what hipOccupancyMaxActiveBlocksPerMultiprocessor says; the grids of
  * top-r and ShiftedNormL1B2 are sized by it and fall back to their any-grid forms -- this key lets a test force that).
  * Key 10 = samples per lane of the top-r front kernel (0, default: 1 / 2 / 4 by n, 16 for a cut in the bulk of a vector of
- * >= 2^26 elements; 1, 2, 4, 16 force it).  (Key 7, round 2's switch to the multi-launch pipelines, is gone with those pipelines.)
+ * >= 2^26 elements; 1, 2, 4, 16 force it).  Key 11 = one-launch top-r with v parked in LDS for 2^20 < n <= 16 Ki x resident
+ * workgroups (1, default; 0: registers up to 2^21, the sample-predicted path above, as in round 2).  (Key 7, round 2's switch
+ * to the multi-launch pipelines, is gone with those pipelines.)
  * Key 9 DOES change results, within the stated tolerance: ShiftedGroupNormL2Binf, 0 (default) = the closed form at the root
  * (within ~1e-15 of the exact value of the reference's formula everywhere), 1 = groups whose root sits next to the pole of
  * step(n) (u < n / 1000) are evaluated literally, operation by operation as src/shiftedGroupNormL2Binf.jl:87-113 with
@@ -318,8 +320,10 @@ int spx_obj_group_l2_binf(spx_ctx* ctx, const double* y, const double* xk, const
 /* ---- top-r selection ------------------------------------------------------------------- */
 /* ShiftedIndBallL0.prox!     src/shiftedIndBallL0.jl:54-72 : keep the r entries of (xk+sj)+q largest in
  * magnitude (ties: lowest index first, = stable sortperm), zero the rest, subtract xk+sj.
- * The result never depends on the route taken, the time does: beyond 2^21 elements a sample predicts a band around the r-th
- * largest magnitude and one streaming pass settles everything outside it (n = 1e8: 0.57-0.66 ms, sorted input included).
+ * The result never depends on the route taken, the time does: up to 2^22 elements (what 256 resident workgroups hold in
+ * registers or LDS) an exact radix select in ONE launch reads the vectors once and writes y once (n = 4e6: 42 us, n = 1e5: 19 us);
+ * beyond, a sample predicts a band around the r-th largest magnitude and one streaming pass settles everything outside it
+ * (n = 1e8: 0.57-0.62 ms, sorted input included).
  * Keys at the threshold that are shared by per cents of the vector (lattice data, constants, a sparse vector's zeros) are
  * counted per wavefront instead of recorded, and the index tie-break (lowest index first) comes from a prefix sum over those
  * counts: 0.59-0.85 ms at n = 1e8 (round 2: 2.6-6.5 ms).  If the sample misleads, the exact radix select queued behind the

@@ -61,6 +61,7 @@ struct spx_ctx {
                                    //        the reference's literal Float64 evaluation (reproduces a reference run bit pattern
                                    //        by bit pattern where the default is the more accurate side: include/spx.h)
   int tune_front_spl = 0;          // key 10: samples per lane of the top-r front kernel (1, 2, 4, 16; 0 = by n and r / n)
+  int tune_sel_reg16 = 1;          // key 11: register-resident one-launch top-r at 16 elements per lane (2 Mi < n <= 4 Mi on 256 CUs)
   int tune_force_grid = 0;         // key 100, test builds only (-DSPX_TEST_HOOKS): launch the one-launch top-r with THIS many workgroups,
                                    //          residency or not -- the planted fault behind tests/test_gpu_robustness.py
   // Device-side status word in host-mapped pinned memory (spx_ctx.hip): a kernel that gives up waiting for the other
@@ -219,14 +220,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 constexpr size_t kSpxSyncSelBytes = (size_t)2 << 20;  // 2 MiB >= sizeof(SelSync) (static_assert in spx_select.hip)
 
 // Head of spx_ctx::sync, shared by every kernel that synchronises inside one launch.
+constexpr int kSpxBarSplit = 8;  // arrival counters per grid barrier (see spx_grid_rendezvous)
 struct SpxSyncHeader {
-  unsigned int bar[2][32];  // grid-barrier counters, one 128-byte line each: a launch uses [parity] and clears [parity ^ 1]
+  unsigned int bar[2][kSpxBarSplit * 32];  // grid-barrier counters, kSpxBarSplit 128-byte lines per set: a launch uses [parity] and clears [parity ^ 1]
   int b2_last_scaled;       // ShiftedNormL1B2: did the previous call on this context find the trust region active?
   int timed_out;            // sticky: a workgroup gave up waiting for the others (kSpxPollLimit); no workgroup waits any more
   int* status;              // device view of spx_ctx::status_host (host-mapped): the failure is reported by the NEXT libspx call
   int pad[28];
 };
-static_assert(sizeof(SpxSyncHeader) == 2 * 32 * 4 + 128, "SpxSyncHeader layout");
+static_assert(sizeof(SpxSyncHeader) == 2 * kSpxBarSplit * 32 * 4 + 128, "SpxSyncHeader layout");
 
 // Every wait of one workgroup for others is bounded: kSpxPollLimit polls (each a memory round trip plus a short sleep: a few
 // seconds in all, against microseconds of legitimate waiting).  A workgroup that gives up sets SpxSyncHeader::timed_out,
@@ -259,25 +261,44 @@ __device__ __forceinline__ bool spx_poisoned(SpxSyncHeader* hdr) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Grid barrier for kernels whose workgroups are all resident (grid <= number of CUs, one workgroup per CU): one
-// monotonic counter in spx_ctx::sync.  Recipe of MI355X_MICROARCH.md ("inter-workgroup visibility"): every storing wave
-// drains its stores, workgroup barrier, ONE lane: agent-scope release (L2 write-back) -> arrive (agent-scope atomic add) ->
-// relaxed polls -> agent-scope acquire (L1 / non-coherent L2 lines invalidated), workgroup barrier, then plain loads.
+// Grid barrier for kernels whose workgroups are all resident (grid <= number of CUs, one workgroup per CU): monotonic
+// counters in spx_ctx::sync.  Recipe of MI355X_MICROARCH.md ("inter-workgroup visibility"): every storing wave drains its
+// stores, workgroup barrier, wave 0: agent-scope release (L2 write-back) -> arrive (agent-scope atomic add) -> relaxed polls
+// -> agent-scope acquire (L1 / non-coherent L2 lines invalidated), workgroup barrier, then plain loads.
 // `target` = (number of barriers passed so far in this launch + 1) * gridDim.x.  Every workgroup of the grid must call
 // it the same number of times (the exit condition every wave reaches: no early return between barriers).
+// Arrivals are spread over kSpxBarSplit counters (workgroup b adds to counter b % 8, each on its own 128-byte line) and
+// lanes 0..7 of wave 0 poll one counter each: atomics on ONE address retire ~12 ns apart and the polls of 256 workgroups
+// queue in front of the last arrivals -- measured without fences (tools/exp/grid_barrier.hip): 3.75 -> 1.44 us per
+// rendezvous with 256 workgroups, 2.0 -> 1.2 with 128, 1.3 -> 1.1 with 64 (16 counters: 2.2 / 1.2 / 1.1; a two-level tree 2.4).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void spx_grid_barrier(unsigned int* counter, unsigned int target, SpxSyncHeader* hdr) {
+__device__ __forceinline__ void spx_bar_arrive_and_wait(unsigned int* counters, unsigned int target, SpxSyncHeader* hdr) {
+  // (wave 0, all 64 lanes)
+  const unsigned int lane = threadIdx.x;
+  const unsigned int phase = target / gridDim.x;
+  if (lane == 0) __hip_atomic_fetch_add(&counters[32u * (blockIdx.x % (unsigned)kSpxBarSplit)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // counter j hears from the workgroups j, j + 8, ...
+  const unsigned int want = (lane < (unsigned)kSpxBarSplit && lane < gridDim.x)
+                                ? ((gridDim.x - lane + (unsigned)kSpxBarSplit - 1u) / (unsigned)kSpxBarSplit) * phase : 0u;
+  unsigned int spins = 0;
+  while (true) {
+    const unsigned int have = lane < (unsigned)kSpxBarSplit ? __hip_atomic_load(&counters[32u * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (__ballot(have < want) == 0ull) break;
+    if (spx_wait_expired(spins, hdr)) break;  // (the same in every lane)
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+// The counters of the set a LATER launch will use are cleared by workgroup 0 of this one.
+__device__ __forceinline__ void spx_bar_reset(unsigned int* counters) {
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)kSpxBarSplit) counters[32u * threadIdx.x] = 0u;
+}
+__device__ __forceinline__ void spx_grid_barrier(unsigned int* counters, unsigned int target, SpxSyncHeader* hdr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned int spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (spx_wait_expired(spins, hdr)) break;
-      __builtin_amdgcn_s_sleep(2);
-    }
+    spx_bar_arrive_and_wait(counters, target, hdr);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -287,18 +308,11 @@ __device__ __forceinline__ void spx_grid_barrier(unsigned int* counter, unsigned
 // The same rendezvous WITHOUT cache maintenance, for kernels whose workgroups exchange nothing but words written and read
 // with agent-scope atomics (spx_atomic_store_f64 / spx_atomic_load_f64 below: `sc1` accesses that bypass the non-coherent
 // caches).  The release / acquire fences are most of a barrier's cost when few workgroups meet (3.5 of ~4 us).
-// ONE lane per workgroup must have issued all of the workgroup's atomic stores before it calls this.
-__device__ __forceinline__ void spx_grid_rendezvous(unsigned int* counter, unsigned int target, SpxSyncHeader* hdr) {
+// Every wave must have waited for its own atomic stores (s_waitcnt vmcnt(0)) before it calls this.
+__device__ __forceinline__ void spx_grid_rendezvous(unsigned int* counters, unsigned int target, SpxSyncHeader* hdr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomic stores have left
   __syncthreads();
-  if (threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's atomic stores have left
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned int spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (spx_wait_expired(spins, hdr)) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
+  if (threadIdx.x < 64) spx_bar_arrive_and_wait(counters, target, hdr);
   __syncthreads();
 }
 __device__ __forceinline__ void spx_atomic_store_f64(double* p, double v) {

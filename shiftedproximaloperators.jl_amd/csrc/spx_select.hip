@@ -70,6 +70,23 @@ __device__ __forceinline__ KeyPos key_pos(uint64_t key, uint64_t base, int shift
   return r;
 }
 
+// A state every lane read from shared memory, moved to scalar registers (the values are the same in every lane, but a load
+// leaves them in 20-odd VECTOR registers for as long as the state is in use: k_sel_lds has none to spare)
+__device__ __forceinline__ int sel_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t sel_uni(uint64_t v) {
+  return ((uint64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+         (uint64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu));
+}
+__device__ __forceinline__ int64_t sel_uni(int64_t v) { return (int64_t)sel_uni((uint64_t)v); }
+__device__ __forceinline__ SelState sel_uniform(const SelState& a) {
+  SelState o;
+  o.phase = sel_uni(a.phase); o.shift = sel_uni(a.shift); o.width = sel_uni(a.width); o.pad = sel_uni(a.pad);
+  o.prefix = sel_uni(a.prefix); o.quota = sel_uni(a.quota); o.t_ge = sel_uni(a.t_ge); o.t_eq = sel_uni(a.t_eq);
+  o.icut = sel_uni(a.icut); o.idx_bits = sel_uni(a.idx_bits); o.pad2 = sel_uni(a.pad2); o.t_floor = sel_uni(a.t_floor);
+  o.base = sel_uni(a.base); o.clamp = sel_uni(a.clamp); o.pad3 = sel_uni(a.pad3);
+  return o;
+}
+
 // state of the sample-predicted path (see "fast path" below)
 struct FastState {
   uint64_t t_hi, t_lo;            // candidate band in key space: t_lo <= key <= t_hi; "above": key > t_hi
@@ -331,14 +348,19 @@ __device__ __forceinline__ uint64_t key_of(float v) {
   const uint32_t k = (uint32_t)__float_as_int(v) & 0x7fffffffu;
   return (uint64_t)(k > 0x7f800000u ? 0x7fc00000u : k) << 32;
 }
+// xs = xk[i] + sj[i], the sum v was formed from
 template <bool BINF, class T>
-__device__ __forceinline__ T sel_out(T v, int64_t i, T x, T s, const SelState& st, T delta) {
+__device__ __forceinline__ T sel_out_xs(T v, int64_t i, T xs, const SelState& st, T delta) {
   const uint64_t key = key_of(v);
   const bool keep = (key >= st.t_ge) || (key == st.t_eq && i <= st.icut);
   const T kept = keep ? v : (T)0;                   // shiftedIndBallL0.jl:69  y[p[r+1:end]] .= 0
-  const T t = kept - (x + s);                       // :70
+  const T t = kept - xs;                            // :70
   if constexpr (BINF) return jl_min(jl_max(t, -delta), delta);  // shiftedIndBallL0BInf.jl:91
   else return t;
+}
+template <bool BINF, class T>
+__device__ __forceinline__ T sel_out(T v, int64_t i, T x, T s, const SelState& st, T delta) {
+  return sel_out_xs<BINF, T>(v, i, x + s, st, delta);
 }
 
 // =============================================================================================
@@ -1111,8 +1133,41 @@ __device__ __forceinline__ void coop_select(T* y, const T* q, const T* xk, const
   constexpr bool kF64 = std::is_same<T, double>::value;
   const bool vec2 = kF64 && !REG && n >= 2 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(q) |
                                         reinterpret_cast<uintptr_t>(xk) | reinterpret_cast<uintptr_t>(sj)) & 15u) == 0;
+  // One element's contribution to the histogram of the pass whose state is st.  REG: plain LDS atomics -- the unrolled visits
+  // are independent and overlap; wave-aggregated (hist_add_agg) each is a serial chain of ballots, 3 us per full sweep of
+  // generic data at 16 waves per CU, and what it saves on one-key data (64 lanes on one LDS address: ~64 clocks per
+  // instruction) is 3 us per pass of 8 elements per lane.  The form that walks the whole vector keeps the aggregation.
+  auto visit_st = [&](const SelState& st, T vv, int64_t i) {
+    const uint64_t key = key_of(vv);
+    bool in = true;
+    unsigned int dg;
+    if (st.phase == 0) {
+      if (st.pad == 1) {
+        dg = fold_digit(key);
+      } else {
+        const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
+        in = kp.in;
+        dg = kp.digit;
+      }
+    } else {
+      const int hs = st.shift + st.width;
+      in = key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix;
+      dg = (unsigned int)((((uint64_t)i) >> st.shift) & (((uint64_t)1 << st.width) - 1));
+    }
+    if constexpr (REG) { if (in) atomicAdd(&sh.lh[dg], 1u); }
+    else hist_add_agg(sh.lh, dg, in);
+  };
+  if (t == 0) {
+    sel_state_init(sh.sst, n, r);
+    if (sh.sst.phase == 0 && kCoopFold && kF64) sh.sst.pad = 1;  // first digit: fold_digit (binades of a Float64)
+  }
   T v[REG ? kCoopEpl : 1];
+  bool fused = false;  // REG: the first digit was histogrammed while the loads were in flight (it depends on the key alone)
   if constexpr (REG) {
+    for (int b = t; b < kBins; b += blockDim.x) sh.lh[b] = 0u;
+    __syncthreads();
+    const SelState st0 = sel_uniform(sh.sst);
+    fused = st0.phase == 0;
 #pragma unroll
     for (int k = 0; k < kCoopEpl; ++k) {
       const int64_t i = gtid + (int64_t)k * NT;
@@ -1120,44 +1175,33 @@ __device__ __forceinline__ void coop_select(T* y, const T* q, const T* xk, const
       const T xv = xk[ic], sv = sj[ic], qv = q[ic];
       v[k] = (i < n) ? (xv + sv) + qv : (T)0;          // shiftedIndBallL0.jl:66
     }
-  }
-  if (t == 0) {
-    sel_state_init(sh.sst, n, r);
-    if (sh.sst.phase == 0 && kCoopFold && kF64) sh.sst.pad = 1;  // first digit: fold_digit (binades of a Float64)
+    if (fused) {
+#pragma unroll
+      for (int k = 0; k < kCoopEpl; ++k) {
+        const int64_t i = gtid + (int64_t)k * NT;
+        if (i < n) visit_st(st0, v[k], i);
+      }
+    }
   }
   SEL_STAMP(32);
   int p = 0;
   for (; p < kCoopMaxPass; ++p) {
     __syncthreads();
-    const SelState st = sh.sst;
+    const SelState st = sel_uniform(sh.sst);
     if (st.phase == 2) break;  // the same in every workgroup: they all computed it from the same histograms
-    for (int b = t; b < kBins; b += blockDim.x) sh.lh[b] = 0u;
-    __syncthreads();
-    const int hs = st.shift + st.width;
-    const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
-    auto visit = [&](T vv, int64_t i) {
-      const uint64_t key = key_of(vv);
-      bool in = true;
-      unsigned int dg;
-      if (st.phase == 0) {
-        if (st.pad == 1) {
-          dg = fold_digit(key);
-        } else {
-          const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
-          in = kp.in;
-          dg = kp.digit;
-        }
-      } else {
-        in = key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix;
-        dg = (unsigned int)((((uint64_t)i) >> st.shift) & dmask);
-      }
-      hist_add_agg(sh.lh, dg, in);
-    };
+    const bool counted = REG && p == 0 && fused;
+    if (!counted) {
+      for (int b = t; b < kBins; b += blockDim.x) sh.lh[b] = 0u;
+      __syncthreads();
+    }
+    auto visit = [&](T vv, int64_t i) { visit_st(st, vv, i); };
     if constexpr (REG) {
+      if (!counted) {
 #pragma unroll
-      for (int k = 0; k < kCoopEpl; ++k) {
-        const int64_t i = gtid + (int64_t)k * NT;
-        if (i < n) visit(v[k], i);
+        for (int k = 0; k < kCoopEpl; ++k) {
+          const int64_t i = gtid + (int64_t)k * NT;
+          if (i < n) visit(v[k], i);
+        }
       }
     } else if (vec2) {
       if constexpr (kF64) {
@@ -1214,7 +1258,7 @@ __device__ __forceinline__ void coop_select(T* y, const T* q, const T* xk, const
     SEL_STAMP(35 + 3 * p);
   }
   __syncthreads();
-  SelState fin = sh.sst;
+  const SelState fin = sel_uniform(sh.sst);
   // A workgroup of this context gave up waiting (spx_wait_expired): the thresholds are not to be trusted.  Every element is
   // then stored as NaN (t_ge above every key, v replaced below) and the next libspx call reports the failure.
   const bool poisoned = spx_poisoned(hdr);
@@ -1253,7 +1297,7 @@ __global__ __launch_bounds__(1024) void k_sel_coop(T* y, const T* q, const T* xk
                                                     int64_t r, T delta, SelSync* ss, int parity, int use_set,
                                                     int clear_set) {
   __shared__ CoopShared sh;
-  if (blockIdx.x == 0 && threadIdx.x == 0) ss->hdr.bar[parity ^ 1][0] = 0u;
+  spx_bar_reset(ss->hdr.bar[parity ^ 1]);
   const int64_t total = (int64_t)kCoopMaxPass * kBins;
   unsigned int nbar = 0;
   if (clear_set >= 0) {
@@ -1261,6 +1305,169 @@ __global__ __launch_bounds__(1024) void k_sel_coop(T* y, const T* q, const T* xk
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total; b += (int64_t)gridDim.x * blockDim.x) z[b] = 0ull;
   }
   coop_select<BINF, REG, T>(y, q, xk, sj, n, r, delta, ss->chist[use_set], ss->hdr.bar[parity], nbar, sh, &ss->hdr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_sel_lds (round 3): the one-launch exact select for 2 Mi < n <= 4 Mi (16 Ki elements per resident workgroup).  v is parked
+// in LDS -- 16 x 1024 doubles, 128 KiB of the CU's 160 -- and xk + sj stays in registers, so the vectors are read ONCE and y is
+// written once: the algorithmic 32 B per element, where the sample-predicted pipeline pays six launches (~50 us of fixed cost:
+// 77 us per call at n = 4e6).  Sixteen elements per lane in REGISTERS spill (the 128 VGPRs of a 1024-lane workgroup hold v and
+// xk + sj, but not what the unrolled digit code of 16 elements wants on top: 492 B of scratch per lane); from LDS the digit
+// loop stays rolled.  Passes, rendezvous and scan are those of coop_select.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLdsEpl = 16;
+constexpr int64_t kLdsMinN = (int64_t)1 << 20;  // k_sel_lds serves the sizes above this (and below what the resident grid holds: run_select)
+// VEC: all four vectors 16-byte aligned -- a lane owns PAIRS of elements (pair gtid + k NT, k < 8) and moves them with 16-byte
+// accesses; otherwise elements gtid + k NT, k < 16, 8 bytes at a time.
+template <bool BINF, bool VEC>
+__global__ __launch_bounds__(1024) void k_sel_lds(double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                                   int64_t r, double delta, SelSync* ss, int parity, int use_set, int clear_set) {
+  __shared__ CoopShared sh;
+  __shared__ __attribute__((aligned(16))) double lv[kLdsEpl * 1024];
+  spx_bar_reset(ss->hdr.bar[parity ^ 1]);
+  if (clear_set >= 0) {
+    const int64_t total = (int64_t)kCoopMaxPass * kBins;
+    unsigned long long* z = &ss->chist[clear_set][0][0];
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total; b += (int64_t)gridDim.x * blockDim.x) z[b] = 0ull;
+  }
+  unsigned long long (*hist)[kBins] = ss->chist[use_set];
+  unsigned int* bar = ss->hdr.bar[parity];
+  SpxSyncHeader* hdr = &ss->hdr;
+  unsigned int nbar = 0;
+  const int t = threadIdx.x;
+  const int nt = (int)(gridDim.x * blockDim.x), gtid = (int)(blockIdx.x * blockDim.x) + t, n32 = (int)n;  // (n <= 16 Ki x gridDim.x)
+  // slot s (0..15) of this lane: element index and where its v sits in LDS
+  constexpr int kSlots = kLdsEpl;
+  auto index_of = [&](int s_) -> int { return VEC ? 2 * (gtid + (s_ >> 1) * nt) + (s_ & 1) : gtid + s_ * nt; };
+  auto lds_of = [&](int s_) -> int { return VEC ? 2 * ((s_ >> 1) * 1024 + t) + (s_ & 1) : s_ * 1024 + t; };
+  double xs[kSlots];
+  SEL_STAMP(31);
+  // The first digit (fold_digit: it depends on nothing but the key) is histogrammed while the loads are in flight -- as its own
+  // sweep over the 16 Ki elements it was 8 us of VALU work that nothing overlapped.
+  for (int b = t; b < kBins; b += 1024) sh.lh[b] = 0u;
+  if (t == 0) {
+    sel_state_init(sh.sst, n, r);
+    if (sh.sst.phase == 0 && kCoopFold) sh.sst.pad = 1;  // first digit: fold_digit (binades of a Float64)
+  }
+  __syncthreads();
+  const bool fused = kCoopFold && sh.sst.phase == 0;
+#pragma unroll
+  for (int s0 = 0; s0 < kSlots; s0 += 4) {  // four elements = twelve 8-byte (six 16-byte) loads in flight per lane
+    double vv[4];
+    // (small n: nothing of this batch belongs to the workgroup -- its first lane's first index is past the end)
+    if ((VEC ? 2 * ((int)(blockIdx.x * blockDim.x) + (s0 >> 1) * nt) : (int)(blockIdx.x * blockDim.x) + s0 * nt) >= n32) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xs[s0 + k] = 0.0;
+      continue;
+    }
+    if constexpr (VEC) {
+      const int n2 = n32 >> 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int s_ = s0 + 2 * h;
+        const int pr = gtid + (s_ >> 1) * nt;
+        const int pc = pr < n2 ? pr : n2 - 1;  // clamped, unconditional (n >= 2 here: n > 2 Mi)
+        const f64x2 xv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(xk) + pc);
+        const f64x2 sv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sj) + pc);
+        const f64x2 qv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(q) + pc);
+        xs[s_] = xv.x + sv.x; xs[s_ + 1] = xv.y + sv.y;
+        vv[2 * h] = xs[s_] + qv.x; vv[2 * h + 1] = xs[s_ + 1] + qv.y;   // shiftedIndBallL0.jl:66
+        if ((n32 & 1) && pr == n2) {  // the odd last element: the first half of the pair behind the last whole one
+          xs[s_] = xk[n32 - 1] + sj[n32 - 1];
+          vv[2 * h] = xs[s_] + q[n32 - 1];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = index_of(s0 + k);
+        const int ic = i < n32 ? i : n32 - 1;  // clamped, unconditional
+        const double xv = __builtin_nontemporal_load(xk + ic), sv = __builtin_nontemporal_load(sj + ic), qv = __builtin_nontemporal_load(q + ic);
+        xs[s0 + k] = xv + sv;
+        vv[k] = xs[s0 + k] + qv;               // shiftedIndBallL0.jl:66
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      lv[lds_of(s0 + k)] = vv[k];              // (slots beyond n are never read)
+      if (fused && index_of(s0 + k) < n32) atomicAdd(&sh.lh[fold_digit(key_of(vv[k]))], 1u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  SEL_STAMP(32);
+  for (int p = 0; p < kCoopMaxPass; ++p) {
+    __syncthreads();
+    const SelState st = sel_uniform(sh.sst);
+    if (st.phase == 2) break;  // the same in every workgroup: they all computed it from the same histograms
+    const int hs = st.shift + st.width;
+    const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
+    if (!(p == 0 && fused)) {
+      for (int b = t; b < kBins; b += 1024) sh.lh[b] = 0u;
+      __syncthreads();
+#pragma unroll 2
+      for (int s_ = 0; s_ < kSlots; ++s_) {
+        const int i = index_of(s_);
+        if (i >= n32) continue;
+        const uint64_t key = key_of(lv[lds_of(s_)]);
+        bool in = true;
+        unsigned int dg;
+        if (st.phase == 0) {
+          if (st.pad == 1) {
+            dg = fold_digit(key);
+          } else {
+            const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
+            in = kp.in;
+            dg = kp.digit;
+          }
+        } else {
+          in = key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix;
+          dg = (unsigned int)((((uint64_t)i) >> st.shift) & dmask);
+        }
+        // (plain LDS atomics: the wave-aggregated form of coop_select cost this rolled loop 3 us per full sweep on generic data;
+        //  on one-key data 64 lanes on one LDS address are ~64 clocks per instruction, 7 us per sweep)
+        if (in) atomicAdd(&sh.lh[dg], 1u);
+      }
+    }
+    if (p < 4) SEL_STAMP(23 + p);
+    __syncthreads();
+    for (int b = t; b < kBins; b += 1024) {
+      const unsigned int c = sh.lh[b];
+      if (c) atomicAdd(&hist[p][b], (unsigned long long)c);
+    }
+    // the histogram atomics of every wave have been performed (vmcnt) before its workgroup arrives; nothing else is exchanged
+    SEL_STAMP(33 + 3 * p);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p < 4) SEL_STAMP(27 + p);
+    spx_grid_rendezvous(bar, (++nbar) * gridDim.x, hdr);
+    SEL_STAMP(34 + 3 * p);
+    coop_scan_step(hist[p], st, &sh.sst, sh.scratch);
+    SEL_STAMP(35 + 3 * p);
+  }
+  __syncthreads();
+  const SelState fin = sel_uniform(sh.sst);
+  const bool poisoned = spx_poisoned(hdr);  // (see coop_select)
+  auto P = [&](double val) -> double { return poisoned ? __longlong_as_double(0x7ff8000000000000ll) : val; };
+  if constexpr (VEC) {
+    const int n2 = n32 >> 1;
+#pragma unroll
+    for (int s_ = 0; s_ < kSlots; s_ += 2) {
+      const int pr = gtid + (s_ >> 1) * nt;
+      const f64x2 vv = *reinterpret_cast<const f64x2*>(&lv[lds_of(s_)]);
+      f64x2 o;
+      o.x = P(sel_out_xs<BINF>(vv.x, (int64_t)(2 * pr), xs[s_], fin, delta));
+      o.y = P(sel_out_xs<BINF>(vv.y, (int64_t)(2 * pr + 1), xs[s_ + 1], fin, delta));
+      if (pr < n2) __builtin_nontemporal_store(o, reinterpret_cast<f64x2*>(y) + pr);
+      else if ((n32 & 1) && pr == n2) y[n32 - 1] = o.x;
+      __builtin_amdgcn_sched_barrier(0);  // (one pair at a time: hoisted, the eight LDS reads do not fit beside xs)
+    }
+  } else {
+#pragma unroll
+    for (int s_ = 0; s_ < kSlots; ++s_) {
+      const int i = index_of(s_);
+      if (i < n32) __builtin_nontemporal_store(P(sel_out_xs<BINF>(lv[lds_of(s_)], (int64_t)i, xs[s_], fin, delta)), y + i);
+    }
+  }
+  SEL_STAMP(63);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1311,7 +1518,7 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
   SpxSyncHeader* hdr = &ss->hdr;
   unsigned int* bar = hdr->bar[parity];
   unsigned int nbar = 0;
-  if (b == 0 && t == 0) hdr->bar[parity ^ 1][0] = 0u;
+  spx_bar_reset(hdr->bar[parity ^ 1]);
   {  // clean slates for the next call's k_s2_front
     unsigned long long* z1 = ss->fhist1;
     unsigned long long* z2 = &ss->fhist2[0][0][0];
@@ -1611,7 +1818,7 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
   unsigned int* bar = ss->hdr.bar[parity];
   unsigned int nbar = 0;
   SelWs* ws = &ss->ws;
-  if (c == 0 && t == 0) ss->hdr.bar[parity ^ 1][0] = 0u;
+  spx_bar_reset(ss->hdr.bar[parity ^ 1]);
   SEL_STAMP(0);
   for (int b = t; b < kBins; b += 1024) lh[b] = 0u;
   // clean slates for the main pass (it runs in a later launch)
@@ -1902,7 +2109,17 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
                                   : reinterpret_cast<const void*>(&k_s2_front<1>);
   const int64_t cap_front = spx_resident_cap(ctx, front_fn, 1024, 0);
   const int64_t reg_cap = (int64_t)kCoopEpl * 1024 * (cap_reg < ctx->num_cu ? cap_reg : ctx->num_cu);  // (2 Mi elements on 256 CUs)
-  const int64_t fast_min = ((int64_t)1 << SPX_SEL_REG_MAX_LOG2) + 1;
+  // ... and 4 Mi with v parked in LDS (k_sel_lds): the sample-predicted pipeline (six launches, ~50 us of them fixed cost) takes
+  // over above what the resident grid holds on chip.  y must not overlap the inputs elsewhere than element for element (a lane
+  // reads all its inputs before it writes: aliasing q, xk or sj exactly is fine, as in the other one-launch forms).
+  int64_t lds_cap = 0;
+  if (ctx->tune_sel_reg16) {
+    const int64_t capl = vec ? spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_sel_lds<BINF, true>), 1024, 0)
+                             : spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_sel_lds<BINF, false>), 1024, 0);
+    lds_cap = (int64_t)kLdsEpl * 1024 * (capl < ctx->num_cu ? capl : ctx->num_cu);
+  }
+  int64_t fast_min = ((int64_t)1 << SPX_SEL_REG_MAX_LOG2) + 1;
+  if (lds_cap >= fast_min) fast_min = lds_cap + 1;
   const bool try_fast = ctx->tune_sel_fast && (vec || ioff) && (n - ioff) >= fast_min && r > 0 && r < n &&
                         cap_front >= kFrontBlocks;  // (the front kernel's sample layout is tied to its grid)
   rc = spx_sync_reserve(ctx, sizeof(SelSync));
@@ -1915,11 +2132,26 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   const int64_t g_tail = cap_tail < 256 ? (cap_tail < ctx->num_cu ? cap_tail : ctx->num_cu) : (ctx->num_cu < 256 ? ctx->num_cu : 256);  // (<= 256: SelSync::tie_part)
   if (!try_fast) {
     // exact select in ONE launch: register-resident up to 8 Ki elements per resident workgroup, v parked in y beyond that
-    const bool reg = n <= reg_cap;
-    // as few workgroups as hold the vector at 8 elements per lane: a grid barrier costs ~2 us with 64 arrivers, ~7 us with 256
-    int64_t g = reg ? (n + (int64_t)kCoopEpl * 1024 - 1) / ((int64_t)kCoopEpl * 1024) : g_mem;
+    // k_sel_lds from 1 Mi elements on (n = 2e6: 34 / 42 us at r = n/100 / n/2 against 39 / 45 with v in registers; n = 1e6:
+    // 36 / 30 against 35 / 29 -- tools/r3/topr_small_grid.py), and wherever the register form's grid does not fit
+    const bool lds = n <= lds_cap && (n > kLdsMinN || n > reg_cap);
+    const bool reg = !lds && n <= reg_cap;
+    // Register form: 1 / 2 / 4 / 8 elements per lane by n -- the fewer elements a lane walks per pass the better, until the
+    // workgroups are so many that their histogram flushes and arrivals cost more (us per call at r = n/100, 1 / 2 / 4 / 8 per
+    // lane: n = 3e4 17.4 / 18.4 / 20.7 / 24.1; n = 1e5 19.8 / 19.3 / 20.8 / 24.4; n = 3e5 26.8 / 22.8 / 22.1 / 24.9; n = 1e6
+    // 35.6 / 35.7 / 36.6 / 34.7 -- tools/r3/topr_small_grid.py)
+    const int64_t epl = n <= 65536 ? 1 : n <= 196608 ? 2 : n <= 655360 ? 4 : kCoopEpl;
+    int64_t g = g_mem;
+    if (reg) {
+      const int64_t gmax = cap_reg < ctx->num_cu ? cap_reg : ctx->num_cu;
+      g = (n + epl * 1024 - 1) / (epl * 1024);
+      if (g > gmax) g = gmax;  // (n <= reg_cap: 8 elements per lane always fit)
+    }
+    // (k_sel_lds: every CU the grid may have -- the load phase is most of the kernel and wants all of them pulling; a rendezvous
+    //  costs 1.4 us with 256 workgroups since the arrivals are spread over eight counters)
+    if (lds) g = lds_cap / ((int64_t)kLdsEpl * 1024);
 #ifdef SPX_TEST_HOOKS  // the planted fault of tests/test_gpu_robustness.py: a grid that cannot be resident
-    if (!reg && ctx->tune_force_grid > 0) g = ctx->tune_force_grid;
+    if (!reg && !lds && ctx->tune_force_grid > 0) g = ctx->tune_force_grid;
 #endif
     int use_set = ctx->sel_hist_next, other = use_set ^ 1;
     int clear_set = ctx->sel_hist_dirty[other] ? other : -1;
@@ -1936,6 +2168,12 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
       if (reg)
         hipLaunchKernelGGL((k_sel_coop<BINF, true>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r,
                            delta, ss, parity, use_set, clear_set);
+      else if (lds && vec)
+        hipLaunchKernelGGL((k_sel_lds<BINF, true>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta, ss,
+                           parity, use_set, clear_set);
+      else if (lds)
+        hipLaunchKernelGGL((k_sel_lds<BINF, false>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta, ss,
+                           parity, use_set, clear_set);
       else
         hipLaunchKernelGGL((k_sel_coop<BINF, false>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r,
                            delta, ss, parity, use_set, clear_set);

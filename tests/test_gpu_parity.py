@@ -352,21 +352,29 @@ def test_indball_l0_ranks_and_scales(s, orc, kind):
     assert _bits_equal(qd.cpu().numpy(), orc.prox_indball_l0(q, x, sj, r)), kind
 
 
-@pytest.mark.parametrize("n", [(1 << 20) - 1, 1 << 20, (1 << 20) + 1, (1 << 20) + 3001, (1 << 21) - 1, 1 << 21, (1 << 21) + 1,
-                               (1 << 21) + 3001])
-def test_indball_l0_at_the_fast_path_threshold(s, orc, n):
-    """Either side of the sizes at which the sample-predicted path takes over: from the register-resident one-launch select
-    (SPX_SEL_REG_MAX_LOG2 = 21) and, with the in-launch forms switched off, from the full-vector radix select
-    (SPX_SEL_FAST_MIN_LOG2 = 20: the sample is then 1/16 of the vector).  Lattice data (ties), all r regimes."""
+@pytest.mark.parametrize("n,lds", [((1 << 20) - 1, 1), (1 << 20, 1), ((1 << 20) + 1, 1), ((1 << 20) + 3001, 1), ((1 << 21) - 1, 1),
+                                   (1 << 21, 0), ((1 << 21) + 1, 0), ((1 << 21) + 3001, 0), ((1 << 21) + 3001, 1),
+                                   ((1 << 22) - 1, 1), (1 << 22, 1), ((1 << 22) + 1, 1), ((1 << 22) + 3001, 1)])
+def test_indball_l0_at_the_fast_path_threshold(s, orc, n, lds):
+    """Either side of the sizes at which the forms hand over: v in registers -> v in LDS (k_sel_lds, above 2^20) -> the
+    sample-predicted pipeline (above 2^22 = what 256 resident workgroups hold in LDS); with the LDS form switched off (tuning
+    key 11 = 0) the pipeline takes over from the register form at 2^21 (SPX_SEL_REG_MAX_LOG2), as in round 2.  Lattice data
+    (ties), all r regimes."""
+    L = s._lib.load()
+    ctx = s.context("cuda:0")
     rng = np.random.default_rng(n)
     x, sj = np.round(rng.normal(size=n) * 16) / 16, np.round(rng.uniform(-0.5, 0.5, size=n) * 16) / 16
     q = np.round(rng.normal(size=n) * 16) / 16
     xd, sd, qd = _dev(x, sj, q)
-    for r in (1, 3, 777, n // 100, n // 3, n - 2):
-        y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.8, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
-        assert _bits_equal(y, orc.prox_indball_l0_binf(q, x, sj, r, 0.8)), (n, r)
-    s.prox_bang(qd, s.shifted(s.shifted(s.IndBallL0(n // 50), xd), sd), qd, 1.0)      # aliased form
-    assert _bits_equal(qd.cpu().numpy(), orc.prox_indball_l0(q, x, sj, n // 50)), n
+    s._lib.check(L.spx_ctx_set_tuning(ctx, 11, lds))
+    try:
+        for r in (1, 3, 777, n // 100, n // 3, n - 2):
+            y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.8, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
+            assert _bits_equal(y, orc.prox_indball_l0_binf(q, x, sj, r, 0.8)), (n, r)
+        s.prox_bang(qd, s.shifted(s.shifted(s.IndBallL0(n // 50), xd), sd), qd, 1.0)      # aliased form
+        assert _bits_equal(qd.cpu().numpy(), orc.prox_indball_l0(q, x, sj, n // 50)), n
+    finally:
+        s._lib.check(L.spx_ctx_set_tuning(ctx, 11, 1))
 
 
 def test_indball_l0_misaligned_views_fast_path(s, orc):

@@ -42,6 +42,7 @@ x = torch.from_numpy(rng.normal(size=n)).cuda(); sj = torch.zeros_like(x); q = t
 y = torch.empty_like(q)
 psi = s.shifted(s.shifted(s.IndBallL0(n // 10), x, 1.0, s.NormLinf(1.0)), sj)
 L.spx_ctx_set_tuning(ctx, 2, 0)              # the one-launch exact select (v parked in y), not the sampled pipeline
+L.spx_ctx_set_tuning(ctx, 11, 0)             # ... nor the form that parks v in LDS (its grid is what the occupancy query allows)
 s.prox_bang(y, psi, q, 1.0); torch.cuda.synchronize()
 good = y.clone()
 assert L.spx_ctx_set_tuning(ctx, 100, 4096) == 0   # 4096 workgroups of 1024 lanes: at most 512 are resident at once
@@ -90,7 +91,7 @@ def test_residency_cap_takes_the_smaller_grid_forms(s, orc):
     ctx = s.context("cuda:0")
     rng = np.random.default_rng(11)
     try:
-        for n in (20_000, 300_000, 2_500_000):
+        for n in (20_000, 300_000, 2_500_000, 4_200_001):
             x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
             xd, sd, qd = (torch.from_numpy(t).cuda() for t in (x, sj, q))
             r = n // 20

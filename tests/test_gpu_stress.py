@@ -179,8 +179,9 @@ def test_binf_lattice_constant_groups(s, orc, gs):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# Top-r on 8-byte-misaligned views, every mix of alignments (csrc/spx_select.hip: scalar full-vector path, the peeled
-# sample-predicted path when all four vectors are off by 8 bytes).
+# Top-r on 8-byte-misaligned views, every mix of alignments (csrc/spx_select.hip: the one-launch forms with 8-byte accesses --
+# v in registers, v in LDS; the peeled sample-predicted path when all four vectors are off by 8 bytes is covered at n > 2^22
+# by test_gpu_parity.py::test_indball_l0_misaligned_views_fast_path).
 # ----------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 2, 3, 1000, 70001, (1 << 21) + 17])
 def test_topr_misaligned_views(s, orc, n):
@@ -205,12 +206,23 @@ def test_topr_misaligned_views(s, orc, n):
 # Top-r, one-launch select (k_sel_coop): its first digit is FOLDED (csrc/spx_select.hip fold_digit: 62 binades around 1.0 x
 # 64 mantissa steps, catch-all bins below 2^-31 and above 2^30).  Data that puts the threshold into a catch-all bin (restart
 # with the plain top digit), onto a bin edge, into ties at key 0 / Inf / NaN, or all of the vector into one bin.
-# Sizes: register-resident grid of 9, 37 and 256 workgroups; the form that parks v in y (mixed alignment, n > 2^21).
+# Sizes: v in registers (grids of 35, 74 and 128 workgroups), v in LDS (k_sel_lds: the first digit is histogrammed while the
+# vectors are loaded), the form that parks v in y (mixed alignment, n > 2^21, k_sel_lds switched off).
 # ----------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("kind", ["tiny", "huge", "tiny+normal", "normal+huge", "zeros", "inf_nan", "constant", "binade_edges",
                                   "wide_exponents"])
-@pytest.mark.parametrize("n", [70_001, 300_000, (1 << 21) - 5, (1 << 21) + 4099])
+@pytest.mark.parametrize("n", [70_001, 300_000, 1_000_003, (1 << 21) - 5, (1 << 21) + 4099, -((1 << 21) + 4099)])
 def test_topr_folded_first_digit(s, orc, kind, n):
+    lds = n > 0                      # (a negative size: the same size with k_sel_lds off)
+    n = abs(n)
+    s._lib.check(s._lib.load().spx_ctx_set_tuning(s.context("cuda:0"), 11, 1 if lds else 0))
+    try:
+        _folded_first_digit_cases(s, orc, kind, n)
+    finally:
+        s._lib.check(s._lib.load().spx_ctx_set_tuning(s.context("cuda:0"), 11, 1))
+
+
+def _folded_first_digit_cases(s, orc, kind, n):
     import torch
     rng = np.random.default_rng(sum(map(ord, kind)) + n)
     x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
@@ -400,9 +412,22 @@ def test_b2_integer_lattices_exact_roots(s, orc):
 # odd n and views from an odd element put members of the classes into the stragglers' slots; y === q takes the form
 # without speculative stores.
 # ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("form", ["pipeline", "one launch"])
 @pytest.mark.parametrize("kind", ["constant", "two values", "lattice 1/4", "lattice 2^-8", "90% zeros", "sorted lattice",
                                   "lattice + noise on half"])
-def test_topr_tie_mode_against_exact_select(s, orc, kind):
+def test_topr_tie_mode_against_exact_select(s, orc, kind, form):
+    """form = "pipeline": tuning key 11 = 0, so that this size (kept small for the CPU oracle) takes the sample-predicted path
+    as every n > 2^22 does; "one launch": the default at this size, v parked in LDS (k_sel_lds) -- the same data through its
+    key and index digits."""
+    import torch
+    s._lib.check(s._lib.load().spx_ctx_set_tuning(s.context("cuda:0"), 11, 0 if form == "pipeline" else 1))
+    try:
+        _tie_mode_cases(s, orc, kind)
+    finally:
+        s._lib.check(s._lib.load().spx_ctx_set_tuning(s.context("cuda:0"), 11, 1))
+
+
+def _tie_mode_cases(s, orc, kind):
     import torch
     rng = np.random.default_rng(sum(map(ord, kind)))
     n = 2_400_001 + int(rng.integers(0, 7)) * 2          # odd: the last element is a straggler of wave 0

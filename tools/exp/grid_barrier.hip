@@ -51,6 +51,38 @@ __device__ __forceinline__ void barrier(unsigned int* c, unsigned int target, un
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+  } else if (V == 5 || V == 6) {  // NO fences, 8 / 16 split counters (one 128-byte line each), polled by 8 / 16 lanes of wave 0
+    constexpr int NC = V == 5 ? 8 : 16;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      if (lane == 0) __hip_atomic_fetch_add(&xc[32 * (blockIdx.x % NC)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int want = lane < NC ? ((gridDim.x - lane + NC - 1) / NC) * phase : 0u;
+      while (true) {
+        const unsigned int have = lane < NC ? __hip_atomic_load(&xc[32 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (__ballot(have < want) == 0ull) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+  } else if (V == 7) {  // NO fences, tree: 16 group counters, the last arriver of a group adds to the top counter, all poll the top
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int grp = blockIdx.x % 16u;
+      const unsigned int members = (gridDim.x - grp + 15u) / 16u;
+      const unsigned int old = __hip_atomic_fetch_add(&xc[32 * grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1 == members * phase) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int groups = gridDim.x < 16u ? gridDim.x : 16u;
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups * phase) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+  } else if (V == 8) {  // NO fences, flat, sleep 1 (spx_grid_rendezvous as shipped)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
   } else if (V == 4) {  // per-XCC counters (8 lines) + one top counter + per-XCC generation words
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -129,6 +161,12 @@ int main() {
     run<2>("flat, fences, sleep 20", 256, block, nb);
     run<3>("last arriver publishes a flag", 256, block, nb);
     run<4>("per-XCC hierarchical", 256, block, nb);
+  }
+  for (int grid : {256, 128, 64}) {
+    run<8>("NO fences, flat (shipped)", grid, 1024, nb);
+    run<5>("NO fences, 8 split counters", grid, 1024, nb);
+    run<6>("NO fences, 16 split counters", grid, 1024, nb);
+    run<7>("NO fences, tree 16 + top", grid, 1024, nb);
   }
   run<0>("flat, fences, sleep 2", 64, 1024, nb);
   run<3>("last arriver publishes a flag", 64, 1024, nb);

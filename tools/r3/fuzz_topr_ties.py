@@ -1,5 +1,6 @@
 """Round 3 hunt: the sample-predicted top-r pipeline (generic band, tie mode, candidate select, speculation + range fix-up)
-against the exact select (tuning key 2 = 0), bit for bit, on random instances: n in (2^21, 7e6], data = mixtures of
+and the one-launch select with v in LDS
+against the exact select that parks v in y (tuning keys 2 = 0, 11 = 0), bit for bit, on random instances: n in (2^21, 7e6], data = mixtures of
 continuous values, lattices at random scales, a few heavy values, exact zeros, sorted stretches, NaN / Inf specks; random r
 (tiny, bulk, near n), views from an odd element, y === q.  usage: fuzz_topr_ties.py [instances] [seed]"""
 import os, sys
@@ -43,7 +44,10 @@ for it in range(N):
     psi = s.shifted(s.shifted(s.IndBallL0(r), xv, delta, s.NormLinf(1.0)), sv)
     yref = torch.empty(n + 1, dtype=torch.float64, device="cuda:0")[head:head + n]
     y = torch.full((n + 1,), float("nan"), dtype=torch.float64, device="cuda:0")[head:head + n]
-    L.spx_ctx_set_tuning(ctx, 2, 0); s.prox_bang(yref, psi, qv, 1.0); L.spx_ctx_set_tuning(ctx, 2, 1)
+    # reference: the exact select that parks v in y (pipeline and LDS form off); under test: the default form of this size --
+    # v in LDS up to 2^22, the pipeline above -- and, on every other instance, the pipeline at any size (key 11 = 0)
+    L.spx_ctx_set_tuning(ctx, 2, 0); L.spx_ctx_set_tuning(ctx, 11, 0); s.prox_bang(yref, psi, qv, 1.0); L.spx_ctx_set_tuning(ctx, 2, 1)
+    L.spx_ctx_set_tuning(ctx, 11, it % 2)
     s.prox_bang(y, psi, qv, 1.0)
     a, b = y.view(torch.int64), yref.view(torch.int64)
     same = bool(torch.equal(a, b)) or bool(((a == b) | (torch.isnan(y) & torch.isnan(yref))).all())
@@ -52,6 +56,7 @@ for it in range(N):
         qa = q.clone()[head:head + n]
         s.prox_bang(qa, psi, qa, 1.0)
         alias_ok = bool(((qa.view(torch.int64) == b) | (torch.isnan(qa) & torch.isnan(yref))).all())
+    L.spx_ctx_set_tuning(ctx, 11, 1)
     rc = L.spx_sync(ctx)
     if not (same and alias_ok and rc == 0):
         bad += 1

@@ -1,3 +1,4 @@
+"""Phase time stamps of workgroup 0 in k_sel_lds (build with -DSPX_SEL_PROFILE as libspx_prof.so)."""
 import ctypes, os, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
@@ -14,10 +15,10 @@ for n in [int(a) for a in sys.argv[1:]]:
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 64)()
     raw.spx_debug_sel_stamps(buf)
-    st = list(buf)
-    def seg(name, ks):
-        ks = [k for k in ks if st[k]]
-        if len(ks) < 2: return
-        print("  %-6s" % name, "  ".join("%d:+%.1fus" % (k, (st[k] - st[ks[0]]) / 100.0) for k in ks))
-    print("n =", n)
-    seg("front", list(range(0, 10))); seg("tail", list(range(16, 23))); seg("coop", list(range(31, 64)))
+    st = list(buf); t0 = st[31]
+    names = {31: "start", 32: "loaded", 63: "stored"}
+    for p in range(4):
+        names[23 + p] = "p%d digits" % p; names[33 + 3 * p] = "p%d flush issued" % p; names[27 + p] = "p%d flush drained" % p
+        names[34 + 3 * p] = "p%d met" % p; names[35 + 3 * p] = "p%d scanned" % p
+    ev = sorted((st[k], k) for k in names if st[k] >= t0 and st[k] - t0 < 100000)
+    print("n = %d:" % n, " | ".join("%s +%.1f" % (names[k], (v - t0) / 100.0) for v, k in ev))
