@@ -130,7 +130,8 @@ int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms); /* records stop, waits, ret
  * top-r and ShiftedNormL1B2 are sized by it and fall back to their any-grid forms -- this key lets a test force that).
  * Key 10 = samples per lane of the top-r front kernel (0, default: 1 / 2 / 4 by n, 16 for a cut in the bulk of a vector of
  * >= 2^26 elements; 1, 2, 4, 16 force it).  Key 11 = one-launch top-r with v parked in LDS for 2^20 < n <= 16 Ki x resident
- * workgroups (1, default; 0: registers up to 2^21, the sample-predicted path above, as in round 2).  (Key 7, round 2's switch
+ * workgroups (1, default; 0: registers up to 2^21, the sample-predicted path above, as in round 2).  Key 12 = ShiftedNormL1B2
+ * with xk parked in LDS for 2^21 < n <= 2^22 (1, default; 0: the two-pass streaming form from 2^21 on).  (Key 7, round 2's switch
  * to the multi-launch pipelines, is gone with those pipelines.)
  * Key 9 DOES change results, within the stated tolerance: ShiftedGroupNormL2Binf, 0 (default) = the closed form at the root
  * (within ~1e-15 of the exact value of the reference's formula everywhere), 1 = groups whose root sits next to the pole of

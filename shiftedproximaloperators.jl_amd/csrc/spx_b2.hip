@@ -175,7 +175,10 @@ __device__ __forceinline__ void b2_st(double* v, int64_t p, f64x2 o) {
 constexpr int kB2DmaKiB = 3;            // KiB per wavefront, vector and tile of the LDS-DMA staged streaming passes (16 waves: 144 KiB)
 constexpr double kB2Bracket = 1.5e-2;   // half-width of the bracket around the sample's root (its statistical error: ~2e-3)
 
-template <bool REG, int EPL, int THREADS, bool VEC>
+// LDSX (round 3; REG with 1024 lanes x 16 elements): xk sits in LDS (128 KiB), sj + q in registers and the box ends are formed
+// from it on the fly -- 16 Ki elements per workgroup, 4 Mi on 256 CUs, where the streaming form pays for its sample, its
+// bracket and two passes over memory (n = 4e6: 111 us per call).
+template <bool REG, int EPL, int THREADS, bool VEC, bool LDSX = false>
 __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q, const double* xk, const double* sj, int64_t n,
                                                    double ls, double delta, double chil, unsigned long long* rows,
                                                    unsigned long long* clear_rows, int clear_g, SpxSyncHeader* hdr,
@@ -195,8 +198,33 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
   B2_STAMP();
   const int last_scaled = hdr->b2_last_scaled;  // (written by the previous call's launch)
   // (sj itself is needed only where a y is stored: reloaded there, so that 16 elements per lane fit the 128 VGPRs)
-  double X[REG ? EPL : 1], LO[REG ? EPL : 1], HI[REG ? EPL : 1];  // xk and the box (sj + q) -+ lambda sigma of each element
-  if constexpr (REG) {
+  static_assert(!LDSX || REG, "LDSX is a register-resident form");
+  double X[(REG && !LDSX) ? EPL : 1], LO[(REG && !LDSX) ? EPL : 1], HI[(REG && !LDSX) ? EPL : 1];  // xk and the box (sj + q) -+ lambda sigma of each element
+  double SQ[LDSX ? EPL : 1];                                      // LDSX: sj + q; xk in lx
+  __shared__ double lx[LDSX ? EPL * THREADS : 1];
+  // element k of this lane: xk and its box
+  // (lsv: lambda sigma, passed through an opaque copy per sweep -- the box ends of all 16 elements are loop invariants the
+  //  compiler would otherwise keep in 64 more registers than a 1024-lane workgroup has)
+  auto elem = [&](int k, double lsv, double& x, double& lo, double& hi) {
+    if constexpr (LDSX) { x = lx[k * THREADS + t]; lo = SQ[k] - lsv; hi = SQ[k] + lsv; }
+    else { x = X[k]; lo = LO[k]; hi = HI[k]; }
+  };
+  auto opaque = [](double v) -> double { if constexpr (LDSX) asm volatile("" : "+v"(v)); return v; };
+  auto opaque_i = [](int64_t v) -> int64_t { if constexpr (LDSX) asm volatile("" : "+v"(v)); return v; };
+  if constexpr (LDSX) {
+#pragma unroll
+    for (int k0 = 0; k0 < EPL; k0 += 4) {  // twelve loads in flight per lane
+#pragma unroll
+      for (int k = k0; k < k0 + 4; ++k) {
+        const int64_t i = gtid + (int64_t)k * NT;
+        const int64_t ic = i < n ? i : n - 1;
+        const double xv = __builtin_nontemporal_load(xk + ic), sv = __builtin_nontemporal_load(sj + ic), qv = __builtin_nontemporal_load(q + ic);
+        SQ[k] = i < n ? (sv + qv) : 0.0;   // `sj .+ q` (:56)
+        lx[k * THREADS + t] = i < n ? xv : 0.0;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (REG) {
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       // clamped index, unconditional loads: all 3 EPL loads in flight at once (a guarded load per element compiles to EPL
@@ -296,12 +324,16 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
     if (sample) {
       if (has_sample) one(ssq - ls, ssq + ls, sx);
     } else if constexpr (REG) {
+      const double lsv = opaque(ls);
+      const int64_t ntv = opaque_i(NT);
 #pragma unroll
       for (int k = 0; k < EPL; ++k) {
-        const int64_t i = gtid + (int64_t)k * NT;
+        const int64_t i = gtid + (int64_t)k * ntv;
         if (i < n) {
-          one(LO[k], HI[k], X[k]);
-          if (store) y[i] = outv(LO[k], HI[k], X[k], sj[i], r, rinv);
+          double x, lo, hi;
+          elem(k, lsv, x, lo, hi);
+          one(lo, hi, x);
+          if (store) y[i] = outv(lo, hi, x, sj[i], r, rinv);
         }
         __builtin_amdgcn_sched_barrier(0);  // one element at a time: interleaved, the unrolled visits spill
       }
@@ -405,7 +437,12 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
 #pragma unroll
       for (int k = 0; k < EPL; ++k) {
         const int64_t i = gtid + (int64_t)k * NT;
-        if (i < n) y[i] = outv(LO[k], HI[k], X[k], sj[i], r, rinv);
+        if (i < n) {
+          double x, lo, hi;
+          elem(k, ls, x, lo, hi);
+          y[i] = outv(lo, hi, x, sj[i], r, rinv);
+        }
+        if constexpr (LDSX) __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
@@ -736,13 +773,23 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   const int64_t gmax_reg = cap_reg < kB2Cols ? cap_reg : kB2Cols;
   const int64_t gmax_mem = cap_mem < kB2Cols ? cap_mem : kB2Cols;
   const bool reg = n <= (int64_t)kB2RegBlock * gmax_reg;
+  // xk parked in LDS, 16 Ki elements per workgroup: between what the register form holds and 4 Mi (256 CUs); tuning key 12 = 0
+  // sends those sizes to the streaming form as in round 2 (n = 4e6: 111 us per call against 61)
+  bool ldsx = false;
+  int64_t gmax_lds = 0;
+  if (!reg && ctx->tune_b2_lds) {
+    const int64_t cap_lds = spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_b2_coop<true, kB2Epl, 1024, true, true>), 1024, 0);
+    gmax_lds = cap_lds < kB2Cols ? cap_lds : kB2Cols;
+    ldsx = n <= (int64_t)kB2Epl * 1024 * gmax_lds;
+  }
   int64_t g = reg ? (n + kB2RegBlock - 1) / kB2RegBlock : gmax_mem;
+  if (ldsx) g = gmax_lds;  // (n > 2 Mi here unless the grid is capped: every resident workgroup, <= 16 elements per lane)
   if (g < 1) g = 1;
   // streaming form: candidate regions, one per wavefront of the grid -- room for 8 % of its share of the vector (the bracket
   // of +-1.5 % around the sample's root holds the breakpoints of 1-2 % on ordinary data; a full region = plain iteration)
   f64x2* cand = nullptr;
   unsigned int cand_cap = 0;
-  if (!reg) {
+  if (!reg && !ldsx) {
     const int64_t waves = g * 16;
     const int64_t share = (n + waves - 1) / waves;
     int64_t cap = share / 12 + 64;
@@ -773,7 +820,10 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   unsigned long long* clear_rows = sets + (size_t)other * kB2SetWords;
   {
     SpxCoopLaunchGuard guard(ctx);
-    if (reg)
+    if (ldsx)
+      hipLaunchKernelGGL((k_b2_coop<true, kB2Epl, 1024, true, true>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q,
+                         xk, sj, n, ls, delta, chi_lambda, rows, clear_rows, clear_g, hdr, can_spec, (f64x2*)nullptr, 0u);
+    else if (reg)
       hipLaunchKernelGGL((k_b2_coop<true, kB2Epl, kB2RegThreads, true>), dim3((unsigned)g), dim3(kB2RegThreads), 0, ctx->stream, y, q,
                          xk, sj, n, ls, delta, chi_lambda, rows, clear_rows, clear_g, hdr, can_spec, (f64x2*)nullptr, 0u);
     else if (vec)

@@ -62,6 +62,7 @@ struct spx_ctx {
                                    //        by bit pattern where the default is the more accurate side: include/spx.h)
   int tune_front_spl = 0;          // key 10: samples per lane of the top-r front kernel (1, 2, 4, 16; 0 = by n and r / n)
   int tune_sel_reg16 = 1;          // key 11: register-resident one-launch top-r at 16 elements per lane (2 Mi < n <= 4 Mi on 256 CUs)
+  int tune_b2_lds = 1;             // key 12: ShiftedNormL1B2 with xk parked in LDS between the register form and the streaming form (2 Mi < n <= 4 Mi)
   int tune_force_grid = 0;         // key 100, test builds only (-DSPX_TEST_HOOKS): launch the one-launch top-r with THIS many workgroups,
                                    //          residency or not -- the planted fault behind tests/test_gpu_robustness.py
   // Device-side status word in host-mapped pinned memory (spx_ctx.hip): a kernel that gives up waiting for the other

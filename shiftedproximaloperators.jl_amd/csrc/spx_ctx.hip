@@ -147,6 +147,7 @@ SPX_EXPORT int spx_ctx_set_tuning(spx_ctx* ctx, int key, int value) {
     case 9: ctx->tune_binf_literal = value ? 1 : 0; return SPX_OK;
     case 10: if (value != 0 && value != 1 && value != 2 && value != 4 && value != 16) break; ctx->tune_front_spl = value; return SPX_OK;
     case 11: ctx->tune_sel_reg16 = value ? 1 : 0; return SPX_OK;
+    case 12: ctx->tune_b2_lds = value ? 1 : 0; return SPX_OK;
 #ifdef SPX_TEST_HOOKS
     case 100: if (value < 0 || value > 65535) break; ctx->tune_force_grid = value; return SPX_OK;
 #endif

@@ -315,8 +315,20 @@ def test_lattice_separable_b2_topr(s, orc, seed):
 # a second trial of the first pass, the bracket closed at the unevaluated a-priori bound (x = 0: the bound IS the root --
 # a version without that bisected for 30 passes), the quadratic stopping rule.  Against the Float64 oracle, 1e-12 of the norms.
 # ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("form", ["streaming", "lds"])
 @pytest.mark.parametrize("kind", ["normal", "x=0", "lattice8", "q*0.01", "x*0.05", "sparse_x"])
-def test_b2_streaming_form_scenarios(s, orc, kind):
+def test_b2_streaming_form_scenarios(s, orc, kind, form):
+    """form = "streaming": tuning key 12 = 0 -- this size (kept small for the CPU oracle) then takes the two-pass streaming form
+    as every n > 2^22 does; "lds": the default at this size, xk parked in LDS (k_b2_coop<.., LDSX>), same scenarios."""
+    L = s._lib.load()
+    s._lib.check(L.spx_ctx_set_tuning(s.context("cuda:0"), 12, 0 if form == "streaming" else 1))
+    try:
+        _b2_scenarios(s, orc, kind)
+    finally:
+        s._lib.check(L.spx_ctx_set_tuning(s.context("cuda:0"), 12, 1))
+
+
+def _b2_scenarios(s, orc, kind):
     rng = np.random.default_rng(sum(map(ord, kind)))
     n = 2_300_001
     x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
@@ -341,11 +353,13 @@ def test_b2_streaming_form_scenarios(s, orc, kind):
 # ----------------------------------------------------------------------------------------------------------------------
 # ShiftedNormL1B2, one-launch forms (csrc/spx_b2.hip k_b2_coop): the register-resident form holds 8192 elements per workgroup
 # (512 lanes x 16) and exchanges partial sums through words that carry their own ready flag (b2_put); sizes either side of
-# one / two / many / all 256 workgroups and of the switch to the streaming form, each with the trust region active,
+# one / two / many / all 256 workgroups, of the switch to the form with xk in LDS (above 2^21) and to the streaming form (above
+# 2^22), each with the trust region active,
 # inactive twice in a row (the second call stores y in its first pass), active again, and y aliased to q.  Two sets of
 # words alternate between launches and a launch zeroes the other set: the sequence of sizes exercises that too.
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 511, 8191, 8192, 8193, 16385, 65_537, 1_000_003, (1 << 21) - 1, 1 << 21, (1 << 21) + 2])
+@pytest.mark.parametrize("n", [1, 511, 8191, 8192, 8193, 16385, 65_537, 1_000_003, (1 << 21) - 1, 1 << 21, (1 << 21) + 2,
+                               (1 << 22) - 1, 1 << 22, (1 << 22) + 2])
 def test_b2_one_launch_forms_at_their_boundaries(s, orc, n):
     import torch
     rng = np.random.default_rng(77 + n)

@@ -1,4 +1,5 @@
-"""Round 3 hunt: ShiftedNormL1B2, two-pass streaming form (n > 2^21) and the register-resident form, against the CPU oracle
+"""Round 3 hunt: ShiftedNormL1B2, two-pass streaming form, the form with xk in LDS
+(2^21 < n <= 2^22, every other instance) and the register-resident form, against the CPU oracle
 (1e-12 of the norms) on random instances: sizes either side of the form switch, random lambda / sigma / Delta over decades,
 data kinds (normal, x = 0, lattices, sparse x, scaled q or x, sorted, heavy tails), views of mixed alignment, y === q.
 usage: fuzz_b2.py [instances] [seed]"""
@@ -32,6 +33,7 @@ for it in range(N):
     with np.errstate(all="ignore"):
         ref = orc.prox_l1_b2(q, x, sj, lam, sigma, delta, 1.0)
     psi = s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(1.0)), sd)
+    L.spx_ctx_set_tuning(ctx, 12, it % 2)      # 2^21 < n <= 2^22: xk parked in LDS (1, the default) / the streaming form (0)
     s.prox_bang(yd, psi, qd, sigma)
     y = yd.cpu().numpy()
     scale = max(np.linalg.norm(ref), np.linalg.norm(x), np.linalg.norm(sj + q), 1e-300)
@@ -40,6 +42,7 @@ for it in range(N):
     if it % 3 == 0:
         qa = qd.clone(); s.prox_bang(qa, psi, qa, sigma)
         ok = ok and float(np.max(np.abs(qa.cpu().numpy() - ref))) / scale <= 1e-12
+    L.spx_ctx_set_tuning(ctx, 12, 1)
     rc = L.spx_sync(ctx)
     if not ok or rc:
         bad += 1
