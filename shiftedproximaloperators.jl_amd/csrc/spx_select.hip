@@ -1095,6 +1095,37 @@ __device__ __forceinline__ void coop_scan_step(unsigned long long* hist, const S
   if (t == 0) *out = sel_advance(st, found[0], found[1], found[2]);
 }
 
+// Called by all lanes of a workgroup right after coop_scan_step (whose lane 0 wrote *out) on a key-digit pass whose bucket
+// statistics were gathered (smallest / largest key and number of elements inside the bucket, agent-scope atomics, complete
+// since the pass's rendezvous).  A bucket that holds ONE key needs no further key digits: all of it kept, or the index
+// tie-break on that key -- the state the remaining digits would arrive at, 2-4 sweeps later.  st = the state of the pass.
+__device__ __forceinline__ void sel_single_key_shortcut(const SelState st, SelState* out, const unsigned long long* cmin,
+                                                        const unsigned long long* cmax, const unsigned long long* ccnt) {
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const unsigned long long lo = __hip_atomic_load(cmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load(cmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long cnt = __hip_atomic_load(ccnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!(lo == hi && cnt > 0 && (unsigned long long)st.quota <= cnt)) return;
+  SelState o = st;
+  o.pad = 0;
+  if ((unsigned long long)st.quota == cnt) {   // the whole bucket is kept
+    o.phase = 2;
+    o.t_ge = lo > st.t_floor ? lo : st.t_floor;
+  } else {                                     // more equal keys than quota: ties by ascending index
+    o.t_ge = lo + 1;
+    o.t_eq = lo;
+    o.phase = 1;
+    o.prefix = 0;
+    const int top = st.idx_bits;
+    const int w = top % kDigitBits ? top % kDigitBits : kDigitBits;
+    if (top == 0) { o.phase = 2; o.icut = 0; }
+    o.shift = top - w;
+    o.width = w;
+  }
+  *out = o;
+}
+
 __device__ __forceinline__ void sel_state_init(SelState& s, int64_t n, int64_t r) {
   int bits = 0;
   while (bits < 63 && ((int64_t)1 << bits) < n) ++bits;
@@ -1324,7 +1355,16 @@ __global__ __launch_bounds__(1024) void k_sel_lds(double* y, const double* q, co
                                                    int64_t r, double delta, SelSync* ss, int parity, int use_set, int clear_set) {
   __shared__ CoopShared sh;
   __shared__ __attribute__((aligned(16))) double lv[kLdsEpl * 1024];
+  __shared__ unsigned long long kmm[3];  // smallest / largest key and number of this workgroup's elements inside the bucket of a pass
   spx_bar_reset(ss->hdr.bar[parity ^ 1]);
+  // (the bucket statistics of the passes after the first: set here, first used behind the first pass's rendezvous)
+  // (agent-scope atomic stores: the words are updated by atomics of every XCD; a plain store could sit in this XCD's L2 and
+  //  land on top of them later -- the launch has no fenced barrier)
+  if (blockIdx.x == 0 && threadIdx.x < kCoopMaxPass) {
+    __hip_atomic_store(&ss->cmin[threadIdx.x], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ss->cmax[threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ss->ccnt[threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (clear_set >= 0) {
     const int64_t total = (int64_t)kCoopMaxPass * kBins;
     unsigned long long* z = &ss->chist[clear_set][0][0];
@@ -1395,15 +1435,30 @@ __global__ __launch_bounds__(1024) void k_sel_lds(double* y, const double* q, co
     __builtin_amdgcn_sched_barrier(0);
   }
   SEL_STAMP(32);
+  unsigned long long cnt_before = ~0ull;  // elements inside the bucket of the previous pass
   for (int p = 0; p < kCoopMaxPass; ++p) {
     __syncthreads();
     const SelState st = sel_uniform(sh.sst);
     if (st.phase == 2) break;  // the same in every workgroup: they all computed it from the same histograms
+    // elements inside the bucket of THIS pass = the count of the bin the previous scan selected (coop_scan_step: found[2])
+    const unsigned long long cnt_in = p > 0 ? sh.scratch[18] : ~0ull - 1ull;
     const int hs = st.shift + st.width;
     const uint64_t dmask = ((uint64_t)1 << st.width) - 1;
+    // A bucket that holds ONE key (lattice data: the usual state after the first digit) needs no further key digits: the
+    // passes after the first also track the smallest and largest key inside their bucket (as k_s2_tail's candidate select)
+    // -- but only once a pass has failed to split its bucket at all (every element of it in one bin): on generic data the
+    // bookkeeping cost 5 us per call (n = 4e6: 42 -> 48 us) for nothing; a lattice now pays one key pass more than it must.
+    const bool track = p > 1 && st.phase == 0 && st.pad == 0 && cnt_in == cnt_before;
+    cnt_before = cnt_in;
+    unsigned long long kmin = ~0ull, kmax = 0ull, kcnt = 0ull;
     if (!(p == 0 && fused)) {
       for (int b = t; b < kBins; b += 1024) sh.lh[b] = 0u;
+      if (t == 0) { kmm[0] = ~0ull; kmm[1] = 0ull; kmm[2] = 0ull; }
       __syncthreads();
+      // (the sweep exists twice, with and without the bucket statistics: as a run-time test per element they cost the
+      //  generic path 2 us per call)
+      auto sweep = [&](auto track_tag) {
+        constexpr bool kTrack = decltype(track_tag)::value;
 #pragma unroll 2
       for (int s_ = 0; s_ < kSlots; ++s_) {
         const int i = index_of(s_);
@@ -1418,6 +1473,7 @@ __global__ __launch_bounds__(1024) void k_sel_lds(double* y, const double* q, co
             const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
             in = kp.in;
             dg = kp.digit;
+            if (kTrack && in) { kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax; ++kcnt; }
           }
         } else {
           in = key == st.t_eq && (((uint64_t)i) >> hs) == st.prefix;
@@ -1427,9 +1483,21 @@ __global__ __launch_bounds__(1024) void k_sel_lds(double* y, const double* q, co
         //  on one-key data 64 lanes on one LDS address are ~64 clocks per instruction, 7 us per sweep)
         if (in) atomicAdd(&sh.lh[dg], 1u);
       }
+      };
+      if (track) sweep(std::true_type{}); else sweep(std::false_type{});
+      if (track) {  // wave -> workgroup (LDS) -> one global atomic of each kind per workgroup (256 per address: ~3 us, under the rendezvous)
+        for (int off = 32; off >= 1; off >>= 1) {
+          const unsigned long long a_ = __shfl_xor(kmin, off, 64), c_ = __shfl_xor(kmax, off, 64);
+          kmin = a_ < kmin ? a_ : kmin;
+          kmax = c_ > kmax ? c_ : kmax;
+          kcnt += __shfl_xor(kcnt, off, 64);
+        }
+        if ((t & 63) == 0 && kcnt) { atomicMin(&kmm[0], kmin); atomicMax(&kmm[1], kmax); atomicAdd(&kmm[2], kcnt); }
+      }
     }
     if (p < 4) SEL_STAMP(23 + p);
     __syncthreads();
+    if (track && t == 0 && kmm[2]) { atomicMin(&ss->cmin[p], kmm[0]); atomicMax(&ss->cmax[p], kmm[1]); atomicAdd(&ss->ccnt[p], kmm[2]); }
     for (int b = t; b < kBins; b += 1024) {
       const unsigned int c = sh.lh[b];
       if (c) atomicAdd(&hist[p][b], (unsigned long long)c);
@@ -1441,6 +1509,7 @@ __global__ __launch_bounds__(1024) void k_sel_lds(double* y, const double* q, co
     spx_grid_rendezvous(bar, (++nbar) * gridDim.x, hdr);
     SEL_STAMP(34 + 3 * p);
     coop_scan_step(hist[p], st, &sh.sst, sh.scratch);
+    if (track) sel_single_key_shortcut(st, &sh.sst, &ss->cmin[p], &ss->cmax[p], &ss->ccnt[p]);
     SEL_STAMP(35 + 3 * p);
   }
   __syncthreads();
@@ -1588,35 +1657,7 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       spx_grid_rendezvous(bar, (++nbar) * G, hdr);
       coop_scan_step(ss->chist[2][p], st, &sh.sst, sh.scratch);
-      if (st.phase == 0) {
-        // A bucket that holds ONE key (lattice data: the usual state after the first digit) needs no further key digits:
-        // all of it kept, or the index tie-break on that key -- the state the remaining digits would arrive at, 2-4 sweeps later.
-        __syncthreads();
-        if (t == 0) {
-          const unsigned long long lo = __hip_atomic_load(&ss->cmin[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned long long hi = __hip_atomic_load(&ss->cmax[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned long long cnt = __hip_atomic_load(&ss->ccnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (lo == hi && cnt > 0 && (unsigned long long)st.quota <= cnt) {
-            SelState o = st;
-            o.pad = 0;
-            if ((unsigned long long)st.quota == cnt) {   // the whole bucket is kept
-              o.phase = 2;
-              o.t_ge = lo > st.t_floor ? lo : st.t_floor;
-            } else {                                     // more equal keys than quota: ties by ascending index
-              o.t_ge = lo + 1;
-              o.t_eq = lo;
-              o.phase = 1;
-              o.prefix = 0;
-              const int top = st.idx_bits;
-              const int w = top % kDigitBits ? top % kDigitBits : kDigitBits;
-              if (top == 0) { o.phase = 2; o.icut = 0; }
-              o.shift = top - w;
-              o.width = w;
-            }
-            sh.sst = o;
-          }
-        }
-      }
+      if (st.phase == 0) sel_single_key_shortcut(st, &sh.sst, &ss->cmin[p], &ss->cmax[p], &ss->ccnt[p]);
     }
     __syncthreads();
     const SelState fin = sh.sst;
