@@ -44,9 +44,9 @@ __device__ __forceinline__ double dpp_f64(double v) {
 }
 template <int TEAM>
 __device__ __forceinline__ double lanes_sum(double v) {
-  static_assert(TEAM == 4 || TEAM == 8 || TEAM == 16 || TEAM == 32 || TEAM == 64, "TEAM");
-  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  static_assert(TEAM == 1 || TEAM == 2 || TEAM == 4 || TEAM == 8 || TEAM == 16 || TEAM == 32 || TEAM == 64, "TEAM");
+  if constexpr (TEAM >= 2) v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  if constexpr (TEAM >= 4) v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
   if constexpr (TEAM >= 8) v += dpp_f64<0x141>(v);  // row_half_mirror: the other quad of each 8
   if constexpr (TEAM >= 16) v += dpp_f64<0x140>(v);  // row_mirror: the other half of each 16-lane row
   if constexpr (TEAM >= 32) v += __shfl_xor(v, 16, 64);
@@ -86,8 +86,8 @@ __device__ __forceinline__ void team_sum2(double& a, double& b, double* lds) {
 // max over the team of a NaN-free value
 template <int TEAM>
 __device__ __forceinline__ double team_max(double v, double* lds) {
-  v = fmax(v, dpp_f64<0xB1>(v));
-  v = fmax(v, dpp_f64<0x4E>(v));
+  if constexpr (TEAM >= 2) v = fmax(v, dpp_f64<0xB1>(v));
+  if constexpr (TEAM >= 4) v = fmax(v, dpp_f64<0x4E>(v));
   if constexpr (TEAM >= 8) v = fmax(v, dpp_f64<0x141>(v));
   if constexpr (TEAM >= 16) v = fmax(v, dpp_f64<0x140>(v));
   if constexpr (TEAM >= 32) v = fmax(v, __shfl_xor(v, 16, 64));
@@ -1214,12 +1214,23 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     int lpg, epl;
     // Binf: as few lanes per group as the registers allow (4 x 4/8, 8 x 8/16, 16 x 16, 32 x 16 elements) -- the wave-uniform
     // scalar work of the root find, which every lane executes, is then shared by more groups per wave
-    if (BINF && gsize <= 16) { lpg = 4; epl = 4; }
+    // Small groups (round 3): tiles that FIT -- a 4 x 4 tile spent four lanes' worth of root find (Binf) or reduction on a group
+    // of two, and three quarters of its loads on padding.  us per call at n = 1.6e7, old -> new tile (tools/r3/binf_small_groups.py):
+    // Binf groups of 2: 1305 -> 368, of 4: 680 -> 208, of 8: 317 -> 174, of 16: 155 -> 142; plain groups of 2: 508 -> 89, of 4:
+    // 283 -> 92, of 8: 162 -> 90, of 10: 132 -> 107.  (One lane per group beyond 8 elements loses more to the 64-byte strides
+    // between its lanes' loads than it saves: Binf 1 x 16 on groups of 16 270 us.)
+    if (BINF && gsize <= 2) { lpg = 1; epl = 2; }
+    else if (BINF && gsize <= 4) { lpg = 1; epl = 4; }
+    else if (BINF && gsize <= 8) { lpg = 1; epl = 8; }
+    else if (BINF && gsize <= 16) { lpg = 2; epl = 8; }
     else if (BINF && gsize <= 32) { lpg = 4; epl = 8; }
     else if (BINF && gsize <= 64) { lpg = 8; epl = 8; }  // (4 x 16 is slower here: 64-byte runs per group and load)
     else if (BINF && gsize <= 128) { lpg = 8; epl = 16; }
     else if (BINF && gsize <= 256) { lpg = 16; epl = 16; }
     else if (BINF && gsize <= 512) { lpg = 32; epl = 16; }
+    else if (gsize <= 2) { lpg = 1; epl = 2; }
+    else if (gsize <= 4) { lpg = 2; epl = 4; }
+    else if (gsize <= 12) { lpg = 4; epl = 4; }
     else if (gsize <= 32) { lpg = 16; epl = 2; }
     else if (gsize <= 64) { lpg = 16; epl = 4; }
     else if (gsize <= 128) { lpg = 16; epl = 8; }
@@ -1252,8 +1263,13 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, false>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,  \
                          (int)gsize, lambda, sigma, delta, deferred, ragged_reg ? offsets : (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal); \
   } while (0)
-    if (lpg == 4 && epl == 4) { if constexpr (BINF) SPX_LAUNCH_REG(4, 4); }
-    else if (lpg == 4 && epl == 8) { if constexpr (BINF) SPX_LAUNCH_REG(4, 8); }
+    if (lpg == 1 && epl == 2) SPX_LAUNCH_REG(1, 2);
+    else if (lpg == 1 && epl == 4) SPX_LAUNCH_REG(1, 4);
+    else if (lpg == 1 && epl == 8) SPX_LAUNCH_REG(1, 8);
+    else if (lpg == 2 && epl == 4) SPX_LAUNCH_REG(2, 4);
+    else if (lpg == 2 && epl == 8) SPX_LAUNCH_REG(2, 8);
+    else if (lpg == 4 && epl == 4) SPX_LAUNCH_REG(4, 4);
+    else if (lpg == 4 && epl == 8) SPX_LAUNCH_REG(4, 8);
     else if (lpg == 8 && epl == 8) { if constexpr (BINF) SPX_LAUNCH_REG(8, 8); }
     else if (lpg == 8) { if constexpr (BINF) SPX_LAUNCH_REG(8, 16); }
     else if (lpg == 16 && epl == 16) { if constexpr (BINF) SPX_LAUNCH_REG(16, 16); }
@@ -1279,11 +1295,12 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, true, false, true>), lgrid, block, 0, ctx->stream, y, q, xk, sj,     \
                          ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal); \
   } while (0)
-        if (lpg == 4 && epl == 4) SPX_LAUNCH_LIT(4, 4);
-        else if (lpg == 4) SPX_LAUNCH_LIT(4, 8);
-        else if (lpg == 8 && epl == 8) SPX_LAUNCH_LIT(8, 8);
-        else if (lpg == 8) SPX_LAUNCH_LIT(8, 16);
-        else if (lpg == 16) SPX_LAUNCH_LIT(16, 16);
+        // (its own tiles, by the group size: the list is short, the literal evaluation wants lanes)
+        if (gsize <= 16) SPX_LAUNCH_LIT(4, 4);
+        else if (gsize <= 32) SPX_LAUNCH_LIT(4, 8);
+        else if (gsize <= 64) SPX_LAUNCH_LIT(8, 8);
+        else if (gsize <= 128) SPX_LAUNCH_LIT(8, 16);
+        else if (gsize <= 256) SPX_LAUNCH_LIT(16, 16);
         else SPX_LAUNCH_LIT(32, 16);
 #undef SPX_LAUNCH_LIT
         SPX_LAUNCH_CHECK();
