@@ -142,8 +142,10 @@ __global__ __launch_bounds__(256) void k_obj(const T* __restrict__ y, const T* _
     atomicOr(&ws->infeasible, 1);
 }
 
-// GroupNormL2: sum_g lambda_g ||xsy[idx_g]||_2, one wavefront per group  (src/groupNormL2.jl:33-39)
-template <class T, int MODE>
+// GroupNormL2: sum_g lambda_g ||xsy[idx_g]||_2  (src/groupNormL2.jl:33-39).  TEAM lanes of a wavefront per group, 64 / TEAM
+// groups per wavefront and trip (round 3: a whole wavefront per group left 62 lanes idle on groups of two -- 1.46 ms per call
+// at n = 1.6e7 against 68 us on groups of 128; TEAM follows the group size, ~4 elements per lane: run_obj_group).
+template <class T, int MODE, int TEAM>
 __global__ __launch_bounds__(256) void k_obj_group(const T* __restrict__ y, const T* __restrict__ xk,
                                                     const T* __restrict__ sj, int64_t n,
                                                     const int64_t* __restrict__ offsets, int64_t gsize, int64_t ngroups,
@@ -154,16 +156,22 @@ __global__ __launch_bounds__(256) void k_obj_group(const T* __restrict__ y, cons
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  double acc = 0.0;  // lane 0 of each wave accumulates lambda_g * norm_g
+  constexpr int GPW = 64 / TEAM;  // groups per wavefront and trip
+  const int j = lane % TEAM, slot = lane / TEAM;
+  double acc = 0.0;  // lane 0 of each team accumulates lambda_g * norm_g
   bool bad = false, bad_index = false;
-  for (int64_t g = wave; g < ngroups; g += nwaves) {
-    int64_t lo, hi;
-    if (offsets) { lo = offsets[g]; hi = offsets[g + 1]; }
-    else { lo = g * gsize; hi = lo + gsize; }
+  for (int64_t g0 = wave * GPW; g0 < ngroups; g0 += nwaves * GPW) {  // wave-uniform trip count
+    const int64_t g = g0 + slot;
+    const bool live = g < ngroups;
+    int64_t lo = 0, hi = 0;
+    if (live) {
+      if (offsets) { lo = offsets[g]; hi = offsets[g + 1]; }
+      else { lo = g * gsize; hi = lo + gsize; }
+    }
     if (lo < 0) lo = 0;
     if (hi > (index ? nnz : n)) hi = index ? nnz : n;
     double ss = 0.0;
-    for (int64_t p = lo + lane; p < hi; p += 64) {
+    for (int64_t p = lo + j; p < hi; p += TEAM) {
       int64_t i = p;
       if (index) {
         i = index[p];
@@ -179,8 +187,9 @@ __global__ __launch_bounds__(256) void k_obj_group(const T* __restrict__ y, cons
       }
       ss += (double)v * (double)v;
     }
-    ss = wave_sum(ss);
-    if (lane == 0) acc += (double)lambda[g] * sqrt(ss);
+#pragma unroll
+    for (int off = TEAM / 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);  // (inside the team's aligned lane range)
+    if (live && j == 0) acc += (double)lambda[g] * sqrt(ss);
   }
   acc = block_sum(acc, lds4);
   if (threadIdx.x == 0) ws->partial[blockIdx.x] = acc;
@@ -293,11 +302,27 @@ int run_obj_group(spx_ctx* ctx, const T* y, const T* xk, const T* sj, int64_t n,
   SPX_ON_DEVICE(ctx);
   ObjWs* ws = reinterpret_cast<ObjWs*>(ctx->ws);
   { const int rz = spx_zero_async(ctx, &ws->infeasible, sizeof(int)); if (rz) return rz; }
-  int64_t blocks = (ngroups + 3) / 4;
+  // lanes per group: about four elements per lane of a typical group (uniform size, the caller's size bound, or the average)
+  const int64_t typical = gsize > 0 ? gsize : (ngroups > 0 ? ((index ? nnz : n) + ngroups - 1) / ngroups : 1);
+  int team = 1;
+  while (team < 64 && (int64_t)team * 4 < typical) team *= 2;
+  const int gpw = 64 / team;
+  int64_t blocks = (ngroups + 4 * gpw - 1) / (4 * gpw);
   if (blocks > kObjBlocks) blocks = kObjBlocks;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((k_obj_group<T, MODE>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, offsets, gsize,
-                     ngroups, index, nnz, lambda, rad, ws);
+#define SPX_OBJ_GROUP(TEAM)                                                                                                  \
+  hipLaunchKernelGGL((k_obj_group<T, MODE, TEAM>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, offsets, \
+                     gsize, ngroups, index, nnz, lambda, rad, ws)
+  switch (team) {
+    case 1: SPX_OBJ_GROUP(1); break;
+    case 2: SPX_OBJ_GROUP(2); break;
+    case 4: SPX_OBJ_GROUP(4); break;
+    case 8: SPX_OBJ_GROUP(8); break;
+    case 16: SPX_OBJ_GROUP(16); break;
+    case 32: SPX_OBJ_GROUP(32); break;
+    default: SPX_OBJ_GROUP(64); break;
+  }
+#undef SPX_OBJ_GROUP
   if (MODE == 2 && offsets) {  // the groups need not tile 0:n: the trust-region indicator covers every index
     int64_t sb = (n + 256 * 8 - 1) / (256 * 8);
     if (sb > kObjBlocks) sb = kObjBlocks;
