@@ -371,7 +371,7 @@ def test_f32_topr_bit_exact(s, orc, n):
 # ------------------------------------------------------------------------------------------------------------------
 # ShiftedGroupNormL2 in Float32 (round 3): elementwise operations in Float32, the norm to a Float32 ulp
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("gs", [1, 7, 64, 128, 1000])
+@pytest.mark.parametrize("gs", [1, 2, 3, 4, 7, 9, 16, 33, 64, 128, 1000])
 def test_f32_group_l2(s, gs):
     """uniform groups and ragged CSR groups (incl. indices in no group: y - (xk + sj), src/shiftedGroupNormL2.jl:77), y === q.
     Reference: the method restated in numpy with Float32 operations and the norm formed in Float64 and rounded once (the

@@ -429,14 +429,15 @@ def _binf_check(orc, y, ref, q, x, sj, lam, sigma, delta, offsets, what=""):
     return arbiter.check_group(orc, y, ref, q, x, sj, lam, sigma, offsets, delta=delta, what=what)
 
 
-@pytest.mark.parametrize("gsize", [64, 128, 256, 512, 1, 2, 6, 7, 33, 66, 100, 130, 250, 257, 383, 386, 510, 511, 513,
-                                   1024, 2048, 2049, 3000, 4096, 4097, 8200])
+@pytest.mark.parametrize("gsize", [64, 128, 256, 512, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 17, 33, 66, 100, 130, 250, 257,
+                                   383, 386, 510, 511, 513, 1024, 2048, 2049, 3000, 4096, 4097, 8200])
 @pytest.mark.parametrize("binf", [False, True])
 @pytest.mark.parametrize("misaligned", [False, True])
 def test_group_uniform(s, orc, gsize, binf, misaligned):
-    # every tile of the register kernel, full and partly filled, even (16-byte pairs) and odd (8-byte loads) sizes;
+    # every tile of the register kernel (from one lane per group of two on), full and partly filled, even (16-byte pairs) and
+    # odd (8-byte loads) sizes;
     # misaligned: all four vectors start 8 bytes off a 16-byte boundary
-    if misaligned and gsize not in (2, 64, 100, 128, 386, 512, 3000):
+    if misaligned and gsize not in (2, 4, 10, 64, 100, 128, 386, 512, 3000):
         pytest.skip("misaligned views are checked on a subset")
     ng = 513 if gsize <= 513 else 19  # > 512: LDS-resident group per workgroup (<= 8192), general kernel above
     n = ng * gsize
@@ -877,6 +878,35 @@ def test_objective_groups_and_reference_identities(s, orc):
     assert abs(psi(zero) - hx) <= 1e-12 * hx            # psi(zeros(n)) == h(x)
     yy = rng.random(m); yy *= 0.01 / np.max(np.abs(yy)) / 2
     assert np.isfinite(psi(_dev(yy)[0])) and psi(_dev(3 * yy)[0]) == np.inf   # inside / outside the trust region
+
+
+@pytest.mark.parametrize("gs", [1, 2, 3, 4, 5, 8, 9, 16, 17, 40, 64, 65, 300])
+def test_objective_group_sizes(s, orc, gs):
+    """psi(y) of both group operators on uniform groups of every lane-team width of k_obj_group (1 .. 64 lanes per group) and on
+    ragged groups with that size as the bound; the last wavefront's idle slots (group count not a multiple of 64 / team)."""
+    rng = np.random.default_rng(4100 + gs)
+    ng = 1237
+    n = ng * gs
+    x, sj, _ = _data(n, 4200 + gs)
+    y = rng.uniform(-0.3, 0.3, size=n)
+    lam = rng.uniform(0.2, 2.0, size=ng)
+    xd, sd, yd = _dev(x, sj, y)
+    import torch
+    h = s.GroupNormL2.uniform(torch.from_numpy(lam).cuda(), gs)
+    ref = orc.obj_group_l2(y, x, sj, lam, offsets=np.arange(0, n + 1, gs))
+    assert abs(s.shifted(s.shifted(h, xd), sd)(yd) - ref) <= 1e-12 * ref
+    for delta in (1.0, 0.2):
+        got = s.shifted(s.shifted(h, xd, delta, s.NormLinf(1.0)), sd)(yd)
+        want = orc.obj_group_l2(y, x, sj, lam, offsets=np.arange(0, n + 1, gs), delta=delta)
+        assert got == want if np.isinf(want) else abs(got - want) <= 1e-12 * want
+    # ragged: sizes 1 .. gs
+    sizes = rng.integers(1, gs + 1, size=ng)
+    offsets = np.concatenate([[0], np.cumsum(sizes)])
+    m = int(offsets[-1])
+    groups = [range(int(a), int(b)) for a, b in zip(offsets[:-1], offsets[1:])]
+    hr = s.GroupNormL2(lam.tolist(), groups)
+    refr = orc.obj_group_l2(y[:m], x[:m], sj[:m], lam, offsets=offsets)
+    assert abs(s.shifted(s.shifted(hr, xd[:m]), sd[:m])(yd[:m]) - refr) <= 1e-12 * refr
 
 
 # ------------------------------------------------------------------ ShiftedNormL1B2 (SURVEY 8f rank 4)
