@@ -1336,10 +1336,21 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     hipLaunchKernelGGL(k_csr_uncovered, dim3(256), dim3(256), 0, ctx->stream, y, xk, sj, offsets, ngroups, n);
   const double avg = (double)n / (double)ngroups;
   if (avg <= 2048.0) {
-    int64_t blocks = (ngroups + 3) / 4;
+    // lanes per group by the average size (ragged groups without a size bound from the caller, or with one above 512): a
+    // whole wavefront per group of a handful of elements left most lanes idle (round 3)
+    const int team = avg <= 8.0 ? 4 : avg <= 24.0 ? 8 : avg <= 64.0 ? 16 : avg <= 160.0 ? 32 : 64;
+    const int tpb = 256 / team;
+    int64_t blocks = (ngroups + tpb - 1) / tpb;
     if (blocks > cap_blocks) blocks = cap_blocks;
-    hipLaunchKernelGGL((k_group_mem<64, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n,
-                       offsets, gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr, ctx->status_dev, ctx->tune_binf_literal);
+#define SPX_LAUNCH_MEM(TEAM)                                                                                              \
+  hipLaunchKernelGGL((k_group_mem<TEAM, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n, offsets, \
+                     gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr, ctx->status_dev, ctx->tune_binf_literal)
+    if (team == 4) SPX_LAUNCH_MEM(4);
+    else if (team == 8) SPX_LAUNCH_MEM(8);
+    else if (team == 16) SPX_LAUNCH_MEM(16);
+    else if (team == 32) SPX_LAUNCH_MEM(32);
+    else SPX_LAUNCH_MEM(64);
+#undef SPX_LAUNCH_MEM
   } else {
     int64_t blocks = ngroups < cap_blocks ? ngroups : cap_blocks;
     hipLaunchKernelGGL((k_group_mem<256, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n,
@@ -1406,8 +1417,19 @@ static int run_group_gather(spx_ctx* ctx, double* y, const double* q, const doub
     if (hflag & 1) { spx_set_error("invalid argument: group index outside [0, n) (BoundsError)"); return SPX_ERR_INVALID_ARG; }
     const double avg = (double)nnz / (double)ngroups;
     if (avg <= 2048.0) {
-      hipLaunchKernelGGL((k_group_gather<64, BINF>), dim3((unsigned)gb), dim3(256), 0, ctx->stream, y, sol, xk, sj, owner,
-                         ptr, index, ngroups, lambda, sigma, delta, ctx->tune_binf_literal);
+      const int team = avg <= 8.0 ? 4 : avg <= 24.0 ? 8 : avg <= 64.0 ? 16 : avg <= 160.0 ? 32 : 64;  // (as run_group)
+      const int tpb = 256 / team;
+      int64_t tb = (ngroups + tpb - 1) / tpb;
+      if (tb > cap_blocks) tb = cap_blocks;
+#define SPX_LAUNCH_GATHER(TEAM)                                                                                           \
+  hipLaunchKernelGGL((k_group_gather<TEAM, BINF>), dim3((unsigned)tb), dim3(256), 0, ctx->stream, y, sol, xk, sj, owner, ptr, \
+                     index, ngroups, lambda, sigma, delta, ctx->tune_binf_literal)
+      if (team == 4) SPX_LAUNCH_GATHER(4);
+      else if (team == 8) SPX_LAUNCH_GATHER(8);
+      else if (team == 16) SPX_LAUNCH_GATHER(16);
+      else if (team == 32) SPX_LAUNCH_GATHER(32);
+      else SPX_LAUNCH_GATHER(64);
+#undef SPX_LAUNCH_GATHER
     } else {
       int64_t blocks = ngroups < cap_blocks ? ngroups : cap_blocks;
       hipLaunchKernelGGL((k_group_gather<256, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, sol, xk, sj,
