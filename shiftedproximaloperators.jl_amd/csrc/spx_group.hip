@@ -845,9 +845,13 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
 #pragma unroll
           for (int k = 0; k < EPL / 2; ++k) {
             const int p = (FULL || k * LPG + j < npairs) ? (k * LPG + j) : 0;
-            vq[k] = __builtin_nontemporal_load(q2 + p);
-            vx[k] = __builtin_nontemporal_load(x2 + p);
-            vs[k] = __builtin_nontemporal_load(s2 + p);
+            if constexpr (LPG <= 2) {  // a lane's pairs share cache lines with each other, not with its neighbours': cached accesses
+              vq[k] = q2[p]; vx[k] = x2[p]; vs[k] = s2[p];
+            } else {
+              vq[k] = __builtin_nontemporal_load(q2 + p);
+              vx[k] = __builtin_nontemporal_load(x2 + p);
+              vs[k] = __builtin_nontemporal_load(s2 + p);
+            }
           }
         }
 #pragma unroll
@@ -916,7 +920,10 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
         f64x2* y2 = reinterpret_cast<f64x2*>(y_ + base);
 #pragma unroll
         for (int k = 0; k < EPL / 2; ++k)
-          if (FULL || k * LPG + j < npairs) __builtin_nontemporal_store(f64x2{out[2 * k], out[2 * k + 1]}, y2 + k * LPG + j);
+          if (FULL || k * LPG + j < npairs) {
+            if constexpr (LPG <= 2) y2[k * LPG + j] = f64x2{out[2 * k], out[2 * k + 1]};  // (merged into whole lines by the L2)
+            else __builtin_nontemporal_store(f64x2{out[2 * k], out[2 * k + 1]}, y2 + k * LPG + j);
+          }
       } else {
 #pragma unroll
         for (int k = 0; k < EPL; ++k)
