@@ -121,7 +121,19 @@ struct FastState {
   // everything at worst): the call moves 32 B/element plus that range instead of 56.
   int spec_hi, spec_lo;
   long long spec_cut;
+  // Speculation on the CANDIDATES (round 3): the main pass stores a candidate as kept when its key is >= t_mid, the middle of
+  // the band -- where the sample puts the cut, +-1 sigma of a +-6 sigma band -- and as dropped below it; the candidate kernels
+  // rewrite those the cut proves wrong (a sixth of what "every candidate dropped" left to rewrite: 3e5 scattered 8-byte stores
+  // at n = 1e8, r = n/2, 29 us of k_s2_compact).  Any value is correct; ~0 = no candidate is stored as kept.
+  uint64_t t_mid;
 };
+// the value of a dropped entry i (shiftedIndBallL0.jl:69-70, shiftedIndBallL0BInf.jl:91), as k_s2_main forms it
+template <bool BINF>
+__device__ __forceinline__ double sel_dropped(const double* xk, const double* sj, int64_t i, double delta) {
+  const double d = 0.0 - (xk[i] + sj[i]);
+  if constexpr (BINF) return jl_min(jl_max(d, -delta), delta);
+  else return d;
+}
 constexpr int kTodoCandSelect = 1;  // the bucket of the first candidate digit overflows the short list: radix select over the candidates
 constexpr int kTodoTieScan = 2;     // the cut lies inside a class: find the index of its quota-th member
 constexpr int kTodoFinal = 4;       // tie mode: y is (re)written from q, xk, sj and the final thresholds -- where the speculative
@@ -528,6 +540,7 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
   const bool has_hi = ws->fs.has_hi != 0, has_lo = ws->fs.has_lo != 0;
   const int spec_hi = ws->fs.spec_hi, spec_lo = ws->fs.spec_lo;
   const int64_t spec_cut = ws->fs.spec_cut;
+  const uint64_t t_mid = ws->fs.t_mid;
   const int64_t gwave = (int64_t)blockIdx.x * 4 + wave;
   const int64_t rbase = gwave * kWaveSlots;  // this wave's candidate region
   const unsigned long long lt_mask = (1ull << lane) - 1;
@@ -582,6 +595,7 @@ __global__ __launch_bounds__(256) void k_s2_main(double* y_, const double* q_, c
       if (c_hi) spec_kept = spec_hi == 1 || (spec_hi == 2 && i <= spec_cut);
       if (c_lo) spec_kept = spec_lo == 1 || (spec_lo == 2 && i <= spec_cut);
     }
+    if (in_band) spec_kept = key >= t_mid;  // (FastState::t_mid)
     const unsigned long long m = __ballot(in_band);
     if (m) {
       const unsigned int pos = ncand + (unsigned int)__popcll(m & lt_mask);
@@ -744,10 +758,13 @@ __device__ __forceinline__ void for_each_candidate(const WaveCount* counts, int6
     unsigned int c = 0;
     if (w < nregions) c = counts[w].cand;
     const int cnt = c < (unsigned)kWaveSlots ? (int)c : kWaveSlots;
-    const int64_t e0 = w * kWaveSlots;
+    const int64_t e0 = (w < nregions ? w : nregions - 1) * kWaveSlots;
     constexpr int U = 8;  // entries in flight per lane (a region holds ~4 on average)
     for (int s0 = 0; __any(s0 < cnt); s0 += U) {
       Cand c[U];
+      // (tried: clamped unconditional loads so that no load waits in a branch block of its own, and 12 / 16 entries in flight:
+      //  k_s2_compact at n = 1e8 13.0 / 25.9 us -> 15.5 / 29.6 and 13.4 / 24.6 -- the walk is bound by its ~2e5 scattered
+      //  128-byte lines, not by latency)
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (s0 + u < cnt) c[u] = cand[e0 + s0 + u];
@@ -843,11 +860,13 @@ __global__ __launch_bounds__(256) void k_s2_scan_verify(SelWs* ws, int64_t r) {
 // after the first candidate digit: the candidates still in play (inside the chosen bin, or tied key) -> short list.
 // WRITE (single-pass form): candidates that the first digit already puts above the cut get their kept value here; the
 // short list carries the values of the rest and k_s2_finish stores those that make it -- no separate fix-up walk.
-template <bool WRITE>
+template <bool WRITE, bool BINF>
 __global__ __launch_bounds__(256) void k_s2_compact(double* y, const Cand* cand, SelWs* ws, uint64_t* list_key,
                                                      int64_t* list_idx, double* list_val, const WaveCount* counts,
-                                                     int64_t nregions, unsigned int ovf_cap) {
+                                                     int64_t nregions, unsigned int ovf_cap, const double* xk, const double* sj,
+                                                     double delta) {
   const SelState st = ws->st;
+  const uint64_t t_mid = ws->fs.t_mid;
   if (!ws->fs.ok || (ws->fs.todo & kTodoCandSelect)) return;
   const bool wr = WRITE;
   if (!wr && st.phase == 2) return;
@@ -884,15 +903,17 @@ __global__ __launch_bounds__(256) void k_s2_compact(double* y, const Cand* cand,
       }
     }
     if constexpr (WRITE) {
-      if (keep && wr) y[i] = val;
+      // decided by the digits so far (not inside the bucket still being refined): rewritten where the main pass guessed wrong
+      const bool spec = key >= t_mid;
+      if (wr && !in && keep != spec) y[i] = keep ? val : sel_dropped<BINF>(xk, sj, i, delta);
     }
   });
 }
 
 // one workgroup: finishes the selection on the short list, entirely in LDS
-template <bool WRITE>
+template <bool WRITE, bool BINF>
 __global__ __launch_bounds__(1024) void k_s2_finish(double* y, SelWs* ws, const uint64_t* list_key, const int64_t* list_idx,
-                                                     const double* list_val) {
+                                                     const double* list_val, const double* xk, const double* sj, double delta) {
   __shared__ uint64_t lk[kShortList];
   __shared__ int64_t li[kShortList];
   __shared__ unsigned int h[kBins];
@@ -934,12 +955,14 @@ __global__ __launch_bounds__(1024) void k_s2_finish(double* y, SelWs* ws, const 
   }
   __syncthreads();
   if (t == 0) ws->st = sst;
-  if (WRITE) {  // the short-list entries that made the cut (everything above it was stored by k_s2_compact)
+  if (WRITE) {  // the short-list entries the main pass guessed wrong (everything outside the list was settled by k_s2_compact)
     const SelState fin = sst;
+    const uint64_t t_mid = ws->fs.t_mid;
     for (unsigned int e = t; e < m; e += 1024) {
       const uint64_t key = lk[e];
       const int64_t i = li[e];
-      if ((key >= fin.t_ge) || (key == fin.t_eq && i <= fin.icut)) y[i] = list_val[e];
+      const bool keep = (key >= fin.t_ge) || (key == fin.t_eq && i <= fin.icut);
+      if (keep != (key >= t_mid)) y[i] = keep ? list_val[e] : sel_dropped<BINF>(xk, sj, i, delta);
     }
   }
 }
@@ -1663,9 +1686,11 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
     const SelState fin = sh.sst;
     if (b == 0 && t == 0) ss->ws.st = fin;  // (every workgroup read the old state before the first rendezvous above)
     if (write && !spx_poisoned(hdr)) {
-      // the candidates that make the cut (k_s2_compact stored those above the first digit's bucket; storing them again is harmless)
+      // every candidate the main pass guessed wrong (FastState::t_mid; what k_s2_compact settled already is stored again: harmless)
+      const uint64_t t_mid = ss->ws.fs.t_mid;
       for_each_candidate(counts, nregions, cand, (int64_t)novf, [&](uint64_t key, int64_t i, double val) {
-        if ((key >= fin.t_ge) || (key == fin.t_eq && i <= fin.icut)) y[i] = val;
+        const bool keep = (key >= fin.t_ge) || (key == fin.t_eq && i <= fin.icut);
+        if (keep != (key >= t_mid)) y[i] = keep ? val : sel_dropped<BINF>(xk, sj, i, delta);
       });
     }
   }
@@ -2046,6 +2071,8 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     f.spec_hi = 1;   // (without a cut inside it, class hi lies above the cut and class lo below)
     f.spec_lo = 0;
     f.spec_cut = -1;
+    f.t_mid = (active[0] && active[1]) ? f.t_lo + ((f.t_hi - f.t_lo) >> 1)
+            : (active[0] ? 0ull : ~0ull);  // (no lower end: r is close to n, the candidates are mostly kept; no upper end: mostly dropped)
     if (tie) {
       // where the sample puts the cut: its rank in the sample is p M; `sabove` samples lie above a class of `m` samples
       const double M = (double)(kFrontBlocks * 1024 * kFrontSpl);
@@ -2295,15 +2322,15 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     //  than the launch they save)
     hipLaunchKernelGGL(k_s2_scan_verify, dim3(1), dim3(256), 0, ctx->stream, sws, r);
     if (write) {
-      hipLaunchKernelGGL((k_s2_compact<true>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, sws, lkey, lidx,
-                         lval, (const WaveCount*)counts, nregions, ovf_cap);
-      hipLaunchKernelGGL((k_s2_finish<true>), dim3(1), dim3(1024), 0, ctx->stream, y, sws, (const uint64_t*)lkey,
-                         (const int64_t*)lidx, (const double*)lval);
+      hipLaunchKernelGGL((k_s2_compact<true, BINF>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, sws, lkey, lidx,
+                         lval, (const WaveCount*)counts, nregions, ovf_cap, xk, sj, delta);
+      hipLaunchKernelGGL((k_s2_finish<true, BINF>), dim3(1), dim3(1024), 0, ctx->stream, y, sws, (const uint64_t*)lkey,
+                         (const int64_t*)lidx, (const double*)lval, xk, sj, delta);
     } else {
-      hipLaunchKernelGGL((k_s2_compact<false>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, sws, lkey, lidx,
-                         lval, (const WaveCount*)counts, nregions, ovf_cap);
-      hipLaunchKernelGGL((k_s2_finish<false>), dim3(1), dim3(1024), 0, ctx->stream, y, sws, (const uint64_t*)lkey,
-                         (const int64_t*)lidx, (const double*)lval);
+      hipLaunchKernelGGL((k_s2_compact<false, BINF>), dim3(512), dim3(256), 0, ctx->stream, y, (const Cand*)cand, sws, lkey, lidx,
+                         lval, (const WaveCount*)counts, nregions, ovf_cap, xk, sj, delta);
+      hipLaunchKernelGGL((k_s2_finish<false, BINF>), dim3(1), dim3(1024), 0, ctx->stream, y, sws, (const uint64_t*)lkey,
+                         (const int64_t*)lidx, (const double*)lval, xk, sj, delta);
     }
     hipLaunchKernelGGL((k_s2_tail<BINF>), dim3((unsigned)g_tail), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta, ss,
                        ctx->coop_parity, (const Cand*)cand, (const WaveCount*)counts, nregions, ovf_cap,
