@@ -306,7 +306,7 @@ def _extra(s, L, ctx, dev, n, torch):
     psi_b2 = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, s.NormL2(1.0)), sj)
     s.prox_bang(y, psi_b2, q, 1.0)
     ms = _time_op(s, L, ctx, lambda: s.prox_bang(y, psi_b2, q, 1.0), iters=5, rounds=3)
-    res["ShiftedNormL1B2"] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4), "kernel": "k_b2_coop<false, 1, 1024, true>",
+    res["ShiftedNormL1B2"] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4), "kernel": "k_b2_coop<false, 1, 1024, true, false>",
                               "gelem_s": round(n / ms / 1e6, 2), "gbs_algorithmic": round(32 * n / ms / 1e6, 1),
                               "frac_of_peak": round(32 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
                               "note": "algorithmic 32 B/element; the call streams 24 + 32 = 56 B/element in ONE launch (round 3: the first "
@@ -328,11 +328,13 @@ def _extra(s, L, ctx, dev, n, torch):
     r = max(1, n // 100)
     # top-r is a sequence: k_s2_front, k_s2_main (dominant, ~88 % of the time), k_s2_scan_verify, k_s2_compact, k_s2_finish and
     # k_s2_tail, which returns at once on generic data; ms is the whole call
-    TOPR = "k_s2_main<true, true> (+ k_s2_front<4>, k_s2_scan_verify, k_s2_compact<true>, k_s2_finish<true>, k_s2_tail<true>)"
+    TOPR = "k_s2_main<true, true> (+ k_s2_front<4>, k_s2_scan_verify, k_s2_compact<true, true>, k_s2_finish<true, true>, k_s2_tail<true>)"
+    TOPR16 = TOPR.replace("k_s2_front<4>", "k_s2_front<16>")   # (a cut in the bulk of a vector of >= 2^26 elements: 16 samples per lane)
     line("ShiftedIndBallL0BInf_r=n/100", s.shifted(s.shifted(s.IndBallL0(r), xk, 1.0, chi), sj), 32, n, y, q, TOPR)
     # the same operator at the two ends of r (band without an upper end / widest band): tools/sweep_topr.py has the rest
     line("ShiftedIndBallL0BInf_r=1000", s.shifted(s.shifted(s.IndBallL0(min(1000, n)), xk, 1.0, chi), sj), 32, n, y, q, TOPR)
-    line("ShiftedIndBallL0BInf_r=n/2", s.shifted(s.shifted(s.IndBallL0(max(1, n // 2)), xk, 1.0, chi), sj), 32, n, y, q, TOPR)
+    line("ShiftedIndBallL0BInf_r=n/2", s.shifted(s.shifted(s.IndBallL0(max(1, n // 2)), xk, 1.0, chi), sj), 32, n, y, q,
+         TOPR16 if n >= (1 << 26) else TOPR)
     # the same operator on TIE-HEAVY data (SURVEY 8d, config 3's tie-stress variant; q rounded to multiples of 1/4: the r-th
     # largest |v| is shared by ~1 % of the vector).  Round 3: the tied key is counted as a class in the same single pass, the
     # index cut comes from a prefix sum over the per-wave counts (k_s2_tail); xk and sj in buffers of their own (honest traffic)
@@ -343,20 +345,25 @@ def _extra(s, L, ctx, dev, n, torch):
         s.prox_bang(y, psi_t, q4, 1.0)
         ms = _time_op(s, L, ctx, lambda: s.prox_bang(y, psi_t, q4, 1.0), iters=5, rounds=3)
         res["ShiftedIndBallL0BInf_r=%s_ties" % tag] = {
-            "ms": round(ms, 4), "avg_launch_ms": round(ms, 4), "kernel": TOPR, "gelem_s": round(n / ms / 1e6, 2),
+            "ms": round(ms, 4), "avg_launch_ms": round(ms, 4), "kernel": TOPR16 if (tag == "n/2" and n >= (1 << 26)) else TOPR,
+            "gelem_s": round(n / ms / 1e6, 2),
             "gbs_algorithmic": round(32 * n / ms / 1e6, 1), "frac_of_peak": round(32 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
             "note": "xk = sj = 0, q on a 1/4 lattice: ties at the threshold; round 2: 2.6-5.8 ms (exact radix select, ~12 passes)"}
     del q4, psi_t, z1, z2
     # per-call latency at solver-iteration sizes: the two operators with a data-dependent scalar (r-th largest, trust-region
     # root) run as ONE launch with in-launch rendezvous, nothing read back (us per call, HIP events over 50 back-to-back calls)
-    for nn in (1_000_000, 10_000):
+    # (round 3: up to 2^22 elements the vector stays on chip -- v / xk parked in LDS above 2^20 / 2^21 elements, registers below)
+    for nn in (4_000_000, 1_000_000, 100_000, 10_000):
         if nn > n:
             continue
         xs, ss_, qs, ys = xk[:nn], sj[:nn], q[:nn], y[:nn]
         for name, psi_s, kern in (
                 ("ShiftedIndBallL0BInf_r=n/100_n=%d" % nn, s.shifted(s.shifted(s.IndBallL0(max(1, nn // 100)), xs, 1.0, chi), ss_),
-                 "k_sel_coop<true, true, double>" if nn > 8192 else "k_sel_small<true, double>"),
-                ("ShiftedNormL1B2_n=%d" % nn, s.shifted(s.shifted(s.NormL1(1.0), xs, 1.0, s.NormL2(1.0)), ss_), "k_b2_coop<true, 16, 512, true>")):
+                 "k_sel_lds<true, true>" if nn > (1 << 20) else "k_sel_coop<true, true, double>" if nn > 8192 else "k_sel_small<true, double>"),
+                ("ShiftedIndBallL0BInf_r=n/2_n=%d" % nn, s.shifted(s.shifted(s.IndBallL0(max(1, nn // 2)), xs, 1.0, chi), ss_),
+                 "k_sel_lds<true, true>" if nn > (1 << 20) else "k_sel_coop<true, true, double>" if nn > 8192 else "k_sel_small<true, double>"),
+                ("ShiftedNormL1B2_n=%d" % nn, s.shifted(s.shifted(s.NormL1(1.0), xs, 1.0, s.NormL2(1.0)), ss_),
+                 "k_b2_coop<true, 16, 1024, true, true>" if nn > (1 << 21) else "k_b2_coop<true, 16, 512, true, false>")):
             s.prox_bang(ys, psi_s, qs, 1.0)
             ms = _time_op(s, L, ctx, lambda: s.prox_bang(ys, psi_s, qs, 1.0), iters=50, rounds=5)
             res[name] = {"us": round(ms * 1e3, 2), "avg_launch_ms": round(ms, 5), "kernel": kern, "n": nn,
@@ -373,6 +380,14 @@ def _extra(s, L, ctx, dev, n, torch):
     bpe = 32 + 8 / 128
     line("ShiftedGroupNormL2_%dx128" % ng, s.shifted(s.shifted(h, xk), sj), bpe, m, y, q, "k_group_reg<16, 8, false, true, false, true>")
     line("ShiftedGroupNormL2Binf_%dx128" % ng, s.shifted(s.shifted(h, xk, 1.0, chi), sj), bpe, m, y, q, "k_group_reg<8, 16, true, true, false, true>")
+    # small groups (round 3: register tiles of one or two lanes per group): n / 8 groups of 8 on the first n elements
+    ng8 = max(1, min(m, n) // 8)
+    m8 = ng8 * 8
+    lam8 = synth(ng8, 4, 0) + 1.0
+    h8 = s.GroupNormL2.uniform(lam8, 8)
+    line("ShiftedGroupNormL2_%dx8" % ng8, s.shifted(s.shifted(h8, xk[:m8]), sj[:m8]), 32 + 1, m8, y[:m8], q[:m8], "k_group_reg<4, 4, false, true, false, false>")
+    line("ShiftedGroupNormL2Binf_%dx8" % ng8, s.shifted(s.shifted(h8, xk[:m8], 1.0, chi), sj[:m8]), 32 + 1, m8, y[:m8], q[:m8], "k_group_reg<1, 8, true, true, false, true>")
+    del lam8, h8
     # a sparse iterate under a strong lambda: 90 % of the groups of xk are zero, sigma*lambda above ||S|| for most groups
     # (the reversed-bracket regime of the reference; tools/sweep_params.py has the full sweep)
     keep = (synth(ng, 9, 0) < -0.4).to(torch.float64).repeat_interleave(128)

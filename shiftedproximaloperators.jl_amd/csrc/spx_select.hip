@@ -248,6 +248,17 @@ __device__ __forceinline__ unsigned int fold_digit(uint64_t key) {
   return ((unsigned int)(e - kFoldLoExp) << 6) | (unsigned int)((key >> 46) & 63u);
 }
 
+// The same fold for the keys of Float32 values (bits(|v|) << 32; SelState::pad == 2, round 3): 62 binades around 1.0
+// (2^-32 .. 2^30) x 64 mantissa steps; the next digit resolves bits 48..37, i.e. 18 of the 23 mantissa bits after two passes.
+constexpr int kFoldLoExp32 = 95;    // biased exponent of the last binade that falls into bin 0
+constexpr int kFoldHiExp32 = 158;   // ... of the first binade that falls into bin 4095
+__device__ __forceinline__ unsigned int fold_digit_f32(uint64_t key) {
+  const int e = (int)(key >> 55);
+  if (e <= kFoldLoExp32) return 0u;
+  if (e >= kFoldHiExp32) return (unsigned int)kBins - 1u;
+  return ((unsigned int)(e - kFoldLoExp32) << 6) | (unsigned int)((key >> 49) & 63u);
+}
+
 // The state after a scan located the bucket of the quota-th element: `before` elements precede the bucket in scan order,
 // `count` are in it.
 __device__ __forceinline__ SelState sel_advance(const SelState st, uint64_t bucket, uint64_t before, uint64_t count) {
@@ -256,20 +267,23 @@ __device__ __forceinline__ SelState sel_advance(const SelState st, uint64_t buck
   const int64_t left = (int64_t)(quota - before);  // to be taken from this bucket
   const uint64_t newprefix = (st.width >= 64 ? 0ull : (st.prefix << st.width)) | bucket;  // (phase 1)
   SelState o = st;
-  if (st.phase == 0 && st.pad == 1) {                   // folded first digit (fold_digit)
+  if (st.phase == 0 && (st.pad == 1 || st.pad == 2)) {  // folded first digit (fold_digit / fold_digit_f32)
     o.pad = 0;
+    const bool f32 = st.pad == 2;
+    const int ebit = f32 ? 55 : 52, mbit = f32 ? 49 : 46;  // lowest bit of the exponent field / of the six mantissa bits in the key
+    const uint64_t hiexp = f32 ? (uint64_t)kFoldHiExp32 : (uint64_t)kFoldHiExp, loexp = f32 ? (uint64_t)kFoldLoExp32 : (uint64_t)kFoldLoExp;
     const bool catch_all = bucket < 64 || bucket >= (uint64_t)(kBins - 64);
     const uint64_t lowkey = bucket < 64 ? 0ull
-                          : bucket >= (uint64_t)(kBins - 64) ? ((uint64_t)kFoldHiExp << 52)
-                          : (((bucket >> 6) + (uint64_t)kFoldLoExp) << 52) | ((bucket & 63ull) << 46);
+                          : bucket >= (uint64_t)(kBins - 64) ? (hiexp << ebit)
+                          : (((bucket >> 6) + loexp) << ebit) | ((bucket & 63ull) << mbit);
     if ((uint64_t)left == count) {                      // the whole bucket is kept
       o.phase = 2;
       o.t_ge = lowkey > st.t_floor ? lowkey : st.t_floor;
-    } else if (!catch_all) {                            // next digit: bits 45..34 of this bucket
+    } else if (!catch_all) {                            // next digit: bits 45..34 (Float32 keys: 48..37) of this bucket
       o.base = lowkey;
       o.clamp = 0;
       o.quota = left;
-      o.shift = 46 - kDigitBits;
+      o.shift = mbit - kDigitBits;
       o.width = kDigitBits;
     }                                                   // else: start over with the plain top digit (o = st, pad = 0)
     return o;
@@ -1198,6 +1212,8 @@ __device__ __forceinline__ void coop_select(T* y, const T* q, const T* xk, const
     if (st.phase == 0) {
       if (st.pad == 1) {
         dg = fold_digit(key);
+      } else if (st.pad == 2) {
+        dg = fold_digit_f32(key);
       } else {
         const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
         in = kp.in;
@@ -1213,7 +1229,7 @@ __device__ __forceinline__ void coop_select(T* y, const T* q, const T* xk, const
   };
   if (t == 0) {
     sel_state_init(sh.sst, n, r);
-    if (sh.sst.phase == 0 && kCoopFold && kF64) sh.sst.pad = 1;  // first digit: fold_digit (binades of a Float64)
+    if (sh.sst.phase == 0 && kCoopFold) sh.sst.pad = kF64 ? 1 : 2;  // first digit: fold_digit / fold_digit_f32 (binades)
   }
   T v[REG ? kCoopEpl : 1];
   bool fused = false;  // REG: the first digit was histogrammed while the loads were in flight (it depends on the key alone)
@@ -1369,15 +1385,25 @@ __global__ __launch_bounds__(1024) void k_sel_coop(T* y, const T* q, const T* xk
 // xk + sj, but not what the unrolled digit code of 16 elements wants on top: 492 B of scratch per lane); from LDS the digit
 // loop stays rolled.  Passes, rendezvous and scan are those of coop_select.
 // ---------------------------------------------------------------------------------------------
-constexpr int kLdsEpl = 16;
+constexpr int kLdsEpl = 16;      // Float64: elements per lane (128 KiB of LDS per 1024-lane workgroup)
+constexpr int kLdsEpl32 = 32;    // Float32
 constexpr int64_t kLdsMinN = (int64_t)1 << 20;  // k_sel_lds serves the sizes above this (and below what the resident grid holds: run_select)
-// VEC: all four vectors 16-byte aligned -- a lane owns PAIRS of elements (pair gtid + k NT, k < 8) and moves them with 16-byte
-// accesses; otherwise elements gtid + k NT, k < 16, 8 bytes at a time.
-template <bool BINF, bool VEC>
-__global__ __launch_bounds__(1024) void k_sel_lds(double* y, const double* q, const double* xk, const double* sj, int64_t n,
-                                                   int64_t r, double delta, SelSync* ss, int parity, int use_set, int clear_set) {
+template <class T> struct SelVec;   // a 16-byte vector of T
+template <> struct SelVec<double> { typedef f64x2 type; };
+template <> struct SelVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
+// VEC: all four vectors 16-byte aligned -- a lane owns 16-byte VECTORS of elements (vector gtid + k NT: pairs of doubles, quads
+// of floats) and moves them with 16-byte accesses; otherwise elements gtid + k NT, one at a time.
+// T = float (round 3): 32 elements per lane, 8 Mi on 256 CUs -- 16 B per element in one launch where the form that parks v in
+// y moves ~44; the first digit is folded as for Float64 (fold_digit_f32).
+template <bool BINF, bool VEC, class T = double>
+__global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk, const T* sj, int64_t n,
+                                                   int64_t r, T delta, SelSync* ss, int parity, int use_set, int clear_set) {
+  constexpr bool kF64 = std::is_same<T, double>::value;
+  constexpr int kSlots = kF64 ? kLdsEpl : kLdsEpl32;   // elements per lane
+  constexpr int W = 16 / (int)sizeof(T);               // elements per 16-byte vector
+  typedef typename SelVec<T>::type VT;
   __shared__ CoopShared sh;
-  __shared__ __attribute__((aligned(16))) double lv[kLdsEpl * 1024];
+  __shared__ __attribute__((aligned(16))) T lv[kSlots * 1024];
   __shared__ unsigned long long kmm[3];  // smallest / largest key and number of this workgroup's elements inside the bucket of a pass
   spx_bar_reset(ss->hdr.bar[parity ^ 1]);
   // (the bucket statistics of the passes after the first: set here, first used behind the first pass's rendezvous)
@@ -1398,62 +1424,74 @@ __global__ __launch_bounds__(1024) void k_sel_lds(double* y, const double* q, co
   SpxSyncHeader* hdr = &ss->hdr;
   unsigned int nbar = 0;
   const int t = threadIdx.x;
-  const int nt = (int)(gridDim.x * blockDim.x), gtid = (int)(blockIdx.x * blockDim.x) + t, n32 = (int)n;  // (n <= 16 Ki x gridDim.x)
-  // slot s (0..15) of this lane: element index and where its v sits in LDS
-  constexpr int kSlots = kLdsEpl;
-  auto index_of = [&](int s_) -> int { return VEC ? 2 * (gtid + (s_ >> 1) * nt) + (s_ & 1) : gtid + s_ * nt; };
-  auto lds_of = [&](int s_) -> int { return VEC ? 2 * ((s_ >> 1) * 1024 + t) + (s_ & 1) : s_ * 1024 + t; };
-  double xs[kSlots];
+  const int nt = (int)(gridDim.x * blockDim.x), gtid = (int)(blockIdx.x * blockDim.x) + t, n32 = (int)n;  // (n <= kSlots Ki x gridDim.x)
+  // slot s of this lane: element index and where its v sits in LDS
+  auto index_of = [&](int s_) -> int { return VEC ? W * (gtid + (s_ / W) * nt) + (s_ % W) : gtid + s_ * nt; };
+  auto lds_of = [&](int s_) -> int { return VEC ? W * ((s_ / W) * 1024 + t) + (s_ % W) : s_ * 1024 + t; };
+  // first digit of a key: it depends on nothing but the key (the state sel_state_init sets up: the folded digit of a Float64,
+  // the plain top digit of a Float32)
+  auto digit0 = [&](uint64_t key) -> unsigned int { if constexpr (kF64) return fold_digit(key); else return fold_digit_f32(key); };
+  T xs[kSlots];
   SEL_STAMP(31);
-  // The first digit (fold_digit: it depends on nothing but the key) is histogrammed while the loads are in flight -- as its own
-  // sweep over the 16 Ki elements it was 8 us of VALU work that nothing overlapped.
+  // The first digit is histogrammed while the loads are in flight -- as its own sweep over the 16 Ki elements it was 8 us of
+  // VALU work that nothing overlapped.
   for (int b = t; b < kBins; b += 1024) sh.lh[b] = 0u;
   if (t == 0) {
     sel_state_init(sh.sst, n, r);
-    if (sh.sst.phase == 0 && kCoopFold) sh.sst.pad = 1;  // first digit: fold_digit (binades of a Float64)
+    if (sh.sst.phase == 0 && kCoopFold) sh.sst.pad = kF64 ? 1 : 2;  // first digit: fold_digit / fold_digit_f32 (binades)
   }
   __syncthreads();
   const bool fused = kCoopFold && sh.sst.phase == 0;
+  constexpr int kBatch = 2 * W;  // elements per batch: two 16-byte vectors of each input (six 16-byte or 3 x 2W narrow loads in flight)
 #pragma unroll
-  for (int s0 = 0; s0 < kSlots; s0 += 4) {  // four elements = twelve 8-byte (six 16-byte) loads in flight per lane
-    double vv[4];
+  for (int s0 = 0; s0 < kSlots; s0 += kBatch) {
+    T vv[kBatch];
     // (small n: nothing of this batch belongs to the workgroup -- its first lane's first index is past the end)
-    if ((VEC ? 2 * ((int)(blockIdx.x * blockDim.x) + (s0 >> 1) * nt) : (int)(blockIdx.x * blockDim.x) + s0 * nt) >= n32) {
+    if ((VEC ? W * ((int)(blockIdx.x * blockDim.x) + (s0 / W) * nt) : (int)(blockIdx.x * blockDim.x) + s0 * nt) >= n32) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) xs[s0 + k] = 0.0;
+      for (int k = 0; k < kBatch; ++k) xs[s0 + k] = (T)0;
       continue;
     }
     if constexpr (VEC) {
-      const int n2 = n32 >> 1;
+      const int nw = n32 / W, tail = n32 % W;  // whole vectors; elements behind the last whole one
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int s_ = s0 + 2 * h;
-        const int pr = gtid + (s_ >> 1) * nt;
-        const int pc = pr < n2 ? pr : n2 - 1;  // clamped, unconditional (n >= 2 here: n > 2 Mi)
-        const f64x2 xv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(xk) + pc);
-        const f64x2 sv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sj) + pc);
-        const f64x2 qv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(q) + pc);
-        xs[s_] = xv.x + sv.x; xs[s_ + 1] = xv.y + sv.y;
-        vv[2 * h] = xs[s_] + qv.x; vv[2 * h + 1] = xs[s_ + 1] + qv.y;   // shiftedIndBallL0.jl:66
-        if ((n32 & 1) && pr == n2) {  // the odd last element: the first half of the pair behind the last whole one
-          xs[s_] = xk[n32 - 1] + sj[n32 - 1];
-          vv[2 * h] = xs[s_] + q[n32 - 1];
+        const int s_ = s0 + W * h;
+        const int pr = gtid + (s_ / W) * nt;
+        const int pc = pr < nw ? pr : nw - 1;  // clamped, unconditional (n >= W here: n > 2^20 or a capped grid)
+        const VT xv = __builtin_nontemporal_load(reinterpret_cast<const VT*>(xk) + pc);
+        const VT sv = __builtin_nontemporal_load(reinterpret_cast<const VT*>(sj) + pc);
+        const VT qv = __builtin_nontemporal_load(reinterpret_cast<const VT*>(q) + pc);
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+          xs[s_ + e] = xv[e] + sv[e];
+          vv[W * h + e] = xs[s_ + e] + qv[e];   // shiftedIndBallL0.jl:66
+        }
+        if (tail && pr == nw) {  // the elements behind the last whole vector: the first `tail` slots of the vector after it
+#pragma unroll
+          for (int e = 0; e < W - 1; ++e) {
+            if (e < tail) {
+              const int i = W * nw + e;
+              xs[s_ + e] = xk[i] + sj[i];
+              vv[W * h + e] = xs[s_ + e] + q[i];
+            }
+          }
         }
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < kBatch; ++k) {
         const int i = index_of(s0 + k);
         const int ic = i < n32 ? i : n32 - 1;  // clamped, unconditional
-        const double xv = __builtin_nontemporal_load(xk + ic), sv = __builtin_nontemporal_load(sj + ic), qv = __builtin_nontemporal_load(q + ic);
+        const T xv = __builtin_nontemporal_load(xk + ic), sv = __builtin_nontemporal_load(sj + ic), qv = __builtin_nontemporal_load(q + ic);
         xs[s0 + k] = xv + sv;
         vv[k] = xs[s0 + k] + qv;               // shiftedIndBallL0.jl:66
       }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kBatch; ++k) {
       lv[lds_of(s0 + k)] = vv[k];              // (slots beyond n are never read)
-      if (fused && index_of(s0 + k) < n32) atomicAdd(&sh.lh[fold_digit(key_of(vv[k]))], 1u);
+      if (fused && index_of(s0 + k) < n32) atomicAdd(&sh.lh[digit0(key_of(vv[k]))], 1u);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -1492,6 +1530,8 @@ __global__ __launch_bounds__(1024) void k_sel_lds(double* y, const double* q, co
         if (st.phase == 0) {
           if (st.pad == 1) {
             dg = fold_digit(key);
+          } else if (st.pad == 2) {
+            dg = fold_digit_f32(key);
           } else {
             const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
             in = kp.in;
@@ -1538,19 +1578,24 @@ __global__ __launch_bounds__(1024) void k_sel_lds(double* y, const double* q, co
   __syncthreads();
   const SelState fin = sel_uniform(sh.sst);
   const bool poisoned = spx_poisoned(hdr);  // (see coop_select)
-  auto P = [&](double val) -> double { return poisoned ? __longlong_as_double(0x7ff8000000000000ll) : val; };
+  auto P = [&](T val) -> T { return poisoned ? (T)__longlong_as_double(0x7ff8000000000000ll) : val; };
   if constexpr (VEC) {
-    const int n2 = n32 >> 1;
+    const int nw = n32 / W, tail = n32 % W;
 #pragma unroll
-    for (int s_ = 0; s_ < kSlots; s_ += 2) {
-      const int pr = gtid + (s_ >> 1) * nt;
-      const f64x2 vv = *reinterpret_cast<const f64x2*>(&lv[lds_of(s_)]);
-      f64x2 o;
-      o.x = P(sel_out_xs<BINF>(vv.x, (int64_t)(2 * pr), xs[s_], fin, delta));
-      o.y = P(sel_out_xs<BINF>(vv.y, (int64_t)(2 * pr + 1), xs[s_ + 1], fin, delta));
-      if (pr < n2) __builtin_nontemporal_store(o, reinterpret_cast<f64x2*>(y) + pr);
-      else if ((n32 & 1) && pr == n2) y[n32 - 1] = o.x;
-      __builtin_amdgcn_sched_barrier(0);  // (one pair at a time: hoisted, the eight LDS reads do not fit beside xs)
+    for (int s_ = 0; s_ < kSlots; s_ += W) {
+      const int pr = gtid + (s_ / W) * nt;
+      const VT vvv = *reinterpret_cast<const VT*>(&lv[lds_of(s_)]);
+      VT o;
+#pragma unroll
+      for (int e = 0; e < W; ++e) o[e] = P(sel_out_xs<BINF>((T)vvv[e], (int64_t)(W * pr + e), xs[s_ + e], fin, delta));
+      if (pr < nw) {
+        __builtin_nontemporal_store(o, reinterpret_cast<VT*>(y) + pr);
+      } else if (tail && pr == nw) {
+#pragma unroll
+        for (int e = 0; e < W - 1; ++e)
+          if (e < tail) y[W * nw + e] = o[e];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (one vector at a time: hoisted, the LDS reads do not fit beside xs)
     }
   } else {
 #pragma unroll
@@ -2367,8 +2412,21 @@ int run_select_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, cons
   SelSync* ss = reinterpret_cast<SelSync*>(ctx->sync);
   const bool graph_safe = spx_capture_check(ctx) || ctx->graph_safe;
   const int64_t reg_cap = (int64_t)kCoopEpl * 1024 * (cap_reg < ctx->num_cu ? cap_reg : ctx->num_cu);
-  const bool reg = n <= reg_cap;
-  const int64_t g = reg ? (n + (int64_t)kCoopEpl * 1024 - 1) / ((int64_t)kCoopEpl * 1024) : (cap_mem < ctx->num_cu ? cap_mem : ctx->num_cu);
+  // v parked in LDS (k_sel_lds<.., float>: 32 Ki elements per resident workgroup, 8 Mi on 256 CUs) above what the register form
+  // holds (2 Mi; below, registers win: n = 2e6 39 / 41 us against 43 / 45 -- the Float32 first digit is not folded and the LDS
+  // form's third pass costs more); beyond what the grid holds: the form that parks v in y (n = 8e6: 97 -> 64 us,
+  // tools/r3/topr_f32_midn.py)
+  const bool vec = spx_aligned16(y) && spx_aligned16(q) && spx_aligned16(xk) && spx_aligned16(sj);
+  int64_t lds_cap = 0;
+  if (ctx->tune_sel_reg16) {
+    const int64_t capl = vec ? spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_sel_lds<BINF, true, float>), 1024, 0)
+                             : spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_sel_lds<BINF, false, float>), 1024, 0);
+    lds_cap = (int64_t)kLdsEpl32 * 1024 * (capl < ctx->num_cu ? capl : ctx->num_cu);
+  }
+  const bool lds = n <= lds_cap && n > reg_cap;
+  const bool reg = !lds && n <= reg_cap;
+  int64_t g = reg ? (n + (int64_t)kCoopEpl * 1024 - 1) / ((int64_t)kCoopEpl * 1024) : (cap_mem < ctx->num_cu ? cap_mem : ctx->num_cu);
+  if (lds) g = lds_cap / ((int64_t)kLdsEpl32 * 1024);
   int use_set = ctx->sel_hist_next, other = use_set ^ 1;
   int clear_set = ctx->sel_hist_dirty[other] ? other : -1;
   int parity = ctx->coop_parity;
@@ -2383,6 +2441,12 @@ int run_select_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, cons
     SpxCoopLaunchGuard guard(ctx);
     if (reg)
       hipLaunchKernelGGL((k_sel_coop<BINF, true, float>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta, ss,
+                         parity, use_set, clear_set);
+    else if (lds && vec)
+      hipLaunchKernelGGL((k_sel_lds<BINF, true, float>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta, ss,
+                         parity, use_set, clear_set);
+    else if (lds)
+      hipLaunchKernelGGL((k_sel_lds<BINF, false, float>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta, ss,
                          parity, use_set, clear_set);
     else
       hipLaunchKernelGGL((k_sel_coop<BINF, false, float>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta, ss,

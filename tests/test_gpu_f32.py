@@ -332,11 +332,25 @@ def test_f32_iprox_asserts_d_positive_and_views(s, orc):
 # ------------------------------------------------------------------------------------------------------------------
 # ShiftedIndBallL0(BInf) in Float32 (round 3): exact select on Float32 keys, every size class of the one-launch kernels
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 5, 1000, 8192, 8193, 50_001, 1_000_003, 2_500_001])
+@pytest.mark.parametrize("n", [1, 5, 1000, 8192, 8193, 50_001, 1_000_003, (1 << 21) + 1, (1 << 21) + 2, (1 << 21) + 3, 2_500_001, 5_000_002,
+                               (1 << 23) - 1, 1 << 23, (1 << 23) + 3, -2_500_001])
 def test_f32_topr_bit_exact(s, orc, n):
-    """one workgroup (n <= 8192), register-resident (<= 2^21), v parked in y (beyond): bit for bit against the numpy
+    """one workgroup (n <= 8192), register-resident (<= 2^21), v parked in LDS (<= 2^23: 32 elements per lane; sizes that leave
+    1, 2, 3 elements behind the last 16-byte vector), v parked in y (beyond, and for a negative n: the same size with the LDS
+    form switched off, tuning key 11 = 0): bit for bit against the numpy
     restatement in Float32 (stable descending sort by |v|): continuous data, a 1/8 lattice (ties: lowest index first), NaN and
     Inf entries (NaN is the largest magnitude, all NaNs tie), y === q, views from an odd element."""
+    lds = n > 0
+    n = abs(n)
+    L = s._lib.load()
+    s._lib.check(L.spx_ctx_set_tuning(s.context("cuda:0"), 11, 1 if lds else 0))
+    try:
+        _f32_topr_cases(s, orc, n)
+    finally:
+        s._lib.check(L.spx_ctx_set_tuning(s.context("cuda:0"), 11, 1))
+
+
+def _f32_topr_cases(s, orc, n):
     for kind in ("continuous", "lattice", "special"):
         x, sj, q = _data(n, 300 + n, quant=8 if kind == "lattice" else None)
         if kind == "special" and n >= 50:
@@ -366,6 +380,46 @@ def test_f32_topr_bit_exact(s, orc, n):
             xo, so, qo = _dev(x, sj, q, off=1)
             yo = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xo), so), qo, 1.0).cpu().numpy()
             assert ((yo.view(np.int32) == ref0.view(np.int32)) | (np.isnan(yo) & np.isnan(ref0))).all(), (n, kind, "view")
+
+
+@pytest.mark.parametrize("kind", ["tiny", "huge", "tiny+normal", "normal+huge", "zeros", "constant", "binade_edges", "wide_exponents"])
+@pytest.mark.parametrize("n", [70_001, 2_500_001])
+def test_f32_topr_folded_first_digit(s, orc, kind, n):
+    """The one-launch selects fold their first digit for Float32 keys too (csrc/spx_select.hip fold_digit_f32: 62 binades around
+    1.0 x 64 mantissa steps, catch-all bins below 2^-32 and above 2^30): data that puts the threshold into a catch-all bin
+    (restart with the plain top digit), onto a bin edge, into ties at key 0, or all of the vector into one bin -- through the
+    register form (n = 70 001) and the LDS form (n = 2 500 001)."""
+    rng = np.random.default_rng(sum(map(ord, kind)) + n)
+    x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
+    if kind == "tiny":
+        x, sj, q = x * 2.0 ** -60, sj * 2.0 ** -60, q * 2.0 ** -60
+    elif kind == "huge":
+        x, sj, q = x * 2.0 ** 70, sj * 2.0 ** 70, q * 2.0 ** 70
+    elif kind == "tiny+normal":
+        m = rng.random(n) < 0.5
+        x, sj, q = np.where(m, x * 2.0 ** -45, x), np.where(m, sj * 2.0 ** -45, sj), np.where(m, q * 2.0 ** -45, q)
+    elif kind == "normal+huge":
+        m = rng.random(n) < 0.3
+        x, sj, q = np.where(m, x * 2.0 ** 40, x), np.where(m, sj * 2.0 ** 40, sj), np.where(m, q * 2.0 ** 40, q)
+    elif kind == "zeros":
+        m = rng.random(n) < 0.7
+        x, sj, q = np.where(m, 0.0, x), np.where(m, 0.0, sj), np.where(m, 0.0, q)
+    elif kind == "constant":
+        x, sj, q = np.full(n, 0.5), np.full(n, 0.25), np.full(n, -2.0)
+    elif kind == "binade_edges":  # |v| on the edges of the folded bins: 2^k (1 + j/64), exactly
+        k = rng.integers(-3, 4, size=n); j = rng.integers(0, 64, size=n)
+        x, sj = np.zeros(n), np.zeros(n); q = 2.0 ** k * (1.0 + j / 64.0) * rng.choice([-1.0, 1.0], size=n)
+    else:
+        e = rng.integers(-40, 40, size=n)
+        x, sj, q = x * 2.0 ** e, sj * 2.0 ** e, q * 2.0 ** e
+    x, sj, q = (a.astype(np.float32) for a in (x, sj, q))
+    xd, sd, qd = _dev(x, sj, q)
+    for r in sorted({1, 2, 26, n // 100, n // 3, n // 2, int(0.7 * n), n - 1}):
+        with np.errstate(all="ignore"):
+            ref = orc.prox_indball_l0_f32(q, x, sj, r, 0.8)
+        y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.8, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
+        same = (y.view(np.int32) == ref.view(np.int32)) | (np.isnan(y) & np.isnan(ref))
+        assert same.all(), (kind, n, r, int((~same).sum()))
 
 
 # ------------------------------------------------------------------------------------------------------------------

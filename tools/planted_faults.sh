@@ -1,7 +1,7 @@
 #!/bin/bash
 # Confirms that the driver-run stress tests FAIL on planted faults.
 #   tools/planted_faults.sh build [ids]   (here, no GPU): patched copies of csrc/ -> lib/libspx_fault<k>.so (all, or the ids listed)
-#   tools/planted_faults.sh run       (on the GPU box): the named tests against each faulty library; every one must fail
+#   tools/planted_faults.sh run [ids] (on the GPU box): the named tests against each faulty library; every one must fail
 # Nothing in the product tree is modified: the patches are applied to a scratch copy under /tmp.
 set -uo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
@@ -19,6 +19,11 @@ FAULTS=(
  "10|spx_b2.hip|s/for (unsigned int e = (unsigned int)(t \& 63); e < ncand_mine; e += 64) {/for (unsigned int e = (unsigned int)(t \& 63); e + 64 < ncand_mine; e += 64) {/|tests/test_gpu_stress.py::test_b2_streaming_form_scenarios"
  "11|spx_select.hip|s/const int64_t lo = (ca < cs ? ca : cs) + 1, hi = ca < cs ? cs : ca;/const int64_t lo = (ca < cs ? ca : cs) + 3, hi = ca < cs ? cs : ca;/|tests/test_gpu_stress.py::test_topr_tie_mode_against_exact_select"
  "12|spx_select.hip|s/(spec_hi == 2 \&\& i <= spec_cut);/(spec_hi == 2 \&\& i < spec_cut);/|tests/test_gpu_stress.py::test_topr_tie_mode_against_exact_select"
+ "13|spx_select.hip|s/if (tail \&\& pr == nw) {  \/\/ the elements behind the last whole vector/if (false) {  \/\/ the elements behind the last whole vector/|tests/test_gpu_parity.py::test_indball_l0_at_the_fast_path_threshold"
+ "14|spx_select.hip|s/if (wr \&\& !in \&\& keep != spec) y\[i\]/if (wr \&\& !in \&\& keep \&\& !spec) y[i]/|tests/test_gpu_parity.py::test_indball_l0_at_the_fast_path_threshold tests/test_gpu_parity.py::test_indball_l0_ranks_and_scales"
+ "15|spx_b2.hip|s/lo = SQ\[k\] - lsv; hi = SQ\[k\] + lsv;/lo = SQ[k] - lsv; hi = SQ[k] - lsv;/|tests/test_gpu_stress.py::test_b2_streaming_form_scenarios tests/test_gpu_stress.py::test_b2_one_launch_forms_at_their_boundaries"
+ "16|spx_group.hip|0,/if constexpr (TEAM >= 2) v += dpp_f64<0xB1>(v);/s//if constexpr (TEAM >= 4) v += dpp_f64<0xB1>(v);/|tests/test_gpu_parity.py::test_group_uniform"
+ "17|spx_objective.hip|s/for (int off = TEAM \/ 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);  \/\/ (inside the team/for (int off = TEAM \/ 2; off >= 2; off >>= 1) ss += __shfl_xor(ss, off, 64);  \/\/ (inside the team/|tests/test_gpu_parity.py::test_objective_group_sizes"
  "4|spx_group.hip|s/if (sb == 0.0) {/if (false) {/;s/for (int k = 0; k < 64; ++k) {/for (int k = 0; k < 12; ++k) { piece_ok = true;/|tests/test_gpu_parity.py::test_group_binf_many_small_groups tests/test_gpu_parity.py::test_group_binf_zero_groups_strong_lambda"
 )
 case "${1:-}" in
@@ -38,8 +43,10 @@ build)
   done ;;
 run)
   cd "$ROOT"; mkdir -p gpurun_out; bad=0
+  only=" ${*:2} "   # (run [ids]: all, or the ids listed)
   for f in "${FAULTS[@]}"; do
     IFS='|' read -r id file expr tests <<< "$f"
+    [ "$only" = "  " ] || [[ "$only" == *" $id "* ]] || continue
     SPX_LIB_NAME="libspx_fault$id.so" SPX_NO_BUILD=1 timeout -k 10 300 python -m pytest $tests -m gpu -q -x -p no:cacheprovider > "gpurun_out/fault$id.log" 2>&1
     rc=$?
     nfail=$(grep -c '^FAILED' "gpurun_out/fault$id.log"); nerr=$(grep -c '^ERROR' "gpurun_out/fault$id.log")
