@@ -359,9 +359,9 @@ def _extra(s, L, ctx, dev, n, torch):
         xs, ss_, qs, ys = xk[:nn], sj[:nn], q[:nn], y[:nn]
         for name, psi_s, kern in (
                 ("ShiftedIndBallL0BInf_r=n/100_n=%d" % nn, s.shifted(s.shifted(s.IndBallL0(max(1, nn // 100)), xs, 1.0, chi), ss_),
-                 "k_sel_lds<true, true>" if nn > (1 << 20) else "k_sel_coop<true, true, double>" if nn > 8192 else "k_sel_small<true, double>"),
+                 "k_sel_lds<true, true, double>" if nn > (1 << 20) else "k_sel_coop<true, true, double>" if nn > 8192 else "k_sel_small<true, double>"),
                 ("ShiftedIndBallL0BInf_r=n/2_n=%d" % nn, s.shifted(s.shifted(s.IndBallL0(max(1, nn // 2)), xs, 1.0, chi), ss_),
-                 "k_sel_lds<true, true>" if nn > (1 << 20) else "k_sel_coop<true, true, double>" if nn > 8192 else "k_sel_small<true, double>"),
+                 "k_sel_lds<true, true, double>" if nn > (1 << 20) else "k_sel_coop<true, true, double>" if nn > 8192 else "k_sel_small<true, double>"),
                 ("ShiftedNormL1B2_n=%d" % nn, s.shifted(s.shifted(s.NormL1(1.0), xs, 1.0, s.NormL2(1.0)), ss_),
                  "k_b2_coop<true, 16, 1024, true, true>" if nn > (1 << 21) else "k_b2_coop<true, 16, 512, true, false>")):
             s.prox_bang(ys, psi_s, qs, 1.0)

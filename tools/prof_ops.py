@@ -29,10 +29,11 @@ if "vecbounds" in which:
     psi = s.shifted(s.shifted(s.NormL1(1.0), xk, lv, uv), sj)
     for _ in range(5): s.prox_bang(y, psi, q, 1.0)
     del lv, uv, psi
-if "small" in which:   # solver-iteration sizes: the one-launch forms
-    for nn in (1_000_000, 10_000):
+if "small" in which:   # solver-iteration sizes: the one-launch forms (v / xk in LDS at 4e6, registers below)
+    for nn in (4_000_000, 1_000_000, 100_000, 10_000):
         if nn <= n:
             for psi in (s.shifted(s.shifted(s.IndBallL0(max(1, nn // 100)), xk[:nn], 1.0, chi), sj[:nn]),
+                        s.shifted(s.shifted(s.IndBallL0(max(1, nn // 2)), xk[:nn], 1.0, chi), sj[:nn]),
                         s.shifted(s.shifted(s.NormL1(1.0), xk[:nn], 1.0, s.NormL2(1.0)), sj[:nn])):
                 for _ in range(5): s.prox_bang(y[:nn], psi, q[:nn], 1.0)
 if "l0box" in which:
@@ -88,4 +89,10 @@ if "group" in which or "binf" in which:
     if "binf" in which:
         psi = s.shifted(s.shifted(h, xk, 1.0, chi), sj)
         for _ in range(5): s.prox_bang(y, psi, q, 1.0)
+    if "group" in which or "binf" in which:   # small groups (round 3: tiles of one or two lanes per group)
+        ng8 = min(m, n) // 8; m8 = ng8 * 8
+        lam8 = torch.rand(ng8, dtype=torch.float64, device=dev, generator=g) + 0.5
+        h8 = s.GroupNormL2.uniform(lam8, 8)
+        for psi in (s.shifted(s.shifted(h8, xk[:m8]), sj[:m8]), s.shifted(s.shifted(h8, xk[:m8], 1.0, chi), sj[:m8])):
+            for _ in range(5): s.prox_bang(y[:m8], psi, q[:m8], 1.0)
 torch.cuda.synchronize()
