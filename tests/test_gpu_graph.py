@@ -23,10 +23,10 @@ def _bits(a, b):
     return np.array_equal(np.asarray(a).view(np.int64), np.asarray(b).view(np.int64))
 
 
-@pytest.mark.parametrize("n", [6_000, 50_000, 1_000_000, 2_600_000])
+@pytest.mark.parametrize("n", [6_000, 50_000, 1_000_000, 2_600_000, 4_300_000])
 def test_iteration_in_a_graph_replays_on_new_data(s, orc, n):
-    """n = 6e3: one-workgroup top-r, one-workgroup B2; 5e4 / 1e6: the register-resident one-launch forms (7 / 123 workgroups);
-    2.6e6: the sample-predicted top-r pipeline and the streaming B2 form."""
+    """n = 6e3: one-workgroup top-r, one-workgroup B2; 5e4 / 1e6: the register-resident one-launch forms; 2.6e6: the forms that
+    park a vector in LDS (256 workgroups); 4.3e6: the sample-predicted top-r pipeline and the streaming B2 form."""
     import torch
     rng = np.random.default_rng(n)
     ng = n // 128
