@@ -1056,6 +1056,11 @@ extern "C" __attribute__((visibility("default"))) int spx_debug_sel_stamps(unsig
 #define SEL_STAMP(k) do { } while (0)
 #endif
 constexpr int kCoopMaxPass = 12;  // <= 6 key digits + <= 6 index digits
+// The one-launch forms that keep the vector on chip (n <= 2^23) never reach their last passes (<= 7 key + 2 index digits): the
+// histogram of pass kSelStatSlot, zero like every other on entry, holds their bucket statistics instead -- word 2p: max(~key),
+// word 2p + 1: max(key) over the elements inside the bucket of pass p, both gathered with atomicMax, so no launch has to
+// initialise them (an explicit reset by workgroup 0 at the start of every launch cost the generic path 0.4 us per call).
+constexpr int kSelStatSlot = kCoopMaxPass - 1;
 #ifndef SPX_COOP_FOLD
 #define SPX_COOP_FOLD 1
 #endif
@@ -1085,6 +1090,7 @@ struct CoopShared {
   unsigned int lh[kBins];
   unsigned long long scratch[24];
   SelState sst;
+  unsigned long long kmm[2];  // register form: smallest / largest key of this workgroup's elements inside the bucket of a pass
 };
 
 // sel_scan_step for the 1024-lane workgroups of k_sel_coop: four bins per lane, read with agent-scope atomic loads -- the
@@ -1136,13 +1142,18 @@ __device__ __forceinline__ void coop_scan_step(unsigned long long* hist, const S
 // statistics were gathered (smallest / largest key and number of elements inside the bucket, agent-scope atomics, complete
 // since the pass's rendezvous).  A bucket that holds ONE key needs no further key digits: all of it kept, or the index
 // tie-break on that key -- the state the remaining digits would arrive at, 2-4 sweeps later.  st = the state of the pass.
+// ccnt == nullptr: the number of elements inside the bucket is known to the caller (cnt_known: the count of the bin the
+// previous scan selected).
 __device__ __forceinline__ void sel_single_key_shortcut(const SelState st, SelState* out, const unsigned long long* cmin,
-                                                        const unsigned long long* cmax, const unsigned long long* ccnt) {
+                                                        const unsigned long long* cmax, const unsigned long long* ccnt,
+                                                        unsigned long long cnt_known = 0ull, bool min_inverted = false) {
   __syncthreads();
   if (threadIdx.x != 0) return;
-  const unsigned long long lo = __hip_atomic_load(cmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (min_inverted: the word holds max(~key) -- gathered with atomicMax into memory that starts out zero, see kSelStatSlot)
+  const unsigned long long lo0 = __hip_atomic_load(cmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long lo = min_inverted ? ~lo0 : lo0;
   const unsigned long long hi = __hip_atomic_load(cmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long cnt = __hip_atomic_load(ccnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long cnt = ccnt ? __hip_atomic_load(ccnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : cnt_known;
   if (!(lo == hi && cnt > 0 && (unsigned long long)st.quota <= cnt)) return;
   SelState o = st;
   o.pad = 0;
@@ -1194,6 +1205,7 @@ template <bool BINF, bool REG, class T = double>
 __device__ __forceinline__ void coop_select(T* y, const T* q, const T* xk, const T* sj, int64_t n,
                                             int64_t r, T delta, unsigned long long (*hist)[kBins], unsigned int* bar,
                                             unsigned int& nbar, CoopShared& sh, SpxSyncHeader* hdr) {
+  unsigned long long* const stat = hist[kSelStatSlot];  // (REG: bucket statistics, see kSelStatSlot)
   const int t = threadIdx.x;
   const int64_t NT = (int64_t)gridDim.x * blockDim.x;
   const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + t;
@@ -1205,7 +1217,10 @@ __device__ __forceinline__ void coop_select(T* y, const T* q, const T* xk, const
   // are independent and overlap; wave-aggregated (hist_add_agg) each is a serial chain of ballots, 3 us per full sweep of
   // generic data at 16 waves per CU, and what it saves on one-key data (64 lanes on one LDS address: ~64 clocks per
   // instruction) is 3 us per pass of 8 elements per lane.  The form that walks the whole vector keeps the aggregation.
-  auto visit_st = [&](const SelState& st, T vv, int64_t i) {
+  struct KeyStat { unsigned long long kmin, kmax; };  // (REG, a tracked pass: keys of this lane's elements inside the bucket)
+  KeyStat nostat{0ull, 0ull};
+  auto visit_st = [&](const SelState& st, T vv, int64_t i, auto track_tag, KeyStat& ks) {
+    constexpr bool kTrack = decltype(track_tag)::value;
     const uint64_t key = key_of(vv);
     bool in = true;
     unsigned int dg;
@@ -1218,6 +1233,7 @@ __device__ __forceinline__ void coop_select(T* y, const T* q, const T* xk, const
         const KeyPos kp = key_pos(key, st.base, st.shift, st.width, st.clamp);
         in = kp.in;
         dg = kp.digit;
+        if (kTrack && in) { ks.kmin = key < ks.kmin ? key : ks.kmin; ks.kmax = key > ks.kmax ? key : ks.kmax; }
       }
     } else {
       const int hs = st.shift + st.width;
@@ -1249,28 +1265,52 @@ __device__ __forceinline__ void coop_select(T* y, const T* q, const T* xk, const
 #pragma unroll
       for (int k = 0; k < kCoopEpl; ++k) {
         const int64_t i = gtid + (int64_t)k * NT;
-        if (i < n) visit_st(st0, v[k], i);
+        if (i < n) visit_st(st0, v[k], i, std::false_type{}, nostat);
       }
     }
   }
   SEL_STAMP(32);
   int p = 0;
+  unsigned long long cnt_before = ~0ull;  // elements inside the bucket of the previous pass
   for (; p < kCoopMaxPass; ++p) {
     __syncthreads();
     const SelState st = sel_uniform(sh.sst);
     if (st.phase == 2) break;  // the same in every workgroup: they all computed it from the same histograms
     const bool counted = REG && p == 0 && fused;
+    // REG: once a pass has failed to split its bucket (every element in one bin: tie-heavy data) the next pass also tracks the
+    // smallest and largest key inside the bucket; equal ends skip the remaining key digits (as k_sel_lds; a constant vector of
+    // 1e6 elements: 95 us per call for six key digits and two index digits)
+    const unsigned long long cnt_in = p > 0 ? sh.scratch[18] : ~0ull - 1ull;  // (coop_scan_step: found[2] of the previous scan)
+    const bool track = REG && p > 1 && p < kSelStatSlot && st.phase == 0 && st.pad == 0 && cnt_in == cnt_before;
+    cnt_before = cnt_in;
     if (!counted) {
       for (int b = t; b < kBins; b += blockDim.x) sh.lh[b] = 0u;
+      if (t == 0) { sh.kmm[0] = ~0ull; sh.kmm[1] = 0ull; }
       __syncthreads();
     }
-    auto visit = [&](T vv, int64_t i) { visit_st(st, vv, i); };
+    auto visit = [&](T vv, int64_t i) { visit_st(st, vv, i, std::false_type{}, nostat); };
     if constexpr (REG) {
       if (!counted) {
+        if (track) {
+          KeyStat ks{~0ull, 0ull};
 #pragma unroll
-        for (int k = 0; k < kCoopEpl; ++k) {
-          const int64_t i = gtid + (int64_t)k * NT;
-          if (i < n) visit(v[k], i);
+          for (int k = 0; k < kCoopEpl; ++k) {
+            const int64_t i = gtid + (int64_t)k * NT;
+            if (i < n) visit_st(st, v[k], i, std::true_type{}, ks);
+          }
+          unsigned long long kmin = ks.kmin, kmax = ks.kmax;
+          for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long a_ = __shfl_xor(kmin, off, 64), c_ = __shfl_xor(kmax, off, 64);
+            kmin = a_ < kmin ? a_ : kmin;
+            kmax = c_ > kmax ? c_ : kmax;
+          }
+          if ((t & 63) == 0 && kmin <= kmax) { atomicMin(&sh.kmm[0], kmin); atomicMax(&sh.kmm[1], kmax); }
+        } else {
+#pragma unroll
+          for (int k = 0; k < kCoopEpl; ++k) {
+            const int64_t i = gtid + (int64_t)k * NT;
+            if (i < n) visit(v[k], i);
+          }
         }
       }
     } else if (vec2) {
@@ -1315,6 +1355,9 @@ __device__ __forceinline__ void coop_select(T* y, const T* q, const T* xk, const
       }
     }
     __syncthreads();
+    if (track && t == 0 && sh.kmm[0] <= sh.kmm[1]) {  // one global atomic of each kind per workgroup
+      atomicMax(&stat[2 * p], ~sh.kmm[0]); atomicMax(&stat[2 * p + 1], sh.kmm[1]);
+    }
     for (int b = t; b < kBins; b += blockDim.x) {
       const unsigned int c = sh.lh[b];
       if (c) atomicAdd(&hist[p][b], (unsigned long long)c);
@@ -1325,6 +1368,7 @@ __device__ __forceinline__ void coop_select(T* y, const T* q, const T* xk, const
     spx_grid_rendezvous(bar, (++nbar) * gridDim.x, hdr);
     SEL_STAMP(34 + 3 * p);
     coop_scan_step(hist[p], st, &sh.sst, sh.scratch);
+    if (track) sel_single_key_shortcut(st, &sh.sst, &stat[2 * p], &stat[2 * p + 1], nullptr, cnt_in, true);
     SEL_STAMP(35 + 3 * p);
   }
   __syncthreads();
@@ -1406,20 +1450,13 @@ __global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk,
   __shared__ __attribute__((aligned(16))) T lv[kSlots * 1024];
   __shared__ unsigned long long kmm[3];  // smallest / largest key and number of this workgroup's elements inside the bucket of a pass
   spx_bar_reset(ss->hdr.bar[parity ^ 1]);
-  // (the bucket statistics of the passes after the first: set here, first used behind the first pass's rendezvous)
-  // (agent-scope atomic stores: the words are updated by atomics of every XCD; a plain store could sit in this XCD's L2 and
-  //  land on top of them later -- the launch has no fenced barrier)
-  if (blockIdx.x == 0 && threadIdx.x < kCoopMaxPass) {
-    __hip_atomic_store(&ss->cmin[threadIdx.x], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&ss->cmax[threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&ss->ccnt[threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   if (clear_set >= 0) {
     const int64_t total = (int64_t)kCoopMaxPass * kBins;
     unsigned long long* z = &ss->chist[clear_set][0][0];
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total; b += (int64_t)gridDim.x * blockDim.x) z[b] = 0ull;
   }
   unsigned long long (*hist)[kBins] = ss->chist[use_set];
+  unsigned long long* const stat = hist[kSelStatSlot];  // bucket statistics of the tracked passes (see kSelStatSlot)
   unsigned int* bar = ss->hdr.bar[parity];
   SpxSyncHeader* hdr = &ss->hdr;
   unsigned int nbar = 0;
@@ -1509,7 +1546,7 @@ __global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk,
     // passes after the first also track the smallest and largest key inside their bucket (as k_s2_tail's candidate select)
     // -- but only once a pass has failed to split its bucket at all (every element of it in one bin): on generic data the
     // bookkeeping cost 5 us per call (n = 4e6: 42 -> 48 us) for nothing; a lattice now pays one key pass more than it must.
-    const bool track = p > 1 && st.phase == 0 && st.pad == 0 && cnt_in == cnt_before;
+    const bool track = p > 1 && p < kSelStatSlot && st.phase == 0 && st.pad == 0 && cnt_in == cnt_before;
     cnt_before = cnt_in;
     unsigned long long kmin = ~0ull, kmax = 0ull, kcnt = 0ull;
     if (!(p == 0 && fused)) {
@@ -1560,7 +1597,7 @@ __global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk,
     }
     if (p < 4) SEL_STAMP(23 + p);
     __syncthreads();
-    if (track && t == 0 && kmm[2]) { atomicMin(&ss->cmin[p], kmm[0]); atomicMax(&ss->cmax[p], kmm[1]); atomicAdd(&ss->ccnt[p], kmm[2]); }
+    if (track && t == 0 && kmm[2]) { atomicMax(&stat[2 * p], ~kmm[0]); atomicMax(&stat[2 * p + 1], kmm[1]); }
     for (int b = t; b < kBins; b += 1024) {
       const unsigned int c = sh.lh[b];
       if (c) atomicAdd(&hist[p][b], (unsigned long long)c);
@@ -1572,7 +1609,7 @@ __global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk,
     spx_grid_rendezvous(bar, (++nbar) * gridDim.x, hdr);
     SEL_STAMP(34 + 3 * p);
     coop_scan_step(hist[p], st, &sh.sst, sh.scratch);
-    if (track) sel_single_key_shortcut(st, &sh.sst, &ss->cmin[p], &ss->cmax[p], &ss->ccnt[p]);
+    if (track) sel_single_key_shortcut(st, &sh.sst, &stat[2 * p], &stat[2 * p + 1], nullptr, cnt_in, true);
     SEL_STAMP(35 + 3 * p);
   }
   __syncthreads();
