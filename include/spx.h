@@ -337,8 +337,8 @@ int spx_prox_indball_l0_binf(spx_ctx* ctx, double* y, const double* q, const dou
 
 /* The same operators on Float32 vectors (round 3; the reference's methods are generic in R, src/shiftedIndBallL0.jl:54-59):
  * v = (xk + sj) + q, the magnitude order and the final subtraction / clamp are Float32 operations -- bit-exact in fp32, ties by
- * lowest index, NaN largest.  Exact select in one launch (one workgroup / register-resident / v parked in y); the
- * sample-predicted single pass is Float64 only. */
+ * lowest index, NaN largest.  Exact select in one launch (one workgroup / register-resident / v parked in LDS up to 2^23
+ * elements: 16 B per element moved / v parked in y beyond); the sample-predicted single pass is Float64 only. */
 int spx_prox_indball_l0_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, const float* sj, int64_t n, int64_t r);
 int spx_prox_indball_l0_binf_f32(spx_ctx* ctx, float* y, const float* q, const float* xk, const float* sj, int64_t n,
                                  int64_t r, float delta);
