@@ -445,6 +445,42 @@ end
 end
 # (group forms: spx_obj_group_l2_f32 / spx_obj_group_l2_binf_f32 with the layout_for(ψ.h, n) arguments and a Float32 λ vector)
 
+# top-r on Float32 vectors (round 3: spx_prox_indball_l0[_binf]_f32; src/shiftedIndBallL0.jl:54-72, shiftedIndBallL0BInf.jl:73-95
+# with R = Float32): v = (xk + sj) + q, the magnitude order and the final subtraction / clamp are Float32 operations.  One launch
+# with the vector on chip up to 2^23 elements.
+function prox!(y::DVec32, ψ::ShiftedIndBallL0{<:Integer, Float32, <:DVec32, <:DVec32, <:DVec32}, q::DVec32, σ::Float32)
+  n = length(ψ.xk)
+  (length(y) == n && length(q) == n) || throw(BoundsError())
+  check(ccall((:spx_prox_indball_l0_f32, libspx), Cint,
+              (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Int64),
+              ctx(), dptr32(y), dptr32(q), dptr32(ψ.xk), dptr32(ψ.sj), n, ψ.r))
+  return y
+end
+function prox!(y::DVec32, ψ::ShiftedIndBallL0BInf{<:Integer, Float32, <:DVec32, <:DVec32, <:DVec32}, q::DVec32, σ::Float32)
+  n = length(ψ.xk)
+  (length(y) == n && length(q) == n) || throw(BoundsError())
+  check(ccall((:spx_prox_indball_l0_binf_f32, libspx), Cint,
+              (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Int64, Cfloat),
+              ctx(), dptr32(y), dptr32(q), dptr32(ψ.xk), dptr32(ψ.sj), n, ψ.r, ψ.Δ))
+  return y
+end
+
+# ShiftedGroupNormL2 on Float32 vectors, contiguous groups (round 3: spx_prox_group_l2_f32; src/shiftedGroupNormL2.jl:52-79 with
+# R = Float32; index sets keep the reference's method).  λ travels as a Float32 device vector, cached per h like the Float64 one.
+const LAMBDA32 = IdDict{Any, Any}()
+function prox!(y::DVec32, ψ::ShiftedGroupNormL2{Float32, <:Any, <:Any, <:DVec32, <:DVec32, <:DVec32}, q::DVec32, σ::Float32)
+  n = length(ψ.xk)
+  (length(y) == n && length(q) == n) || throw(BoundsError())
+  L = layout_for(ψ.h, n)
+  L.gather && return invoke(prox!, Tuple{AbstractVector{Float32}, typeof(ψ), AbstractVector{Float32}, Float32}, y, ψ, q, σ)  # index sets: the reference's own method
+  lam32 = get!(() -> ROCVector{Float32}(collect(Float32, ψ.h.lambda)), LAMBDA32, ψ.h)
+  offp = L.offsets === nothing ? Ptr{Int64}(C_NULL) : Ptr{Int64}(UInt(pointer(L.offsets)))
+  check(ccall((:spx_prox_group_l2_f32, libspx), Cint,
+              (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Ptr{Int64}, Int64, Int64, Ptr{Cfloat}, Cfloat),
+              ctx(), dptr32(y), dptr32(q), dptr32(ψ.xk), dptr32(ψ.sj), n, offp, L.gsize, L.ngroups, dptr32(lam32), σ))
+  return y
+end
+
 # ---------------------------------------------------------------------------------------------
 # Device-resident values (round 2): `device_values(out::ROCVector{Float64}) do ... end` -- inside the block ψ(y) and prox_value!
 # store their Float64 result in out[1] and return NaN; nothing is read back (spx_ctx_set_value_target).
