@@ -356,7 +356,16 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
   constexpr int64_t kTilePairs = (VEC && !REG) ? (int64_t)(THREADS / 64) * 64 * kB2DmaKiB : (int64_t)THREADS * KP;
   const int64_t ntiles = (n2 + kTilePairs - 1) / kTilePairs;
   __shared__ __attribute__((aligned(16))) char dma[(VEC && !REG) ? (THREADS / 64) * 3 * kB2DmaKiB * 1024 : 16];
-  auto stream = [&](auto&& visit_pair) {  // visit_pair(valid, pair index, q pair, xk pair, sj pair), called by every lane
+  // dynamic (the storing pass, when it is the only pass of the launch that stores y): tiles are handed out by an atomic counter
+  // instead of workgroup-strided -- a persistent grid with a static partition waits for its slowest CU (5.5 TB/s); handed out on
+  // demand, with the next index fetched while the current tile is processed, the same grid streams at 6.3
+  // (tools/exp/persistent_stream.hip: 5467 -> 6317 GB/s; four tiles per atomic: 5794).  Only where nothing depends on which
+  // workgroup saw which element: the sums of a pass are formed per workgroup in a fixed order (results reproducible from run to
+  // run), and two passes that store y must use the same element -> lane mapping -- so the reduction passes stay static.
+  __shared__ unsigned int next_tile;
+  unsigned int* const tile_ctr = reinterpret_cast<unsigned int*>(rows + (size_t)(kB2MaxPass - 1) * kB2Cols * kB2Words + 7);  // (row 63 is
+  // never reached by a reduction; word 7 of a slot is never a partial sum; zeroed with the set like everything else in it)
+  auto stream = [&](auto&& visit_pair, bool dynamic = false) {  // visit_pair(valid, pair index, q pair, xk pair, sj pair), called by every lane
     if constexpr (VEC && !REG) {
       typedef __attribute__((address_space(3))) void lds_void;
       const int wave = t >> 6, lane = t & 63;
@@ -364,7 +373,17 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
       const f64x2* q2 = reinterpret_cast<const f64x2*>(q);
       const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
       const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
-      for (int64_t tile = blockIdx.x; tile < ntiles; tile += G) {
+      int64_t tile = blockIdx.x;
+      if (dynamic) {
+        if (t == 0) next_tile = __hip_atomic_fetch_add(tile_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        tile = (int64_t)next_tile;
+      }
+      while (tile < ntiles) {
+        if (dynamic) {
+          __syncthreads();  // every lane has read next_tile
+          if (t == 0) next_tile = __hip_atomic_fetch_add(tile_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (in flight during this tile)
+        }
         const int64_t base = tile * kTilePairs + (int64_t)wave * (64 * kB2DmaKiB) + lane;
 #pragma unroll
         for (int k = 0; k < kB2DmaKiB; ++k) {
@@ -384,6 +403,12 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
           visit_pair(i < n2, i, a, b, d);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's LDS reads are done before the next tile's loads are issued
+        if (dynamic) {
+          __syncthreads();
+          tile = (int64_t)next_tile;
+        } else {
+          tile += G;
+        }
       }
     } else {
     auto ld = [&](int64_t tile, f64x2* a, f64x2* b, f64x2* d) {
@@ -420,6 +445,7 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
     }
   };
   // the storing pass: y = ProjB((-xk) r) rinv - sj
+  bool y_written = false;  // (!REG) an earlier pass of this launch stored y: the storing pass must then keep the static mapping
   auto store_pass = [&](double r, double rinv) {
     if constexpr (!REG) {
       if (n2 > 0)
@@ -428,7 +454,7 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
             const double sq0 = d.x + a.x, sq1 = d.y + a.y;
             b2_st<VEC>(y, i, f64x2{outv(sq0 - ls, sq0 + ls, b.x, d.x, r, rinv), outv(sq1 - ls, sq1 + ls, b.y, d.y, r, rinv)});
           }
-        });
+        }, !y_written && G > 1 && ntiles >= 8 * (int64_t)G);  // (a few tiles per workgroup: the hand-out costs more than it balances -- n = 6e6, 4 tiles each: 128 -> 135 us; n = 1.6e7, 10 each: 220 -> 212)
       if ((n & 1) && blockIdx.x == 0 && t == 0) {
         const double sql = sj[n - 1] + q[n - 1];
         y[n - 1] = outv(sql - ls, sql + ls, xk[n - 1], sj[n - 1], r, rinv);
@@ -450,6 +476,7 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
   auto pass_stream = [&](double r, double rinv, bool store) {
     double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     bad = false;
+    if (store) y_written = true;
     if constexpr (!REG) {
       auto one = [&](double qv, double x, double s) -> double {
         const double sq = s + qv;
@@ -556,6 +583,7 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
       }
       return o;
     };
+    if (store_first) y_written = true;
     if (n2 > 0)
       stream([&](bool valid, int64_t i, f64x2 a, f64x2 b, f64x2 d) {
         const f64x2 o{one(valid, a.x, b.x, d.x), one(valid, a.y, b.y, d.y)};
