@@ -500,6 +500,50 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
     P = v[0]; C = v[1];
     B2_STAMP();
   };
+  bool store_first = can_spec && !last_scaled;
+  // Streaming form, the previous call found the trust region inactive: the speculative pass (y = ProjB(-xk) - sj stored, the
+  // sums at r = 1 formed) takes its tiles on demand like the storing pass -- its OUTPUT does not depend on which workgroup saw
+  // which element; its sums do, in the last bits, so they decide only a CLEAR `Delta > chi(y)` (margin 1e-12).  Anything else
+  // (the trust region has become active, or the call is too close to say) falls through to the ordinary first pass with its
+  // static partition and fixed summation order, and y counts as written: the storing pass then keeps the static mapping, and
+  // every workgroup has written its speculative stores back (release fence) before any partial sum of this pass is published --
+  // i.e. before any workgroup can get as far as storing the same element again.  It runs BEFORE the sample is solved (an
+  // inactive call never needs the sample's root: ~25 us of exchanges).
+  if constexpr (!REG && VEC) {
+    if (store_first && G > 1 && ntiles >= 8 * (int64_t)G) {
+      double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      bad = false;
+      auto one0 = [&](double qv, double x, double s) -> double {
+        const double sq = s + qv;
+        const double lo = sq - ls, hi = sq + ls;
+        acc(lo, hi, x, 1.0, v[0], v[1]);
+        return outv(lo, hi, x, s, 1.0, 1.0);
+      };
+      if (n2 > 0)
+        stream([&](bool valid, int64_t i, f64x2 a, f64x2 b, f64x2 d) {
+          if (valid) b2_st<VEC>(y, i, f64x2{one0(a.x, b.x, d.x), one0(a.y, b.y, d.y)});
+        }, true);
+      if ((n & 1) && blockIdx.x == 0 && t == 0) y[n - 1] = one0(q[n - 1], xk[n - 1], sj[n - 1]);
+      // (one wavefront per workgroup issues the write-back, after all of the workgroup's stores have left: a fence per
+      //  wavefront -- 4096 L2 write-back scans -- made the pass slower than the static one)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (bad) v[0] = __longlong_as_double(0x7ff8000000000000ll);
+      reduce(v, 3u);
+      const double chi0 = chil * sqrt(v[0] + v[1]);
+      if (delta > chi0 * (1.0 + 1e-12)) {  // (NaN sums compare false: the ordinary pass decides)
+        if (blockIdx.x == 0 && t == 0) hdr->b2_last_scaled = 0;
+        return;  // (after the exchange: every workgroup formed the same sums and takes the same way)
+      }
+      store_first = false;
+      y_written = true;
+      B2_STAMP();
+    }
+  }
   // ---- the sample's root (streaming form): same iteration, chi scaled by sqrt(n / sample size), nothing stored
   double eta_s = -1.0;
   if (has_sample) {
@@ -532,7 +576,6 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
   // Its clamp state (below lo / inside / above hi) moves one way only as r grows, so equal states at both ends mean that
   // state on the whole bracket: a fixed term of P (inside: x^2) or of C (clamped: bound^2).  The others -- a breakpoint
   // inside the bracket, 1-2 % of the vector -- are recorded (x, sj + q) in this wavefront's own region: no atomics.
-  const bool store_first = can_spec && !last_scaled;
   double eta_a = -1.0, eta_b = -1.0, Pf = 0.0, Cf = 0.0;
   bool have_bracket = false;
   unsigned int ncand = 0;    // (wave-uniform) candidates of this wavefront

@@ -384,6 +384,38 @@ def test_b2_one_launch_forms_at_their_boundaries(s, orc, n):
         assert np.array_equal(np.isnan(y), np.isnan(ref)), n
 
 
+def test_b2_streaming_form_tiles_on_demand(s, orc):
+    """n = 2e7: enough tiles per workgroup for the passes that take their tiles from an atomic counter (csrc/spx_b2.hip: the
+    storing pass; the speculative pass of a call that follows an inactive one).  Sequence on one context: active, inactive,
+    inactive (speculation right: one pass), active (speculation wrong: the ordinary passes follow, static mapping), a barely
+    inactive / barely active pair around Delta = chi(y), y === q.  Against the Float64 oracle, 1e-12 of the norms; the inactive
+    results bit for bit (y = ProjB(-xk) - sj is elementwise)."""
+    import torch
+    n = 20_000_001
+    rng = np.random.default_rng(2026)
+    x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
+    xd, sd, qd = _dev(x, sj, q)
+    nrm = float(np.linalg.norm(x))
+    # chi(y) of the unscaled result: Delta just above / below it
+    y1 = orc.prox_l1_b2(q, x, sj, 1.0, 1.0, 1e12, 1.0)
+    chi1 = float(np.linalg.norm(sj + y1))
+    seq = [(1.0, 1.0), (1.0, 1e12), (1.0, 1e12), (1.0, 0.3 * nrm), (1.0, chi1 * (1 + 1e-9)), (1.0, chi1 * (1 - 1e-9)), (1.0, 1e12), (0.2, 5.0)]
+    for lam, delta in seq:
+        psi = s.shifted(s.shifted(s.NormL1(lam), xd, delta, s.NormL2(1.0)), sd)
+        ref = orc.prox_l1_b2(q, x, sj, lam, 1.0, delta, 1.0)
+        y = s.prox(psi, qd, 1.0).cpu().numpy()
+        scale = max(np.linalg.norm(ref), nrm, np.linalg.norm(sj + q))
+        assert float(np.max(np.abs(y - ref))) <= 1e-12 * scale, (lam, delta, float(np.max(np.abs(y - ref))) / scale)
+        if delta == 1e12:
+            assert _bits(y, ref), "inactive trust region: elementwise result"
+    qa = qd.clone()
+    psi = s.shifted(s.shifted(s.NormL1(1.0), xd, 1.0, s.NormL2(1.0)), sd)
+    s.prox_bang(qa, psi, qa, 1.0)
+    ref = orc.prox_l1_b2(q, x, sj, 1.0, 1.0, 1.0, 1.0)
+    assert float(np.max(np.abs(qa.cpu().numpy() - ref))) <= 1e-12 * max(np.linalg.norm(ref), nrm), "aliased"
+    s._lib.check(s._lib.load().spx_sync(s.context("cuda:0")))
+
+
 def test_b2_alternating_sizes_share_the_exchange_words(s, orc):
     """Calls of different sizes on one context, interleaved: the partial-sum words of a 256-workgroup launch must be clean
     again when a 2-workgroup launch (and then another 256-workgroup one) comes to use the same set."""
