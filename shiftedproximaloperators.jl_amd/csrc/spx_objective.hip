@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void k_obj(const T* __restrict__ y, const T* _
 // GroupNormL2: sum_g lambda_g ||xsy[idx_g]||_2  (src/groupNormL2.jl:33-39).  TEAM lanes of a wavefront per group, 64 / TEAM
 // groups per wavefront and trip (round 3: a whole wavefront per group left 62 lanes idle on groups of two -- 1.46 ms per call
 // at n = 1.6e7 against 68 us on groups of 128; TEAM follows the group size, ~4 elements per lane: run_obj_group).
-template <class T, int MODE, int TEAM>
+// PAIRS (Float64, uniform groups of even size, 16-byte aligned vectors): a lane reads 16-byte pairs.
+template <class T, int MODE, int TEAM, bool PAIRS = false>
 __global__ __launch_bounds__(256) void k_obj_group(const T* __restrict__ y, const T* __restrict__ xk,
                                                     const T* __restrict__ sj, int64_t n,
                                                     const int64_t* __restrict__ offsets, int64_t gsize, int64_t ngroups,
@@ -171,6 +172,24 @@ __global__ __launch_bounds__(256) void k_obj_group(const T* __restrict__ y, cons
     if (lo < 0) lo = 0;
     if (hi > (index ? nnz : n)) hi = index ? nnz : n;
     double ss = 0.0;
+    if constexpr (PAIRS) {
+      const f64x2* y2 = reinterpret_cast<const f64x2*>(y);
+      const f64x2* x2 = reinterpret_cast<const f64x2*>(xk);
+      const f64x2* s2 = reinterpret_cast<const f64x2*>(sj);
+      for (int64_t p = (lo >> 1) + j; p < (hi >> 1); p += TEAM) {
+        const f64x2 a = y2[p], b = x2[p], c = s2[p];
+        double v0, v1;
+        if constexpr (MODE == 2) {
+          const double t0 = c.x + a.x, t1 = c.y + a.y;
+          bad |= (t0 < -rad) || (t0 > rad) || (t1 < -rad) || (t1 > rad);
+          v0 = t0 + b.x; v1 = t1 + b.y;
+        } else {
+          v0 = (b.x + c.x) + a.x; v1 = (b.y + c.y) + a.y;
+        }
+        ss += v0 * v0;
+        ss += v1 * v1;
+      }
+    } else
     for (int64_t p = lo + j; p < hi; p += TEAM) {
       int64_t i = p;
       if (index) {
@@ -310,9 +329,20 @@ int run_obj_group(spx_ctx* ctx, const T* y, const T* xk, const T* sj, int64_t n,
   int64_t blocks = (ngroups + 4 * gpw - 1) / (4 * gpw);
   if (blocks > kObjBlocks) blocks = kObjBlocks;
   if (blocks < 1) blocks = 1;
+  constexpr bool kF64 = std::is_same<T, double>::value;
+  const bool pairs = kF64 && !offsets && !index && gsize > 0 && (gsize & 1) == 0 && spx_aligned16(y) && spx_aligned16(xk) && spx_aligned16(sj);
 #define SPX_OBJ_GROUP(TEAM)                                                                                                  \
-  hipLaunchKernelGGL((k_obj_group<T, MODE, TEAM>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, offsets, \
-                     gsize, ngroups, index, nnz, lambda, rad, ws)
+  do {                                                                                                                       \
+    if constexpr (kF64) {                                                                                                    \
+      if (pairs) {                                                                                                           \
+        hipLaunchKernelGGL((k_obj_group<T, MODE, TEAM, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, \
+                           offsets, gsize, ngroups, index, nnz, lambda, rad, ws);                                            \
+        break;                                                                                                               \
+      }                                                                                                                      \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((k_obj_group<T, MODE, TEAM>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, offsets, \
+                       gsize, ngroups, index, nnz, lambda, rad, ws);                                                         \
+  } while (0)
   switch (team) {
     case 1: SPX_OBJ_GROUP(1); break;
     case 2: SPX_OBJ_GROUP(2); break;
