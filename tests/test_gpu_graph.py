@@ -23,10 +23,12 @@ def _bits(a, b):
     return np.array_equal(np.asarray(a).view(np.int64), np.asarray(b).view(np.int64))
 
 
-@pytest.mark.parametrize("n", [6_000, 50_000, 1_000_000, 2_600_000, 4_300_000])
+@pytest.mark.parametrize("n", [6_000, 50_000, 1_000_000, 2_600_000, 4_300_000, 15_000_000])
 def test_iteration_in_a_graph_replays_on_new_data(s, orc, n):
     """n = 6e3: one-workgroup top-r, one-workgroup B2; 5e4 / 1e6: the register-resident one-launch forms; 2.6e6: the forms that
-    park a vector in LDS (256 workgroups); 4.3e6: the sample-predicted top-r pipeline and the streaming B2 form."""
+    park a vector in LDS (256 workgroups); 4.3e6: the sample-predicted top-r pipeline and the streaming B2 form; 1.5e7: the B2
+    passes that take their tiles from an atomic counter (zeroed by a node of the graph) -- the iteration then also calls B2 with
+    an inactive trust region twice, so that the speculative pass is wrong once and right once per replay."""
     import torch
     rng = np.random.default_rng(n)
     ng = n // 128
@@ -37,13 +39,15 @@ def test_iteration_in_a_graph_replays_on_new_data(s, orc, n):
     with torch.cuda.stream(side):
         xd, sd = torch.from_numpy(x).cuda(), torch.from_numpy(sj).cuda()
         qd = torch.zeros(n, dtype=torch.float64, device="cuda")
-        ys = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(4)]
+        ys = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(6)]
+        big = n >= 10_000_000
         val = torch.zeros(1, dtype=torch.float64, device="cuda")
         chi = s.NormLinf(1.0)
         r = max(1, n // 50)
         psi_box = s.shifted(s.shifted(s.NormL1(1.0), xd, 1.0, chi), sd)
         psi_top = s.shifted(s.shifted(s.IndBallL0(r), xd, 0.8, chi), sd)
         psi_b2 = s.shifted(s.shifted(s.NormL1(1.0), xd, 1.0, s.NormL2(1.0)), sd)
+        psi_b2_in = s.shifted(s.shifted(s.NormL1(1.0), xd, 1e12, s.NormL2(1.0)), sd)
         psi_grp = s.shifted(s.shifted(s.GroupNormL2.uniform(torch.from_numpy(lam_g).cuda(), 128), xd[:m], 1.0, chi), sd[:m])
 
         def iteration():
@@ -53,6 +57,10 @@ def test_iteration_in_a_graph_replays_on_new_data(s, orc, n):
             s.prox_bang(ys[1], psi_top, qd, 1.0)
             s.prox_bang(ys[2], psi_b2, qd, 1.0)
             s.prox_bang(ys[3][:m], psi_grp, qd[:m], 1.0)
+            if big:
+                s.prox_bang(ys[4], psi_b2_in, qd, 1.0)   # follows an active call: no speculation
+                s.prox_bang(ys[5], psi_b2_in, qd, 1.0)   # follows an inactive call: the speculative pass is right
+                # (and the next replay's first B2 call follows an inactive one with an active trust region: speculation wrong)
 
         qd.copy_(torch.from_numpy(rng.normal(size=n)))
         iteration(); iteration()           # warm-up on the capture stream: the workspaces reach their sizes
@@ -73,6 +81,9 @@ def test_iteration_in_a_graph_replays_on_new_data(s, orc, n):
         ref = orc.prox_group_l2_binf(q[:m], x[:m], sj[:m], lam_g, 1.0, 1.0, gsize=128)
         err = np.max(np.abs(ys[3][:m].cpu().numpy() - ref))
         assert err <= 1e-9 * max(1.0, np.max(np.abs(ref))), (what, err)   # (the arbiter-based bar lives in test_gpu_parity.py)
+        if big:
+            ref = orc.prox_l1_b2(q, x, sj, 1.0, 1.0, 1e12, 1.0)
+            assert _bits(ys[4].cpu().numpy(), ref) and _bits(ys[5].cpu().numpy(), ref), what
 
     for rep in range(4):
         q = rng.normal(size=n) * (1.0 + rep)
