@@ -855,6 +855,15 @@ SPX_EXPORT int spx_prox_l1_b2(spx_ctx* ctx, double* y, const double* q, const do
   }
   int64_t g = reg ? (n + kB2RegBlock - 1) / kB2RegBlock : gmax_mem;
   if (ldsx) g = gmax_lds;  // (n > 2 Mi here unless the grid is capped: every resident workgroup, <= 16 elements per lane)
+  if (reg) {
+    // the register form: 4 / 8 / 16 elements per lane by n -- more workgroups sweep fewer elements each, until their exchange
+    // costs more than the sweep saves (us per call, Delta = 1, 16 / 8 / 4 / 2 per lane: n = 1e4 22.2 / 21.3 / 20.5 / 20.5;
+    // n = 1e5 25.4 / 23.3 / 22.5 / 23.4; n = 3e5 26.6 / 24.8 / 25.4 / 28.3; n = 1e6 30.4 / 31.9 / 31.1 / 31.4 -- tools/r3/b2_midn.py)
+    const int64_t epl = n <= 131072 ? 4 : n <= 524288 ? 8 : kB2Epl;
+    int64_t gg = (n + epl * kB2RegThreads - 1) / (epl * kB2RegThreads);
+    if (gg > gmax_reg) gg = gmax_reg;
+    if (gg > g) g = gg;
+  }
   if (g < 1) g = 1;
   // streaming form: candidate regions, one per wavefront of the grid -- room for 8 % of its share of the vector (the bracket
   // of +-1.5 % around the sample's root holds the breakpoints of 1-2 % on ordinary data; a full region = plain iteration)
