@@ -13,9 +13,7 @@
 // per-group scalar arithmetic of the Binf root find (divisions, square roots), which every lane of a
 // group executes redundantly.  Other shapes: a wavefront or a 256-lane workgroup per group, elements
 // re-read from L1/L2 for every reduction.
-#include <cmath>
-
-#include "spx_common.hpp"
+#include "spx_group_common.hpp"
 
 #ifdef SPX_DEBUG_PEEK  // diagnostic builds only: [0] last raw count the LIT launch read, [1] LIT launches that read a count
                        // outside [0, ngroups], [2] LIT launches, [3] count at the entry of the last main launch, [4] main
@@ -32,705 +30,6 @@ extern "C" __attribute__((visibility("default"))) int spx_debug_group_words(long
 }
 #endif
 
-// ---------------------------------------------------------------------------------------------
-// team reductions: TEAM lanes (8, 16, 32, 64: aligned lane ranges of one wave; 256: the workgroup)
-// ---------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-template <int TEAM>
-__device__ __forceinline__ double lanes_sum(double v) {
-  static_assert(TEAM == 1 || TEAM == 2 || TEAM == 4 || TEAM == 8 || TEAM == 16 || TEAM == 32 || TEAM == 64, "TEAM");
-  if constexpr (TEAM >= 2) v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
-  if constexpr (TEAM >= 4) v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-  if constexpr (TEAM >= 8) v += dpp_f64<0x141>(v);  // row_half_mirror: the other quad of each 8
-  if constexpr (TEAM >= 16) v += dpp_f64<0x140>(v);  // row_mirror: the other half of each 16-lane row
-  if constexpr (TEAM >= 32) v += __shfl_xor(v, 16, 64);
-  if constexpr (TEAM >= 64) v += __shfl_xor(v, 32, 64);
-  return v;
-}
-template <int TEAM>
-__device__ __forceinline__ double team_sum(double v, double* lds /* 8 doubles per block, TEAM == 256 only */) {
-  if constexpr (TEAM == 256) {
-    v = lanes_sum<64>(v);
-    const int w = threadIdx.x >> 6;
-    __syncthreads();  // previous use of lds finished
-    if ((threadIdx.x & 63) == 0) lds[w] = v;
-    __syncthreads();
-    return (lds[0] + lds[1]) + (lds[2] + lds[3]);
-  } else {
-    return lanes_sum<TEAM>(v);
-  }
-}
-template <int TEAM>
-__device__ __forceinline__ void team_sum2(double& a, double& b, double* lds) {
-  if constexpr (TEAM == 256) {
-    a = lanes_sum<64>(a);
-    b = lanes_sum<64>(b);
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { lds[w] = a; lds[4 + w] = b; }
-    __syncthreads();
-    a = (lds[0] + lds[1]) + (lds[2] + lds[3]);
-    b = (lds[4] + lds[5]) + (lds[6] + lds[7]);
-  } else {
-    a = lanes_sum<TEAM>(a);
-    b = lanes_sum<TEAM>(b);
-  }
-}
-
-// max over the team of a NaN-free value
-template <int TEAM>
-__device__ __forceinline__ double team_max(double v, double* lds) {
-  if constexpr (TEAM >= 2) v = fmax(v, dpp_f64<0xB1>(v));
-  if constexpr (TEAM >= 4) v = fmax(v, dpp_f64<0x4E>(v));
-  if constexpr (TEAM >= 8) v = fmax(v, dpp_f64<0x141>(v));
-  if constexpr (TEAM >= 16) v = fmax(v, dpp_f64<0x140>(v));
-  if constexpr (TEAM >= 32) v = fmax(v, __shfl_xor(v, 16, 64));
-  if constexpr (TEAM >= 64) v = fmax(v, __shfl_xor(v, 32, 64));
-  if constexpr (TEAM == 256) {
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) lds[w] = v;
-    __syncthreads();
-    v = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
-  }
-  return v;
-}
-
-// softthres(x, a) = sign(x) * max(0, |x| - a)          src/shiftedGroupNormL2Binf.jl:82
-__device__ __forceinline__ double softthres(double x, double a) { return jl_sign(x) * jl_max(0.0, fabs(x) - a); }
-
-// 1/x to a few ulp: hardware seed + 2 Newton steps.  Only used inside the self-correcting Newton iteration.
-__device__ __forceinline__ double fast_rcp(double x) {
-  const double y0 = __builtin_amdgcn_rcp(x);  // +-inf for +-0, +-0 for +-inf
-  double y = __builtin_fma(__builtin_fma(-x, y0, 1.0), y0, y0);
-  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
-  return (y == y) ? y : y0;  // the Newton steps turn 1/0 and 1/inf into NaN: keep the seed there
-}
-
-// ---------------------------------------------------------------------------------------------
-// Per-group element access.  Two providers with the same interface:
-//   RegGroup<EPL>  : S = (q + xk) + sj and X = xk of this lane's EPL elements live in registers
-//   MemGroup<TEAM> : elements are re-read from global memory (L1/L2 resident for moderate groups)
-// for_each(f) calls f(S_i, X_i) for every element this lane owns.
-// ---------------------------------------------------------------------------------------------
-template <int EPL>
-struct RegGroup {
-  static constexpr bool kReg = true;
-  static constexpr int kEpl = EPL;
-  double S[EPL], X[EPL], XS[EPL];  // XS = xk + sj (subtracted at the end)
-  template <class F>
-  __device__ __forceinline__ void for_each(F&& f) const {
-#pragma unroll
-    for (int k = 0; k < EPL; ++k) f(S[k], X[k]);
-  }
-};
-
-template <int TEAM>
-struct MemGroup {
-  static constexpr bool kReg = false;
-  static constexpr int kEpl = 1;
-  const double* q;
-  const double* xk;
-  const double* sj;
-  int64_t lo, hi;
-  int lane;  // index inside the team
-  template <class F>
-  __device__ __forceinline__ void for_each(F&& f) const {
-    for (int64_t i = lo + lane; i < hi; i += TEAM) {
-      double x = xk[i];
-      f((q[i] + x) + sj[i], x);
-    }
-  }
-  // y[i] = f(S, X) - (xk + sj) for every element this lane owns (q[i] is read before y[i] is written: y may alias q)
-  template <class F>
-  __device__ __forceinline__ void store(double* y, F&& f) const {
-    for (int64_t i = lo + lane; i < hi; i += TEAM) {
-      const double x = xk[i], s = sj[i];
-      const double S = (q[i] + x) + s;
-      y[i] = f(S, x) - (x + s);
-    }
-  }
-};
-
-// ---------------------------------------------------------------------------------------------
-// Binf root find.  src/shiftedGroupNormL2Binf.jl:85-108
-//   froot(n) = n - || sigma * softthres(S/sigma - step X, Delta step) - S ||,  step = n / (sigma (n - sl))
-//
-// Structure used here.  With u = n - sl > 0 and tau = u / n = 1 / (sigma step) in (0, 1) an element is
-// thresholded to zero iff |tau S_i - X_i| <= Delta (its term is then -S_i); otherwise the term equals
-// -(n/u) b_i,  b_i = X_i + Delta sgn(tau S_i - X_i).  So
-//   froot(n) = (n/u) * psi(u),   psi(u) = u - phi(u),   phi(u) = sqrt(B(u) + tau^2 A(u)),
-//   A = sum_{inactive} S_i^2,  B = sum_{active} b_i^2,
-// and the prox itself is  w_i = S_i - sigma softthres(...) = (n/u) b_i (active) or S_i (inactive)  (:111).
-// Every |term| is non-increasing in n, hence froot is strictly increasing on n > sl: the root inside the
-// reference's bracket [lmin, lmax] is unique, and a bracketing iteration of any kind lands on the root the
-// reference's bisection (Roots.fzero) converges to.  We solve psi(u) = 0 in u (no cancellation in n - sl, no
-// pole) by a bracket-safeguarded Newton iteration and keep the root AS u: at the root ||w|| = n, so the last step
-// alpha = 1 - sl/||w|| (:83) is u/n = tau and  alpha w_i = b_i (active) or tau S_i (inactive)  -- a closed form without
-// the two cancellations (n - sl, 1 - sl/||w||) the reference's Float64 evaluation goes through.  Where u << n those
-// cancellations cost the REFERENCE up to ~1e-9 of its own result (the granularity of the double n next to the pole of
-// step(n)); round 1 reproduced that error by "polishing" n to the double Roots' bisection returns and then sat, like the
-// reference, 1e-9 away from the exact value -- and further away than the reference in half of such groups.  Adjudicated in
-// round 2 with the binary128 arbiter (tests/arbiter.py): the closed form is within ~1e-15 of the exact value of the
-// reference's formula everywhere, so it is never the worse side.  All loops are bounded.
-// The reference's literal expression is kept for the degenerate bracket only (binf_froot_literal).
-// ---------------------------------------------------------------------------------------------
-#define SPX_BINF_NEWTON_MAXIT 60
-#ifndef SPX_BINF_CONFIRM
-#define SPX_BINF_CONFIRM 1  // A/B switch of the cheap active-set confirmation (binf_same_active_set)
-#endif
-// (tried: a first piece solve without its final accurate Newton step -- slower, 0.99 vs 0.85 ms: the next pass then
-//  starts from a point that is not a piece root and an extra pass follows)
-
-// literal froot(n)  (:87-93)
-template <int TEAM, class G>
-__device__ __forceinline__ double binf_froot_literal(const G& grp, double n, double sigma, double sl, double delta,
-                                                     double* lds) {
-  const double step = n / (sigma * (n - sl));
-  const double thr = delta * step;
-  double sw = 0.0;
-  grp.for_each([&](double S, double X) {
-    double w = sigma * softthres(S / sigma - step * X, thr) - S;
-    sw += w * w;
-  });
-  return n - sqrt(team_sum<TEAM>(sw, lds));
-}
-
-// Delta with the sign of z
-__device__ __forceinline__ double signed_delta(double delta, double z) {
-  return __hiloint2double((__double2hiint(delta) & 0x7fffffff) | (__double2hiint(z) & 0x80000000), __double2loint(delta));
-}
-
-// v if keep, else (essentially) zero: clears the high dword only -> one v_cndmask instead of two; the leftover
-// low dword is a denormal below 2^-1042, invisible in the sums below
-__device__ __forceinline__ double keep_if(double v, bool keep) {
-  return __hiloint2double(keep ? __double2hiint(v) : 0, __double2loint(v));
-}
-
-// sums A (inactive S^2) and B (active b^2) at a given tau
-template <int TEAM, class G>
-__device__ __forceinline__ void binf_ab(const G& grp, double tau, double delta, double* lds, double& sa, double& sb) {
-  sa = 0.0;
-  sb = 0.0;
-  grp.for_each([&](double S, double X) {
-    const double z = __builtin_fma(tau, S, -X);
-    const bool act = fabs(z) > delta;
-    const double b = X + signed_delta(delta, z);
-    // masked operand, then one fma per sum (8 VALU instructions per element instead of 10 with mul + mask + add: the
-    // kernel is VALU-bound and this loop is half of it); the leftover low dword of a masked operand squares to zero
-    const double Sm = keep_if(S, !act), bm = keep_if(b, act);
-    sa = __builtin_fma(Sm, Sm, sa);
-    sb = __builtin_fma(bm, bm, sb);
-  });
-  team_sum2<TEAM>(sa, sb, lds);
-  // keep_if leaves sub-2^-1042 residues of the masked-out terms in the sums: an empty set must sum to exactly 0 (the
-  // piece confirmation compares sums bit for bit, and sb == 0 identifies the all-inactive piece)
-  sa = (sa < 1e-300) ? 0.0 : sa;
-  sb = (sb < 1e-300) ? 0.0 : sb;
-}
-
-// Register-resident groups: true in the lanes of a team whose active set {i : |tau S_i - X_i| > Delta} is the same at
-// tau_a and tau_b (2 fma + 2 compares per element; nothing is stored between passes -- keeping the previous pass's lane
-// masks alive costs more registers than the kernel has, measured: 0.83 -> 1.01 ms).
-template <int TEAM, class G>
-__device__ __forceinline__ bool binf_same_active_set(const G& grp, double tau_a, double tau_b, double delta) {
-  unsigned long long diff = 0ull;
-#pragma unroll
-  for (int k = 0; k < G::kEpl; ++k) {
-    const double za = __builtin_fma(tau_a, grp.S[k], -grp.X[k]);
-    const double zb = __builtin_fma(tau_b, grp.S[k], -grp.X[k]);
-    diff |= __ballot((fabs(za) > delta) != (fabs(zb) > delta));
-  }
-  const int lane = threadIdx.x & 63;
-  const unsigned long long mine = (TEAM >= 64) ? ~0ull : (((1ull << (TEAM & 63)) - 1ull) << ((lane / TEAM) * TEAM));
-  return (diff & mine) == 0ull;
-}
-
-__device__ __forceinline__ double sqrt_pos(double v) {  // sqrt for v >= 0: rsq seed + two corrections
-  const double r = __builtin_amdgcn_rsq(v);
-  double s = v * r;
-  s = __builtin_fma(0.5 * r, __builtin_fma(-s, s, v), s);
-  s = __builtin_fma(0.5 * r, __builtin_fma(-s, s, v), s);
-  return (v > 0.0) ? s : 0.0;
-}
-
-// psi(u) and psi'(u)
-template <int TEAM, class G>
-__device__ __forceinline__ void binf_psi(const G& grp, double u, double sl, double delta, double* lds, double& psi,
-                                         double& dpsi) {
-  const double n = sl + u;
-  const double rn = fast_rcp(n);
-  const double tau = u * rn;
-  double sa, sb;
-  binf_ab<TEAM>(grp, tau, delta, lds, sa, sb);
-  const double phi = sqrt_pos(__builtin_fma(tau * tau, sa, sb));
-  psi = u - phi;
-  const double dtau = sl * rn * rn;
-  dpsi = 1.0 - ((phi > 0.0) ? (sa * tau * dtau * fast_rcp(phi)) : 0.0);
-}
-// Roots.__middle for positive doubles: the double whose bit pattern is the mean of the two bit patterns
-__device__ __forceinline__ double bit_middle(double a, double b) {
-  const unsigned long long m = ((unsigned long long)__double_as_longlong(fabs(a)) +
-                                (unsigned long long)__double_as_longlong(fabs(b))) >> 1;
-  return jl_sign(a + b) * __longlong_as_double((long long)m);
-}
-
-// Roots.fzero(froot, a, b) literally: sorted bracket, bit-pattern midpoint, sign bisection to exhaustion,
-// the end with the smaller |f| (a NaN value moves the lower end, as `sign(fa) * sign(fc) < 0` is false).
-template <int TEAM, class G>
-__device__ __forceinline__ double binf_bisect(const G& grp, double a, double fa, double b, double fb, double sigma,
-                                              double sl, double delta, double* lds) {
-  if (a > b) { double t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
-  if (fa == 0.0) return a;
-  if (fb == 0.0) return b;
-  for (int it = 0; it < 130; ++it) {
-    const double m = bit_middle(a, b);
-    if (!(a < m && m < b)) break;
-    const double fmid = binf_froot_literal<TEAM>(grp, m, sigma, sl, delta, lds);
-    if (jl_sign(fa) * jl_sign(fmid) < 0) { b = m; fb = fmid; }
-    else { a = m; fa = fmid; }
-  }
-  return (fabs(fa) < fabs(fb)) ? a : b;
-}
-
-// The reference's own evaluation, literally: froot at both ends (:95,:101), `fl * fm > 0` -> zeros (:102), else
-// Roots.fzero (:105).  Used for degenerate brackets, exact zeros at an end and NaNs, where the A/B form of the
-// fast path (which assumes n > sl) does not describe what the reference computes.
-template <int TEAM, class G>
-__device__ __forceinline__ bool binf_literal_root(const G& grp, double lam, double sigma, double delta, double* lds,
-                                                  double& root) {
-  const double eps = 2.220446049250313e-16;
-  const double sl = lam * sigma;
-  const double lmin = sl * (1 + eps);                                     // :94
-  const double fl = binf_froot_literal<TEAM>(grp, lmin, sigma, sl, delta, lds);  // :95
-  const double ansatz = lmin + 1.0;                                       // :97
-  const double step = ansatz / (sigma * (ansatz - sl));                   // :98
-  double sz = 0.0, sS = 0.0, sX = 0.0, mX = 0.0, gap = INFINITY;
-  grp.for_each([&](double S, double X) {
-    const double z = softthres(S / sigma - step * X, delta * step);       // :99
-    sz += z * z;
-    sS += S * S;
-    sX += X * X;
-    mX = fmax(mX, fabs(X));
-    gap = fmin(gap, fabs(fabs(X) - delta));
-  });
-  team_sum2<TEAM>(sz, sS, lds);
-  sX = team_sum<TEAM>(sX, lds);
-  const double lmax = sqrt(sS) + sigma * (sqrt(sz) + 1.0 * lam * sqrt(sX));  // :100
-  // Reversed bracket with entries outside the trust region: the piece iteration of binf_literal_reg (derivation and
-  // guards there), for the element providers of the general / LDS / gather kernels.  `false` = the reference writes zeros.
-  {
-    mX = team_max<TEAM>(mX, lds);
-    gap = -team_max<TEAM>(-gap, lds);
-    if (lmax < lmin * (1.0 - 1e-9) && lmin > sl && (sS + sX < INFINITY) && sqrt(sS) <= 1e6 * delta && sl <= 1e6 * delta &&
-        mX - delta >= 1e-6 * sl && gap > 1e-9 * delta) {
-      auto rsq_at = [&](double n) -> double {  // R(n)^2
-        const double a = n / (sigma * (sl - n));
-        double acc = 0.0;
-        grp.for_each([&](double S, double X) {
-          const double z = __builtin_fma(a, X, S / sigma);
-          const double b = (z == 0.0) ? X : X + signed_delta(delta, z);
-          acc += b * b;
-        });
-        return team_sum<TEAM>(acc, lds);
-      };
-      double r2 = rsq_at(lmax);
-      double R = sqrt(r2);
-      const double g0 = (sl - lmax) - R;
-      bool decided = g0 < -1e-9 * sl;
-      if (!decided && g0 > 1e-9 * sl) {
-        for (int k = 0; k < 8 && !decided; ++k) {
-          if (!(sl - R > 0.0)) break;
-          const double r2n = rsq_at(sl - R);
-          decided = (r2n == r2);
-          r2 = r2n;
-          R = sqrt(r2);
-        }
-      }
-      if (decided) return false;
-    }
-  }
-  const double fm = binf_froot_literal<TEAM>(grp, lmax, sigma, sl, delta, lds);  // :101
-  if (fl * fm > 0) return false;                                          // :102
-  root = binf_bisect<TEAM>(grp, lmin, fl, lmax, fm, sigma, sl, delta, lds);  // :105
-  return true;
-}
-
-// The same for a register-resident group (the deferred list of k_group_reg, run by its LIT instantiation): the ~60
-// dependent passes of fzero then cost arithmetic only -- with the group re-read from memory for every pass (k_group_mem)
-// a list that holds a large share of the groups is bound by L2 misses, 14 ms for 2.7e5 groups of 128.  S/sigma (:89) is
-// loop-invariant and formed once.  out[k] = y before the final "- (xk + sj)".
-template <int LPG, int EPL>
-__device__ __forceinline__ void binf_literal_reg(const RegGroup<EPL>& grp, double lam, double sigma, double delta,
-                                                 double* out) {
-  const double eps = 2.220446049250313e-16;
-  const double sl = lam * sigma;
-  double Sd[EPL];
-#pragma unroll
-  for (int k = 0; k < EPL; ++k) Sd[k] = grp.S[k] / sigma;
-  auto froot = [&](double n) -> double {  // :87-93
-    const double step = n / (sigma * (n - sl));
-    const double thr = delta * step;
-    double sw = 0.0;
-#pragma unroll
-    for (int k = 0; k < EPL; ++k) {
-      const double w = sigma * softthres(Sd[k] - step * grp.X[k], thr) - grp.S[k];
-      sw += w * w;
-    }
-    return n - sqrt(lanes_sum<LPG>(sw));
-  };
-  const double lmin = sl * (1 + eps);  // :94
-  double fa = froot(lmin);             // :95
-  const double ansatz = lmin + 1.0;    // :97
-  const double stepa = ansatz / (sigma * (ansatz - sl));  // :98
-  double sz = 0.0, sS = 0.0, sX = 0.0;
-#pragma unroll
-  for (int k = 0; k < EPL; ++k) {
-    const double z = softthres(Sd[k] - stepa * grp.X[k], delta * stepa);  // :99
-    sz += z * z;
-    sS += grp.S[k] * grp.S[k];
-    sX += grp.X[k] * grp.X[k];
-  }
-  sz = lanes_sum<LPG>(sz);
-  sS = lanes_sum<LPG>(sS);
-  sX = lanes_sum<LPG>(sX);
-  const double lmax = sqrt(sS) + sigma * (sqrt(sz) + 1.0 * lam * sqrt(sX));  // :100
-  // Reversed bracket (lmax < lmin) with entries OUTSIDE the trust region (|X_i| > Delta: X is the iterate, Delta the radius
-  // of the step -- the normal state of a small group late in a run), decided without the ~60 literal passes of fzero.
-  // froot(lmin) is hugely negative (an active entry next to the pole).  Below the pole step < 0, softthres only adds, and
-  //   froot(n) = n (1 - R(n) / (sl - n)),  R^2 = sum (X_i + sgn(z_i) Delta)^2,  z_i = S_i/sigma + |step| X_i;
-  // a z_i changes sign only from sgn(S_i) to sgn(X_i) as n grows, raising its term from (|X_i| - Delta)^2 to
-  // (|X_i| + Delta)^2: R is non-decreasing, sl - n - R(n) strictly decreasing, the bracket holds ONE sign change and any
-  // bracketing iteration finds the one fzero finds:
-  //   * sl - lmax - R(lmax) < 0: froot(lmax) < 0 as well -> :102-103, zeros;
-  //   * else iterate n <- sl - R(n) (the root of the current piece; the iterates close in on the sign change from both
-  //     sides): when R comes back unchanged the sign change is a genuine root n* = sl - R inside a piece, where
-  //     ||w|| = n* < sl and :111 is l2prox(w, sl) = 0 -- zeros again;
-  //   * no repeat within a few steps: the sign change sits on a jump of R, fzero returns one side of it and the result is
-  //     not zero in general -> the literal evaluation below (0.7 % of such groups).
-  // Guards: bracket reversed by 1e-9, no |X_i| within 1e-9 Delta of Delta, ||S|| and sl <= 1e6 Delta (froot(lmin) safely
-  // negative), max|X| - Delta >= 1e-6 sl (R is not lost in the rounding of ||w|| against sl).  Checked on CPU against the
-  // literal restatement: 5.4e5 such groups, 99.3 % decided, none wrongly (tools/fuzz_binf_reversed.py pins it on the GPU).
-  {
-    double mX = 0.0, gap = INFINITY;
-#pragma unroll
-    for (int k = 0; k < EPL; ++k) {
-      mX = fmax(mX, fabs(grp.X[k]));
-      gap = fmin(gap, fabs(fabs(grp.X[k]) - delta));
-    }
-    mX = team_max<LPG>(mX, nullptr);
-    gap = -team_max<LPG>(-gap, nullptr);
-    const double nS = sqrt(sS);
-    if (lmax < lmin * (1.0 - 1e-9) && lmin > sl && (sS + sX < INFINITY) && nS <= 1e6 * delta && sl <= 1e6 * delta &&
-        mX - delta >= 1e-6 * sl && gap > 1e-9 * delta) {
-      auto rsq_at = [&](double n) -> double {  // R(n)^2
-        const double a = n / (sigma * (sl - n));
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-          const double z = __builtin_fma(a, grp.X[k], Sd[k]);
-          const double b = (z == 0.0) ? grp.X[k] : grp.X[k] + signed_delta(delta, z);
-          acc += b * b;
-        }
-        return lanes_sum<LPG>(acc);
-      };
-      double r2 = rsq_at(lmax);
-      double R = sqrt(r2);
-      const double g0 = (sl - lmax) - R;
-      bool decided = g0 < -1e-9 * sl;
-      if (!decided && g0 > 1e-9 * sl) {
-        for (int k = 0; k < 8 && !decided; ++k) {
-          if (!(sl - R > 0.0)) break;  // (R can exceed sl after a jump: leave it to the literal evaluation)
-          const double r2n = rsq_at(sl - R);
-          decided = (r2n == r2);
-          r2 = r2n;
-          R = sqrt(r2);
-        }
-      }
-      if (decided) {
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) out[k] = 0.0;
-        return;
-      }
-    }
-  }
-  double fb = froot(lmax);                                                   // :101
-  bool zeros = fa * fb > 0;                                                  // :102
-  double root = lmin;
-  if (!zeros) {  // Roots.fzero(froot, lmin, lmax), as binf_bisect
-    double a = lmin, b = lmax;
-    if (a > b) { double t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
-    if (fa == 0.0) root = a;
-    else if (fb == 0.0) root = b;
-    else {
-      for (int it = 0; it < 130; ++it) {
-        const double m = bit_middle(a, b);
-        if (!(a < m && m < b)) break;
-        const double fmid = froot(m);
-        if (jl_sign(fa) * jl_sign(fmid) < 0) { b = m; fb = fmid; }
-        else { a = m; fa = fmid; }
-      }
-      root = (fabs(fa) < fabs(fb)) ? a : b;
-    }
-    zeros = (root - sl) == 0.0;  // :107
-  }
-  if (zeros) {
-#pragma unroll
-    for (int k = 0; k < EPL; ++k) out[k] = 0.0;
-    return;
-  }
-  const double step = root / (sigma * (root - sl));  // :106
-  double sw = 0.0;
-#pragma unroll
-  for (int k = 0; k < EPL; ++k) {
-    out[k] = grp.S[k] - sigma * softthres(Sd[k] - step * grp.X[k], delta * step);  // :111
-    sw += out[k] * out[k];
-  }
-  const double nw = sqrt(lanes_sum<LPG>(sw));
-  const double alpha = jl_max(0.0, 1 - sl / nw);  // :83
-#pragma unroll
-  for (int k = 0; k < EPL; ++k) out[k] = alpha * out[k];
-}
-
-enum { BINF_ZERO = 0, BINF_ROOT = 1, BINF_LITERAL = 2 };
-// BINF_ROOT: the root n = sl + u, returned as u (> 0) in `root_u`;  BINF_ZERO: fl * fm > 0, the reference writes zeros
-// (:102-103);  BINF_LITERAL: degenerate bracket / exact zero at an end / NaN -> the caller must run binf_literal_root.
-template <int TEAM, class G>
-__device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma, double delta, double* lds,
-                                         double& root_u, bool pole_lit) {
-  const double eps = 2.220446049250313e-16;
-  const double sl = lam * sigma;          // :85
-  const double lmin = sl * (1 + eps);     // :94
-  // lmax, zlmax and froot(lmin) only steer the bracket (their exact rounding never reaches y): the wave-uniform
-  // divisions and square roots below use the few-ulp fast forms
-  // first pass: ||S||, ||X|| and max |X_i|
-  const double ul = lmin - sl;
-  const double taul = ul * fast_rcp(lmin);
-  double sS = 0.0, sX = 0.0, mX = 0.0;
-  grp.for_each([&](double S, double X) {
-    sS = __builtin_fma(S, S, sS);
-    sX = __builtin_fma(X, X, sX);
-    mX = fmax(mX, fabs(X));
-  });
-  team_sum2<TEAM>(sS, sX, lds);
-  mX = team_max<TEAM>(mX, lds);
-  const double nS = sqrt_pos(sS), nX = sqrt_pos(sX);
-  // X == 0 in the whole group and sigma lambda > ||S||: the group of a sparse iterate that stays zero -- the bulk of the
-  // groups in a group-lasso run, so it must not take the literal path its (usually degenerate: lmax = ||S|| + sigma zlmax
-  // < lmin) bracket would otherwise send it to.  The reference returns zeros whichever way it goes:
-  //  * lmax >= lmin: on n >= lmin every |w_i| <= |S_i|, so froot(n) >= n - ||S|| > 0 at both ends -> :102-103;
-  //  * lmax < lmin: froot(lmin) > 0 as before; froot(lmax) = lmax (1 - Delta sqrt(#S_i != 0) / (sigma lambda - lmax)) (step < 0:
-  //    softthres only ADDS |thr|); if positive -> :102-103, if negative the only sign change in (lmax, lmin] is the pole
-  //    n = sigma lambda (froot -> -inf below it, n - ||w|| > 0 above it), fzero ends on a double just above the pole, and
-  //    there :111 is l2prox(v, sigma lambda) with ||v|| <= ||S|| < sigma lambda, i.e. zeros again.
-  // (1e-9 away from the tie sigma lambda = ||S||, which stays with the general code below.)
-  if (mX == 0.0 && sl < INFINITY && sl * (1.0 - 1e-9) > nS) return BINF_ZERO;
-  const double ub = sqrt_pos(sS + sX) * (1.0 + 8 * eps);  // a-priori bound on the root in u (see below)
-  // lmax = ||S|| + sigma (zlmax + lambda ||X||) (:100) needs one more pass for zlmax (:99).  zlmax >= 0, so
-  // lmax >= lmax_lb := ||S|| + sigma lambda ||X||.  If already lmax_lb clears both lmin (bracket not degenerate) and
-  // sl + ub (the iteration starts from the bound ub, not from lmax) the exact lmax is never used: skip the pass.
-  const double lmax_lb = nS + sigma * (lam * nX);
-  double lmax;
-  bool lmax_is_normS = false;  // lmax == ||S|| exactly in the reference: zlmax == 0 and lambda ||X|| == 0
-  if (lmax_lb > lmin * (1.0 + 8 * eps) && (lmax_lb - sl) > ub * (1.0 + 8 * eps)) {
-    lmax = sl + ub * (1.0 + 8 * eps);  // any point >= the root serves as the upper end from here on
-  } else {
-    const double ansatz = lmin + 1.0;                                      // :97 (epsilon = 1)
-    const double rsig = fast_rcp(sigma);
-    const double stepa = ansatz * rsig * fast_rcp(ansatz - sl);            // :98
-    const double thra = delta * stepa;
-    double sz = 0.0;
-    grp.for_each([&](double S, double X) {
-      const double za = fabs(__builtin_fma(-stepa, X, S * rsig)) - thra;  // |softthres| = max(0, |.| - thr)  (:99)
-      sz += (za > 0.0) ? za * za : 0.0;
-    });
-    sz = team_sum<TEAM>(sz, lds);
-    lmax = nS + sigma * (sqrt_pos(sz) + 1.0 * lam * nX);                   // :100 (|(eps-1)/eps + 1| = 1)
-    lmax_is_normS = (sz == 0.0) && (lam * nX == 0.0);
-    // Reversed bracket (lmax < lmin: ||S|| + sigma (zlmax + lambda ||X||) below sigma lambda -- a small group about to be
-    // zeroed) with every |X_i| inside the trust region: the reference returns zeros, decided here without its literal
-    // bisection (whole data sets fell into that path: 16 ms instead of 0.7 ms at 1e6 x 128, tools/sweep_params.py).
-    //  * froot(lmin) = lmin - ||S|| > 0: at lmin (1-2 ulp above the pole) step ~ 1/(sigma eps), |S_i/sigma - step X_i| <=
-    //    step Delta for every i (|X_i| < Delta(1 - 1e-9), ||S|| <= 1e6 Delta), all entries thresholded; ||S|| <= lmax < lmin.
-    //  * below the pole step < 0 and softthres only adds: froot(n) = n (1 - R(n) / (sigma lambda - n)) with
-    //    R^2 = sum (X_i + sgn(z_i) Delta)^2, z_i = S_i/sigma + |step| X_i.  A z_i changes sign only from sgn(S_i) to
-    //    sgn(X_i) as n grows, which raises its term from (|X_i| - Delta)^2 to (|X_i| + Delta)^2: R is non-decreasing, so
-    //    sigma lambda - n - R(n) is decreasing -- if froot(lmax) > 0 the signs agree (:102-103: zeros); if froot(lmax) < 0
-    //    froot stays negative up to the pole, the only sign change of the bracket is the pole itself, fzero ends on a
-    //    double just above it, everything is thresholded there and :111 is l2prox(S, sigma lambda) = 0 (||S|| < sigma lambda).
-    // (tests/test_gpu_parity.py::test_group_binf_small_groups_being_zeroed and tools/fuzz_binf_reversed.py pin this regime.)
-    const bool reversed = lmax < lmin * (1.0 - 1e-9) && ul > 0.0 && nS <= 1e6 * delta && (sS + sX < INFINITY);
-    if (reversed && mX < delta * (1.0 - 1e-9)) return BINF_ZERO;
-    // (Reversed brackets with entries OUTSIDE the trust region go to the deferred list: binf_literal_reg decides most of
-    //  them without the literal bisection, see there -- the code would cost this kernel its register budget.)
-  }
-  // fl = froot(lmin) (:95): only its sign is used.  lmin sits eps above the pole of step(n): tau(lmin) ~ eps, the element
-  // with the largest |X_i| has |tau S_i - X_i| >= max|X| - tau ||S||; if that exceeds Delta by a relative 1e-9 the
-  // element is active with |b_i| >= 1e-9 Delta, so froot(lmin) <= lmin - (lmin/ul) 1e-9 Delta < 0 as soon as
-  // ul = eps sl < 1e-9 Delta -- decided without the A/B sums at lmin.  Otherwise (all |X_i| <= Delta, huge lambda) they
-  // are formed as in every other evaluation.
-  double fl;
-  if ((sS + sX < INFINITY) && (mX - taul * nS > delta * (1.0 + 1e-9)) && (ul < 1e-9 * delta)) {
-    fl = -1.0;
-  } else {
-    // No entry is safely active at lmin.  The A/B form gives the exact value of froot(lmin); the reference's own
-    // evaluation agrees with it unless some |X_i| equals Delta to the last bits: lmin sits one ulp above the pole of
-    // step(n), S/sigma - step X is formed at magnitude ~1e16, and such an entry comes out of softthres as 0, 1 or 2 by
-    // rounding alone -- which then decides the sign of froot(lmin), the bracket, and a bisection that ends on a spurious
-    // root next to the pole.  Those groups are handed to the literal evaluation, which reproduces exactly that
-    // (found by tools/fuzz_binf_scenarios.py: |X_i| = Delta gave the exact-arithmetic answer, not the reference's, in
-    // ~1 % of 2-element groups).
-    double gap = INFINITY;  // min over the group of | |X_i| - Delta |
-    grp.for_each([&](double, double X) { gap = fmin(gap, fabs(fabs(X) - delta)); });
-    gap = -team_max<TEAM>(-gap, lds);
-    if (gap <= 1e-9 * delta) return BINF_LITERAL;
-    double sal, sbl;
-    binf_ab<TEAM>(grp, taul, delta, lds, sal, sbl);
-    fl = lmin - (lmin * fast_rcp(ul)) * sqrt_pos(__builtin_fma(taul * taul, sal, sbl));
-  }
-  if (!(lmin < lmax) || !(ul > 0.0) || !(fl == fl)) return BINF_LITERAL;  // degenerate bracket, sl == 0, NaN
-  // regular bracket sl < lmin < lmax:  fm = froot(lmax) has the sign of psi(uhi)   (:101).
-  // |b_i| <= max(|S_i|, |X_i|) gives phi(u) <= ub := sqrt(||S||^2 + ||X||^2) for every u, so the root is <= ub:
-  // if uhi >= ub then psi(uhi) >= 0 is known without evaluating it and the iteration starts from ub instead.
-  //
-  // Iteration: psi is piecewise smooth -- on a fixed active set it is u - sqrt(B + A tau(u)^2) with constant
-  // A, B.  Each pass over the group yields (A, B) of the current u; the root of THAT piece is then found by a
-  // scalar Newton iteration (no element work), and the next pass checks it: if the sums come back bit-identical
-  // the active set did not change and u is the root; otherwise continue from the new piece.  2-3 passes on
-  // the BASELINE data instead of 5-6 for Newton on psi itself; bracket-safeguarded, bounded.
-  double ulo = ul, uhi = lmax - sl;
-  const bool from_bound = (uhi > ub && ub > ulo);
-  if (from_bound) uhi = ub;
-  double u = uhi;
-  double sa, sb, psi;
-  double tau_full;  // tau of the last full pass (the one sa, sb belong to)
-  {
-    const double tau = u * fast_rcp(sl + u);
-    binf_ab<TEAM>(grp, tau, delta, lds, sa, sb);
-    psi = u - sqrt_pos(__builtin_fma(tau * tau, sa, sb));
-    tau_full = tau;
-  }
-#ifdef SPX_DEBUG_BINF
-  if ((threadIdx.x % TEAM) == 0 && blockIdx.x == 0 && threadIdx.x < TEAM)
-    printf("[binf] sl %.17g lmin %.17g lmax %.17g ub %.17g nS %.17g nX %.17g mX %.17g fl %.17g from_bound %d u %.17g sa %.17g sb %.17g psi %.17g\n",
-           sl, lmin, lmax, ub, nS, nX, mX, fl, (int)from_bound, u, sa, sb, psi);
-#endif
-  {
-    // fm = froot(lmax) (:101).  When the bracket's upper end IS the root -- X = 0 and every entry thresholded at lmax,
-    // the usual state at x0 = 0 with a wide trust region: lmax = ||S|| and froot(lmax) = ||S|| - ||S|| = 0 exactly in
-    // the reference -- the A/B form returns a rounding-sized psi of either sign.  Its sign must not decide :102: such
-    // groups (and a froot(lmin) that is not safely negative) go to the literal evaluation.
-    if (!from_bound && fabs(psi) <= 1e-12 * u) {
-      // The common instance, decided here: lmax = ||S|| (zlmax = 0, lambda ||X|| = 0) and no entry active at lmax.  The
-      // reference then has froot(lmax) = ||S|| - ||-S|| = 0 exactly, fzero returns lmax, and w = S whatever the last bits
-      // of the root are (:111 with everything thresholded): root = lmax, sums of the all-inactive piece.
-      if (lmax_is_normS && sb == 0.0) {
-        root_u = u;  // = lmax - sl
-        return BINF_ROOT;
-      }
-      return BINF_LITERAL;
-    }
-    if (fabs(fl) <= 1e-12 * lmin) return BINF_LITERAL;
-    const double fm = from_bound ? ((psi > 0.0) ? psi : 1.0) : (lmax * fast_rcp(u)) * psi;
-    if (fl * fm > 0) return BINF_ZERO;                      // :102
-    if (!(fl < 0.0) || !(fm > 0.0)) return BINF_LITERAL;    // an exact zero at an end (or NaN)
-  }
-  double pa = -1.0, pb = -1.0;  // sums of the piece solved last (A, B >= 0 always)
-  for (int it = 0; it < SPX_BINF_NEWTON_MAXIT; ++it) {
-    // converged: psi vanishes to rounding (|psi| <= 4 eps u: u is the root of its own piece to the last bits), or the piece
-    // just solved is confirmed by identical sums
-    if (fabs(psi) <= 4 * eps * u || (sa == pa && sb == pb)) break;
-    if (psi < 0.0) ulo = u; else uhi = u;
-    // root of the current piece: g(v) = v - sqrt(sb + sa (v / (sl + v))^2), scalar Newton from u
-    // (the slope only steers the step: unrefined v_rcp/v_rsq seeds, ~1e-8 relative, are enough there; the step that
-    // follows a relative move below 1e-8 lands within ~1e-16 by quadratic convergence, so it is the last one)
-    // (round 2: the result now depends on u itself -- the closed form of the last step -- so the piece root must be
-    //  converged, not merely close in n.  g has a second root at v = 0; when the wanted one is small against sl the two
-    //  are close on the scale of the start, Newton halves its way down (log2(n/u) steps: 12 were not always enough and the
-    //  unconverged v was then "confirmed" by identical sums), and the all-inactive piece (sb == 0) is solved directly.)
-    double v = u;
-    bool piece_ok = false;
-    if (sb == 0.0) {
-      v = sqrt_pos(sa) - sl;  // g(v) = v (1 - sqrt(sa) / (sl + v)): the reference's 1 - sl/||S|| in disguise
-      piece_ok = true;
-    } else {
-      for (int k = 0; k < 64; ++k) {
-        const double rn = fast_rcp(sl + v);
-        const double t = v * rn;
-        const double ph2 = __builtin_fma(t * t, sa, sb);
-        const double rph = __builtin_amdgcn_rsq(ph2);
-        double ph = ph2 * rph;
-        ph = (ph2 > 0.0) ? __builtin_fma(0.5 * rph, __builtin_fma(-ph, ph, ph2), ph) : 0.0;
-        ph = (ph2 > 0.0) ? __builtin_fma(0.5 * rph, __builtin_fma(-ph, ph, ph2), ph) : 0.0;
-        const double g = v - ph;
-        const double gp = 1.0 - ((ph2 > 0.0) ? sa * t * (sl * rn * rn) * rph : 0.0);
-        const double vn = v - g * __builtin_amdgcn_rcp(gp);
-        const bool last = fabs(vn - v) <= 1e-8 * fabs(vn);
-        v = vn;
-        if (last) {
-          // one more, fully accurate step
-          const double rn2 = fast_rcp(sl + v);
-          const double t2 = v * rn2;
-          const double p2 = __builtin_fma(t2 * t2, sa, sb);
-          const double ph_ = sqrt_pos(p2);
-          const double gp2 = 1.0 - ((ph_ > 0.0) ? sa * t2 * (sl * rn2 * rn2) * fast_rcp(ph_) : 0.0);
-          v = v - (v - ph_) * fast_rcp(gp2);
-          piece_ok = true;
-          break;
-        }
-      }
-    }
-    // the piece's root is u itself (to rounding): converged -- must be seen BEFORE the bracket test below, which would
-    // otherwise reject v == u (u has just become a bracket end) and bisect away from the root
-    if (fabs(v - u) <= 4 * eps * fabs(u)) break;
-    const bool exact_step = piece_ok && (v > ulo && v < uhi);  // v is the (converged) root of the piece (sa, sb)
-    if (!exact_step) v = sqrt_pos(ulo) * sqrt_pos(uhi);  // safeguard: geometric bisection of the bracket
-    if (!(v > ulo && v < uhi)) break;
-    const bool small = fabs(v - u) <= 4 * eps * v;
-    pa = exact_step ? sa : -1.0;  // only an exact piece root may be "confirmed" by identical sums in the next pass
-    pb = exact_step ? sb : -1.0;
-    u = v;
-    if (small) break;
-    const double tau = u * fast_rcp(sl + u);
-    if constexpr (G::kReg) {
-      // Cheap confirmation instead of a pass whose sums would only come back bit-identical: the active set at the piece's
-      // root is the one the piece was built from (and no active z can have changed sign: |d tau| ||S|| <= 2 Delta) -> u
-      // is the root.  Not tried after the first pass (it == 0): the start from the bound is far from the root and a
-      // wavefront of several groups almost never confirms there.
-      if (SPX_BINF_CONFIRM && exact_step && it >= 1 && fabs(tau - tau_full) * nS <= 2.0 * delta &&
-          binf_same_active_set<TEAM>(grp, tau, tau_full, delta))
-        break;
-    }
-    binf_ab<TEAM>(grp, tau, delta, lds, sa, sb);
-    psi = u - sqrt_pos(__builtin_fma(tau * tau, sa, sb));
-    tau_full = tau;
-#ifdef SPX_DEBUG_BINF
-    if ((threadIdx.x % TEAM) == 0 && blockIdx.x == 0 && threadIdx.x < TEAM)
-      printf("[binf] it %d u %.17g sa %.17g sb %.17g psi %.17g ulo %.17g uhi %.17g exact %d\n", it, u, sa, sb, psi, ulo, uhi, (int)exact_step);
-#endif
-  }
-  root_u = fmin(fmax(u, ul), lmax - sl);  // inside the reference's bracket [lmin, lmax]
-  // spx_ctx_set_tuning key 9 (pole_lit): a root next to the pole of step(n) (u < n / 1000) is where the reference's own
-  // Float64 evaluation is up to 4.5e-9 of the scale off its formula (n - sigma lambda and 1 - sigma lambda / ||w|| cancel);
-  // the closed form above is the accurate side, the literal evaluation reproduces the reference's doubles -- for callers
-  // who must reproduce a reference run (src/shiftedGroupNormL2Binf.jl:105-113)
-  if (pole_lit && root_u * 1000.0 < sl + root_u) return BINF_LITERAL;
-  return BINF_ROOT;
-}
-
-// the prox of one element at the root (:110-113): alpha w_i with alpha = tau and w_i = b_i / tau (active) or S_i
-// (inactive), i.e. b_i = X_i + Delta sgn(tau S_i - X_i) or tau S_i -- continuous across the activity boundary
-__device__ __forceinline__ double binf_y(double S, double X, double tau, double delta) {
-  const double z = __builtin_fma(tau, S, -X);
-  const double b = X + signed_delta(delta, z);
-  return (fabs(z) > delta) ? b : tau * S;
-}
 
 // ---------------------------------------------------------------------------------------------
 // fast path kernel: uniform groups of LPG*EPL elements; LPG lanes own a group, 64/LPG groups per wave;
@@ -973,45 +272,6 @@ struct GatherGroup {
   }
 };
 
-template <int TEAM, bool BINF, class GRP>
-__device__ __forceinline__ void group_body(const GRP& grp, double* y, double lam, double sigma, double delta, double* lds,
-                                           bool literal_only, bool pole_lit) {
-  if constexpr (!BINF) {
-    double ss = 0.0;
-    grp.for_each([&](double S, double) { ss += S * S; });
-    const double snorm = sqrt(team_sum<TEAM>(ss, lds));
-    const double alpha = (snorm == 0.0) ? 0.0 : jl_max(1 - sigma * lam / snorm, 0.0);
-    grp.store(y, [&](double S, double) { return (snorm == 0.0) ? 0.0 : alpha * S; });
-  } else {
-    double root, ru = 0.0;
-    int status = literal_only ? BINF_LITERAL : binf_root<TEAM>(grp, lam, sigma, delta, lds, ru, pole_lit);
-    const double sl = lam * sigma;
-    if (status == BINF_LITERAL) {
-      // the reference, literally, including its last step (:106-113) -- the root may lie below sl here
-      const bool ok = binf_literal_root<TEAM>(grp, lam, sigma, delta, lds, root);
-      if (!ok || (root - sl) == 0.0) {
-        grp.store(y, [&](double, double) { return 0.0; });
-      } else {
-        const double step = root / (sigma * (root - sl));
-        double sw = 0.0;
-        grp.for_each([&](double S, double X) {
-          double w = S - sigma * softthres(S / sigma - step * X, delta * step);
-          sw += w * w;
-        });
-        const double nw = sqrt(team_sum<TEAM>(sw, lds));
-        const double alpha = jl_max(0.0, 1 - sl / nw);
-        grp.store(y, [&](double S, double X) {
-          return alpha * (S - sigma * softthres(S / sigma - step * X, delta * step));
-        });
-      }
-    } else if (status == BINF_ZERO || ru == 0.0) {
-      grp.store(y, [&](double, double) { return 0.0; });
-    } else {
-      const double tau = ru / (sl + ru);  // = alpha at the root
-      grp.store(y, [&](double S, double X) { return binf_y(S, X, tau, delta); });
-    }
-  }
-}
 
 template <int TEAM, bool BINF>
 __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, const double* xk, const double* sj,
