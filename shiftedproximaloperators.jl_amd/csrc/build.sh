@@ -12,7 +12,7 @@ mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden
        -Wall -Wno-unused-variable -Wno-unused-but-set-variable -I"$ROOT/include" -I"$HERE" "$@")
-SRCS=(spx_ctx spx_separable spx_separable_f32 spx_select spx_group spx_group_f32 spx_objective spx_b2 spx_host)
+SRCS=(spx_ctx spx_separable spx_separable_f32 spx_select spx_group spx_group_team spx_group_f32 spx_objective spx_b2 spx_host)
 pids=()
 objs=()
 for s in "${SRCS[@]}"; do

@@ -123,6 +123,7 @@ constexpr int kB2Cols = 256;   // workgroups at most
 constexpr int kB2Words = 8;
 constexpr size_t kB2SetWords = (size_t)kB2MaxPass * kB2Cols * kB2Words;
 constexpr size_t kB2SyncBytes = 2 * kB2SetWords * sizeof(unsigned long long);   // 2 MiB, behind the select state
+static_assert(kB2SyncBytes == kSpxSyncB2Bytes, "spx_ctx::sync layout");
 __device__ __forceinline__ void b2_put(unsigned long long* slot, double v) {
   const unsigned long long b = (v != v) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(v);
   __hip_atomic_store(slot, b + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (an atomic swap instead: no faster)

@@ -42,6 +42,7 @@ struct spx_ctx {
   int graph_safe = 0;
   int b2_set = 0;                 // ShiftedNormL1B2: the set of partial-sum words the next launch uses (spx_b2.hip, b2_put)
   int b2_dirty_g[2] = {0, 0};     // ... and how many workgroups wrote into each set (0 = clean)
+  int team_set = 0;               // spx_group_team.hip: the set of exchange words the next team launch uses (it clears the other one)
   int sel_hist_next = 0;            // spx_select.hip: histogram set (0/1) the next k_sel_coop launch uses ...
   int sel_hist_dirty[2] = {0, 0};   // ... and which sets a previous launch left non-zero
   // spx_ctx_set_value_target: when non-NULL, the value-returning entry points (spx_obj_*, spx_proxval_*) store their
@@ -63,6 +64,10 @@ struct spx_ctx {
   int tune_front_spl = 0;          // key 10: samples per lane of the top-r front kernel (1, 2, 4, 16; 0 = by n and r / n)
   int tune_sel_reg16 = 1;          // key 11: register-resident one-launch top-r at 16 elements per lane (2 Mi < n <= 4 Mi on 256 CUs)
   int tune_b2_lds = 1;             // key 12: ShiftedNormL1B2 with xk parked in LDS between the register form and the streaming form (2 Mi < n <= 4 Mi)
+  int tune_team = 1;               // key 13: large contiguous groups (first of all ONE group over the whole vector) are owned by a team of
+                                   //         workgroups (spx_group_team.hip); 0 = one workgroup per group as in rounds 1-3
+  int tune_team_fast = 1;          // key 14: ... and the Binf form of that takes its sample-predicted two-pass path (0 = generic body: one
+                                   //         streaming pass per reduction)
   int tune_force_grid = 0;         // key 100, test builds only (-DSPX_TEST_HOOKS): launch the one-launch top-r with THIS many workgroups,
                                    //          residency or not -- the planted fault behind tests/test_gpu_robustness.py
   // Device-side status word in host-mapped pinned memory (spx_ctx.hip): a kernel that gives up waiting for the other
@@ -104,6 +109,14 @@ int spx_zero_async(spx_ctx* ctx, void* ptr, size_t bytes);
 int spx_zero2d_async(spx_ctx* ctx, void* ptr, size_t pitch_bytes, size_t width_bytes, size_t rows);
 bool spx_capture_check(spx_ctx* ctx);
 int spx_require_not_capturing(spx_ctx* ctx, const char* what);
+
+// spx_group_team.hip (large contiguous groups on teams of workgroups), called from run_group in spx_group.hip
+int spx_group_team_max_grid(spx_ctx* ctx, bool binf);
+int spx_group_team_plan(spx_ctx* ctx, bool binf, const double* y, const double* q, const double* xk, const double* sj,
+                        int64_t n, const int64_t* offsets, int64_t ngroups, int64_t big_min, const int** active_dev);
+int spx_group_team_launch(spx_ctx* ctx, bool binf, double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                          const int64_t* offsets, int64_t gsize, int64_t ngroups, const double* lambda, double sigma,
+                          double delta);
 
 // Two launches that synchronise inside themselves must not run side by side on one device: each would hold CUs while it
 // waits for workgroups of its own that cannot be placed.  Contexts on different streams are therefore chained through one
@@ -219,6 +232,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // spx_ctx::sync: [0, kSpxSyncSelBytes) belongs to spx_select.hip (SelSync, whose head is the SpxSyncHeader below), the
 // partial-sum words of spx_b2.hip follow.  Zero-filled when (re)allocated; the host-side flags are reset with it.
 constexpr size_t kSpxSyncSelBytes = (size_t)2 << 20;  // 2 MiB >= sizeof(SelSync) (static_assert in spx_select.hip)
+constexpr size_t kSpxSyncB2Bytes = (size_t)2 << 20;   // the exchange words of spx_b2.hip (static_assert there)
+constexpr size_t kSpxSyncTeamOffset = kSpxSyncSelBytes + kSpxSyncB2Bytes;  // ... and behind them those of spx_group_team.hip:
+constexpr size_t kSpxSyncTeamBytes = (size_t)512 << 10;                    // two sets of kGtSetWords words (static_assert in spx_group_common.hpp)
 
 // Head of spx_ctx::sync, shared by every kernel that synchronises inside one launch.
 constexpr int kSpxBarSplit = 8;  // arrival counters per grid barrier (see spx_grid_rendezvous)

@@ -148,6 +148,8 @@ SPX_EXPORT int spx_ctx_set_tuning(spx_ctx* ctx, int key, int value) {
     case 10: if (value != 0 && value != 1 && value != 2 && value != 4 && value != 16) break; ctx->tune_front_spl = value; return SPX_OK;
     case 11: ctx->tune_sel_reg16 = value ? 1 : 0; return SPX_OK;
     case 12: ctx->tune_b2_lds = value ? 1 : 0; return SPX_OK;
+    case 13: ctx->tune_team = value ? 1 : 0; return SPX_OK;
+    case 14: ctx->tune_team_fast = value ? 1 : 0; return SPX_OK;
 #ifdef SPX_TEST_HOOKS
     case 100: if (value < 0 || value > 65535) break; ctx->tune_force_grid = value; return SPX_OK;
 #endif
@@ -189,6 +191,7 @@ SPX_EXPORT int spx_sync(spx_ctx* ctx) {
       ctx->coop_parity = 0;
       ctx->b2_set = 0;
       ctx->b2_dirty_g[0] = ctx->b2_dirty_g[1] = 0;
+      ctx->team_set = 0;
       ctx->sel_hist_next = 0;
       ctx->sel_hist_dirty[0] = ctx->sel_hist_dirty[1] = 0;
     }
@@ -340,6 +343,7 @@ int spx_sync_reserve(spx_ctx* ctx, size_t bytes) {
   ctx->coop_parity = 0;
   ctx->b2_set = 0;
   ctx->b2_dirty_g[0] = ctx->b2_dirty_g[1] = 0;
+  ctx->team_set = 0;
   ctx->sel_hist_next = 0;
   ctx->sel_hist_dirty[0] = ctx->sel_hist_dirty[1] = 0;
   return SPX_OK;

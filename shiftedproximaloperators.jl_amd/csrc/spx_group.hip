@@ -278,8 +278,11 @@ __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, c
                                                     int64_t n, const int64_t* __restrict__ offsets, int64_t gsize,
                                                     int64_t ngroups, const double* __restrict__ lambda, double sigma,
                                                     double delta, const long long* list /* NULL, or [0] = count, [1..] */,
-                                                    int* status /* spx_ctx::status_dev */, int pole_lit) {
+                                                    int* status /* spx_ctx::status_dev */, int pole_lit,
+                                                    const int* big_active /* NULL, or a device word: skip groups of >= big_min elements (spx_group_team.hip has them) */,
+                                                    int64_t big_min) {
   __shared__ double lds[8];
+  const bool skip_big = big_active != nullptr && *big_active != 0;
   constexpr int TPB = 256 / TEAM;  // teams per block
   const int lane = threadIdx.x % TEAM;
   const int64_t team = (int64_t)blockIdx.x * TPB + threadIdx.x / TEAM;
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(256) void k_group_mem(double* y, const double* q, c
     else { lo = g * gsize; hi = lo + gsize; }
     if (lo < 0) lo = 0;
     if (hi > n) hi = n;
+    if (skip_big && hi - lo >= big_min) continue;  // (team- and block-uniform)
     MemGroup<TEAM> grp{q, xk, sj, lo, hi, lane};
     group_body<TEAM, BINF>(grp, y, lambda[g], sigma, delta, lds, list != nullptr, pole_lit != 0);
     if constexpr (TEAM == 256) __syncthreads();
@@ -577,7 +581,7 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     if (BINF || ragged_reg) {  // usually an empty list: the kernel returns at once
       hipLaunchKernelGGL((k_group_mem<64, BINF>), dim3((unsigned)(ctx->num_cu * 2)), dim3(256), 0, ctx->stream, y, q, xk,
                          sj, n, ragged_reg ? offsets : (const int64_t*)nullptr, gsize, ngroups, lambda, sigma, delta,
-                         (const long long*)deferred, ctx->status_dev, ctx->tune_binf_literal);
+                         (const long long*)deferred, ctx->status_dev, ctx->tune_binf_literal, (const int*)nullptr, (int64_t)0);
     }
     SPX_LAUNCH_CHECK();
     return SPX_OK;
@@ -599,6 +603,22 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     SPX_LAUNCH_CHECK();
     return SPX_OK;
   }
+  // Few, large groups -- first of all ONE group over the whole vector, the reference's default GroupNormL2
+  // (src/groupNormL2.jl:30-31, shifted(NormL2(lambda), xk): src/shiftedGroupNormL2.jl:34-35): a team of workgroups per
+  // group (spx_group_team.hip) instead of one workgroup (n = 1e8: 384 ms plain / 1349 ms Binf that way).  With at least two
+  // groups per CU the one-workgroup-per-group kernel below fills the chip by itself.
+  const int* big_active = nullptr;   // ragged layouts: device word of the team plan, "the large groups are taken care of"
+  const int64_t big_min = 16384;     // ragged layouts: a group of at least this many elements is a large one
+  if (ctx->tune_team) {
+    if (!offsets) {
+      const int tg = spx_group_team_max_grid(ctx, BINF);
+      if (tg >= 1 && ngroups < 2 * (int64_t)tg)
+        return spx_group_team_launch(ctx, BINF, y, q, xk, sj, n, nullptr, gsize, ngroups, lambda, sigma, delta);
+    } else if (ngroups <= 65536) {
+      rc = spx_group_team_plan(ctx, BINF, y, q, xk, sj, n, offsets, ngroups, big_min, &big_active);
+      if (rc) return rc;
+    }
+  }
   if (!BINF && offsets)
     hipLaunchKernelGGL(k_csr_uncovered, dim3(256), dim3(256), 0, ctx->stream, y, xk, sj, offsets, ngroups, n);
   const double avg = (double)n / (double)ngroups;
@@ -611,7 +631,8 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     if (blocks > cap_blocks) blocks = cap_blocks;
 #define SPX_LAUNCH_MEM(TEAM)                                                                                              \
   hipLaunchKernelGGL((k_group_mem<TEAM, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n, offsets, \
-                     gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr, ctx->status_dev, ctx->tune_binf_literal)
+                     gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr, ctx->status_dev, ctx->tune_binf_literal, \
+                     big_active, big_min)
     if (team == 4) SPX_LAUNCH_MEM(4);
     else if (team == 8) SPX_LAUNCH_MEM(8);
     else if (team == 16) SPX_LAUNCH_MEM(16);
@@ -621,9 +642,12 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   } else {
     int64_t blocks = ngroups < cap_blocks ? ngroups : cap_blocks;
     hipLaunchKernelGGL((k_group_mem<256, BINF>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, xk, sj, n,
-                       offsets, gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr, ctx->status_dev, ctx->tune_binf_literal);
+                       offsets, gsize, ngroups, lambda, sigma, delta, (const long long*)nullptr, ctx->status_dev, ctx->tune_binf_literal,
+                       big_active, big_min);
   }
   SPX_LAUNCH_CHECK();
+  if (big_active)  // the large groups of a ragged layout (the kernel returns at once when the plan found none)
+    return spx_group_team_launch(ctx, BINF, y, q, xk, sj, n, offsets, gsize, ngroups, lambda, sigma, delta);
   return SPX_OK;
 }
 

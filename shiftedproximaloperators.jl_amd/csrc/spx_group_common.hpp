@@ -27,9 +27,116 @@ __device__ __forceinline__ double lanes_sum(double v) {
   if constexpr (TEAM >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
+// ---------------------------------------------------------------------------------------------
+// TEAM == kTeamGrid: the team is a range of 1024-lane WORKGROUPS of one resident grid (spx_group_team.hip: a group too
+// large for one workgroup -- first of all the reference's default GroupNormL2, one group over the whole vector).  The `lds`
+// argument of the team reductions then points at a GridTeam in LDS.  A reduction = wavefront butterflies, the 16 wave slots
+// in a fixed order, then -- for a team of more than one workgroup -- an exchange of the workgroup totals through words in
+// spx_ctx::sync that carry their own ready flag (bits(v) + 1, never 0: the idea of spx_b2.hip), read back by the lanes
+// t < W and combined in the same fixed shape: every workgroup of the team forms bit-identical totals, so the scalar
+// decisions that follow are taken alike everywhere.  Rows are reused cyclically: a workgroup clears its own words of row
+// k - 1 once it has read all of row k (every member stored into row k after it was done with row k - 1); the words of the
+// last two reductions are left behind and the next launch, which works on the other set, clears them.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTeamGrid = 1024;
+constexpr int kGtRows = 8;      // exchange rows, reused cyclically
+constexpr int kGtCols = 256;    // workgroups of a launch at most
+constexpr int kGtWords = 16;    // words per workgroup and row (one 128-byte line)
+constexpr int kGtVals = 10;     // values per reduction at most
+constexpr size_t kGtSetWords = (size_t)kGtRows * kGtCols * kGtWords;
+static_assert(2 * kGtSetWords * sizeof(unsigned long long) <= kSpxSyncTeamBytes, "team exchange words");
+struct GridTeam {
+  double slot[kGtVals][16];     // wave totals
+  unsigned long long* rows;     // this launch's set of exchange words
+  SpxSyncHeader* hdr;
+  int first, W;                 // the team = workgroups [first, first + W) of the grid
+  int np;                       // reductions this team has exchanged so far in this launch
+};
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// v[k] <- sum (or max, where bit k of maxmask is set; NaN-free values) of v[k] over all lanes of all workgroups of the team
+template <int NV>
+__device__ __forceinline__ void grid_team_reduce(GridTeam* gt, double (&v)[NV], unsigned int maxmask) {
+  static_assert(NV <= kGtVals && NV <= kGtWords, "NV");
+  const int t = threadIdx.x, w = t >> 6;
+  auto block_combine = [&](double (&x)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) x[k] = ((maxmask >> k) & 1u) ? wave_max(x[k]) : wave_sum(x[k]);
+    __syncthreads();  // the slots are free (and gt->np of the previous reduction is visible)
+    if ((t & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) gt->slot[k][w] = x[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double acc = gt->slot[k][0];
+      if ((maxmask >> k) & 1u) {
+#pragma unroll
+        for (int j = 1; j < 16; ++j) acc = fmax(acc, gt->slot[k][j]);
+      } else {
+#pragma unroll
+        for (int j = 1; j < 16; ++j) acc += gt->slot[k][j];
+      }
+      x[k] = acc;
+    }
+  };
+  block_combine(v);
+  const int W = gt->W;
+  if (W > 1) {
+    const int np = gt->np;
+    unsigned long long* row = gt->rows + (size_t)(np % kGtRows) * kGtCols * kGtWords;
+    if (t == 0) {
+      unsigned long long* mine = row + (size_t)blockIdx.x * kGtWords;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const unsigned long long b = (v[k] != v[k]) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(v[k]);
+        __hip_atomic_store(mine + k, b + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    double g[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) g[k] = ((maxmask >> k) & 1u) ? -INFINITY : 0.0;
+    if (t < W) {
+      const unsigned long long* theirs = row + (size_t)(gt->first + t) * kGtWords;
+      unsigned long long word[NV];
+      unsigned int spins = 0;
+      for (;;) {  // (every workgroup of the team is resident and stores these words once per reduction; bounded all the same)
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          word[k] = __hip_atomic_load(theirs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          all = all && (word[k] != 0ull);
+        }
+        if (all) break;
+        if (spx_wait_expired(spins, gt->hdr)) break;  // (the totals come out as garbage: the caller stores NaN, spx_poisoned)
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) g[k] = __longlong_as_double((long long)(word[k] - 1ull));
+    }
+    block_combine(g);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = g[k];
+    // this workgroup's words of the previous row: nobody reads them any more
+    if (np > 0 && t < kGtWords)
+      __hip_atomic_store(gt->rows + (size_t)((np - 1) % kGtRows) * kGtCols * kGtWords + (size_t)blockIdx.x * kGtWords + t, 0ull,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();  // everyone has read gt->np
+    if (t == 0) gt->np = np + 1;
+  }
+}
+
 template <int TEAM>
 __device__ __forceinline__ double team_sum(double v, double* lds /* 8 doubles per block, TEAM == 256 only */) {
-  if constexpr (TEAM == 256) {
+  if constexpr (TEAM == kTeamGrid) {
+    double a[1] = {v};
+    grid_team_reduce<1>(reinterpret_cast<GridTeam*>(lds), a, 0u);
+    return a[0];
+  } else if constexpr (TEAM == 256) {
     v = lanes_sum<64>(v);
     const int w = threadIdx.x >> 6;
     __syncthreads();  // previous use of lds finished
@@ -42,7 +149,12 @@ __device__ __forceinline__ double team_sum(double v, double* lds /* 8 doubles pe
 }
 template <int TEAM>
 __device__ __forceinline__ void team_sum2(double& a, double& b, double* lds) {
-  if constexpr (TEAM == 256) {
+  if constexpr (TEAM == kTeamGrid) {
+    double ab[2] = {a, b};
+    grid_team_reduce<2>(reinterpret_cast<GridTeam*>(lds), ab, 0u);
+    a = ab[0];
+    b = ab[1];
+  } else if constexpr (TEAM == 256) {
     a = lanes_sum<64>(a);
     b = lanes_sum<64>(b);
     const int w = threadIdx.x >> 6;
@@ -60,6 +172,11 @@ __device__ __forceinline__ void team_sum2(double& a, double& b, double* lds) {
 // max over the team of a NaN-free value
 template <int TEAM>
 __device__ __forceinline__ double team_max(double v, double* lds) {
+  if constexpr (TEAM == kTeamGrid) {
+    double a[1] = {v};
+    grid_team_reduce<1>(reinterpret_cast<GridTeam*>(lds), a, 1u);
+    return a[0];
+  }
   if constexpr (TEAM >= 2) v = fmax(v, dpp_f64<0xB1>(v));
   if constexpr (TEAM >= 4) v = fmax(v, dpp_f64<0x4E>(v));
   if constexpr (TEAM >= 8) v = fmax(v, dpp_f64<0x141>(v));
