@@ -234,7 +234,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 constexpr size_t kSpxSyncSelBytes = (size_t)2 << 20;  // 2 MiB >= sizeof(SelSync) (static_assert in spx_select.hip)
 constexpr size_t kSpxSyncB2Bytes = (size_t)2 << 20;   // the exchange words of spx_b2.hip (static_assert there)
 constexpr size_t kSpxSyncTeamOffset = kSpxSyncSelBytes + kSpxSyncB2Bytes;  // ... and behind them those of spx_group_team.hip:
-constexpr size_t kSpxSyncTeamBytes = (size_t)512 << 10;                    // two sets of kGtSetWords words (static_assert in spx_group_common.hpp)
+constexpr size_t kSpxSyncTeamBytes = ((size_t)512 << 10) + 4096;           // two sets of kGtSetWords words + two sets of tile counters (static_assert in spx_group_common.hpp)
 
 // Head of spx_ctx::sync, shared by every kernel that synchronises inside one launch.
 constexpr int kSpxBarSplit = 8;  // arrival counters per grid barrier (see spx_grid_rendezvous)

@@ -44,90 +44,117 @@ constexpr int kGtCols = 256;    // workgroups of a launch at most
 constexpr int kGtWords = 16;    // words per workgroup and row (one 128-byte line)
 constexpr int kGtVals = 10;     // values per reduction at most
 constexpr size_t kGtSetWords = (size_t)kGtRows * kGtCols * kGtWords;
-static_assert(2 * kGtSetWords * sizeof(unsigned long long) <= kSpxSyncTeamBytes, "team exchange words");
+static_assert(2 * kGtSetWords * sizeof(unsigned long long) + 2 * kGtCols * sizeof(unsigned int) <= kSpxSyncTeamBytes, "team exchange words");
 struct GridTeam {
-  double slot[kGtVals][16];     // wave totals
+  double slot[2][kGtVals][16];  // wave totals; two sets, alternating between calls (one workgroup barrier per combine)
   unsigned long long* rows;     // this launch's set of exchange words
   SpxSyncHeader* hdr;
   int first, W;                 // the team = workgroups [first, first + W) of the grid
-  int np;                       // reductions this team has exchanged so far in this launch
+  // per WAVEFRONT copies (lane 0 of a wavefront writes its own, the wavefront reads its own: program order, no barrier):
+  int wnp[16];                  // reductions this team has exchanged so far in this launch (the row of the exchange words)
+  int wcalls[16];               // workgroup combines so far (parity = slot set)
 };
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+// sum / max over the 64 lanes of a wavefront, result in every lane: DPP inside the 16-lane rows, two permutes across them
+// (the xor butterfly of wave_sum is six permutes per double: the reductions of a root find are latency, not bandwidth)
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {
+  v = fmax(v, dpp_f64<0xB1>(v));
+  v = fmax(v, dpp_f64<0x4E>(v));
+  v = fmax(v, dpp_f64<0x141>(v));
+  v = fmax(v, dpp_f64<0x140>(v));
+  v = fmax(v, __shfl_xor(v, 16, 64));
+  v = fmax(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+// x[k] <- sum / max over the 1024 lanes of the workgroup, the same bits in every lane: wavefront reductions, one slot per
+// wavefront, ONE barrier, then every 16-lane row reads the 16 slots and folds them by DPP (a fixed shape; every lane reading
+// all 16 slots itself cost 16 NV LDS instructions per wavefront: 5.7 us for ten values, tools/exp/team_reduce.hip).
+// `set`: the slot set of this call (the callers alternate, so that no barrier is needed before the slots are rewritten).
+template <int NV>
+__device__ __forceinline__ void grid_team_block_combine(GridTeam* gt, double (&x)[NV], unsigned int maxmask, int set) {
+  const int t = threadIdx.x, w = t >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) x[k] = ((maxmask >> k) & 1u) ? wave_max_dpp(x[k]) : wave_sum_dpp(x[k]);
+  if ((t & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) gt->slot[set][k][w] = x[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double v = gt->slot[set][k][t & 15];
+    if ((maxmask >> k) & 1u) {
+      v = fmax(v, dpp_f64<0xB1>(v));
+      v = fmax(v, dpp_f64<0x4E>(v));
+      v = fmax(v, dpp_f64<0x141>(v));
+      v = fmax(v, dpp_f64<0x140>(v));
+    } else {
+      v += dpp_f64<0xB1>(v);
+      v += dpp_f64<0x4E>(v);
+      v += dpp_f64<0x141>(v);
+      v += dpp_f64<0x140>(v);
+    }
+    x[k] = v;
+  }
 }
 // v[k] <- sum (or max, where bit k of maxmask is set; NaN-free values) of v[k] over all lanes of all workgroups of the team
 template <int NV>
 __device__ __forceinline__ void grid_team_reduce(GridTeam* gt, double (&v)[NV], unsigned int maxmask) {
   static_assert(NV <= kGtVals && NV <= kGtWords, "NV");
   const int t = threadIdx.x, w = t >> 6;
-  auto block_combine = [&](double (&x)[NV]) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) x[k] = ((maxmask >> k) & 1u) ? wave_max(x[k]) : wave_sum(x[k]);
-    __syncthreads();  // the slots are free (and gt->np of the previous reduction is visible)
-    if ((t & 63) == 0) {
-#pragma unroll
-      for (int k = 0; k < NV; ++k) gt->slot[k][w] = x[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      double acc = gt->slot[k][0];
-      if ((maxmask >> k) & 1u) {
-#pragma unroll
-        for (int j = 1; j < 16; ++j) acc = fmax(acc, gt->slot[k][j]);
-      } else {
-#pragma unroll
-        for (int j = 1; j < 16; ++j) acc += gt->slot[k][j];
-      }
-      x[k] = acc;
-    }
-  };
-  block_combine(v);
+  const int calls = gt->wcalls[w];
+  grid_team_block_combine<NV>(gt, v, maxmask, calls & 1);
   const int W = gt->W;
-  if (W > 1) {
-    const int np = gt->np;
-    unsigned long long* row = gt->rows + (size_t)(np % kGtRows) * kGtCols * kGtWords;
-    if (t == 0) {
-      unsigned long long* mine = row + (size_t)blockIdx.x * kGtWords;
+  if (W == 1) {
+    if ((t & 63) == 0) gt->wcalls[w] = calls + 1;
+    return;
+  }
+  const int np = gt->wnp[w];
+  unsigned long long* row = gt->rows + (size_t)(np % kGtRows) * kGtCols * kGtWords;
+  if (t < NV) {  // lane k publishes word k
+    double mine = v[0];
+#pragma unroll
+    for (int k = 1; k < NV; ++k) mine = (t == k) ? v[k] : mine;
+    const unsigned long long b = (mine != mine) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(mine);
+    __hip_atomic_store(row + (size_t)blockIdx.x * kGtWords + t, b + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  double g[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) g[k] = ((maxmask >> k) & 1u) ? -INFINITY : 0.0;
+  if (t < W) {
+    const unsigned long long* theirs = row + (size_t)(gt->first + t) * kGtWords;
+    unsigned long long word[NV];
+    unsigned int spins = 0;
+    for (;;) {  // (every workgroup of the team is resident and stores these words once per reduction; bounded all the same)
+      bool all = true;
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
-        const unsigned long long b = (v[k] != v[k]) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(v[k]);
-        __hip_atomic_store(mine + k, b + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        word[k] = __hip_atomic_load(theirs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        all = all && (word[k] != 0ull);
       }
+      if (all) break;
+      if (spx_wait_expired(spins, gt->hdr)) break;  // (the totals come out as garbage: the caller stores NaN, spx_poisoned)
+      __builtin_amdgcn_s_sleep(1);
     }
-    double g[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) g[k] = ((maxmask >> k) & 1u) ? -INFINITY : 0.0;
-    if (t < W) {
-      const unsigned long long* theirs = row + (size_t)(gt->first + t) * kGtWords;
-      unsigned long long word[NV];
-      unsigned int spins = 0;
-      for (;;) {  // (every workgroup of the team is resident and stores these words once per reduction; bounded all the same)
-        bool all = true;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-          word[k] = __hip_atomic_load(theirs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          all = all && (word[k] != 0ull);
-        }
-        if (all) break;
-        if (spx_wait_expired(spins, gt->hdr)) break;  // (the totals come out as garbage: the caller stores NaN, spx_poisoned)
-        __builtin_amdgcn_s_sleep(1);
-      }
-#pragma unroll
-      for (int k = 0; k < NV; ++k) g[k] = __longlong_as_double((long long)(word[k] - 1ull));
-    }
-    block_combine(g);
-#pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = g[k];
-    // this workgroup's words of the previous row: nobody reads them any more
-    if (np > 0 && t < kGtWords)
-      __hip_atomic_store(gt->rows + (size_t)((np - 1) % kGtRows) * kGtCols * kGtWords + (size_t)blockIdx.x * kGtWords + t, 0ull,
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();  // everyone has read gt->np
-    if (t == 0) gt->np = np + 1;
+    for (int k = 0; k < NV; ++k) g[k] = __longlong_as_double((long long)(word[k] - 1ull));
   }
+  grid_team_block_combine<NV>(gt, g, maxmask, (calls + 1) & 1);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = g[k];
+  // this workgroup's words of the previous row: nobody reads them any more
+  if (np > 0 && t < kGtWords)
+    __hip_atomic_store(gt->rows + (size_t)((np - 1) % kGtRows) * kGtCols * kGtWords + (size_t)blockIdx.x * kGtWords + t, 0ull,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((t & 63) == 0) { gt->wnp[w] = np + 1; gt->wcalls[w] = calls + 2; }
 }
 
 template <int TEAM>

@@ -217,6 +217,133 @@ __global__ __launch_bounds__(256) void k_obj_group(const T* __restrict__ y, cons
   if (__any(bad_index) && (threadIdx.x & 63) == 0) atomicOr(&ws->infeasible, 2);
 }
 
+// LARGE contiguous groups -- first of all ONE group over the whole vector, the reference's default GroupNormL2
+// (src/groupNormL2.jl:30-31; psi(y) of shifted(NormL2(lambda), xk)): k_obj_group gives a group to (at most) one wavefront,
+// i.e. the whole vector to 64 lanes (n = 1e8: 380 ms, profiles/r04_big_groups_baseline.txt).  Here every group is cut into
+// chunks of kObjChunk elements, one 256-lane workgroup per chunk (16 elements per lane, 24 16-byte loads in flight), the
+// chunk sums land in library scratch and k_obj_chunk_groups adds the chunks of each group in index order: reproducible.
+constexpr int kObjChunk = 4096;
+// chunks before group g (CSR layouts; uniform groups need no table)
+__global__ __launch_bounds__(1024) void k_obj_chunk_prefix(const int64_t* __restrict__ offsets, int64_t ngroups, int64_t n,
+                                                            int64_t* __restrict__ prefix /* ngroups + 1 */) {
+  __shared__ long long part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (ngroups + 1023) / 1024;
+  const int64_t g0 = (int64_t)t * per, g1 = (g0 + per < ngroups) ? g0 + per : ngroups;
+  auto chunks_of = [&](int64_t g) -> int64_t {
+    int64_t lo = offsets[g], hi = offsets[g + 1];
+    if (lo < 0) lo = 0;
+    if (hi > n) hi = n;
+    return hi > lo ? (hi - lo + kObjChunk - 1) / kObjChunk : 0;
+  };
+  long long mine = 0;
+  for (int64_t g = g0; g < g1; ++g) mine += chunks_of(g);
+  part[t] = mine;
+  __syncthreads();
+  if (t == 0) {
+    long long acc = 0;
+    for (int k = 0; k < 1024; ++k) { const long long c = part[k]; part[k] = acc; acc += c; }
+    prefix[ngroups] = acc;
+  }
+  __syncthreads();
+  long long acc = part[t];
+  for (int64_t g = g0; g < g1; ++g) { prefix[g] = acc; acc += chunks_of(g); }
+}
+// sum of squares of xsy over one chunk -> chunk_ss[k].  par: bit 3 of the vectors' addresses when they agree (16-byte pairs
+// from the first element on the pair grid, the at most two others by lane 0), -1: 8-byte loads.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_obj_chunks(const double* __restrict__ y, const double* __restrict__ xk,
+                                                     const double* __restrict__ sj, int64_t n,
+                                                     const int64_t* __restrict__ offsets, int64_t gsize, int64_t ngroups,
+                                                     const int64_t* __restrict__ prefix, int64_t nchunks_uniform, int par,
+                                                     double rad, double* __restrict__ chunk_ss, ObjWs* ws) {
+  __shared__ double lds4[4];
+  const int t = threadIdx.x;
+  const int64_t K = prefix ? prefix[ngroups] : nchunks_uniform;
+  const int64_t cpg = (gsize + kObjChunk - 1) / kObjChunk;  // (uniform groups)
+  bool bad = false;
+  for (int64_t k = blockIdx.x; k < K; k += gridDim.x) {
+    int64_t lo, hi;
+    if (prefix) {
+      int64_t a = 0, b = ngroups;  // the last g with prefix[g] <= k
+      while (b - a > 1) {
+        const int64_t m = (a + b) >> 1;
+        if (prefix[m] <= k) a = m; else b = m;
+      }
+      int64_t glo = offsets[a], ghi = offsets[a + 1];
+      if (glo < 0) glo = 0;
+      if (ghi > n) ghi = n;
+      lo = glo + (k - prefix[a]) * kObjChunk;
+      hi = lo + kObjChunk < ghi ? lo + kObjChunk : ghi;
+    } else {
+      const int64_t g = k / cpg, c = k % cpg;
+      lo = g * gsize + c * kObjChunk;
+      hi = (c + 1) * (int64_t)kObjChunk < gsize ? lo + kObjChunk : (g + 1) * gsize;
+    }
+    double ss = 0.0;
+    auto visit = [&](double yi, double xi, double si) {
+      double v;
+      if constexpr (MODE == 2) {
+        const double tt = si + yi;
+        bad |= (tt < -rad) || (tt > rad);
+        v = tt + xi;
+      } else {
+        v = (xi + si) + yi;
+      }
+      ss = __builtin_fma(v, v, ss);
+    };
+    if (par >= 0) {
+      const int64_t a = lo + ((lo + par) & 1);
+      const int64_t np = a < hi ? (hi - a) >> 1 : 0;
+      const f64x2* y2 = reinterpret_cast<const f64x2*>(y + a);
+      const f64x2* x2 = reinterpret_cast<const f64x2*>(xk + a);
+      const f64x2* s2 = reinterpret_cast<const f64x2*>(sj + a);
+      f64x2 yv[8], xv[8], sv[8];
+      if (np > 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int64_t i = (t + j * 256 < np) ? t + j * 256 : np - 1;
+          yv[j] = __builtin_nontemporal_load(y2 + i);
+          xv[j] = __builtin_nontemporal_load(x2 + i);
+          sv[j] = __builtin_nontemporal_load(s2 + i);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (t + j * 256 < np) {
+            visit(yv[j].x, xv[j].x, sv[j].x);
+            visit(yv[j].y, xv[j].y, sv[j].y);
+          }
+        }
+      }
+      if (t == 0) {
+        if (lo < a && lo < hi) visit(y[lo], xk[lo], sj[lo]);
+        if (a + 2 * np < hi && hi - 1 >= a) visit(y[hi - 1], xk[hi - 1], sj[hi - 1]);
+      }
+    } else {
+      for (int64_t i = lo + t; i < hi; i += 256) visit(y[i], xk[i], sj[i]);
+    }
+    ss = block_sum(ss, lds4);
+    if (t == 0) chunk_ss[k] = ss;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0 && (__hip_atomic_load(&ws->infeasible, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) == 0)
+    atomicOr(&ws->infeasible, 1);
+}
+// ws->partial[b] = sum over the groups b, b + grid, ... of lambda_g sqrt(sum of the group's chunk sums, in index order)
+__global__ __launch_bounds__(256) void k_obj_chunk_groups(const double* __restrict__ chunk_ss, const int64_t* __restrict__ prefix,
+                                                           int64_t cpg, int64_t ngroups, const double* __restrict__ lambda,
+                                                           ObjWs* ws) {
+  __shared__ double lds4[4];
+  double acc = 0.0;
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t c0 = prefix ? prefix[g] : g * cpg, c1 = prefix ? prefix[g + 1] : (g + 1) * cpg;
+    double ss = 0.0;
+    for (int64_t c = c0 + threadIdx.x; c < c1; c += 256) ss += chunk_ss[c];
+    ss = block_sum(ss, lds4);
+    if (threadIdx.x == 0) acc += lambda[g] * sqrt(ss);
+  }
+  if (threadIdx.x == 0) ws->partial[blockIdx.x] = acc;
+}
+
 // IndBallLinf(1.1 Delta)(sj + y) over EVERY index (src/shiftedGroupNormL2Binf.jl:35-36), for groups that need not tile 1:n
 template <class T>
 __global__ __launch_bounds__(256) void k_obj_linf_scan(const T* __restrict__ y, const T* __restrict__ sj,
@@ -321,6 +448,40 @@ int run_obj_group(spx_ctx* ctx, const T* y, const T* xk, const T* sj, int64_t n,
   SPX_ON_DEVICE(ctx);
   ObjWs* ws = reinterpret_cast<ObjWs*>(ctx->ws);
   { const int rz = spx_zero_async(ctx, &ws->infeasible, sizeof(int)); if (rz) return rz; }
+  if constexpr (std::is_same<T, double>::value) {
+    // large contiguous groups (uniform size, or CSR offsets with a large average): chunked, the whole chip on every group
+    const int64_t avg = ngroups > 0 ? n / ngroups : 0;
+    if (!index && ngroups > 0 && ctx->tune_team && (offsets ? avg >= 2 * kObjChunk : gsize >= 2 * kObjChunk)) {
+      const int64_t cpg = offsets ? 0 : (gsize + kObjChunk - 1) / kObjChunk;
+      const int64_t kmax = offsets ? n / kObjChunk + ngroups : cpg * ngroups;  // chunks (at most, for CSR layouts)
+      const size_t ss_off = (sizeof(ObjWs) + 255) & ~(size_t)255;
+      const size_t pre_off = ss_off + (((size_t)kmax * sizeof(double) + 255) & ~(size_t)255);
+      rc = spx_ws_reserve(ctx, pre_off + (offsets ? (size_t)(ngroups + 1) * sizeof(int64_t) : 0) + 256);
+      if (rc) return rc;
+      ws = reinterpret_cast<ObjWs*>(ctx->ws);
+      { const int rz = spx_zero_async(ctx, &ws->infeasible, sizeof(int)); if (rz) return rz; }
+      double* chunk_ss = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + ss_off);
+      int64_t* prefix = offsets ? reinterpret_cast<int64_t*>(static_cast<char*>(ctx->ws) + pre_off) : nullptr;
+      if (offsets) hipLaunchKernelGGL(k_obj_chunk_prefix, dim3(1), dim3(1024), 0, ctx->stream, offsets, ngroups, n, prefix);
+      const auto bit3 = [](const void* p) { return (int)((reinterpret_cast<uintptr_t>(p) >> 3) & 1u); };
+      const int par = (bit3(y) == bit3(xk) && bit3(y) == bit3(sj)) ? bit3(y) : -1;
+      int64_t cb = kmax < (int64_t)ctx->num_cu * 64 ? kmax : (int64_t)ctx->num_cu * 64;
+      if (cb < 1) cb = 1;
+      hipLaunchKernelGGL((k_obj_chunks<MODE>), dim3((unsigned)cb), dim3(256), 0, ctx->stream, (const double*)y, (const double*)xk,
+                         (const double*)sj, n, offsets, gsize, ngroups, (const int64_t*)prefix, cpg * ngroups, par, rad, chunk_ss, ws);
+      int64_t gb = ngroups < kObjBlocks ? ngroups : kObjBlocks;
+      hipLaunchKernelGGL(k_obj_chunk_groups, dim3((unsigned)gb), dim3(256), 0, ctx->stream, (const double*)chunk_ss,
+                         (const int64_t*)prefix, cpg, ngroups, (const double*)lambda, ws);
+      if (MODE == 2 && offsets) {  // the groups need not tile 0:n: the trust-region indicator covers every index
+        int64_t sb = (n + 256 * 8 - 1) / (256 * 8);
+        if (sb > kObjBlocks) sb = kObjBlocks;
+        hipLaunchKernelGGL(k_obj_linf_scan<T>, dim3((unsigned)sb), dim3(256), 0, ctx->stream, y, sj, n, rad, ws);
+      }
+      SPX_LAUNCH_CHECK();
+      int bad_;
+      return obj_finish(ctx, ws, (int)gb, kRuleGroup, 1.0, 0.0, value, &bad_);
+    }
+  }
   // lanes per group: about four elements per lane of a typical group (uniform size, the caller's size bound, or the average)
   const int64_t typical = gsize > 0 ? gsize : (ngroups > 0 ? ((index ? nnz : n) + ngroups - 1) / ngroups : 1);
   int team = 1;

@@ -43,6 +43,13 @@ def case(n, cuts, lamscale, delta, tag, fast=1, x0=False, offset=0):
         for _ in range(5): s.prox_bang(yd, psi, qd, 0.7)
         L.spx_timer_stop(ctx, ctypes.byref(ms))
         ok = w <= 1e-12
+        # psi(y) at the prox and at a point outside the trust region
+        for yy in (yd, yd * 1.7):
+            v = psi(yy)
+            vr = oracle.obj_group_l2(yy.cpu().numpy(), xk, sj, lam, offsets=np.array(offs, dtype=np.int64), delta=(delta if name == "binf" else None))
+            okv = (v == vr) or abs(v - vr) <= 1e-12 * abs(vr)
+            if not okv: print("   psi(y) %r vs oracle %r" % (v, vr))
+            ok = ok and okv
         bad += 0 if ok else 1
         print("%-28s n %9d groups %d %-4s fast %d  worst %.2e  %s  %8.1f us  nnz(y+xs) %d" % (tag, n, len(groups), name, fast, w, "ok" if ok else "FAIL", ms.value / 5 * 1e3, int(np.count_nonzero(y + (xk + sj)))), flush=True)
     L.spx_ctx_set_tuning(ctx, 14, 1)
