@@ -358,6 +358,28 @@ __global__ __launch_bounds__(256) void k_obj_linf_scan(const T* __restrict__ y, 
     atomicOr(&ws->infeasible, 1);
 }
 
+// ... the same over the indices OUTSIDE [offsets[0], offsets[ngroups]) only (contiguous CSR groups cover that range themselves;
+// the chunked form has looked at every element of it already)
+__global__ __launch_bounds__(256) void k_obj_linf_uncovered(const double* __restrict__ y, const double* __restrict__ sj, int64_t n,
+                                                             const int64_t* __restrict__ offsets, int64_t ngroups, double rad,
+                                                             ObjWs* ws) {
+  int64_t head = offsets[0], tail0 = offsets[ngroups];
+  if (head < 0) head = 0;
+  if (head > n) head = n;
+  if (tail0 < head) tail0 = head;
+  if (tail0 > n) tail0 = n;
+  const int64_t total = head + (n - tail0);
+  bool bad = false;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t i = (t < head) ? t : tail0 + (t - head);
+    const double v = sj[i] + y[i];
+    bad |= (v < -rad) || (v > rad);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0 && (__hip_atomic_load(&ws->infeasible, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) == 0)
+    atomicOr(&ws->infeasible, 1);
+}
+
 // How the reduced sum and the infeasibility flags turn into psi(y):
 enum ObjRule {
   kRuleScaled = 0,   // lambda * sum                                        (generic forms)
@@ -472,11 +494,9 @@ int run_obj_group(spx_ctx* ctx, const T* y, const T* xk, const T* sj, int64_t n,
       int64_t gb = ngroups < kObjBlocks ? ngroups : kObjBlocks;
       hipLaunchKernelGGL(k_obj_chunk_groups, dim3((unsigned)gb), dim3(256), 0, ctx->stream, (const double*)chunk_ss,
                          (const int64_t*)prefix, cpg, ngroups, (const double*)lambda, ws);
-      if (MODE == 2 && offsets) {  // the groups need not tile 0:n: the trust-region indicator covers every index
-        int64_t sb = (n + 256 * 8 - 1) / (256 * 8);
-        if (sb > kObjBlocks) sb = kObjBlocks;
-        hipLaunchKernelGGL(k_obj_linf_scan<T>, dim3((unsigned)sb), dim3(256), 0, ctx->stream, y, sj, n, rad, ws);
-      }
+      if (MODE == 2 && offsets)  // the groups need not tile 0:n: the trust-region indicator covers every index
+        hipLaunchKernelGGL(k_obj_linf_uncovered, dim3(256), dim3(256), 0, ctx->stream, (const double*)y, (const double*)sj, n, offsets,
+                           ngroups, rad, ws);
       SPX_LAUNCH_CHECK();
       int bad_;
       return obj_finish(ctx, ws, (int)gb, kRuleGroup, 1.0, 0.0, value, &bad_);

@@ -174,6 +174,55 @@ def test_full_size_groups(s, orc, binf):
         assert v.n_checked == 0, v       # the BASELINE distribution meets the plain 1e-12 bar everywhere
 
 
+def test_one_group_over_1e8_elements(s, orc, data):
+    # shifted(NormL2(lambda), xk): the reference's default GroupNormL2, ONE group over the whole vector
+    # (/root/reference/src/shiftedGroupNormL2.jl:34-35, src/groupNormL2.jl:30-31) -- the team form, streamed (csrc/spx_group_team.hip).
+    # ALL 1e8 elements against the oracle, plain 1e-12 bar (scale: tests/test_gpu_parity.py, GROUP_TOL).
+    import torch
+    lam, sigma = 0.4 * N ** 0.5, 0.9
+    psi = s.shifted(s.shifted(s.NormL2(lam), data["x"]), data["s"])
+    assert type(psi).__name__ == "ShiftedGroupNormL2" and list(psi.λ) == [lam]
+    y = s.prox_bang(data["y"], psi, data["q"], sigma)
+    S = (data["q"] + data["x"]) + data["s"]
+    nS = float(S.norm())
+    # block soft-threshold over every element on the device (src/shiftedGroupNormL2.jl:69-75)
+    W = y + (data["x"] + data["s"])
+    assert abs(float(W.norm()) - max(nS - sigma * lam, 0.0)) <= 1e-12 * nS
+    del W, S
+    yh = y.cpu().numpy()
+    q, x, sj = _host(data)
+    ref = orc.prox_group_l2(q, x, sj, [lam], sigma, offsets=np.array([0, N], dtype=np.int64))
+    scale = np.maximum(np.maximum(np.abs(ref), np.abs(x + sj)), nS)
+    assert float(np.max(np.abs(yh - ref) / scale)) <= 1e-12
+    assert np.count_nonzero(yh + (x + sj)) == N
+    # psi(y) = lambda ||xk + sj + y|| on the same group (the chunked form of csrc/spx_objective.hip)
+    v = psi(y)
+    vr = orc.obj_group_l2(yh, x, sj, [lam], offsets=np.array([0, N], dtype=np.int64))
+    assert abs(v - vr) <= 1e-12 * abs(vr)
+
+
+@pytest.mark.parametrize("delta", [1.0, 0.05])
+def test_one_group_binf_over_1e7_elements(s, orc, data, delta):
+    # shifted(NormL2(lambda), xk, Delta, NormLinf(1.0)) (/root/reference/src/shiftedGroupNormL2Binf.jl:48-49): one group, streamed
+    # form, the sample-predicted two-pass path; all 1e7 elements against the oracle (plain 1e-12 bar, the arbiter above it)
+    n = 10_000_000
+    x, sj, q = (data[k][:n] for k in ("x", "s", "q"))
+    lam, sigma = 0.4 * n ** 0.5, 0.9
+    psi = s.shifted(s.shifted(s.NormL2(lam), x, delta, s.NormLinf(1.0)), sj)
+    assert type(psi).__name__ == "ShiftedGroupNormL2Binf"
+    y = s.prox_bang(data["y"][:n], psi, q, sigma)
+    assert float((sj + y).abs().max()) <= delta * (1 + 1e-12)   # inside the trust region
+    yh = y.cpu().numpy()
+    qh, xh, sh = (t.cpu().numpy() for t in (q, x, sj))
+    ref = orc.prox_group_l2_binf(qh, xh, sh, [lam], sigma, delta, offsets=np.array([0, n], dtype=np.int64))
+    v = arbiter.check_group(orc, yh, ref, qh, xh, sh, [lam], sigma, [0, n], delta=delta, what="one group binf 1e7", max_arbitrated=1)
+    assert v.n_checked == 0, v
+    assert np.count_nonzero(yh + (xh + sh)) == n
+    vpsi = psi(y)
+    vr = orc.obj_group_l2(yh, xh, sh, [lam], offsets=np.array([0, n], dtype=np.int64), delta=delta)
+    assert abs(vpsi - vr) <= 1e-12 * abs(vr)
+
+
 @pytest.mark.parametrize("case", ["normal", "quant", "all_equal", "sorted", "two_values", "spike"])
 def test_indball_fast_path_and_fallback(s, orc, case):
     """n = 2^22 + 12345 (the fast-path threshold is 2^20): the sample-predicted band path, its verification and

@@ -97,6 +97,53 @@ def test_norml2_as_one_group(s, orc):  # runtests.jl:216-277
     assert _close(phi(np.zeros(6)), lam * np.linalg.norm(psi.xk + sv))
 
 
+@pytest.mark.parametrize("binf", [False, True])
+def test_norml2_as_one_group_1e6_on_the_device(s, orc, binf):
+    """The reference's NormL2 flow (/root/reference/test/runtests.jl:213-284 plain, :555-606 with the l-infinity trust region) at
+    n = 1e6 on device vectors: `shifted(NormL2(lambda), x)` is ONE group over the vector -- the team form of csrc/spx_group_team.hip
+    (on chip at this size) and the chunked psi(y)."""
+    import torch
+    n = 1_000_000
+    rng = np.random.default_rng(11)
+    lam, nu, Delta = float(rng.random()) * 40.0, float(rng.random()), 0.01
+    xh = np.ones(n)
+    qh = rng.normal(size=n)
+    x = torch.from_numpy(xh).cuda()
+    q = torch.from_numpy(qh).cuda()
+    chi = s.NormLinf(1.0)
+    psi = s.shifted(s.NormL2(lam), x, Delta, chi) if binf else s.shifted(s.NormL2(lam), x)
+    assert type(psi).__name__ == ("ShiftedGroupNormL2Binf" if binf else "ShiftedGroupNormL2")
+    assert bool((psi.sj == 0).all()) and psi.xk is x and list(psi.λ) == [lam]
+    h = lambda z: lam * np.linalg.norm(z)
+    assert _close(psi(torch.zeros_like(x)), h(xh))                      # psi(0) == h(x)
+    yh = rng.random(n)
+    if binf:
+        yh *= Delta / np.max(np.abs(yh)) / 2                             # inside the trust region (:579-581)
+    y = torch.from_numpy(yh).cuda()
+    assert _close(psi(y), h(xh + yh))
+    if binf:
+        assert psi(3 * y) == np.inf                                      # outside the trust region
+    ypsi = s.prox_bang(torch.empty_like(x), psi, q, nu).cpu().numpy()
+    zero = np.zeros(n)
+    off = np.array([0, n], dtype=np.int64)
+    if binf:
+        ref = orc.prox_group_l2_binf(qh, xh, zero, [lam], nu, Delta, offsets=off)
+        assert np.max(np.abs(ypsi)) <= Delta * (1 + 1e-12)               # chi(s) <= Delta (:603)
+    else:
+        v = qh + xh                                                      # NormL2 prox [ext]: max(1 - nu lam / ||v||, 0) v  (:247-251)
+        yp = max(1 - nu * lam / np.linalg.norm(v), 0.0) * v
+        assert np.sqrt(np.sum((ypsi - (yp - xh)) ** 2)) <= 1e-11 * np.sqrt(n)
+        ref = orc.prox_group_l2(qh, xh, zero, [lam], nu, offsets=off)
+    scale = np.maximum(np.maximum(np.abs(ref), np.abs(xh)), np.linalg.norm(qh + xh))
+    assert float(np.max(np.abs(ypsi - ref) / scale)) <= 1e-12
+    s.shift_bang(psi, y)                                                 # shift update (:253-256): xk is the caller's array
+    assert bool((psi.sj == 0).all()) and bool((psi.xk == y).all()) and psi.xk is x
+    sv = torch.full_like(x, 0.5) * (Delta if binf else 1.0)
+    phi = s.shifted(psi, sv)                                             # shift a shifted operator (:258-264)
+    assert phi.sj is sv and phi.xk is psi.xk
+    assert _close(phi(torch.zeros_like(x)), h(yh + sv.cpu().numpy()))
+
+
 def test_groupnorml2_index_vectors(s, orc):  # runtests.jl:286-330: v = [collect(1:3), collect(4:6)]
     rng = np.random.default_rng(2)
     v = [[0, 1, 2], [3, 4, 5]]
