@@ -368,6 +368,41 @@ def _extra(s, L, ctx, dev, n, torch):
             ms = _time_op(s, L, ctx, lambda: s.prox_bang(ys, psi_s, qs, 1.0), iters=50, rounds=5)
             res[name] = {"us": round(ms * 1e3, 2), "avg_launch_ms": round(ms, 5), "kernel": kern, "n": nn,
                          "note": "one launch per call; 32 B/element at 8 TB/s would be %.2f us" % (32 * nn / 8e6)}
+    # ONE group over the whole vector = shifted(NormL2(lambda), xk), the reference's default GroupNormL2 (src/shiftedGroupNormL2.jl:34-35,
+    # src/shiftedGroupNormL2Binf.jl:48-49), and a handful of ragged groups of 0.05 n .. 0.33 n: a team of workgroups per group
+    # (csrc/spx_group_team.hip; round 3: one workgroup per group, 384 / 1349 ms at n = 1e8, profiles/r04_big_groups_baseline.txt).
+    # 32 B/element algorithmic; the streamed form moves 24 + 32 = 56 B/element (one reducing pass, one storing pass).
+    cuts = sorted(set([0, n] + [int(n * f) for f in (0.09, 0.22, 0.31, 0.55, 0.6, 0.93)]))
+    layouts = (("1x%d" % n, s.GroupNormL2([0.5 * n ** 0.5])),
+               ("7ragged_n=%d" % n, s.GroupNormL2([0.5 * (b - a) ** 0.5 for a, b in zip(cuts, cuts[1:])], [range(a, b) for a, b in zip(cuts, cuts[1:])])))
+    big = n > 2_359_296  # (beyond 256 workgroups x 9216 elements the team form streams)
+    for tag, hg in layouts:
+        psi_g, psi_gb = s.shifted(s.shifted(hg, xk), sj), s.shifted(s.shifted(hg, xk, 1.0, chi), sj)
+        line("ShiftedGroupNormL2_" + tag, psi_g, 32, n, y, q, "k_group_team<false, true, 1>" if big else "k_group_team<false, true, 0>")
+        line("ShiftedGroupNormL2Binf_" + tag, psi_gb, 32, n, y, q,
+             "k_group_team<true, true, 2> (+ k_group_team<true, true, 1>, which returns at once)" if big else "k_group_team<true, true, 0>")
+        for nm, pg in (("objective_ShiftedGroupNormL2_" + tag, psi_g), ("objective_ShiftedGroupNormL2Binf_" + tag, psi_gb)):
+            s.prox_bang(y, pg, q, 1.0)
+            with s.device_values(vout):
+                ms = _time_op(s, L, ctx, lambda: pg(y))
+            res[nm] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4), "kernel": "k_obj_chunks<%d> (+ k_obj_chunk_groups, k_obj_final)" % (2 if "Binf" in nm else 0),
+                       "gelem_s": round(n / ms / 1e6, 2), "gbs_algorithmic": round(24 * n / ms / 1e6, 1),
+                       "frac_of_peak": round(24 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+                       "note": "psi(y) at the prox, 24 B/element, value stored in a device double"}
+    for nn in (4_000_000, 1_000_000, 100_000):   # per-call latency of the one-group forms at solver-iteration sizes
+        if nn > n:
+            continue
+        xs, ss_, qs, ys = xk[:nn], sj[:nn], q[:nn], y[:nn]
+        hs_ = s.GroupNormL2([0.5 * nn ** 0.5])
+        for name, psi_s, kern in (("ShiftedGroupNormL2_1x%d" % nn, s.shifted(s.shifted(hs_, xs), ss_), "k_group_team<false, true, %d>" % (1 if nn > 2_359_296 else 0)),
+                                  ("ShiftedGroupNormL2Binf_1x%d" % nn, s.shifted(s.shifted(hs_, xs, 1.0, chi), ss_),
+                                   "k_group_team<true, true, 2>" if nn > 2_359_296 else "k_group_team<true, true, 0>")):
+            if name in res:
+                continue
+            s.prox_bang(ys, psi_s, qs, 1.0)
+            ms = _time_op(s, L, ctx, lambda: s.prox_bang(ys, psi_s, qs, 1.0), iters=50, rounds=5)
+            res[name] = {"us": round(ms * 1e3, 2), "avg_launch_ms": round(ms, 5), "kernel": kern, "n": nn,
+                         "note": "one group over the vector; 32 B/element at 8 TB/s would be %.2f us" % (32 * nn / 8e6)}
     # group config: (n // 100) groups of 128  (10^6 x 128 at n = 10^8)
     ng = max(1, n // 100)
     m = ng * 128
