@@ -50,6 +50,10 @@ def lib():
         L.orc_prox_lhalf_box.argtypes = box
         L.orc_prox_indball_l0.argtypes = base + [i64]
         L.orc_prox_indball_l0_binf.argtypes = base + [i64, d]
+        L.orc_sortperm_indball.argtypes = [ip, dp, dp, dp, i64]
+        L.orc_sortperm_indball.restype = None
+        L.orc_prox_indball_l0_perm.argtypes = base + [ip, i64, d, ctypes.c_int]
+        L.orc_prox_indball_l0_perm.restype = None
         L.orc_prox_group_l2.argtypes = base + [ip, i64, i64, dp, d]
         L.orc_prox_group_l2_binf.argtypes = base + [ip, i64, i64, dp, d, d]
         ib = [dp, dp, dp, dp, dp, i64, d]
@@ -543,7 +547,33 @@ def iprox_f32(op, g, d, xk, sj, lam, l=None, u=None, mask=None):
     return y
 
 
-def prox_indball_l0_f32(q, xk, sj, r, delta=None):
+def topr_order_f32(q, xk, sj):
+    """the stable descending sort of prox_indball_l0_f32, for reuse over many r (its `_order` argument)"""
+    q, xk, sj = _f32(q), _f32(xk), _f32(sj)
+    v = ((xk + sj).astype(np.float32) + q).astype(np.float32)
+    key = (v.view(np.uint32) & np.uint32(0x7fffffff)).astype(np.int64)
+    key = np.where(key > 0x7f800000, 0x7fc00000, key)
+    return np.argsort(-key, kind="stable")
+
+
+class TopR:
+    """ShiftedIndBallL0(BInf).prox! for MANY r on one (q, xk, sj): the reference's sortperm (:68 / :87 -- stable, |v| descending)
+    is computed once, each prox(r[, delta]) then zeroes all but the first r of it and finishes as the reference does.  Bit for
+    bit what prox_indball_l0 / prox_indball_l0_binf return (tests/test_oracle_golden.py checks that)."""
+
+    def __init__(self, q, xk, sj):
+        self.q, self.xk, self.sj, self.n, _ = _prep(q, xk, sj)
+        self.p = np.empty(max(self.n, 1), dtype=np.int64)
+        lib().orc_sortperm_indball(self.p.ctypes.data_as(_c_int64_p), _dp(self.q), _dp(self.xk), _dp(self.sj), self.n)
+
+    def prox(self, r, delta=None):
+        y = np.empty(self.n, dtype=np.float64)
+        lib().orc_prox_indball_l0_perm(_dp(y), _dp(self.q), _dp(self.xk), _dp(self.sj), self.n, self.p.ctypes.data_as(_c_int64_p),
+                                       int(r), 0.0 if delta is None else float(delta), 0 if delta is None else 1)
+        return y
+
+
+def prox_indball_l0_f32(q, xk, sj, r, delta=None, _order=None):
     """ShiftedIndBallL0(BInf).prox! with R = Float32 (src/shiftedIndBallL0.jl:54-72, shiftedIndBallL0BInf.jl:73-95), restated in
     numpy: v = (xk + sj) + q in Float32, stable descending sort by |v| (isless order: NaN largest, all NaNs tie; ties by
     ascending index), zero all but the first r, subtract xk + sj, clamp to +-delta.  Small cases only (a full argsort)."""
@@ -551,9 +581,12 @@ def prox_indball_l0_f32(q, xk, sj, r, delta=None):
     n = q.shape[0]
     xs = (xk + sj).astype(np.float32)
     v = (xs + q).astype(np.float32)
-    key = (v.view(np.uint32) & np.uint32(0x7fffffff)).astype(np.int64)
-    key = np.where(key > 0x7f800000, 0x7fc00000, key)
-    order = np.argsort(-key, kind="stable")
+    if _order is None:
+        key = (v.view(np.uint32) & np.uint32(0x7fffffff)).astype(np.int64)
+        key = np.where(key > 0x7f800000, 0x7fc00000, key)
+        order = np.argsort(-key, kind="stable")
+    else:
+        order = _order  # (the caller's cached sort of the same q, xk, sj: topr_order_f32)
     kept = v.copy()
     kept[order[max(int(r), 0):]] = np.float32(0)
     y = (kept - xs).astype(np.float32)

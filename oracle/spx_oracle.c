@@ -344,6 +344,25 @@ ORC_API void orc_prox_indball_l0_binf(double* y, const double* q, const double* 
   free(p);
 }
 
+/* The same two operators with the permutation of :68 / :87 handed in: tests that evaluate many r on one (q, xk, sj) sort once
+ * (the sort is most of the oracle's time; the permutation does not depend on r).  p = orc_sortperm_indball(...). */
+ORC_API void orc_sortperm_indball(int64_t* p, const double* q, const double* xk, const double* sj, int64_t n) {
+  double* v = (double*)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+  for (int64_t i = 0; i < n; ++i) v[i] = (xk[i] + sj[i]) + q[i]; /* :66 / :85 */
+  stable_sortperm_desc_abs(p, v, n);                             /* :68 / :87 */
+  free(v);
+}
+ORC_API void orc_prox_indball_l0_perm(double* y, const double* q, const double* xk, const double* sj, int64_t n,
+                                      const int64_t* p, int64_t r, double delta, int binf) {
+  for (int64_t i = 0; i < n; ++i) y[i] = (xk[i] + sj[i]) + q[i];
+  for (int64_t k = (r < 0 ? 0 : r); k < n; ++k) y[p[k]] = 0.0;   /* :69 / :88 */
+  if (binf) {
+    for (int64_t i = 0; i < n; ++i) y[i] = jl_min(jl_max(y[i] - (xk[i] + sj[i]), -delta), delta); /* :90-92 */
+  } else {
+    for (int64_t i = 0; i < n; ++i) y[i] = y[i] - (xk[i] + sj[i]); /* :70 */
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * Groups: contiguous index ranges.  offsets != NULL: group g = [offsets[g], offsets[g+1]) (0-based);
  * offsets == NULL: uniform groups of `gsize`, group g = [g*gsize, (g+1)*gsize).

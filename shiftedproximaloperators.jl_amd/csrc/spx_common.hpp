@@ -70,6 +70,7 @@ struct spx_ctx {
                                    //         streaming pass per reduction)
   int tune_force_grid = 0;         // key 100, test builds only (-DSPX_TEST_HOOKS): launch the one-launch top-r with THIS many workgroups,
                                    //          residency or not -- the planted fault behind tests/test_gpu_robustness.py
+  int tune_force_tail = 0;         // key 101, test builds only: the same for the tail kernel of the sampled top-r pipeline (k_s2_tail)
   // Device-side status word in host-mapped pinned memory (spx_ctx.hip): a kernel that gives up waiting for the other
   // workgroups of its launch, or finds library-owned state outside its layout, stores a non-zero code here (system-scope
   // store); every entry point looks at it before it enqueues anything (SPX_ON_DEVICE) and fails with SPX_ERR_INTERNAL from

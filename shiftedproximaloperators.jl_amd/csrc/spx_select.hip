@@ -987,6 +987,7 @@ __global__ __launch_bounds__(256) void k_sel_final_q(double* y_, const double* q
                                                       int64_t n, const SelWs* ws, double delta, int ioff) {
   // (ioff: as k_s2_main)
   if (!ws->fs.ok) return;  // prediction not verified: the host runs the full-vector path afterwards
+  const bool poisoned = ws->fs.ok == 2;  // k_s2_tail gave up waiting for its own workgroups: the thresholds are garbage -> NaN
   const SelState st = ws->st;
   constexpr int UNROLL = 6;  // KiB per wave and vector, as k_sep_lds
   __shared__ __attribute__((aligned(16))) char dma[4 * 3 * UNROLL * 1024];
@@ -1018,15 +1019,19 @@ __global__ __launch_bounds__(256) void k_sel_final_q(double* y_, const double* q
       f64x2 r;
       r.x = sel_out<BINF>((b.x + c.x) + a.x, 2 * i + ioff, b.x, c.x, st, delta);
       r.y = sel_out<BINF>((b.y + c.y) + a.y, 2 * i + 1 + ioff, b.y, c.y, st, delta);
+      if (poisoned) r = f64x2{__longlong_as_double(0x7ff8000000000000ll), __longlong_as_double(0x7ff8000000000000ll)};
       __builtin_nontemporal_store(r, y + i);
     }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
-    y_[i] = sel_out<BINF>((xk_[i] + sj_[i]) + q_[i], i + ioff, xk_[i], sj_[i], st, delta);
+    const double o = sel_out<BINF>((xk_[i] + sj_[i]) + q_[i], i + ioff, xk_[i], sj_[i], st, delta);
+    y_[i] = poisoned ? __longlong_as_double(0x7ff8000000000000ll) : o;
   }
-  if (ioff && blockIdx.x == 0 && threadIdx.x == 64)
-    y_[-1] = sel_out<BINF>((xk_[-1] + sj_[-1]) + q_[-1], 0, xk_[-1], sj_[-1], st, delta);
+  if (ioff && blockIdx.x == 0 && threadIdx.x == 64) {
+    const double o = sel_out<BINF>((xk_[-1] + sj_[-1]) + q_[-1], 0, xk_[-1], sj_[-1], st, delta);
+    y_[-1] = poisoned ? __longlong_as_double(0x7ff8000000000000ll) : o;
+  }
 }
 
 // =============================================================================================
@@ -1683,7 +1688,8 @@ template <bool BINF>
 __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, const double* xk, const double* sj, int64_t n,
                                                    int64_t r, double delta, SelSync* ss, int parity, const Cand* cand,
                                                    const WaveCount* counts, int64_t nregions, unsigned int ovf_cap,
-                                                   const ClassCount* cls, int ioff, int write) {
+                                                   const ClassCount* cls, int ioff, int write_flags) {
+  const int write = write_flags & 1;
   __shared__ CoopShared sh;
   __shared__ unsigned long long tl[20];
   __shared__ unsigned long long tparts[256];
@@ -1703,6 +1709,9 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
   // written by earlier launches: the same values in every workgroup
   const int ok = ss->ws.fs.ok, todo = ss->ws.fs.todo, tie = ss->ws.fs.tie;
   if (ok && todo == 0) return;
+#ifdef SPX_TEST_HOOKS
+  if ((write_flags & 2) && G > 1 && b == G - 1) return;  // (planted: this workgroup is "not resident")
+#endif
   if (t == 0) { sh.sst = ss->ws.st; tl[17] = ~0ull; tl[18] = 0ull; tl[19] = ~0ull; }
   const int64_t total_hist = (int64_t)kCoopMaxPass * kBins;
   if (!ok || (todo & kTodoCandSelect)) {  // histogram set 2 belongs to this launch: cleared here, one barrier
@@ -1864,6 +1873,18 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
     }
   }
   __syncthreads();
+  // A workgroup that gave up waiting for the others has made the counts / the cut garbage (spx_wait_expired: the candidate
+  // select's histograms, the tie scan's made-up icut).  Never a plausible wrong result (include/spx.h): the single-pass form has
+  // speculative values in y already -- NaN over the whole vector, by every workgroup that sees the flag (the kTodoFinal rewrite
+  // below does that itself); the two-pass form has not stored anything yet -- FastState::ok = 2 makes k_sel_final_q store NaN.
+  if (spx_poisoned(hdr) && !((todo & kTodoFinal) && write)) {
+    if (write) {
+      for (int64_t i = gt; i < n; i += nt) y[i] = __longlong_as_double(0x7ff8000000000000ll);
+    } else if (t == 0) {
+      ss->ws.fs.ok = 2;
+    }
+    return;
+  }
   if ((todo & kTodoFinal) && write) {
     // The main pass stored the class members on the sample's guess of the cut (FastState::spec_*); now the cut is known.
     // Both rules are "kept up to an index c" per class (c = -1: none, n - 1: all): the guess was wrong on (min(c_spec,
@@ -2280,6 +2301,10 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
   const int64_t cap_tail = spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_s2_tail<BINF>), 1024, 0);
   if (cap_tail < 1) return SPX_ERR_INTERNAL;
   const int64_t g_tail = cap_tail < 256 ? (cap_tail < ctx->num_cu ? cap_tail : ctx->num_cu) : (ctx->num_cu < 256 ? ctx->num_cu : 256);  // (<= 256: SelSync::tie_part)
+  int tail_hook = 0;
+#ifdef SPX_TEST_HOOKS  // the planted fault of tests/test_gpu_robustness.py (key 101): the last workgroup of the tail kernel leaves
+  tail_hook = ctx->tune_force_tail > 0 ? 2 : 0;  // without arriving anywhere, as if it had never been placed -- the others give up waiting
+#endif
   if (!try_fast) {
     // exact select in ONE launch: register-resident up to 8 Ki elements per resident workgroup, v parked in y beyond that
     // k_sel_lds from 1 Mi elements on (n = 2e6: 34 / 42 us at r = n/100 / n/2 against 39 / 45 with v in registers; n = 1e6:
@@ -2416,7 +2441,7 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     }
     hipLaunchKernelGGL((k_s2_tail<BINF>), dim3((unsigned)g_tail), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta, ss,
                        ctx->coop_parity, (const Cand*)cand, (const WaveCount*)counts, nregions, ovf_cap,
-                       (const ClassCount*)cls, ioff, write ? 1 : 0);
+                       (const ClassCount*)cls, ioff, (write ? 1 : 0) | tail_hook);
     ctx->coop_parity ^= 1;
   }
   if (!write)

@@ -23,7 +23,7 @@ def _bits(a, b):
     return np.array_equal(np.asarray(a).view(np.int64), np.asarray(b).view(np.int64))
 
 
-@pytest.mark.parametrize("n", [6_000, 50_000, 1_000_000, 2_600_000, 4_300_000, 15_000_000])
+@pytest.mark.parametrize("n", [6_000, 50_000, 1_000_000, 2_600_000, 4_300_000, pytest.param(15_000_000, marks=pytest.mark.soak)])
 def test_iteration_in_a_graph_replays_on_new_data(s, orc, n):
     """n = 6e3: one-workgroup top-r, one-workgroup B2; 5e4 / 1e6: the register-resident one-launch forms; 2.6e6: the forms that
     park a vector in LDS (256 workgroups); 4.3e6: the sample-predicted top-r pipeline and the streaming B2 form; 1.5e7: the B2
@@ -85,7 +85,7 @@ def test_iteration_in_a_graph_replays_on_new_data(s, orc, n):
             ref = orc.prox_l1_b2(q, x, sj, 1.0, 1.0, 1e12, 1.0)
             assert _bits(ys[4].cpu().numpy(), ref) and _bits(ys[5].cpu().numpy(), ref), what
 
-    for rep in range(4):
+    for rep in range(4 if n < 1_000_000 else 2):   # (each check is five oracle calls on n elements)
         q = rng.normal(size=n) * (1.0 + rep)
         qd.copy_(torch.from_numpy(q))
         for t in ys:

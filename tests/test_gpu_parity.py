@@ -317,10 +317,12 @@ def test_indball_l0_nan_inf(s, orc):
         q[inf_at[:3]] = np.inf
         q[inf_at[3:]] = -np.inf
         xd, sd, qd = _dev(x, sj, q)
+        with np.errstate(all="ignore"):
+            top = orc.TopR(q, x, sj)
         for r in (1, 4, 9, 12, 15, 16, n // 7):
             with np.errstate(all="ignore"):
-                ref = orc.prox_indball_l0_binf(q, x, sj, r, 0.6)
-                ref0 = orc.prox_indball_l0(q, x, sj, r)
+                ref = top.prox(r, 0.6)
+                ref0 = top.prox(r)
             y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.6, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
             assert _same_or_both_nan(y, ref), (n, r)
             y0 = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qd, 1.0).cpu().numpy()
@@ -343,13 +345,14 @@ def test_indball_l0_ranks_and_scales(s, orc, kind):
         x, sj = np.zeros(n), np.zeros(n)
         q = (1.0 + 1e-9 * rng.normal(size=n)) * rng.choice([-1.0, 1.0], size=n)
     xd, sd, qd = _dev(x, sj, q)
+    top = orc.TopR(q, x, sj)   # (the reference's sortperm once, every r from it)
     for r in (1, 50, 5000, n // 100, n // 2, n - 5000):
-        ref = orc.prox_indball_l0_binf(q, x, sj, r, 0.9)
+        ref = top.prox(r, 0.9)
         y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.9, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
         assert _bits_equal(y, ref), (kind, r)
     r = n // 37  # aliased form (y === q)
     s.prox_bang(qd, s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qd, 1.0)
-    assert _bits_equal(qd.cpu().numpy(), orc.prox_indball_l0(q, x, sj, r)), kind
+    assert _bits_equal(qd.cpu().numpy(), top.prox(r)), kind
 
 
 @pytest.mark.parametrize("n,lds", [((1 << 20) - 1, 1), (1 << 20, 1), ((1 << 20) + 1, 1), ((1 << 20) + 3001, 1), ((1 << 21) - 1, 1),
@@ -393,8 +396,9 @@ def test_indball_l0_misaligned_views_fast_path(s, orc):
             mk = lambda a: torch.cat([torch.zeros(1, dtype=torch.float64), torch.from_numpy(a)]).cuda()[1:]
             xd, sd, qd = mk(x), mk(sj), mk(q)
             assert all(t.data_ptr() % 16 == 8 for t in (xd, sd, qd))
+            top = orc.TopR(q, x, sj)   # (the reference's sortperm once per input, every r from it)
             for r in (1, n // 50, n - 3):
-                ref = orc.prox_indball_l0_binf(q, x, sj, r, 0.7)
+                ref = top.prox(r, 0.7)
                 psi = s.shifted(s.shifted(s.IndBallL0(r), xd, 0.7, s.NormLinf(1.0)), sd)
                 yv = mk(np.zeros(n))
                 s.prox_bang(yv, psi, qd, 1.0)
@@ -405,7 +409,7 @@ def test_indball_l0_misaligned_views_fast_path(s, orc):
             q2 = qd.clone()
             q2v = mk(q2.cpu().numpy())
             s.prox_bang(q2v, s.shifted(s.shifted(s.IndBallL0(n // 9), xd), sd), q2v, 1.0)   # aliased
-            assert _bits_equal(q2v.cpu().numpy(), orc.prox_indball_l0(q, x, sj, n // 9)), (n, head)
+            assert _bits_equal(q2v.cpu().numpy(), top.prox(n // 9)), (n, head)
 
 
 # ------------------------------------------------------------------ groups
@@ -1415,6 +1419,7 @@ def test_indball_l0_front_sample_sizes(s, orc):
         if quant:
             x, sj, q = (np.round(v * quant) / quant for v in (x, sj, q))
         xd, sd, qd = _dev(x, sj, q)
+        top = orc.TopR(q, x, sj)
         for r in (5, n // 100, n // 2, n - 1000):
             y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.8, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
-            assert _bits_equal(y, orc.prox_indball_l0_binf(q, x, sj, r, 0.8)), (quant, r)
+            assert _bits_equal(y, top.prox(r, 0.8)), (quant, r)

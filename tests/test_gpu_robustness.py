@@ -83,6 +83,63 @@ def test_a_grid_beyond_residency_is_an_error_never_garbage(s):
     assert same == 1, "the context works again after the acknowledgement"
 
 
+_CHILD_TAIL = r"""
+import ctypes, os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import __graft_entry__ as ge
+s = ge.build(); L = s._lib.load(); ctx = s.context("cuda:0")
+n = 6_000_000                                  # above what the one-launch forms hold on chip: the sampled pipeline
+rng = np.random.default_rng(5)
+res = []
+for case in ("ties", "moderate_ties", "ties_aliased"):
+    if case == "moderate_ties":                # thousands of candidates share the cut's key: k_s2_finish hands over (kTodoCandSelect)
+        q = torch.from_numpy(np.round(rng.normal(size=n) * 2e4) / 2e4).cuda()
+    else:                                      # a lattice: the cut lies inside a class (kTodoTieScan + kTodoFinal)
+        q = torch.from_numpy(np.round(rng.normal(size=n) * 4) / 4).cuda()
+    x = torch.zeros_like(q); sj = torch.zeros_like(q)
+    y = q if case == "ties_aliased" else torch.empty_like(q)   # y === q: the two-pass form (k_sel_final_q stores y)
+    q0 = q.clone()
+    r = n // 3
+    rc0 = L.spx_prox_indball_l0_binf(ctx, y.data_ptr(), q.data_ptr(), x.data_ptr(), sj.data_ptr(), n, r, ctypes.c_double(1.0))
+    torch.cuda.synchronize()
+    good = y.clone(); q.copy_(q0)
+    assert rc0 == 0 and not bool(torch.isnan(good).any())
+    assert L.spx_ctx_set_tuning(ctx, 101, 1) == 0   # the last workgroup of k_s2_tail never arrives
+    if y is not q: y.fill_(7.0)
+    rc_launch = L.spx_prox_indball_l0_binf(ctx, y.data_ptr(), q.data_ptr(), x.data_ptr(), sj.data_ptr(), n, r, ctypes.c_double(1.0))
+    torch.cuda.synchronize()
+    L.spx_ctx_set_tuning(ctx, 101, 0)
+    nan = int(torch.isnan(y).sum())
+    rc_next = L.spx_prox_l1(ctx, good.data_ptr(), q0.data_ptr(), x.data_ptr(), sj.data_ptr(), n, ctypes.c_double(1.0), ctypes.c_double(1.0))
+    rc_sync = L.spx_sync(ctx)
+    q.copy_(q0)
+    rc_after = L.spx_prox_indball_l0_binf(ctx, y.data_ptr(), q.data_ptr(), x.data_ptr(), sj.data_ptr(), n, r, ctypes.c_double(1.0))
+    torch.cuda.synchronize()
+    res.append((case, rc_launch, nan, rc_next, rc_sync, rc_after, int(torch.isnan(y).sum())))
+print("RESULT", res)
+"""
+
+
+def test_the_top_r_tail_kernel_poisons_its_result_too(s):
+    """a wait that expires inside k_s2_tail (the candidate select over the regions, the tie scan) used to leave the
+    main pass's speculative values / a made-up index cut in y.  Hooks build, key 101: one workgroup of the tail never arrives."""
+    lib = os.path.join(ROOT, "shiftedproximaloperators.jl_amd", "lib", "libspx_hooks.so")
+    if not os.path.exists(lib):
+        pytest.skip("libspx_hooks.so not built")
+    env = dict(os.environ, SPX_LIB_NAME="libspx_hooks.so", SPX_NO_BUILD="1")
+    out = subprocess.run([sys.executable, "-c", _CHILD_TAIL % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+    assert line, (out.stdout[-2000:], out.stderr[-2000:])
+    res = eval(line[0][len("RESULT"):])
+    assert len(res) == 3
+    for case, rc_launch, nan, rc_next, rc_sync, rc_after, nan_after in res:
+        assert rc_launch == 0, case
+        assert nan == 6_000_000, "%s: the abandoned tail must poison the whole result (%d NaN)" % (case, nan)
+        assert rc_next == 7 and rc_sync == 7, case
+        assert rc_after == 0 and nan_after == 0, case
+
+
 def test_residency_cap_takes_the_smaller_grid_forms(s, orc):
     """key 8: B2 and top-r with the resident grid capped at 1, 5 and 100 workgroups (register-resident forms hand over to the
     streaming / parked forms, the sampled pipeline to the exact select) -- bits / 1e-12 as without the cap."""

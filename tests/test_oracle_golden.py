@@ -462,3 +462,25 @@ def test_l1b2_exact_zero_at_a_bracket_end(orc):
     got = orc.prox_l1_b2(q, x, sj, 1.0, 1.0, 1.0, 1.0)
     assert np.array_equal(got, want)
     assert np.max(np.abs(orc.q_prox_l1_b2(q, x, sj, 1.0, 1.0, 1.0, 1.0) - want)) <= 1e-15
+
+
+def test_topr_many_ranks_from_one_sort(orc):
+    """oracle.TopR (the reference's sortperm computed once, reused for every r) returns what the literal restatements return,
+    bit for bit: ties (index order), NaN / Inf (isless order), r = 0 ... n + 3, with and without the clamp."""
+    rng = np.random.default_rng(4)
+    n = 5000
+    x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = np.round(rng.normal(size=n) * 4) / 4
+    q[[7, 99, 1234]] = np.nan
+    q[[8, 100]] = np.inf
+    x[17] = -np.inf
+    with np.errstate(all="ignore"):
+        top = orc.TopR(q, x, sj)
+        for r in (0, 1, 2, 5, 6, 7, 50, n // 2, n - 1, n, n + 3):
+            a, b = top.prox(r), orc.prox_indball_l0(q, x, sj, r)
+            assert np.array_equal(a.view(np.int64), b.view(np.int64)) or np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+            a, b = top.prox(r, 0.6), orc.prox_indball_l0_binf(q, x, sj, r, 0.6)
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.int64), b[~np.isnan(b)].view(np.int64))
+        o = orc.topr_order_f32(q, x, sj)
+        for r in (1, 7, n // 3):
+            a, b = orc.prox_indball_l0_f32(q, x, sj, r, 0.6, _order=o), orc.prox_indball_l0_f32(q, x, sj, r, 0.6)
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.int32), b[~np.isnan(b)].view(np.int32))

@@ -24,6 +24,9 @@ FAULTS=(
  "15|spx_b2.hip|s/lo = SQ\[k\] - lsv; hi = SQ\[k\] + lsv;/lo = SQ[k] - lsv; hi = SQ[k] - lsv;/|tests/test_gpu_stress.py::test_b2_streaming_form_scenarios tests/test_gpu_stress.py::test_b2_one_launch_forms_at_their_boundaries"
  "16|spx_group.hip|0,/if constexpr (TEAM >= 2) v += dpp_f64<0xB1>(v);/s//if constexpr (TEAM >= 4) v += dpp_f64<0xB1>(v);/|tests/test_gpu_parity.py::test_group_uniform"
  "17|spx_objective.hip|s/for (int off = TEAM \/ 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);  \/\/ (inside the team/for (int off = TEAM \/ 2; off >= 2; off >>= 1) ss += __shfl_xor(ss, off, 64);  \/\/ (inside the team/|tests/test_gpu_parity.py::test_objective_group_sizes"
+ "18|spx_separable.hip|s/^        st2<NT>(y + i, r);\$/        if (blockIdx.x != gridDim.x \/ 2) st2<NT>(y + i, r);/|tests/test_gpu_fullsize.py::test_full_size_lhalf"
+ "19|spx_group.hip|s/^    if (valid) {\$/    if (valid \&\& blockIdx.x != gridDim.x \/ 2) {/|tests/test_gpu_fullsize.py::test_full_size_groups"
+ "20|spx_group_team.hip|s/        visit(i < npairs, i, qa, xa, sa);/        visit(i < npairs \&\& !(wl == W \/ 2 \&\& tile == wl + W), i, qa, xa, sa);/|tests/test_gpu_team.py::test_one_group_over_the_vector tests/test_gpu_fullsize.py::test_one_group_over_1e8_elements"
  "4|spx_group.hip|s/if (sb == 0.0) {/if (false) {/;s/for (int k = 0; k < 64; ++k) {/for (int k = 0; k < 12; ++k) { piece_ok = true;/|tests/test_gpu_parity.py::test_group_binf_many_small_groups tests/test_gpu_parity.py::test_group_binf_zero_groups_strong_lambda"
 )
 case "${1:-}" in
