@@ -1709,10 +1709,17 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
   // written by earlier launches: the same values in every workgroup
   const int ok = ss->ws.fs.ok, todo = ss->ws.fs.todo, tie = ss->ws.fs.tie;
   if (ok && todo == 0) return;
+  bool late = false;
 #ifdef SPX_TEST_HOOKS
-  if ((write_flags & 2) && G > 1 && b == G - 1) return;  // (planted: this workgroup is "not resident")
+  // planted (key 101): this workgroup behaves as one that was not resident while the others waited for it -- it takes part in
+  // nothing they synchronise on and only runs once they have given up (the flag), like a workgroup placed after they left
+  if ((write_flags & 2) && G > 1 && b == G - 1) {
+    late = true;
+    for (unsigned int spins = 0; !spx_poisoned(hdr) && spins < (1u << 22); ++spins) __builtin_amdgcn_s_sleep(20);
+  }
 #endif
   if (t == 0) { sh.sst = ss->ws.st; tl[17] = ~0ull; tl[18] = 0ull; tl[19] = ~0ull; }
+  if (!late) {
   const int64_t total_hist = (int64_t)kCoopMaxPass * kBins;
   if (!ok || (todo & kTodoCandSelect)) {  // histogram set 2 belongs to this launch: cleared here, one barrier
     unsigned long long* z = &ss->chist[2][0][0];
@@ -1872,6 +1879,7 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
       if (t == 0) { ss->tie_cut = 0ull; ss->ws.st = sh.sst; }
     }
   }
+  }  // (!late)
   __syncthreads();
   // A workgroup that gave up waiting for the others has made the counts / the cut garbage (spx_wait_expired: the candidate
   // select's histograms, the tie scan's made-up icut).  Never a plausible wrong result (include/spx.h): the single-pass form has

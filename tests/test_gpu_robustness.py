@@ -93,14 +93,18 @@ n = 6_000_000                                  # above what the one-launch forms
 rng = np.random.default_rng(5)
 res = []
 for case in ("ties", "moderate_ties", "ties_aliased"):
-    if case == "moderate_ties":                # thousands of candidates share the cut's key: k_s2_finish hands over (kTodoCandSelect)
-        q = torch.from_numpy(np.round(rng.normal(size=n) * 2e4) / 2e4).cuda()
+    if case == "moderate_ties":                # 5000 candidates share the cut's key (more than the short list of k_s2_finish
+        qh = rng.normal(size=n)                # holds, fewer than the 0.1 %% of the vector that make a class): kTodoCandSelect
+        at = rng.choice(n, size=5000, replace=False)
+        qh[at] = np.where(rng.random(5000) < 0.5, 1.0, -1.0)
+        r = int((np.abs(qh) > 1.0).sum()) + 2500
+        q = torch.from_numpy(qh).cuda()
     else:                                      # a lattice: the cut lies inside a class (kTodoTieScan + kTodoFinal)
         q = torch.from_numpy(np.round(rng.normal(size=n) * 4) / 4).cuda()
+        r = n // 3
     x = torch.zeros_like(q); sj = torch.zeros_like(q)
     y = q if case == "ties_aliased" else torch.empty_like(q)   # y === q: the two-pass form (k_sel_final_q stores y)
     q0 = q.clone()
-    r = n // 3
     rc0 = L.spx_prox_indball_l0_binf(ctx, y.data_ptr(), q.data_ptr(), x.data_ptr(), sj.data_ptr(), n, r, ctypes.c_double(1.0))
     torch.cuda.synchronize()
     good = y.clone(); q.copy_(q0)
