@@ -114,7 +114,12 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
         }
       }
     }
-    RegGroup<EPL> grp;
+    RegGroup<EPL, BINF && !FULL && !LIT> grp;
+    if constexpr (BINF && !FULL && !LIT) {  // live slots of the tile (wave-uniform: the launch's group size / size bound)
+      const int slices = PAIRS ? (npairs + LPG - 1) / LPG : ((gsize + LPG - 1) / LPG + 1) / 2;
+      grp.live = (2 * slices < EPL && offsets == nullptr) ? 2 * slices : EPL;  // (ragged groups: `gsize` is only the caller's hint -- a
+                                                                                 //  group above it that still fits the tile is served here)
+    }
     {
       if constexpr (PAIRS) {
         const f64x2* q2 = reinterpret_cast<const f64x2*>(q_ + base);
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
 #pragma unroll
       for (int k = 0; k < EPL; ++k) out[k] = ((snorm == 0.0) ? 0.0 : alpha * grp.S[k]) - grp.XS[k];  // :74,:77
     } else if constexpr (LIT) {
-      binf_literal_reg<LPG, EPL>(grp, lam, sigma, delta, out);
+      binf_literal_reg<LPG, EPL, false>(grp, lam, sigma, delta, out);
 #pragma unroll
       for (int k = 0; k < EPL; ++k) out[k] = out[k] - grp.XS[k];  // :116
     } else {

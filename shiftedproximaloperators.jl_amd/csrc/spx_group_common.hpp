@@ -237,15 +237,27 @@ __device__ __forceinline__ double fast_rcp(double x) {
 //   MemGroup<TEAM> : elements are re-read from global memory (L1/L2 resident for moderate groups)
 // for_each(f) calls f(S_i, X_i) for every element this lane owns.
 // ---------------------------------------------------------------------------------------------
-template <int EPL>
+// PADDED (round 4): the groups do not fill the tile -- the slots from `live` on (wave-uniform: the same for every lane and every
+// group of the launch) hold zeros in every lane; the element loops skip them behind a scalar branch instead of adding zeros
+// (a group of 100 on the 8 x 16 tile: 7 of 8 pair-slices live; a group of 66: 5 of 8 -- the Binf form is VALU-bound on such
+// sizes).  The full-tile instantiations (PADDED = false) are unchanged.
+template <int EPL, bool PADDED = false>
 struct RegGroup {
   static constexpr bool kReg = true;
   static constexpr int kEpl = EPL;
   double S[EPL], X[EPL], XS[EPL];  // XS = xk + sj (subtracted at the end)
+  int live = EPL;                  // (PADDED) slots < live may hold elements; even
   template <class F>
   __device__ __forceinline__ void for_each(F&& f) const {
+    if constexpr (PADDED) {
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) f(S[k], X[k]);
+      for (int k = 0; k < EPL; k += 2) {
+        if (k < live) { f(S[k], X[k]); f(S[k + 1], X[k + 1]); }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) f(S[k], X[k]);
+    }
   }
 };
 
@@ -361,9 +373,11 @@ __device__ __forceinline__ bool binf_same_active_set(const G& grp, double tau_a,
   unsigned long long diff = 0ull;
 #pragma unroll
   for (int k = 0; k < G::kEpl; ++k) {
-    const double za = __builtin_fma(tau_a, grp.S[k], -grp.X[k]);
-    const double zb = __builtin_fma(tau_b, grp.S[k], -grp.X[k]);
-    diff |= __ballot((fabs(za) > delta) != (fabs(zb) > delta));
+    if (k < grp.live) {  // (wave-uniform; always true for the full-tile instantiations)
+      const double za = __builtin_fma(tau_a, grp.S[k], -grp.X[k]);
+      const double zb = __builtin_fma(tau_b, grp.S[k], -grp.X[k]);
+      diff |= __ballot((fabs(za) > delta) != (fabs(zb) > delta));
+    }
   }
   const int lane = threadIdx.x & 63;
   const unsigned long long mine = (TEAM >= 64) ? ~0ull : (((1ull << (TEAM & 63)) - 1ull) << ((lane / TEAM) * TEAM));
@@ -484,8 +498,8 @@ __device__ __forceinline__ bool binf_literal_root(const G& grp, double lam, doub
 // dependent passes of fzero then cost arithmetic only -- with the group re-read from memory for every pass (k_group_mem)
 // a list that holds a large share of the groups is bound by L2 misses, 14 ms for 2.7e5 groups of 128.  S/sigma (:89) is
 // loop-invariant and formed once.  out[k] = y before the final "- (xk + sj)".
-template <int LPG, int EPL>
-__device__ __forceinline__ void binf_literal_reg(const RegGroup<EPL>& grp, double lam, double sigma, double delta,
+template <int LPG, int EPL, bool PADDED>
+__device__ __forceinline__ void binf_literal_reg(const RegGroup<EPL, PADDED>& grp, double lam, double sigma, double delta,
                                                  double* out) {
   const double eps = 2.220446049250313e-16;
   const double sl = lam * sigma;
