@@ -132,7 +132,11 @@ int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms); /* records stop, waits, ret
  * >= 2^26 elements; 1, 2, 4, 16 force it).  Key 11 = one-launch top-r with v parked in LDS for 2^20 < n <= 16 Ki x resident
  * workgroups (1, default; 0: registers up to 2^21, the sample-predicted path above, as in round 2).  Key 12 = ShiftedNormL1B2
  * with xk parked in LDS for 2^21 < n <= 2^22 (1, default; 0: the two-pass streaming form from 2^21 on).  (Key 7, round 2's switch
- * to the multi-launch pipelines, is gone with those pipelines.)
+ * to the multi-launch pipelines, is gone with those pipelines.)  Key 13 = large contiguous groups of ShiftedGroupNormL2(Binf)
+ * -- first of all ONE group over the whole vector, the reference's `shifted(NormL2(lambda), xk)` -- are owned by a team of
+ * workgroups and psi(y) on them is evaluated in chunks (1, default; 0: one workgroup / one wavefront per group as in rounds 1-3).
+ * Key 14 = the Binf form of that takes its sample-predicted two-pass path when the group does not fit on chip (1, default;
+ * 0: the generic body, one streaming pass per reduction of the root find).
  * Key 9 DOES change results, within the stated tolerance: ShiftedGroupNormL2Binf, 0 (default) = the closed form at the root
  * (within ~1e-15 of the exact value of the reference's formula everywhere), 1 = groups whose root sits next to the pole of
  * step(n) (u < n / 1000) are evaluated literally, operation by operation as src/shiftedGroupNormL2Binf.jl:87-113 with
@@ -365,7 +369,15 @@ int spx_obj_l1_b2(spx_ctx* ctx, const double* y, const double* xk, const double*
  *                           <= 512 selects the register-tile kernels (a group that exceeds it is still computed
  *                           correctly, by the general kernel).
  *   group_offsets == NULL : uniform groups of group_size, ngroups * group_size == n.
- * lambda_vec: device, length ngroups (GroupNormL2.lambda, src/groupNormL2.jl:15-28). */
+ * lambda_vec: device, length ngroups (GroupNormL2.lambda, src/groupNormL2.jl:15-28).
+ * ONE group over the whole vector (group_offsets == NULL, group_size == n, ngroups == 1) is what the reference's
+ * `shifted(NormL2(lambda), xk[, Delta, chi])` builds (src/shiftedGroupNormL2.jl:34-35, src/shiftedGroupNormL2Binf.jl:48-49: idx = [:],
+ * the default of src/groupNormL2.jl:30-31).  Groups too large for one workgroup -- that one, or a handful of ranges of
+ * 1e5-1e8 elements, uniform or among the CSR ranges -- are owned by a TEAM of workgroups of one resident grid (round 4,
+ * csrc/spx_group_team.hip): read once when a group fits the LDS of its team (2.36 Mi elements on 256 CUs), two streaming passes
+ * beyond (56 B/element: n = 1e8 0.90 ms / 0.99 ms with the trust region); rounds 1-3 gave such a group one workgroup (384 /
+ * 1349 ms).  These launches synchronise inside themselves (as top-r and ShiftedNormL1B2: bounded waits, NaN + SPX_ERR_INTERNAL
+ * on the next call if a wait cannot be satisfied). */
 /* ShiftedGroupNormL2.prox!     src/shiftedGroupNormL2.jl:52-79 */
 int spx_prox_group_l2(spx_ctx* ctx, double* y, const double* q, const double* xk, const double* sj,
                       int64_t n, const int64_t* group_offsets, int64_t group_size, int64_t ngroups,

@@ -106,6 +106,58 @@ def test_iteration_in_a_graph_replays_on_new_data(s, orc, n):
     check(q, "replay after eager")
 
 
+@pytest.mark.parametrize("n", [120_000, 2_600_000])
+def test_one_group_over_the_vector_in_a_graph(s, orc, n):
+    """Round 4: shifted(NormL2(lambda), x[, Delta, chi]) -- one group over the vector, the team form (csrc/spx_group_team.hip) and
+    the chunked psi(y) -- captured and replayed on new data: n = 1.2e5 on chip, 2.6e6 streamed (three launches per Binf call:
+    their exchange words and tile counters are zeroed by nodes of the graph)."""
+    import torch
+    rng = np.random.default_rng(n + 1)
+    x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n)
+    lam = 0.4 * n ** 0.5
+    off = np.array([0, n], dtype=np.int64)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        xd, sd = torch.from_numpy(x).cuda(), torch.from_numpy(sj).cuda()
+        qd = torch.zeros(n, dtype=torch.float64, device="cuda")
+        ys = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(2)]
+        vals = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(2)]
+        psi_g = s.shifted(s.shifted(s.NormL2(lam), xd), sd)
+        psi_b = s.shifted(s.shifted(s.NormL2(lam), xd, 0.8, s.NormLinf(1.0)), sd)
+
+        def iteration():
+            s.prox_bang(ys[0], psi_g, qd, 0.9)
+            with s.device_values(vals[0]):
+                psi_g(ys[0])
+            s.prox_bang(ys[1], psi_b, qd, 0.9)
+            with s.device_values(vals[1]):
+                psi_b(ys[1])
+
+        qd.copy_(torch.from_numpy(rng.normal(size=n)))
+        iteration(); iteration()
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        iteration()
+    for rep in range(3):
+        q = rng.normal(size=n) * (1.0 + rep)
+        qd.copy_(torch.from_numpy(q))
+        for t in ys:
+            t.fill_(-777.0)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        nS = np.linalg.norm((q + x) + sj)
+        for k, delta in ((0, None), (1, 0.8)):
+            ref = orc.prox_group_l2(q, x, sj, [lam], 0.9, offsets=off) if delta is None else orc.prox_group_l2_binf(q, x, sj, [lam], 0.9, delta, offsets=off)
+            y = ys[k].cpu().numpy()
+            scale = np.maximum(np.maximum(np.abs(ref), np.abs(x + sj)), nS)
+            assert float(np.max(np.abs(y - ref) / scale)) <= 1e-12, (rep, k)
+            vr = orc.obj_group_l2(y, x, sj, [lam], offsets=off, delta=delta)
+            got = float(vals[k].item())
+            assert got == vr or abs(got - vr) <= 1e-12 * abs(vr), (rep, k, got, vr)
+
+
 def test_calls_that_synchronise_refuse_to_be_captured(s):
     import torch
     n = 10_000
