@@ -466,14 +466,26 @@ function prox!(y::DVec32, ψ::ShiftedIndBallL0BInf{<:Integer, Float32, <:DVec32,
 end
 
 # ShiftedGroupNormL2 on Float32 vectors, contiguous groups (round 3: spx_prox_group_l2_f32; src/shiftedGroupNormL2.jl:52-79 with
-# R = Float32; index sets keep the reference's method).  λ travels as a Float32 device vector, cached per h like the Float64 one.
-const LAMBDA32 = IdDict{Any, Any}()
+# R = Float32; index sets keep the reference's method).  λ travels as a Float32 device vector, cached per h (and per content).
+# (ADVICE r3: the cache is keyed on the lambda ARRAY (mutable, so it can be held weakly: entries die with it) and on a hash of
+#  its contents -- `h.lambda .= ...` in a continuation loop must not leave a stale device copy behind)
+const LAMBDA32 = WeakKeyDict{Any, Any}()
+function lambda32_for(h)
+  lam = h.lambda
+  key = hash(lam)
+  ent = get(LAMBDA32, lam, nothing)
+  if ent === nothing || ent[1] != key
+    ent = (key, ROCVector{Float32}(collect(Float32, lam)))
+    LAMBDA32[lam] = ent
+  end
+  return ent[2]
+end
 function prox!(y::DVec32, ψ::ShiftedGroupNormL2{Float32, <:Any, <:Any, <:DVec32, <:DVec32, <:DVec32}, q::DVec32, σ::Float32)
   n = length(ψ.xk)
   (length(y) == n && length(q) == n) || throw(BoundsError())
   L = layout_for(ψ.h, n)
   L.gather && return invoke(prox!, Tuple{AbstractVector{Float32}, typeof(ψ), AbstractVector{Float32}, Float32}, y, ψ, q, σ)  # index sets: the reference's own method
-  lam32 = get!(() -> ROCVector{Float32}(collect(Float32, ψ.h.lambda)), LAMBDA32, ψ.h)
+  lam32 = lambda32_for(ψ.h)
   offp = L.offsets === nothing ? Ptr{Int64}(C_NULL) : Ptr{Int64}(UInt(pointer(L.offsets)))
   check(ccall((:spx_prox_group_l2_f32, libspx), Cint,
               (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Ptr{Int64}, Int64, Int64, Ptr{Cfloat}, Cfloat),

@@ -80,6 +80,11 @@ struct spx_ctx {
   // Blocks that a captured graph may still reference (graph_safe): never freed before the context is destroyed.
   void* retired[64] = {};
   int nretired = 0;
+  // ... those of them that are synchronisation-state blocks (spx_sync_reserve), with their sizes: a captured graph that timed out
+  // on such a block would replay NaN for ever if spx_sync reset the current block only
+  void* retired_sync[16] = {};
+  size_t retired_sync_bytes[16] = {};
+  int nretired_sync = 0;
   // resident workgroups per CU of the in-launch synchronised kernels (hipOccupancyMaxActiveBlocksPerMultiprocessor),
   // queried once per kernel and context: spx_resident_cap
   const void* occ_fn[32] = {};

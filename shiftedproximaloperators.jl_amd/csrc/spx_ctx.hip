@@ -196,6 +196,11 @@ SPX_EXPORT int spx_sync(spx_ctx* ctx) {
       ctx->sel_hist_next = 0;
       ctx->sel_hist_dirty[0] = ctx->sel_hist_dirty[1] = 0;
     }
+    // ... and the retired blocks a captured graph may still replay on (their sticky timed_out flag, counters, words)
+    for (int k = 0; k < ctx->nretired_sync; ++k) {
+      SPX_HIP(hipMemset(ctx->retired_sync[k], 0, ctx->retired_sync_bytes[k]));
+      SPX_HIP(hipMemcpy(&reinterpret_cast<SpxSyncHeader*>(ctx->retired_sync[k])->status, &ctx->status_dev, sizeof(int*), hipMemcpyHostToDevice));
+    }
     *ctx->status_host = 0;
     return rc;
   }
@@ -326,6 +331,10 @@ int spx_sync_reserve(spx_ctx* ctx, size_t bytes) {
         return SPX_ERR_INVALID_ARG;
       }
       ctx->retired[ctx->nretired++] = ctx->sync;
+      if (ctx->nretired_sync < 16) {
+        ctx->retired_sync[ctx->nretired_sync] = ctx->sync;
+        ctx->retired_sync_bytes[ctx->nretired_sync++] = ctx->sync_bytes;
+      }
     } else {
       SPX_HIP(hipFree(ctx->sync));
     }
