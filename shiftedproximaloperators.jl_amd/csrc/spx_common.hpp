@@ -68,6 +68,8 @@ struct spx_ctx {
                                    //         workgroups (spx_group_team.hip); 0 = one workgroup per group as in rounds 1-3
   int tune_team_fast = 1;          // key 14: ... and the Binf form of that takes its sample-predicted two-pass path (0 = generic body: one
                                    //         streaming pass per reduction)
+  int tune_team_factor = 0;        // key 16: the team form serves uniform large groups while there are fewer than this many per workgroup of its
+                                   //         grid (0 = default, see run_group in spx_group.hip); an A/B knob
   int tune_force_grid = 0;         // key 100, test builds only (-DSPX_TEST_HOOKS): launch the one-launch top-r with THIS many workgroups,
                                    //          residency or not -- the planted fault behind tests/test_gpu_robustness.py
   int tune_force_tail = 0;         // key 101, test builds only: the same for the tail kernel of the sampled top-r pipeline (k_s2_tail)

@@ -150,6 +150,7 @@ SPX_EXPORT int spx_ctx_set_tuning(spx_ctx* ctx, int key, int value) {
     case 12: ctx->tune_b2_lds = value ? 1 : 0; return SPX_OK;
     case 13: ctx->tune_team = value ? 1 : 0; return SPX_OK;
     case 14: ctx->tune_team_fast = value ? 1 : 0; return SPX_OK;
+    case 16: if (value < 0 || value > 1000000) break; ctx->tune_team_factor = value; return SPX_OK;
 #ifdef SPX_TEST_HOOKS
     case 100: if (value < 0 || value > 65535) break; ctx->tune_force_grid = value; return SPX_OK;
     case 101: if (value < 0 || value > 65535) break; ctx->tune_force_tail = value; return SPX_OK;

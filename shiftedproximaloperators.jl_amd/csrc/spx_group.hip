@@ -608,16 +608,19 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     SPX_LAUNCH_CHECK();
     return SPX_OK;
   }
-  // Few, large groups -- first of all ONE group over the whole vector, the reference's default GroupNormL2
+  // Large groups -- first of all ONE group over the whole vector, the reference's default GroupNormL2
   // (src/groupNormL2.jl:30-31, shifted(NormL2(lambda), xk): src/shiftedGroupNormL2.jl:34-35): a team of workgroups per
-  // group (spx_group_team.hip) instead of one workgroup (n = 1e8: 384 ms plain / 1349 ms Binf that way).  With at least two
-  // groups per CU the one-workgroup-per-group kernel below fills the chip by itself.
+  // group (spx_group_team.hip) instead of one workgroup (n = 1e8: 384 ms plain / 1349 ms Binf that way).
   const int* big_active = nullptr;   // ragged layouts: device word of the team plan, "the large groups are taken care of"
   const int64_t big_min = 16384;     // ragged layouts: a group of at least this many elements is a large one
   if (ctx->tune_team) {
     if (!offsets) {
       const int tg = spx_group_team_max_grid(ctx, BINF);
-      if (tg >= 1 && ngroups < 2 * (int64_t)tg)
+      // (teams of ONE workgroup that take several groups in turn beat the one-workgroup-per-group kernels below at every count
+      //  of large groups -- 1e8 elements in groups of 5000 ... 200 000: plain 0.88-1.07 -> 0.62-0.99 ms, Binf 2.0-3.4 -> 1.0-1.8 ms,
+      //  tools/r4/team_crossover.py -- on chip up to 9216 elements, two passes instead of one per reduction beyond; tuning key 16
+      //  = groups per workgroup up to which the team form is used, for that A/B)
+      if (tg >= 1 && (ctx->tune_team_factor == 0 || ngroups < (int64_t)ctx->tune_team_factor * tg))
         return spx_group_team_launch(ctx, BINF, y, q, xk, sj, n, nullptr, gsize, ngroups, lambda, sigma, delta);
     } else if (ngroups <= 65536) {
       rc = spx_group_team_plan(ctx, BINF, y, q, xk, sj, n, offsets, ngroups, big_min, &big_active);

@@ -37,6 +37,7 @@ constexpr int kTmLdsBytes = (kTmThreads / 64) * 3 * kTmDmaKiB * 1024;  // 144 Ki
 constexpr int kTmChipElems = kTmLdsBytes / 16;                         // S and X of 9216 elements per workgroup
 constexpr int64_t kTmTilePairs = (int64_t)(kTmThreads / 64) * 64 * kTmDmaKiB;  // 3072 pairs = 6144 elements per tile
 constexpr int kTmMaxSpl = 4;                                           // samples per lane at most
+constexpr int kTmMaxJobs = 65536;                                      // large groups a device-side plan holds at most
 enum { kFormChip = 0, kFormStream = 1, kFormFast = 2 };               // the three kernels (k_group_team)
 
 // Device-side plan of a ragged layout (CSR offsets): which groups are large, and which workgroups own them.
@@ -45,7 +46,7 @@ struct TeamJob {
   int gid, first, W, pad;
 };
 struct TeamPlanHdr {
-  int active;   // 0: no large group (or too many: the one-workgroup-per-group kernel fills the chip) -- nothing to do here
+  int active;   // 0: no large group (or more than the plan holds) -- nothing to do here
   int njobs;
   int loop;     // 1: more jobs than workgroups, W = 1, workgroup b takes jobs b, b + grid, ...
   int pad;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(1024) void k_team_plan(const int64_t* __restrict__ 
     for (int k = 0; k < 16; ++k) M += msum[k];
     msum[0] = M;
     hdr->njobs = acc;
-    hdr->active = (acc > 0 && acc <= max_jobs && acc < 2 * G) ? 1 : 0;
+    hdr->active = (acc > 0 && acc <= max_jobs) ? 1 : 0;
     hdr->loop = (acc > G) ? 1 : 0;
   }
   __syncthreads();
@@ -911,8 +912,12 @@ int team_layout(spx_ctx* ctx, bool binf, const double* y, const double* q, const
     }
     per_wg = (gsize + L->Wu - 1) / L->Wu;
   }
-  L->plan_bytes = offsets ? ((sizeof(TeamPlanHdr) + 2 * (size_t)kGtCols * sizeof(TeamJob) + 255) & ~(size_t)255) : 0;
-  L->status_bytes = 2 * (size_t)kGtCols * sizeof(int);  // one word per job (fewer than 2 * kGtCols jobs per launch)
+  L->plan_bytes = offsets ? ((sizeof(TeamPlanHdr) + (size_t)kTmMaxJobs * sizeof(TeamJob) + 255) & ~(size_t)255) : 0;
+  {  // one word per job: at most kTmMaxJobs jobs in a device-side plan, ngroups jobs for uniform groups
+    size_t jobs_max = (size_t)kTmMaxJobs;
+    if (!offsets && (size_t)ngroups > jobs_max) jobs_max = (size_t)ngroups;
+    L->status_bytes = (jobs_max * sizeof(int) + 255) & ~(size_t)255;
+  }
   L->cand_cap = 0;
   L->cand_bytes = 0;
   if (binf && ctx->tune_team_fast) {
@@ -945,7 +950,7 @@ int spx_group_team_plan(spx_ctx* ctx, bool binf, const double* y, const double* 
   if (rc) return rc;
   TeamPlanHdr* plan = reinterpret_cast<TeamPlanHdr*>(ctx->ws);
   TeamJob* jobs = reinterpret_cast<TeamJob*>(static_cast<char*>(ctx->ws) + sizeof(TeamPlanHdr));
-  hipLaunchKernelGGL(k_team_plan, dim3(1), dim3(1024), 0, ctx->stream, offsets, ngroups, n, L.G, big_min, plan, jobs, 2 * kGtCols);
+  hipLaunchKernelGGL(k_team_plan, dim3(1), dim3(1024), 0, ctx->stream, offsets, ngroups, n, L.G, big_min, plan, jobs, kTmMaxJobs);
   SPX_LAUNCH_CHECK();
   *active_dev = &plan->active;
   return SPX_OK;
