@@ -470,4 +470,42 @@ def test_beyond_int32_indexing_groups(s, orc):
     nrmS = np.repeat(np.linalg.norm(((qh + xh) + sh).reshape(-1, gs), axis=1), gs)
     scale = np.maximum(np.maximum(np.abs(ref), np.abs(xh + sh)), nrmS)
     assert np.all(np.abs(got - ref) <= 1e-12 * scale), float(np.max(np.abs(got - ref) / scale))
+    # ONE group over the same 2^31 + 4224 elements (shifted(NormL2(lambda), x[, Delta, chi])): the team form streams tiles, sample
+    # chunks and candidate regions with 64-bit indices.  Plain: y + x + s = alpha S on the chunks; Binf: inside the trust region,
+    # and the root's fixed point ||y + x + s|| = u = tau (sigma lambda + u) recovered from the free coordinates (y + x + s = tau S there).
+    lam1 = 0.4 * float(n) ** 0.5
+    s.prox_bang(y, s.shifted(s.shifted(s.NormL2(lam1), x), sj), q, sigma)
+    torch.cuda.synchronize()
+    ss_, sw_ = 0.0, 0.0
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        S = (q[lo:hi] + x[lo:hi]) + sj[lo:hi]
+        ss_ += float((S * S).sum()); sw_ += float(((y[lo:hi] + (x[lo:hi] + sj[lo:hi])) ** 2).sum())
+        del S
+    nS = ss_ ** 0.5
+    alpha = max(1.0 - sigma * lam1 / nS, 0.0)
+    assert alpha > 0.1 and abs(sw_ ** 0.5 - alpha * nS) <= 1e-11 * nS
+    for lo in list(range(0, n, step))[::3] + [n - 4099]:
+        hi = min(n, lo + step)
+        S = (q[lo:hi] + x[lo:hi]) + sj[lo:hi]
+        assert float(((y[lo:hi] + (x[lo:hi] + sj[lo:hi])) - alpha * S).abs().max()) <= 1e-11 * nS, lo
+        del S
+    s.prox_bang(y, s.shifted(s.shifted(s.NormL2(lam1), x, delta, s.NormLinf(1.0)), sj), q, sigma)
+    torch.cuda.synchronize()
+    sw_, taus = 0.0, []
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        st = sj[lo:hi] + y[lo:hi]
+        assert float(st.abs().max()) <= delta * (1.0 + 1e-12), lo
+        W = y[lo:hi] + (x[lo:hi] + sj[lo:hi])
+        sw_ += float((W * W).sum())
+        S = (q[lo:hi] + x[lo:hi]) + sj[lo:hi]
+        free = (st.abs() < delta * (1 - 1e-9)) & (S.abs() > 0.5)
+        r_ = (W / S)[free]
+        taus.append((float(r_.min()), float(r_.max())))
+        del st, W, S, free, r_
+    tau_lo, tau_hi = min(a for a, _ in taus), max(b for _, b in taus)
+    assert tau_hi - tau_lo <= 1e-11 and 0.0 < tau_lo < 1.0            # one tau on every free coordinate of the group
+    u = sw_ ** 0.5                                                    # ||w|| at the root = n - sigma lambda =: u, tau = u / (sigma lambda + u)
+    assert abs(tau_lo - u / (sigma * lam1 + u)) <= 1e-10
     assert s._lib.load().spx_sync(s.context("cuda:0")) == 0
