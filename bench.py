@@ -225,7 +225,7 @@ def _extra(s, L, ctx, dev, n, torch):
 
     def line(name, psi, bytes_per_elem, nel, yy, qq, kernel):
         # ms = avg_launch_ms: HIP events around 10 back-to-back calls on the launching stream / 10, median of 5 rounds.
-        # kernel = the dominant kernel of the call as rocprofv3 --kernel-trace names it (profiles/r03_all_ops_kernel_stats.txt;
+        # kernel = the dominant kernel of the call as rocprofv3 --kernel-trace names it (profiles/r04_all_ops_kernel_stats.txt;
         # tools/r3/check_bench_kernels.py checks every string here against that file)
         ms = _time_op(s, L, ctx, lambda: s.prox_bang(yy, psi, qq, 1.0))
         res[name] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4), "kernel": kernel, "gelem_s": round(nel / ms / 1e6, 2),

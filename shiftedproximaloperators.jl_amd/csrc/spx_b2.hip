@@ -128,10 +128,14 @@ __device__ __forceinline__ void b2_put(unsigned long long* slot, double v) {
   const unsigned long long b = (v != v) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(v);
   __hip_atomic_store(slot, b + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (an atomic swap instead: no faster)
 }
-// sums of up to 6 values over a workgroup of <= 16 wavefronts; lds = [6][16]
+// sums of up to 6 values over a workgroup of <= 16 wavefronts; lds = [6][16] (the slots of absent wavefronts stay zero).
+// Round 4: wavefront sums by DPP (four row steps + two permutes instead of six permutes per double), and every 16-lane row reads
+// the 16 slots ONCE and folds them by DPP -- every lane reading all 16 slots itself was 96 LDS instructions per wavefront and
+// call, 3.5 us per call with 16 wavefronts (tools/exp/team_reduce.hip: 1.9 us this way); a call of the one-launch forms makes
+// 20-30 of them.  A fixed shape: all lanes, and all workgroups on the same partial sums, form the same bits.
 __device__ __forceinline__ void b2_block_sum6(double (&v)[6], double (*lds)[16]) {
 #pragma unroll
-  for (int k = 0; k < 6; ++k) v[k] = wave_sum(v[k]);
+  for (int k = 0; k < 6; ++k) v[k] = wave_sum_dpp(v[k]);
   const int w = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) {
@@ -140,12 +144,7 @@ __device__ __forceinline__ void b2_block_sum6(double (&v)[6], double (*lds)[16])
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    double acc = 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc += lds[k][j];
-    v[k] = acc;
-  }
+  for (int k = 0; k < 6; ++k) v[k] = fold16_sum(lds[k][threadIdx.x & 15]);
 }
 
 #ifdef SPX_B2_PROFILE  // A/B builds only: time stamps of workgroup 0 (10 ns units), read with spx_debug_b2_stamps

@@ -237,6 +237,43 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// A double moved between lanes by DPP (row operations: quad_perm, row_half_mirror, row_mirror -- inside a 16-lane row)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// sum / max over the 64 lanes of a wavefront, result in every lane: DPP inside the 16-lane rows, two permutes across them
+// (the xor butterfly of wave_sum is six permutes per double: the reductions of a root find are latency, not bandwidth)
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {
+  v = fmax(v, dpp_f64<0xB1>(v));
+  v = fmax(v, dpp_f64<0x4E>(v));
+  v = fmax(v, dpp_f64<0x141>(v));
+  v = fmax(v, dpp_f64<0x140>(v));
+  v = fmax(v, __shfl_xor(v, 16, 64));
+  v = fmax(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+// sum over the 16 lanes of a row, result in every lane of the row (a fixed shape: the same bits in every row that holds the same 16 values)
+__device__ __forceinline__ double fold16_sum(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  return v;
+}
+
 // spx_ctx::sync: [0, kSpxSyncSelBytes) belongs to spx_select.hip (SelSync, whose head is the SpxSyncHeader below), the
 // partial-sum words of spx_b2.hip follow.  Zero-filled when (re)allocated; the host-side flags are reset with it.
 constexpr size_t kSpxSyncSelBytes = (size_t)2 << 20;  // 2 MiB >= sizeof(SelSync) (static_assert in spx_select.hip)

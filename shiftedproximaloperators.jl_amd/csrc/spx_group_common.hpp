@@ -9,13 +9,7 @@
 // ---------------------------------------------------------------------------------------------
 // team reductions: TEAM lanes (8, 16, 32, 64: aligned lane ranges of one wave; 256: the workgroup)
 // ---------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
+// (dpp_f64, wave_sum_dpp, wave_max_dpp, fold16_sum: spx_common.hpp)
 template <int TEAM>
 __device__ __forceinline__ double lanes_sum(double v) {
   static_assert(TEAM == 1 || TEAM == 2 || TEAM == 4 || TEAM == 8 || TEAM == 16 || TEAM == 32 || TEAM == 64, "TEAM");
@@ -54,26 +48,6 @@ struct GridTeam {
   int wnp[16];                  // reductions this team has exchanged so far in this launch (the row of the exchange words)
   int wcalls[16];               // workgroup combines so far (parity = slot set)
 };
-// sum / max over the 64 lanes of a wavefront, result in every lane: DPP inside the 16-lane rows, two permutes across them
-// (the xor butterfly of wave_sum is six permutes per double: the reductions of a root find are latency, not bandwidth)
-__device__ __forceinline__ double wave_sum_dpp(double v) {
-  v += dpp_f64<0xB1>(v);
-  v += dpp_f64<0x4E>(v);
-  v += dpp_f64<0x141>(v);
-  v += dpp_f64<0x140>(v);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
-}
-__device__ __forceinline__ double wave_max_dpp(double v) {
-  v = fmax(v, dpp_f64<0xB1>(v));
-  v = fmax(v, dpp_f64<0x4E>(v));
-  v = fmax(v, dpp_f64<0x141>(v));
-  v = fmax(v, dpp_f64<0x140>(v));
-  v = fmax(v, __shfl_xor(v, 16, 64));
-  v = fmax(v, __shfl_xor(v, 32, 64));
-  return v;
-}
 // x[k] <- sum / max over the 1024 lanes of the workgroup, the same bits in every lane: wavefront reductions, one slot per
 // wavefront, ONE barrier, then every 16-lane row reads the 16 slots and folds them by DPP (a fixed shape; every lane reading
 // all 16 slots itself cost 16 NV LDS instructions per wavefront: 5.7 us for ten values, tools/exp/team_reduce.hip).

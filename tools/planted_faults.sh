@@ -8,9 +8,9 @@ ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 CSRC="$ROOT/shiftedproximaloperators.jl_amd/csrc"
 # id | file | sed expression | tests that must catch it
 FAULTS=(
- "1|spx_group.hip|0,/bool decided = g0 < -1e-9 \* sl;/s//bool decided = g0 < 1e300;/|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region"
- "2|spx_group.hip|s/decided = (r2n == r2);/decided = true;/g|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region"
- "3|spx_group.hip|s/if (reversed \&\& mX < delta \* (1.0 - 1e-9)) return BINF_ZERO;/if (reversed) return BINF_ZERO;/|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region tests/test_gpu_stress.py::test_binf_reversed_bracket_regimes"
+ "1|spx_group_common.hpp|0,/bool decided = g0 < -1e-9 \* sl;/s//bool decided = g0 < 1e300;/|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region"
+ "2|spx_group_common.hpp|s/decided = (r2n == r2);/decided = true;/g|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region"
+ "3|spx_group_common.hpp|s/if (reversed \&\& mX < delta \* (1.0 - 1e-9)) return BINF_ZERO;/if (reversed) return BINF_ZERO;/|tests/test_gpu_stress.py::test_binf_reversed_bracket_entries_outside_trust_region tests/test_gpu_stress.py::test_binf_reversed_bracket_regimes"
  "5|spx_select.hip|s/} else if (!catch_all) {  /} else if (true) {  /|tests/test_gpu_stress.py::test_topr_folded_first_digit"
  "6|spx_b2.hip|s/clear_rows\[pass_i \* kB2Cols \* kB2Words + rem\] = 0ull;/(void)rem;/|tests/test_gpu_stress.py::test_b2_alternating_sizes_share_the_exchange_words tests/test_gpu_stress.py::test_b2_one_launch_forms_at_their_boundaries"
  "7|spx_select.hip|s/rc = spx_zero_async(ctx, &ss->chist\[0\]\[0\]\[0\], sizeof(ss->chist\[0\]));/rc = 0;/|tests/test_gpu_graph.py::test_iteration_in_a_graph_replays_on_new_data"
@@ -22,12 +22,12 @@ FAULTS=(
  "13|spx_select.hip|s/if (tail \&\& pr == nw) {  \/\/ the elements behind the last whole vector/if (false) {  \/\/ the elements behind the last whole vector/|tests/test_gpu_parity.py::test_indball_l0_at_the_fast_path_threshold"
  "14|spx_select.hip|s/if (wr \&\& !in \&\& keep != spec) y\[i\]/if (wr \&\& !in \&\& keep \&\& !spec) y[i]/|tests/test_gpu_parity.py::test_indball_l0_at_the_fast_path_threshold tests/test_gpu_parity.py::test_indball_l0_ranks_and_scales"
  "15|spx_b2.hip|s/lo = SQ\[k\] - lsv; hi = SQ\[k\] + lsv;/lo = SQ[k] - lsv; hi = SQ[k] - lsv;/|tests/test_gpu_stress.py::test_b2_streaming_form_scenarios tests/test_gpu_stress.py::test_b2_one_launch_forms_at_their_boundaries"
- "16|spx_group.hip|0,/if constexpr (TEAM >= 2) v += dpp_f64<0xB1>(v);/s//if constexpr (TEAM >= 4) v += dpp_f64<0xB1>(v);/|tests/test_gpu_parity.py::test_group_uniform"
+ "16|spx_group_common.hpp|0,/if constexpr (TEAM >= 2) v += dpp_f64<0xB1>(v);/s//if constexpr (TEAM >= 4) v += dpp_f64<0xB1>(v);/|tests/test_gpu_parity.py::test_group_uniform"
  "17|spx_objective.hip|s/for (int off = TEAM \/ 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);  \/\/ (inside the team/for (int off = TEAM \/ 2; off >= 2; off >>= 1) ss += __shfl_xor(ss, off, 64);  \/\/ (inside the team/|tests/test_gpu_parity.py::test_objective_group_sizes"
  "18|spx_separable.hip|s/^        st2<NT>(y + i, r);\$/        if (blockIdx.x != gridDim.x \/ 2) st2<NT>(y + i, r);/|tests/test_gpu_fullsize.py::test_full_size_lhalf"
  "19|spx_group.hip|s/^    if (valid) {\$/    if (valid \&\& blockIdx.x != gridDim.x \/ 2) {/|tests/test_gpu_fullsize.py::test_full_size_groups"
  "20|spx_group_team.hip|s/        visit(i < npairs, i, qa, xa, sa);/        visit(i < npairs \&\& !(wl == W \/ 2 \&\& tile == wl + W), i, qa, xa, sa);/|tests/test_gpu_team.py::test_one_group_over_the_vector tests/test_gpu_fullsize.py::test_one_group_over_1e8_elements"
- "4|spx_group.hip|s/if (sb == 0.0) {/if (false) {/;s/for (int k = 0; k < 64; ++k) {/for (int k = 0; k < 12; ++k) { piece_ok = true;/|tests/test_gpu_parity.py::test_group_binf_many_small_groups tests/test_gpu_parity.py::test_group_binf_zero_groups_strong_lambda"
+ "4|spx_group_common.hpp|s/if (sb == 0.0) {/if (false) {/;s/for (int k = 0; k < 64; ++k) {/for (int k = 0; k < 12; ++k) { piece_ok = true;/|tests/test_gpu_parity.py::test_group_binf_many_small_groups tests/test_gpu_parity.py::test_group_binf_zero_groups_strong_lambda"
 )
 case "${1:-}" in
 build)

@@ -1,6 +1,6 @@
 """Do the `kernel` strings of a bench.py JSON line name kernels that rocprofv3 saw?  usage: check_bench_kernels.py <bench json> <kernel stats txt>
 Every template instantiation named in the JSON (tokens like k_xxx<...> or k_xxx) must occur, with the namespace prefixes removed,
-in the kernel-stats file (profiles/r03_all_ops_kernel_stats.txt)."""
+in the kernel-stats file (profiles/r04_all_ops_kernel_stats.txt)."""
 import json, re, sys
 line = [l for l in open(sys.argv[1]) if l.lstrip().startswith("{")][-1]
 d = json.loads(line)
