@@ -612,7 +612,8 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   // (src/groupNormL2.jl:30-31, shifted(NormL2(lambda), xk): src/shiftedGroupNormL2.jl:34-35): a team of workgroups per
   // group (spx_group_team.hip) instead of one workgroup (n = 1e8: 384 ms plain / 1349 ms Binf that way).
   const int* big_active = nullptr;   // ragged layouts: device word of the team plan, "the large groups are taken care of"
-  const int64_t big_min = 16384;     // ragged layouts: a group of at least this many elements is a large one
+  const int64_t big_min = (BINF ? kLdsGroupMax : kLdsGroupMaxPlain) + 1;  // ragged layouts: a group of at least this many elements is
+                                                                          // a large one (what the LDS-resident kernel does not hold, as for uniform groups)
   if (ctx->tune_team) {
     if (!offsets) {
       const int tg = spx_group_team_max_grid(ctx, BINF);

@@ -624,8 +624,16 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
     sX = __builtin_fma(X, X, sX);
     mX = fmax(mX, fabs(X));
   });
-  team_sum2<TEAM>(sS, sX, lds);
-  mX = team_max<TEAM>(mX, lds);
+  if constexpr (TEAM == kTeamGrid) {  // (a team of workgroups: one exchange for the three values instead of two)
+    double v3[3] = {sS, sX, mX};
+    grid_team_reduce<3>(reinterpret_cast<GridTeam*>(lds), v3, 4u);
+    sS = v3[0];
+    sX = v3[1];
+    mX = v3[2];
+  } else {
+    team_sum2<TEAM>(sS, sX, lds);
+    mX = team_max<TEAM>(mX, lds);
+  }
   const double nS = sqrt_pos(sS), nX = sqrt_pos(sX);
   // X == 0 in the whole group and sigma lambda > ||S||: the group of a sparse iterate that stays zero -- the bulk of the
   // groups in a group-lasso run, so it must not take the literal path its (usually degenerate: lmax = ||S|| + sigma zlmax

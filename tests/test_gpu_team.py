@@ -131,7 +131,7 @@ def _ragged_offsets(n, cuts):
 @pytest.mark.parametrize("binf", [False, True])
 @pytest.mark.parametrize("layout", ["seven", "small_and_large", "many_large"])
 def test_ragged_layouts_plan_on_the_device(s, orc, binf, layout):
-    # CSR offsets: the large groups (>= 16384 elements) go to teams sized by their share of the elements (k_team_plan), the
+    # CSR offsets: the large groups (more than the LDS-resident kernel holds: > 2048 plain / > 4096 Binf) go to teams sized by their share of the elements (k_team_plan), the
     # others to the one-workgroup-per-group kernel, which skips the large ones
     n = 3_000_000
     if layout == "seven":
