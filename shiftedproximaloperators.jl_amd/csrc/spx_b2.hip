@@ -133,18 +133,28 @@ __device__ __forceinline__ void b2_put(unsigned long long* slot, double v) {
 // the 16 slots ONCE and folds them by DPP -- every lane reading all 16 slots itself was 96 LDS instructions per wavefront and
 // call, 3.5 us per call with 16 wavefronts (tools/exp/team_reduce.hip: 1.9 us this way); a call of the one-launch forms makes
 // 20-30 of them.  A fixed shape: all lanes, and all workgroups on the same partial sums, form the same bits.
-__device__ __forceinline__ void b2_block_sum6(double (&v)[6], double (*lds)[16]) {
+// NV: only the first NV of the six are formed (most reductions carry two sums, P and C: every wavefront of the workgroup does
+// this work, so a sum that nobody reads costs as much as one that is read).
+template <int NV>
+__device__ __forceinline__ void b2_block_sum_n(double (&v)[6], double (*lds)[16]) {
 #pragma unroll
-  for (int k = 0; k < 6; ++k) v[k] = wave_sum_dpp(v[k]);
+  for (int k = 0; k < NV; ++k) v[k] = wave_sum_dpp(v[k]);
   const int w = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) lds[k][w] = v[k];
+    for (int k = 0; k < NV; ++k) lds[k][w] = v[k];
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 6; ++k) v[k] = fold16_sum(lds[k][threadIdx.x & 15]);
+  for (int k = 0; k < NV; ++k) v[k] = fold16_sum(lds[k][threadIdx.x & 15]);
+}
+// mask: which of the six sums travel (3, 7, 15 or 63: the first two, three, four or all)
+__device__ __forceinline__ void b2_block_sum6(double (&v)[6], double (*lds)[16], unsigned int mask = 63u) {
+  if (mask <= 3u) b2_block_sum_n<2>(v, lds);
+  else if (mask <= 7u) b2_block_sum_n<3>(v, lds);
+  else if (mask <= 15u) b2_block_sum_n<4>(v, lds);
+  else b2_block_sum_n<6>(v, lds);
 }
 
 #ifdef SPX_B2_PROFILE  // A/B builds only: time stamps of workgroup 0 (10 ns units), read with spx_debug_b2_stamps
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
   int np = 0;  // reductions exchanged so far (row of the exchange words)
   // One reduction: the six sums of this workgroup -> totals, identical in every workgroup.  mask: which words travel.
   auto reduce = [&](double (&v)[6], unsigned int mask) {
-    b2_block_sum6(v, lds6);
+    b2_block_sum6(v, lds6, mask);
     if (G > 1) {
       // the partial sums are the ONLY data the workgroups exchange: agent-scope atomic stores / loads (`sc1`, past the
       // non-coherent caches) of words that carry their own ready flag (see b2_put)
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(THREADS) void k_b2_coop(double* y, const double* q,
 #pragma unroll
         for (int k = 0; k < 6; ++k) g[k] = (mask & (1u << k)) ? __longlong_as_double((long long)(w[k] - 1ull)) : 0.0;
       }
-      b2_block_sum6(g, lds6);
+      b2_block_sum6(g, lds6, mask);
 #pragma unroll
       for (int k = 0; k < 6; ++k) v[k] = g[k];
     }
