@@ -201,6 +201,29 @@ def test_views_and_aliasing(s, orc, binf, n):
     assert torch.equal(y1.view(torch.int64), y2.view(torch.int64))
 
 
+def test_objective_on_structured_data_against_an_exact_sum(s, orc):
+    """psi(y) of ONE group over 2e6 lattice-valued elements: the Float64 oracle adds the squares one after the other, and on data
+    with few distinct values its rounding errors line up (found by tools/r4/fuzz_team.py: up to 1.6e-11 relative, the GPU's
+    chunked fixed-order sum 2e-16).  Adjudicated like the prox values (tests/arbiter.py): against the exact sum of the squares
+    (math.fsum, square root in extended precision) the GPU must be within 1e-12 + the oracle's own error."""
+    import math
+    import torch
+    n = 2_000_000
+    x, sj, q = _data(n, 21, quant=4)
+    lam = 0.7
+    off = np.array([0, n], dtype=np.int64)
+    xd, sd, qd = _dev(x, sj, q)
+    psi = s.shifted(s.shifted(s.NormL2(lam), xd), sd)
+    y = s.prox(psi, qd, 0.9)
+    yh = y.cpu().numpy()
+    v = psi(y)
+    vr = orc.obj_group_l2(yh, x, sj, [lam], offsets=off)
+    w = (x + sj) + yh
+    exact = float(np.longdouble(lam) * np.sqrt(np.longdouble(math.fsum((w * w).tolist()))))
+    assert abs(v - exact) <= 1e-12 * exact + abs(vr - exact), (v, vr, exact)
+    assert abs(v - exact) <= 1e-14 * exact, (v, exact)   # (the GPU's own error: a few ulps)
+
+
 @pytest.mark.parametrize("layout", ["one", "uniform", "ragged"])
 @pytest.mark.parametrize("binf", [False, True])
 def test_objective_on_large_groups(s, orc, layout, binf):

@@ -15,7 +15,7 @@ ctx = s.context("cuda:0"); chi = s.NormLinf(1.0)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-t0 = time.time(); ncase = 0; nfail = 0; narb = 0
+t0 = time.time(); ncase = 0; nfail = 0; narb = 0; nval_arb = 0; worst_or = 0.0; worst_gpu = 0.0
 def dev(a, off):
     t = torch.zeros(a.shape[0] + 2, dtype=torch.float64, device="cuda:0"); t[off:off + a.shape[0]] = torch.from_numpy(a).cuda(); return t[off:off + a.shape[0]]
 while time.time() - t0 < budget:
@@ -54,7 +54,31 @@ while time.time() - t0 < budget:
         y = s.prox(psi, qd, sigma).cpu().numpy()
         with np.errstate(all="ignore"):
             ref = oracle.prox_group_l2_binf(q, x, sj, lam, sigma, delta, offsets=offs) if binf else oracle.prox_group_l2(q, x, sj, lam, sigma, offsets=offs)
+        # psi(y) at the prox (the chunked form on large groups), against the oracle
+        yd = torch.from_numpy(y).cuda() if off8 == 0 else dev(y, off8)
+        if np.all(np.isfinite(y)):
+            val = psi(yd)
+            with np.errstate(all="ignore"):
+                vr = oracle.obj_group_l2(y, x, sj, lam, offsets=offs, delta=(delta if binf else None))
+            if not (val == vr or abs(val - vr) <= 1e-12 * abs(vr)):
+                # above the plain bar: which side is off?  The oracle adds the squares of a group one after the other (as a generic
+                # `norm` loop would): on data with few distinct values its rounding errors line up (n eps, not sqrt(n) eps).  Exact
+                # value: math.fsum of the squares (error-free), the square root in extended precision.
+                import math
+                if binf and np.any(np.abs(sj + y) > 1.1 * delta):
+                    exact = float("inf")
+                else:
+                    w = ((sj + y) + x) if binf else ((x + sj) + y)
+                    exact = float(sum(np.longdouble(l) * np.sqrt(np.longdouble(math.fsum((w[a:b] * w[a:b]).tolist()))) for l, a, b in zip(lam, offsets[:-1], offsets[1:])))
+                eg, eo = abs(val - exact), abs(vr - exact)
+                nval_arb += 1
+                if not (eg <= 1e-12 * abs(exact) + eo):
+                    nfail += 1
+                    print("FAIL psi(y) kind %s data %s n %d groups %d binf %d: gpu %r oracle %r exact %r" % (kind, data, n, len(groups), binf, val, vr, exact), flush=True)
+                else:
+                    worst_or = max(worst_or, eo / abs(exact)); worst_gpu = max(worst_gpu, eg / abs(exact))
         ncase += 1
+        if ncase % 100 == 0: print("... %d cases, %.0f s, %d failures, %d groups arbitrated" % (ncase, time.time() - t0, nfail, narb), flush=True)
         try:
             assert np.array_equal(np.isnan(y), np.isnan(ref))
             v = arbiter.check_group(oracle, y, ref, q, x, sj, np.asarray(lam), sigma, offs, delta=delta if binf else None, what="fuzz", max_arbitrated=4 if n > 1_500_000 else 64)
@@ -64,4 +88,5 @@ while time.time() - t0 < budget:
             print("FAIL kind %s data %s n %d groups %d binf %d fast %d off %d delta %.4g sigma %.4g lam %s: %s" % (kind, data, n, len(groups), binf, fast, off8, delta, sigma, lam[:4], str(e)[:200]), flush=True)
     L.spx_ctx_set_tuning(ctx, 14, 1)
 print("fuzz_team: %d cases in %.0f s, %d failures, %d groups arbitrated in binary128 (all sided with the GPU or within the bar)" % (ncase, time.time() - t0, nfail, narb))
+print("   psi(y): %d values above the plain 1e-12 bar against the Float64 oracle, adjudicated with an exact sum: worst relative error of the oracle's sequential sum %.2e, of the GPU %.2e" % (nval_arb, worst_or, worst_gpu))
 sys.exit(1 if nfail else 0)
