@@ -72,6 +72,7 @@ struct spx_ctx {
                                    //         grid (0 = default, see run_group in spx_group.hip); an A/B knob
   int tune_force_grid = 0;         // key 100, test builds only (-DSPX_TEST_HOOKS): launch the one-launch top-r with THIS many workgroups,
                                    //          residency or not -- the planted fault behind tests/test_gpu_robustness.py
+  int tune_force_team = 0;         // key 102, test builds only: the last workgroup of every team of k_group_team arrives late (spx_group_team.hip)
   int tune_force_tail = 0;         // key 101, test builds only: the same for the tail kernel of the sampled top-r pipeline (k_s2_tail)
   // Device-side status word in host-mapped pinned memory (spx_ctx.hip): a kernel that gives up waiting for the other
   // workgroups of its launch, or finds library-owned state outside its layout, stores a non-zero code here (system-scope

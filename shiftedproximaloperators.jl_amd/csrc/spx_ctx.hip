@@ -154,6 +154,7 @@ SPX_EXPORT int spx_ctx_set_tuning(spx_ctx* ctx, int key, int value) {
 #ifdef SPX_TEST_HOOKS
     case 100: if (value < 0 || value > 65535) break; ctx->tune_force_grid = value; return SPX_OK;
     case 101: if (value < 0 || value > 65535) break; ctx->tune_force_tail = value; return SPX_OK;
+    case 102: if (value < 0 || value > 65535) break; ctx->tune_force_team = value; return SPX_OK;
 #endif
     default: break;
   }

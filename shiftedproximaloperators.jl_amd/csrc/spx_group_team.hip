@@ -715,7 +715,7 @@ __global__ __launch_bounds__(kTmThreads) void k_group_team(double* y, const doub
                                                              int64_t n, int64_t gsize, int64_t ngroups, int Wu,
                                                              const TeamPlanHdr* plan, const TeamJob* jobs,
                                                              const double* __restrict__ lambda, double sigma, double delta,
-                                                             int pole_lit, int par, int* job_status, int use_status,
+                                                             int pole_lit, int par, int* job_status, int use_status /* bit 1: test hook */,
                                                              unsigned long long* rows, unsigned long long* clear_rows,
                                                              unsigned int* tile_ctr, unsigned int* clear_ctr, SpxSyncHeader* hdr,
                                                              f64x2* cand, unsigned int cand_cap) {
@@ -762,6 +762,16 @@ __global__ __launch_bounds__(kTmThreads) void k_group_team(double* y, const doub
   __syncthreads();
   double* const lds = reinterpret_cast<double*>(&gt);
   const double kNaN = __longlong_as_double(0x7ff8000000000000ll);
+  bool late = false;
+#ifdef SPX_TEST_HOOKS
+  // planted (tuning key 102, tests/test_gpu_robustness.py): the last workgroup of a team behaves as one that was not resident while
+  // the others waited for it -- it takes part in no reduction and only runs once they have given up (the flag), then stores its share
+  if ((use_status & 2) && W > 1 && wl == W - 1) {
+    late = true;
+    for (unsigned int spins = 0; !spx_poisoned(hdr) && spins < (1u << 22); ++spins) __builtin_amdgcn_s_sleep(20);
+  }
+  use_status &= 1;
+#endif
   for (; job < njobs; job += job_step) {
     int64_t lo, hi;
     int gid;
@@ -770,6 +780,26 @@ __global__ __launch_bounds__(kTmThreads) void k_group_team(double* y, const doub
     const int64_t m = hi - lo;
     const double lam = lambda[gid];
     const bool on_chip = m <= (int64_t)W * kTmChipElems;
+    if (late) {  // (test builds only) its share of the group, poisoned: NaN
+      if (on_chip == (FORM == kFormChip)) {
+        if (on_chip) {
+          const int64_t chunk = (m + W - 1) / W;
+          const int64_t base = lo + (int64_t)wl * chunk;
+          int64_t c64 = hi - base;
+          if (c64 > chunk) c64 = chunk;
+          ChipGroup lg{reinterpret_cast<double*>(dma), reinterpret_cast<double*>(dma) + kTmChipElems, sj, base, c64 > 0 ? (int)c64 : 0, hdr};
+          lg.store(y, [&](double, double) { return 0.0; });
+        } else if (FORM != kFormStream || !BINF || !use_status || job_status[job] != 0) {
+          StreamGroup<VEC> lg;
+          lg.q = q; lg.xk = xk; lg.sj = sj; lg.lo = lo; lg.hi = hi;
+          lg.a = VEC ? lo + ((lo + par) & 1) : lo;
+          lg.npairs = (hi - lg.a) >> 1;
+          lg.wl = wl; lg.W = W; lg.dma = dma; lg.ctr = nullptr; lg.next = &next_tile; lg.hdr = hdr;
+          lg.store(y, [&](double, double) { return 0.0; });
+        }
+      }
+      continue;
+    }
     if constexpr (FORM == kFormChip) {
       if (!on_chip) continue;
       // ---- on chip: S = (q + xk) + sj and X = xk of this workgroup's share in LDS, the vectors are read once
@@ -993,7 +1023,10 @@ int spx_group_team_launch(spx_ctx* ctx, bool binf, double* y, const double* q, c
     unsigned long long* clear_rows = sets + (size_t)other * kGtSetWords;
     unsigned int* tile_ctr = ctrs + (size_t)use * kGtCols;
     unsigned int* clear_ctr = ctrs + (size_t)other * kGtCols;
-    const int use_status = (form == kFormStream && fast) ? 1 : 0;
+    int use_status = (form == kFormStream && fast) ? 1 : 0;
+#ifdef SPX_TEST_HOOKS
+    if (ctx->tune_force_team > 0) use_status |= 2;
+#endif
     {
       SpxCoopLaunchGuard guard(ctx);
 #define SPX_TEAM_LAUNCH(B, V, F)                                                                                                \

@@ -144,6 +144,66 @@ def test_the_top_r_tail_kernel_poisons_its_result_too(s):
         assert rc_after == 0 and nan_after == 0, case
 
 
+_CHILD_TEAM = r"""
+import ctypes, os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import __graft_entry__ as ge
+s = ge.build(); L = s._lib.load(); ctx = s.context("cuda:0")
+rng = np.random.default_rng(5)
+res = []
+for n, binf, fast in ((120_000, 0, 1), (120_000, 1, 1), (3_000_000, 0, 1), (3_000_000, 1, 1), (3_000_000, 1, 0)):
+    x = torch.from_numpy(rng.normal(size=n)).cuda(); sj = torch.from_numpy(rng.uniform(-0.5, 0.5, size=n)).cuda()
+    q = torch.from_numpy(rng.normal(size=n)).cuda(); y = torch.empty_like(q)
+    lam = torch.tensor([0.4 * n ** 0.5], dtype=torch.float64, device="cuda")
+    L.spx_ctx_set_tuning(ctx, 14, fast)
+    def call():
+        if binf:
+            return L.spx_prox_group_l2_binf(ctx, y.data_ptr(), q.data_ptr(), x.data_ptr(), sj.data_ptr(), n, None, n, 1, lam.data_ptr(), ctypes.c_double(0.9), ctypes.c_double(1.0))
+        return L.spx_prox_group_l2(ctx, y.data_ptr(), q.data_ptr(), x.data_ptr(), sj.data_ptr(), n, None, n, 1, lam.data_ptr(), ctypes.c_double(0.9))
+    assert call() == 0
+    torch.cuda.synchronize()
+    good = y.clone()
+    assert not bool(torch.isnan(good).any())
+    assert L.spx_ctx_set_tuning(ctx, 102, 1) == 0      # the last workgroup of the team arrives late
+    y.fill_(7.0)
+    rc_launch = call()
+    torch.cuda.synchronize()
+    L.spx_ctx_set_tuning(ctx, 102, 0)
+    nan = int(torch.isnan(y).sum())
+    rc_next = L.spx_prox_l1(ctx, good.data_ptr(), q.data_ptr(), x.data_ptr(), sj.data_ptr(), n, ctypes.c_double(1.0), ctypes.c_double(1.0))
+    rc_sync = L.spx_sync(ctx)
+    rc_after = call()
+    torch.cuda.synchronize()
+    same = bool(torch.equal(y.view(torch.int64), (good if True else y).view(torch.int64))) if False else int(torch.isnan(y).sum()) == 0
+    res.append((n, binf, fast, rc_launch, nan, rc_next, rc_sync, rc_after, int(same)))
+L.spx_ctx_set_tuning(ctx, 14, 1)
+print("RESULT", res)
+"""
+
+
+def test_a_team_of_workgroups_poisons_its_result_too(s):
+    """Round 4: the team form (csrc/spx_group_team.hip) synchronises inside its launches like top-r and B2.  Hooks build, tuning key
+    102: the last workgroup of the team takes part in no reduction and only runs once the others have given up -- on chip and
+    streamed, plain and Binf (fast path and generic body): NaN over the whole group, SPX_ERR_INTERNAL on the next call, a clean
+    result after spx_sync."""
+    lib = os.path.join(ROOT, "shiftedproximaloperators.jl_amd", "lib", "libspx_hooks.so")
+    if not os.path.exists(lib):
+        pytest.skip("libspx_hooks.so not built")
+    env = dict(os.environ, SPX_LIB_NAME="libspx_hooks.so", SPX_NO_BUILD="1")
+    out = subprocess.run([sys.executable, "-c", _CHILD_TEAM % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+    assert line, (out.stdout[-2000:], out.stderr[-2000:])
+    res = eval(line[0][len("RESULT"):])
+    assert len(res) == 5
+    for n, binf, fast, rc_launch, nan, rc_next, rc_sync, rc_after, clean in res:
+        what = (n, binf, fast)
+        assert rc_launch == 0, what
+        assert nan == n, "%r: the abandoned launch must poison the whole group (%d of %d NaN)" % (what, nan, n)
+        assert rc_next == 7 and rc_sync == 7, what
+        assert rc_after == 0 and clean == 1, what
+
+
 def test_residency_cap_takes_the_smaller_grid_forms(s, orc):
     """key 8: B2 and top-r with the resident grid capped at 1, 5 and 100 workgroups (register-resident forms hand over to the
     streaming / parked forms, the sampled pipeline to the exact select) -- bits / 1e-12 as without the cap."""
