@@ -289,6 +289,9 @@ struct MemGroup {
 #ifndef SPX_BINF_CONFIRM
 #define SPX_BINF_CONFIRM 1  // A/B switch of the cheap active-set confirmation (binf_same_active_set)
 #endif
+#ifndef SPX_BINF_POLY
+#define SPX_BINF_POLY 1  // A/B switch (round 4): approach to a piece's root on the quartic in t instead of Newton in v
+#endif
 // (tried: a first piece solve without its final accurate Newton step -- slower, 0.99 vs 0.85 ms: the next pass then
 //  starts from a point that is not a piece root and an extra pass follows)
 
@@ -774,7 +777,47 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
       v = sqrt_pos(sa) - sl;  // g(v) = v (1 - sqrt(sa) / (sl + v)): the reference's 1 - sl/||S|| in disguise
       piece_ok = true;
     } else {
-      for (int k = 0; k < 64; ++k) {
+      // Round 4: the approach to the piece's root runs on the quartic the piece equation becomes in t = v / (sl + v),
+      //   P(t) = (1 - t)^2 (sb + sa t^2) - sl^2 t^2  (the unique root in (0, 1) is the wanted one: both sides of
+      //   sl t / (1 - t) = sqrt(sb + sa t^2) are positive there),
+      // by Newton in its factored form: 6 fma/mul for P, 4 for P'/2, one v_rcp -- no square root, no refined reciprocal
+      // (~18 issue slots a step against ~40 for the step in v below; on groups of <= 8 elements, one lane per group, the
+      // piece solves were 40 % of the kernel's vector instructions and a wavefront waits for its slowest lane:
+      // tools/r4/binf_small_emul.py).  It stops within 1e-8 of the root relative to min(t, 1 - t), i.e. within 2e-8 of v;
+      // the fully accurate Newton step in v that follows is the one the iteration in v ended with, so the piece root has
+      // the accuracy it had.  A piece on which this does not settle (t leaves (0, 1), sl^2 overflows, a vanishing slope)
+      // takes the iteration in v as before.
+      bool poly_ok = false;
+#if SPX_BINF_POLY
+      {
+        const double c2 = sl * sl;
+        double t = tau_full;  // = u / (sl + u): (sa, sb) belong to u
+        for (int k = 0; k < 24; ++k) {
+          const double om = 1.0 - t, t2 = t * t;
+          const double w = __builtin_fma(sa, t2, sb);
+          const double P = __builtin_fma(om * om, w, -(c2 * t2));
+          const double dPh = __builtin_fma(-c2, t, om * __builtin_fma(om, sa * t, -w));  // P'(t) / 2
+          const double tn = __builtin_fma(-0.5 * P, __builtin_amdgcn_rcp(dPh), t);
+          const bool last = fabs(tn - t) <= 1e-8 * fmin(tn, 1.0 - tn);
+          t = tn;
+          if (!(t > 0.0 && t < 1.0)) break;  // (also NaN)
+          if (last) { poly_ok = true; break; }
+        }
+        if (poly_ok) {
+          v = sl * t * fast_rcp(1.0 - t);
+          const double rn2 = fast_rcp(sl + v);
+          const double t2 = v * rn2;
+          const double p2 = __builtin_fma(t2 * t2, sa, sb);
+          const double ph_ = sqrt_pos(p2);
+          const double gp2 = 1.0 - ((ph_ > 0.0) ? sa * t2 * (sl * rn2 * rn2) * fast_rcp(ph_) : 0.0);
+          v = v - (v - ph_) * fast_rcp(gp2);
+          piece_ok = (v == v);
+          poly_ok = piece_ok;
+          if (!poly_ok) v = u;
+        }
+      }
+#endif
+      for (int k = 0; k < 64 && !poly_ok; ++k) {
         const double rn = fast_rcp(sl + v);
         const double t = v * rn;
         const double ph2 = __builtin_fma(t * t, sa, sb);
