@@ -108,6 +108,7 @@ int spx_ctx_count(int device);                     // live contexts on a device
 // synchronises inside itself sizes its grid with this and takes a smaller-grid form when the grid it wants does not fit --
 // a workgroup must never wait for one that cannot be placed.  0 with an error set if the kernel cannot run at all.
 int64_t spx_resident_cap(spx_ctx* ctx, const void* fn, int block_threads, size_t dyn_lds);
+int spx_blocks_per_cu(spx_ctx* ctx, const void* fn, int block_threads, size_t dyn_lds);  // workgroups a CU holds at once; -1: error
 int spx_status_report(spx_ctx* ctx);               // SPX_ERR_INTERNAL + message for a non-zero device status word
 // Is ctx's stream being captured into a graph?  Sets spx_ctx::graph_safe (sticky) when it is.  Calls that would have to
 // synchronise the stream or (re)allocate refuse to run while capturing (SPX_ERR_INVALID_ARG, spx_require_not_capturing).

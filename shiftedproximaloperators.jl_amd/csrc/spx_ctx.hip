@@ -209,21 +209,25 @@ SPX_EXPORT int spx_sync(spx_ctx* ctx) {
   return SPX_OK;
 }
 
-int64_t spx_resident_cap(spx_ctx* ctx, const void* fn, int block_threads, size_t dyn_lds) {
-  int per_cu = -1;
+// workgroups of `fn` a CU holds at once (hipOccupancyMaxActiveBlocksPerMultiprocessor, asked once per kernel and context);
+// -1 after an error (spx_set_error has the text)
+int spx_blocks_per_cu(spx_ctx* ctx, const void* fn, int block_threads, size_t dyn_lds) {
   for (int k = 0; k < ctx->nocc; ++k)
-    if (ctx->occ_fn[k] == fn) per_cu = ctx->occ_blocks[k];
-  if (per_cu < 0) {
-    int nb = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, block_threads, dyn_lds);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      spx_set_error("hipOccupancyMaxActiveBlocksPerMultiprocessor failed: %s", hipGetErrorString(e));
-      return 0;
-    }
-    per_cu = nb;
-    if (ctx->nocc < 32) { ctx->occ_fn[ctx->nocc] = fn; ctx->occ_blocks[ctx->nocc] = nb; ++ctx->nocc; }
+    if (ctx->occ_fn[k] == fn) return ctx->occ_blocks[k];
+  int nb = 0;
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, block_threads, dyn_lds);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    spx_set_error("hipOccupancyMaxActiveBlocksPerMultiprocessor failed: %s", hipGetErrorString(e));
+    return -1;
   }
+  if (ctx->nocc < 32) { ctx->occ_fn[ctx->nocc] = fn; ctx->occ_blocks[ctx->nocc] = nb; ++ctx->nocc; }
+  return nb;
+}
+
+int64_t spx_resident_cap(spx_ctx* ctx, const void* fn, int block_threads, size_t dyn_lds) {
+  const int per_cu = spx_blocks_per_cu(ctx, fn, block_threads, dyn_lds);
+  if (per_cu < 0) return 0;
   // The algorithms never want more than one workgroup per CU, and the query is known to promise one block per CU too many
   // for some register counts (MI355X_MICROARCH.md, "Residency and cooperative launch"): count ONE per CU, or none.
   int64_t cap = per_cu >= 1 ? (int64_t)ctx->num_cu : 0;

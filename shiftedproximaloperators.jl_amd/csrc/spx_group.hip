@@ -35,6 +35,9 @@ extern "C" __attribute__((visibility("default"))) int spx_debug_group_words(long
 // fast path kernel: uniform groups of LPG*EPL elements; LPG lanes own a group, 64/LPG groups per wave;
 // the group is resident in registers.  Lane j of a group owns the 16-byte pairs j, j + LPG, j + 2 LPG, ...
 // ---------------------------------------------------------------------------------------------
+#ifndef SPX_GROUP_PREFETCH
+#define SPX_GROUP_PREFETCH 1  // A/B switch (round 4): Binf tiles of one / two lanes x 8 elements come in through LDS as whole kilobytes (kPre)
+#endif
 #ifndef SPX_GROUP_WAVES
 #define SPX_GROUP_WAVES 3  // min waves/SIMD (VGPR cap) of the 8-element tiles.  Binf 1e6x128 on 16 lanes x 8: 3 (162 VGPRs, no spill) 0.84 ms; 4 (128, cold paths spill) 0.93 ms; 5: 1.49 ms
 // Binf tiles with 16 elements per lane (8 x 16 for 128-element groups: 8 groups per wave) run at 2 waves/SIMD (253 VGPRs):
@@ -66,7 +69,10 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
   // plain GroupNormL2 stages its loads through LDS (LDS-DMA, +2 %: 0.650-0.664 vs 0.666-0.677 ms at 1e6 x 128);
   // the Binf form is VALU-bound and loses 6 % to the lower occupancy the LDS footprint allows, so it keeps register loads
   constexpr bool kDma = !BINF && PAIRS;
-  __shared__ __attribute__((aligned(16))) char dma_lds[kDma ? 4 * 3 * (EPL / 2) * 1024 : 16];
+  // Round 4 -- Binf on the one- and two-lane tiles of 8 elements per lane (groups of 5 .. 16): the tile comes in and goes out
+  // through a buffer of the wavefront in LDS, as whole kilobytes (tile_dma / tile_regs below).
+  constexpr bool kPre = BINF && PAIRS && !LIT && EPL == 8 && LPG <= 2 && !(LPG == 2 && FULL) && SPX_GROUP_PREFETCH;
+  __shared__ __attribute__((aligned(16))) char dma_lds[(kDma || kPre) ? 4 * 3 * (EPL / 2) * 1024 : 16];
   const int npairs = gsize >> 1;
   // (the list can hold at most every group once: a count outside [0, ngroups] is never followed into memory -- and never
   //  skipped silently either: the context's status word is raised and every later call fails, spx_common.hpp)
@@ -87,6 +93,49 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
     }
   }
 #endif
+  typedef __attribute__((address_space(3))) void lds_void;
+  char* const wl = dma_lds + (threadIdx.x >> 6) * (3 * (EPL / 2) * 1024);  // (kDma / kPre) this wavefront's staging buffer
+  // kPre (round 4, Binf on the one- and two-lane tiles of 8 elements per lane): the tile goes through the wavefront's buffer.
+  //   tile_dma(t)  : the tile of wave iteration t -- GPW consecutive groups, GPW * npairs consecutive 16-byte pairs -- comes in
+  //                  as whole kilobytes (lane l fetches pair 64 k + l) and lies linearly in the buffer (direct loads had every
+  //                  lane fetch 16 bytes of its own 64-byte run per instruction: 32 lines touched four times each);
+  //   tile_regs(t) : every lane picks up its own pairs (a 64-byte run per lane on the one-lane tiles: 4-way bank conflicts on
+  //                  12 LDS reads, nothing next to the root find);
+  // Groups of 8 at n = 1e8: 660 -> 636 us; of 6 / 12 / 14: -4 .. -7 %; y sent back the same way (parked in the buffer, stored as
+  // whole kilobytes) changes nothing (634 us) and costs registers: the lanes store their own pairs.
+  // (Tried on top and dropped: a resident grid whose wavefronts fetch tile i + 1 during the root find of tile i -- one buffer
+  //  per wavefront is enough, the tile is copied to registers before the next DMA is issued; stores never waited for.  Bit
+  //  identical and SLOWER: 665 us on groups of 8, and the second tile's registers spill on the partly filled tiles.  The
+  //  hardware's own hand-out of one-tile workgroups hides the loads at least as well.)
+  auto tile_dma = [&](int64_t t0) {
+    const int64_t left = ntodo - t0;
+    const int tile_pairs = (int)(left < GPW ? left : GPW) * npairs;  // (wave-uniform)
+    const f64x2* tq = reinterpret_cast<const f64x2*>(q_ + t0 * GS);
+    const f64x2* tx = reinterpret_cast<const f64x2*>(xk_ + t0 * GS);
+    const f64x2* ts = reinterpret_cast<const f64x2*>(sj_ + t0 * GS);
+#pragma unroll
+    for (int k = 0; k < EPL / 2; ++k) {
+      if (k * 64 < tile_pairs) {  // (wave-uniform)
+        const int pp = (k * 64 + lane < tile_pairs) ? (k * 64 + lane) : 0;
+        __builtin_amdgcn_global_load_lds((const void*)(tq + pp), (lds_void*)(wl + (0 * (EPL / 2) + k) * 1024), 16, 0, 2);
+        __builtin_amdgcn_global_load_lds((const void*)(tx + pp), (lds_void*)(wl + (1 * (EPL / 2) + k) * 1024), 16, 0, 2);
+        __builtin_amdgcn_global_load_lds((const void*)(ts + pp), (lds_void*)(wl + (2 * (EPL / 2) + k) * 1024), 16, 0, 2);
+      }
+    }
+  };
+  auto tile_regs = [&](int64_t t0, f64x2 (&nq)[EPL / 2], f64x2 (&nx)[EPL / 2], f64x2 (&ns)[EPL / 2]) {
+    const int64_t left = ntodo - t0;
+    const int slot_e = ((t0 + slot) < ntodo) ? slot : (int)(left - 1);  // idle slots shadow the last group of the tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < EPL / 2; ++k) {
+      const int p = (FULL || k * LPG + j < npairs) ? (slot_e * npairs + k * LPG + j) : 0;  // masked pairs: zeroed below
+      nq[k] = *reinterpret_cast<const f64x2*>(wl + (0 * (EPL / 2)) * 1024 + p * 16);
+      nx[k] = *reinterpret_cast<const f64x2*>(wl + (1 * (EPL / 2)) * 1024 + p * 16);
+      ns[k] = *reinterpret_cast<const f64x2*>(wl + (2 * (EPL / 2)) * 1024 + p * 16);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
   for (int64_t g0 = wave * GPW; g0 < ntodo; g0 += nwaves * GPW) {  // wave-uniform trip count
     bool valid = (g0 + slot) < ntodo;
     const int64_t gi = valid ? (g0 + slot) : (ntodo - 1);  // idle slots shadow the last group, no store
@@ -126,11 +175,12 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
         const f64x2* x2 = reinterpret_cast<const f64x2*>(xk_ + base);
         const f64x2* s2 = reinterpret_cast<const f64x2*>(sj_ + base);
         f64x2 vq[EPL / 2], vx[EPL / 2], vs[EPL / 2];
-        if constexpr (kDma) {
+        if constexpr (kPre) {
+          tile_dma(g0);
+          tile_regs(g0, vq, vx, vs);
+        } else if constexpr (kDma) {
           // LDS-DMA staging (as k_sep_lds): piece k of a wave = the k-th 16-byte pair of each lane; lane `lane` of the
           // wave lands at byte 16*lane of the piece, whichever group slot it serves
-          typedef __attribute__((address_space(3))) void lds_void;
-          char* wl = dma_lds + (threadIdx.x >> 6) * (3 * (EPL / 2) * 1024);
 #pragma unroll
           for (int k = 0; k < EPL / 2; ++k) {
             const int p = (FULL || k * LPG + j < npairs) ? (k * LPG + j) : 0;  // masked pairs re-read pair 0, zeroed below
@@ -529,13 +579,13 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
       hipLaunchKernelGGL(k_csr_uncovered, dim3(256), dim3(256), 0, ctx->stream, y, xk, sj, offsets, ngroups, n);
 #define SPX_LAUNCH_REG(LPG, EPL)                                                                                    \
   do {                                                                                                              \
-    if (pairs && gsize == (LPG) * (EPL))                                                                            \
+    if (pairs && gsize == (LPG) * (EPL)) {                                                                          \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, true, false, true>), grid, block, 0, ctx->stream, y, q, xk, sj, \
                          ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal); \
-    else if (pairs)                                                                                                 \
+    } else if (pairs) {                                                                                             \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, true>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,   \
                          (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal);    \
-    else                                                                                                            \
+    } else                                                                                                            \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, false>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,  \
                          (int)gsize, lambda, sigma, delta, deferred, ragged_reg ? offsets : (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal); \
   } while (0)

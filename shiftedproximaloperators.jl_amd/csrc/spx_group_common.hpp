@@ -289,6 +289,9 @@ struct MemGroup {
 #ifndef SPX_BINF_CONFIRM
 #define SPX_BINF_CONFIRM 1  // A/B switch of the cheap active-set confirmation (binf_same_active_set)
 #endif
+#ifndef SPX_BINF_LAZY
+#define SPX_BINF_LAZY 1  // A/B switch (round 4): lmax (the zlmax pass), froot(lmin) inside the trust region and the start -- see binf_root
+#endif
 #ifndef SPX_BINF_POLY
 #define SPX_BINF_POLY 1  // A/B switch (round 4): approach to a piece's root on the quartic in t instead of Newton in v
 #endif
@@ -614,6 +617,8 @@ template <int TEAM, class G>
 __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma, double delta, double* lds,
                                          double& root_u, bool pole_lit) {
   const double eps = 2.220446049250313e-16;
+  // (the team-of-workgroups kernels sit at their 128-VGPR cap and have a sample-predicted fast path of their own: as they were)
+  constexpr bool kLazy = SPX_BINF_LAZY && TEAM != kTeamGrid;
   const double sl = lam * sigma;          // :85
   const double lmin = sl * (1 + eps);     // :94
   // lmax, zlmax and froot(lmin) only steer the bracket (their exact rounding never reaches y): the wave-uniform
@@ -653,10 +658,23 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
   // lmax >= lmax_lb := ||S|| + sigma lambda ||X||.  If already lmax_lb clears both lmin (bracket not degenerate) and
   // sl + ub (the iteration starts from the bound ub, not from lmax) the exact lmax is never used: skip the pass.
   const double lmax_lb = nS + sigma * (lam * nX);
+  // Round 4: lmax on demand.  With several groups in a wavefront -- 64 of them on the one-lane tiles of groups of <= 8
+  // elements -- a branch that 5 % of the groups take is executed by every wavefront: the zlmax pass below and the A/B sums
+  // at lmin were ~15 % of the vector instructions of the kernel on groups of 8, for 6 % / 5 % of the groups.  So, when the
+  // lower bound lmax_lb alone says that the bracket is regular (lmin < lmax_lb <= lmax), round 0 looks for the root in
+  // (lmin, sl + ub) as the `from_bound` iteration does and accepts it if it lies below lmax_lb with a margin: froot is
+  // increasing, so froot(lmax) >= froot(lmax_lb) > 0 then, :102 does not fire and the reference's bisection converges to
+  // this root; likewise froot(lmin) > 0 means froot(lmax) > 0 and :102 fires whatever lmax is exactly.  A root that is
+  // not safely below lmax_lb has the zlmax pass run then, and is accepted against the exact lmax or handed to the literal
+  // evaluation (lmax is the reference's upper BOUND on the root: next to never).
   double lmax;
   bool lmax_is_normS = false;  // lmax == ||S|| exactly in the reference: zlmax == 0 and lambda ||X|| == 0
+  bool lazy = false;
   if (lmax_lb > lmin * (1.0 + 8 * eps) && (lmax_lb - sl) > ub * (1.0 + 8 * eps)) {
     lmax = sl + ub * (1.0 + 8 * eps);  // any point >= the root serves as the upper end from here on
+  } else if (kLazy && lmax_lb > lmin * (1.0 + 8 * eps) && ub > ul * (1.0 + 8 * eps) && (sS + sX < INFINITY)) {
+    lazy = true;
+    lmax = sl + ub * (1.0 + 8 * eps);
   } else {
     const double ansatz = lmin + 1.0;                                      // :97 (epsilon = 1)
     const double rsig = fast_rcp(sigma);
@@ -695,6 +713,11 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
   double fl;
   if ((sS + sX < INFINITY) && (mX - taul * nS > delta * (1.0 + 1e-9)) && (ul < 1e-9 * delta)) {
     fl = -1.0;
+  } else if (kLazy && (sS + sX < INFINITY) && (mX + taul * nS < delta * (1.0 - 1e-9))) {
+    // (round 4) every entry safely inside the trust region at lmin: |tau S_i - X_i| <= max|X| + tau ||S|| < Delta, nothing is
+    // active, A = ||S||^2 and B = 0: froot(lmin) = lmin - (lmin/ul) tau(lmin) ||S|| = lmin - ||S|| without a pass (46 % of
+    // random groups of 2, 5 % of groups of 8 -- and so nearly every wavefront of 64 such groups took the branch below)
+    fl = lmin - nS;
   } else {
     // No entry is safely active at lmin.  The A/B form gives the exact value of froot(lmin); the reference's own
     // evaluation agrees with it unless some |X_i| equals Delta to the last bits: lmin sits one ulp above the pole of
@@ -725,6 +748,17 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
   const bool from_bound = (uhi > ub && ub > ulo);
   if (from_bound) uhi = ub;
   double u = uhi;
+  if (kLazy && from_bound) {
+    // (round 4) from the bound fm > 0 is known: the decisions of :102 that only need fl are taken before the first pass
+    // (a group being zeroed -- froot(lmin) > 0, the bulk of a sparse iterate with xk != 0 -- then costs no pass at all)
+    if (fabs(fl) <= 1e-12 * lmin) return BINF_LITERAL;
+    if (fl > 0.0) return BINF_ZERO;
+    // (round 4) nothing is decided on psi at the bound (fm > 0 is known), so the iteration may start anywhere inside the
+    // bracket: ||S|| - sl is the root when nothing is active and close to it when little is -- fewer passes and piece steps
+    // for the slowest lane of a wavefront (tools/r4/binf_small_emul.py: 2.68 -> 2.36 passes, 10.9 -> 7.9 steps on groups of 8)
+    const double us = nS - sl;
+    if (us > ulo && us < uhi) u = us;
+  }
   double sa, sb, psi;
   double tau_full;  // tau of the last full pass (the one sa, sb belong to)
   {
@@ -755,6 +789,7 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
     }
     if (fabs(fl) <= 1e-12 * lmin) return BINF_LITERAL;
     const double fm = from_bound ? ((psi > 0.0) ? psi : 1.0) : (lmax * fast_rcp(u)) * psi;
+    if (lazy && !from_bound) return BINF_LITERAL;           // (cannot happen: lazy requires ub > ul)
     if (fl * fm > 0) return BINF_ZERO;                      // :102
     if (!(fl < 0.0) || !(fm > 0.0)) return BINF_LITERAL;    // an exact zero at an end (or NaN)
   }
@@ -873,6 +908,25 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
 #endif
   }
   root_u = fmin(fmax(u, ul), lmax - sl);  // inside the reference's bracket [lmin, lmax]
+  if (lazy) {
+    // accepted only if psi at the (unknown) upper end lmax - sl >= lmax_lb - sl is positive beyond the 1e-12 u of the tie test
+    // above: psi(uhi) >= tau (uhi - root) -- otherwise round 1 with the exact lmax
+    const double tau_r = root_u * fast_rcp(sl + root_u);
+    if (!(tau_r * ((lmax_lb - sl) - root_u) > 1e-9 * root_u)) {
+      const double ansatz = lmin + 1.0;                                      // :97 (epsilon = 1)
+      const double rsig = fast_rcp(sigma);
+      const double stepa = ansatz * rsig * fast_rcp(ansatz - sl);            // :98
+      const double thra = delta * stepa;
+      double sz = 0.0;
+      grp.for_each([&](double S, double X) {
+        const double za = fabs(__builtin_fma(-stepa, X, S * rsig)) - thra;  // :99
+        sz += (za > 0.0) ? za * za : 0.0;
+      });
+      sz = team_sum<TEAM>(sz, lds);
+      const double lmax_x = nS + sigma * (sqrt_pos(sz) + 1.0 * lam * nX);    // :100
+      if (!(tau_r * ((lmax_x - sl) - root_u) > 1e-9 * root_u)) return BINF_LITERAL;
+    }
+  }
   // spx_ctx_set_tuning key 9 (pole_lit): a root next to the pole of step(n) (u < n / 1000) is where the reference's own
   // Float64 evaluation is up to 4.5e-9 of the scale off its formula (n - sigma lambda and 1 - sigma lambda / ||w|| cancel);
   // the closed form above is the accurate side, the literal evaluation reproduces the reference's doubles -- for callers

@@ -66,7 +66,7 @@ def piece_newton_poly(sa, sb, sl, u, start="cur"):
     return v, steps
 
 
-def run(ngroups, gs, solver, seed=1, start_ns=False):
+def run(ngroups, gs, solver, seed=1, start_ns=False, confirm_from=1):
     rng = np.random.default_rng(seed)
     xk = rng.standard_normal((ngroups, gs))
     sj = rng.random((ngroups, gs)) - 0.5
@@ -95,6 +95,10 @@ def run(ngroups, gs, solver, seed=1, start_ns=False):
     pa = np.full(ngroups, -1.0)
     pb = np.full(ngroups, -1.0)
     done = np.zeros(ngroups, bool)
+    nS = np.sqrt(sS)
+    tau_full = tau.copy()
+    wave_conf = np.zeros(ngroups // 64, int)   # iterations in which some lane of the wavefront ran the cheap confirmation
+    wave_full = np.ones(ngroups // 64, int)    # ... a full pass (the first one included)
     zero = psi < 0  # froot(lmax) < 0 with fl < 0 -> zeros (only when starting from the bound)
     if not start_ns:
         done |= zero
@@ -120,6 +124,18 @@ def run(ngroups, gs, solver, seed=1, start_ns=False):
         pb = np.where(live, np.where(exact, sb, -1.0), pb)
         u = np.where(live, v, u)
         tau = u / (sl + u)
+        # the cheap confirmation (binf_same_active_set) in place of a pass whose sums would come back identical
+        W_ = (ngroups // 64) * 64
+        if it >= confirm_from:
+            tryc = live & exact & (np.abs(tau - tau_full) * nS <= 2.0 * delta)
+            za = tau[:, None] * S - X
+            zb = tau_full[:, None] * S - X
+            same_set = ((np.abs(za) > delta) == (np.abs(zb) > delta)).all(1)
+            wave_conf += tryc[:W_].reshape(-1, 64).any(1)
+            done |= tryc & same_set
+            live &= ~(tryc & same_set)
+        wave_full += live[:W_].reshape(-1, 64).any(1)
+        tau_full = np.where(live, tau, tau_full)
         sa2, sb2 = ab(S, X, tau, delta)
         sa = np.where(live, sa2, sa)
         sb = np.where(live, sb2, sb)
@@ -128,13 +144,14 @@ def run(ngroups, gs, solver, seed=1, start_ns=False):
     W = (ngroups // 64) * 64
     pw = passes[:W].reshape(-1, 64).max(1)
     return dict(passes_mean=passes.mean(), passes_wave=pw.mean(), steps_mean=nsteps.mean(), steps_wave=wave_steps.mean(),
-                pieces_wave=wave_pieces.mean(), zero_frac=zero.mean(), u=u)
+                pieces_wave=wave_pieces.mean(), conf_wave=wave_conf.mean(), full_wave=wave_full.mean(), zero_frac=zero.mean(), u=u)
 
 
 if __name__ == "__main__":
     ng = int(sys.argv[1]) if len(sys.argv) > 1 else 64 * 2000
     for name, solver in (("newton_v", piece_newton_v), ("newton_poly", piece_newton_poly)):
         for sn in (False, True):
-            r = run(ng, 8, solver, start_ns=sn)
-            u = r.pop("u")
-            print(name, "start_ns" if sn else "start_ub", {k: round(float(v), 3) for k, v in r.items()})
+            for cf in (1, 0):
+                r = run(ng, 8, solver, start_ns=sn, confirm_from=cf)
+                u = r.pop("u")
+                print(name, "start_ns" if sn else "start_ub", "confirm_from", cf, {k: round(float(v), 3) for k, v in r.items()})
