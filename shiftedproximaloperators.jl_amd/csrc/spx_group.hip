@@ -35,6 +35,9 @@ extern "C" __attribute__((visibility("default"))) int spx_debug_group_words(long
 // fast path kernel: uniform groups of LPG*EPL elements; LPG lanes own a group, 64/LPG groups per wave;
 // the group is resident in registers.  Lane j of a group owns the 16-byte pairs j, j + LPG, j + 2 LPG, ...
 // ---------------------------------------------------------------------------------------------
+#ifndef SPX_PADDED_CACHED
+#define SPX_PADDED_CACHED 1  // A/B switch (round 4): cached accesses on partly filled tiles of <= 16 lanes per group (kPaddedCached)
+#endif
 #ifndef SPX_GROUP_PREFETCH
 #define SPX_GROUP_PREFETCH 1  // A/B switch (round 4): Binf tiles of one / two lanes x 8 elements come in through LDS as whole kilobytes (kPre)
 #endif
@@ -69,6 +72,14 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
   // plain GroupNormL2 stages its loads through LDS (LDS-DMA, +2 %: 0.650-0.664 vs 0.666-0.677 ms at 1e6 x 128);
   // the Binf form is VALU-bound and loses 6 % to the lower occupancy the LDS footprint allows, so it keeps register loads
   constexpr bool kDma = !BINF && PAIRS;
+  // Round 4 -- partly filled tiles (a group size that is not lanes x elements, e.g. 100 on 8 x 16): the 16-byte pairs a group's
+  // lanes fetch per instruction are a run of 16 LPG bytes that starts wherever the group does -- 800-byte groups: three runs
+  // of four straddle two 128-byte lines -- and the next run of the group continues in the line the last one ended in.
+  // Non-temporal accesses gave that line up in between; cached ones keep it: Binf groups of 20 / 50 / 66 / 100 / 120 at
+  // n = 1e8: 1001 / 809 / 936 / 708 / 607 -> 807 / 719 / 840 / 652 / 583 us (4.52 -> 4.91 TB/s on groups of 100), the plain
+  // operator on groups of 10 / 66 / 100: 671 / 664 / 600 -> 611 / 585 / 567 us.  Runs of 512 bytes and more (32 and 64 lanes
+  // per group) are better off streaming (groups of 300 / 500: 2-4 % slower cached).
+  constexpr bool kPaddedCached = SPX_PADDED_CACHED && PAIRS && !FULL && !LIT && LPG <= 16;
   // Round 4 -- Binf on the one- and two-lane tiles of 8 elements per lane (groups of 5 .. 16): the tile comes in and goes out
   // through a buffer of the wavefront in LDS, as whole kilobytes (tile_dma / tile_regs below).
   constexpr bool kPre = BINF && PAIRS && !LIT && EPL == 8 && LPG <= 2 && !(LPG == 2 && FULL) && SPX_GROUP_PREFETCH;
@@ -184,9 +195,9 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
 #pragma unroll
           for (int k = 0; k < EPL / 2; ++k) {
             const int p = (FULL || k * LPG + j < npairs) ? (k * LPG + j) : 0;  // masked pairs re-read pair 0, zeroed below
-            __builtin_amdgcn_global_load_lds((const void*)(q2 + p), (lds_void*)(wl + (0 * (EPL / 2) + k) * 1024), 16, 0, 2);
-            __builtin_amdgcn_global_load_lds((const void*)(x2 + p), (lds_void*)(wl + (1 * (EPL / 2) + k) * 1024), 16, 0, 2);
-            __builtin_amdgcn_global_load_lds((const void*)(s2 + p), (lds_void*)(wl + (2 * (EPL / 2) + k) * 1024), 16, 0, 2);
+            __builtin_amdgcn_global_load_lds((const void*)(q2 + p), (lds_void*)(wl + (0 * (EPL / 2) + k) * 1024), 16, 0, kPaddedCached ? 0 : 2);
+            __builtin_amdgcn_global_load_lds((const void*)(x2 + p), (lds_void*)(wl + (1 * (EPL / 2) + k) * 1024), 16, 0, kPaddedCached ? 0 : 2);
+            __builtin_amdgcn_global_load_lds((const void*)(s2 + p), (lds_void*)(wl + (2 * (EPL / 2) + k) * 1024), 16, 0, kPaddedCached ? 0 : 2);
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
 #pragma unroll
           for (int k = 0; k < EPL / 2; ++k) {
             const int p = (FULL || k * LPG + j < npairs) ? (k * LPG + j) : 0;
-            if constexpr (LPG <= 2) {  // a lane's pairs share cache lines with each other, not with its neighbours': cached accesses
+            if constexpr (LPG <= 2 || kPaddedCached) {  // a lane's pairs share cache lines with each other, not with its neighbours': cached accesses
               vq[k] = q2[p]; vx[k] = x2[p]; vs[k] = s2[p];
             } else {
               vq[k] = __builtin_nontemporal_load(q2 + p);
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
 #pragma unroll
         for (int k = 0; k < EPL / 2; ++k)
           if (FULL || k * LPG + j < npairs) {
-            if constexpr (LPG <= 2) y2[k * LPG + j] = f64x2{out[2 * k], out[2 * k + 1]};  // (merged into whole lines by the L2)
+            if constexpr (LPG <= 2 || kPaddedCached) y2[k * LPG + j] = f64x2{out[2 * k], out[2 * k + 1]};  // (merged into whole lines by the L2)
             else __builtin_nontemporal_store(f64x2{out[2 * k], out[2 * k + 1]}, y2 + k * LPG + j);
           }
       } else {

@@ -1,6 +1,6 @@
 """ShiftedGroupNormL2Binf on small / odd uniform groups on bench.py's inputs (spx_synth_fill, seed + 1000): time per call and the
 rate of the 32 B per element, for A/B builds (SPX_LIB_NAME).  SPX_N (default 1e8), SPX_GS (comma list, default 2,4,8,16,100,128),
-SPX_DUMP=path: the first 2^18 elements of y per group size as .npy (to compare two builds bit for bit / to 1e-12)."""
+SPX_BINF=0: the plain ShiftedGroupNormL2.  SPX_DUMP=path: the first 2^18 elements of y per group size as .npy (to compare two builds bit for bit / to 1e-12)."""
 import ctypes, os, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
@@ -29,7 +29,7 @@ for gs in sizes:
     ng = n // gs; m = ng * gs
     lam = synth(ng, 4, 0) + 1.0
     H = s.GroupNormL2.uniform(lam, gs)
-    psi = s.shifted(s.shifted(H, x[:m], 1.0, chi), sj[:m])
+    psi = s.shifted(s.shifted(H, x[:m], 1.0, chi), sj[:m]) if os.environ.get("SPX_BINF", "1") == "1" else s.shifted(s.shifted(H, x[:m]), sj[:m])
     for _ in range(3): s.prox_bang(y[:m], psi, q[:m], 1.0)
     torch.cuda.synchronize()
     best = 1e9; allr = []
