@@ -5,6 +5,7 @@ import torch
 import __graft_entry__ as ge
 s = ge.build(); L = s._lib.load(); ctx = s.context("cuda:0")
 raw = ctypes.CDLL(s._lib.LIB_PATH)
+if "SPX_KEY10" in os.environ: L.spx_ctx_set_tuning(ctx, 10, int(os.environ["SPX_KEY10"]))  # (round 4: the front kernel's sample, tools/r4/topr_front_ab.py)
 for n in [int(a) for a in sys.argv[1:]]:
     g = torch.Generator(device="cuda:0").manual_seed(1)
     x = torch.randn(n, dtype=torch.float64, device="cuda:0", generator=g); sj = torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g) - 0.5
