@@ -137,6 +137,10 @@ int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms); /* records stop, waits, ret
  * workgroups and psi(y) on them is evaluated in chunks (1, default; 0: one workgroup / one wavefront per group as in rounds 1-3).
  * Key 14 = the Binf form of that takes its sample-predicted two-pass path when the group does not fit on chip (1, default;
  * 0: the generic body, one streaming pass per reduction of the root find).
+ * Key 17 = launches per call at solver sizes (1, default): psi(y) (spx_obj_*) is ONE launch -- the workgroup that finishes
+ * last adds the partial sums, in the order the separate final launch did -- and ShiftedGroupNormL2Binf on uniform groups
+ * runs without the zero-fill launch of its deferred list (two count words that alternate between calls; under a stream
+ * capture the zero-fill node stays); 0 = three launches each, as in rounds 1-3.  Same bits either way.
  * Key 9 DOES change results, within the stated tolerance: ShiftedGroupNormL2Binf, 0 (default) = the closed form at the root
  * (within ~1e-15 of the exact value of the reference's formula everywhere), 1 = groups whose root sits next to the pole of
  * step(n) (u < n / 1000) are evaluated literally, operation by operation as src/shiftedGroupNormL2Binf.jl:87-113 with

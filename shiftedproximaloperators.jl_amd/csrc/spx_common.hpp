@@ -70,6 +70,9 @@ struct spx_ctx {
                                    //         streaming pass per reduction)
   int tune_team_factor = 0;        // key 16: the team form serves uniform large groups while there are fewer than this many per workgroup of its
                                    //         grid (0 = default, see run_group in spx_group.hip); an A/B knob
+  int tune_fewer_launches = 1;     // key 17: psi(y) in one launch (the last workgroup finishes: spx_fin_ticket) and the Binf group operators without the
+                                   //         zero-fill launch of their deferred list (count words that alternate); 0 = the launches of rounds 1-3
+  int grp_def_set = 0;             // spx_group.hip: which of SpxSyncHeader::grp_deferred the next call uses (it clears the other one)
   int tune_force_grid = 0;         // key 100, test builds only (-DSPX_TEST_HOOKS): launch the one-launch top-r with THIS many workgroups,
                                    //          residency or not -- the planted fault behind tests/test_gpu_robustness.py
   int tune_force_team = 0;         // key 102, test builds only: the last workgroup of every team of k_group_team arrives late (spx_group_team.hip)
@@ -290,9 +293,14 @@ struct SpxSyncHeader {
   int b2_last_scaled;       // ShiftedNormL1B2: did the previous call on this context find the trust region active?
   int timed_out;            // sticky: a workgroup gave up waiting for the others (kSpxPollLimit); no workgroup waits any more
   int* status;              // device view of spx_ctx::status_host (host-mapped): the failure is reported by the NEXT libspx call
-  int pad[28];
+  // Round 4 (launch counts at solver sizes: a call below ~1e6 elements costs what its launches cost):
+  long long grp_deferred[2];  // count words of the Binf group operators' deferred list: a call uses [set] and clears [set ^ 1] (spx_group.hip)
+  unsigned int fin_top;       // the objective kernels' "last workgroup" tickets (spx_fin_ticket below); zero between launches
+  int fin_flag;               // ... and their infeasibility bits; zero between launches
+  int pad[22];
+  unsigned int fin_class[kSpxBarSplit * 32];  // first-level tickets, one 128-byte line each
 };
-static_assert(sizeof(SpxSyncHeader) == 2 * kSpxBarSplit * 32 * 4 + 128, "SpxSyncHeader layout");
+static_assert(sizeof(SpxSyncHeader) == 2 * kSpxBarSplit * 32 * 4 + 128 + kSpxBarSplit * 32 * 4, "SpxSyncHeader layout");
 
 // Every wait of one workgroup for others is bounded: kSpxPollLimit polls (each a memory round trip plus a short sleep: a few
 // seconds in all, against microseconds of legitimate waiting).  A workgroup that gives up sets SpxSyncHeader::timed_out,
@@ -386,4 +394,24 @@ __device__ __forceinline__ void spx_atomic_store_f64(double* p, double v) {
 __device__ __forceinline__ double spx_atomic_load_f64(const double* p) {
   return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
                                                            __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// "Am I the last workgroup of this launch?" -- for kernels that end in a small serial step (the ordered sum of the workgroups'
+// partial results) which used to be a launch of its own.  Called by ONE lane per workgroup, after that lane has waited for the
+// agent-scope atomic stores of everything the last workgroup will read (s_waitcnt vmcnt(0)); the workgroup that gets `true`
+// reads those words with agent-scope atomic loads.  Two levels: workgroup b takes a ticket on counter b % 8 (a 128-byte line
+// each: returning atomics on ONE address retire ~12 ns apart, 2048 workgroups ending together would queue for 25 us), the last
+// of a class takes one on the top counter.  Every counter is reset by the lane that takes its last ticket, so the words are
+// zero between launches -- nothing to clear in front of a launch, nothing that alternates: the same node replays in a graph.
+__device__ __forceinline__ bool spx_fin_ticket(SpxSyncHeader* hdr) {
+  const unsigned int grid = gridDim.x, j = blockIdx.x % (unsigned)kSpxBarSplit;
+  const unsigned int want = (grid - j + (unsigned)kSpxBarSplit - 1u) / (unsigned)kSpxBarSplit;  // workgroups j, j + 8, ...
+  const unsigned int c = __hip_atomic_fetch_add(&hdr->fin_class[32u * j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (c + 1u != want) return false;
+  __hip_atomic_store(&hdr->fin_class[32u * j], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned int classes = grid < (unsigned)kSpxBarSplit ? grid : (unsigned)kSpxBarSplit;
+  const unsigned int t = __hip_atomic_fetch_add(&hdr->fin_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t + 1u != classes) return false;
+  __hip_atomic_store(&hdr->fin_top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
 }

@@ -151,6 +151,7 @@ SPX_EXPORT int spx_ctx_set_tuning(spx_ctx* ctx, int key, int value) {
     case 13: ctx->tune_team = value ? 1 : 0; return SPX_OK;
     case 14: ctx->tune_team_fast = value ? 1 : 0; return SPX_OK;
     case 16: if (value < 0 || value > 1000000) break; ctx->tune_team_factor = value; return SPX_OK;
+    case 17: ctx->tune_fewer_launches = value ? 1 : 0; return SPX_OK;
 #ifdef SPX_TEST_HOOKS
     case 100: if (value < 0 || value > 65535) break; ctx->tune_force_grid = value; return SPX_OK;
     case 101: if (value < 0 || value > 65535) break; ctx->tune_force_tail = value; return SPX_OK;
@@ -195,6 +196,8 @@ SPX_EXPORT int spx_sync(spx_ctx* ctx) {
       ctx->b2_set = 0;
       ctx->b2_dirty_g[0] = ctx->b2_dirty_g[1] = 0;
       ctx->team_set = 0;
+  ctx->grp_def_set = 0;
+      ctx->grp_def_set = 0;
       ctx->sel_hist_next = 0;
       ctx->sel_hist_dirty[0] = ctx->sel_hist_dirty[1] = 0;
     }
@@ -360,6 +363,7 @@ int spx_sync_reserve(spx_ctx* ctx, size_t bytes) {
   ctx->b2_set = 0;
   ctx->b2_dirty_g[0] = ctx->b2_dirty_g[1] = 0;
   ctx->team_set = 0;
+  ctx->grp_def_set = 0;
   ctx->sel_hist_next = 0;
   ctx->sel_hist_dirty[0] = ctx->sel_hist_dirty[1] = 0;
   return SPX_OK;

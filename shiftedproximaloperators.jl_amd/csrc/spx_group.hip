@@ -58,9 +58,11 @@ template <int LPG, int EPL, bool BINF, bool PAIRS, bool LIT = false, bool FULL =
 __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) void k_group_reg(double* y_, const double* q_, const double* xk_, const double* sj_,
                                                     int64_t ngroups, int gsize, const double* __restrict__ lambda,
                                                     double sigma, double delta,
-                                                    long long* deferred /* [0] = count, [1..] = groups */,
+                                                    long long* deferred /* [1..] = groups ([0]: the count, unless dcount points elsewhere) */,
                                                     const int64_t* __restrict__ offsets /* !PAIRS only: ragged groups */,
-                                                    int* status /* spx_ctx::status_dev */, int pole_lit /* tuning key 9 */) {
+                                                    int* status /* spx_ctx::status_dev */, int pole_lit /* tuning key 9 */,
+                                                    unsigned long long* dcount /* the list's count word: deferred[0], or one of SpxSyncHeader::grp_deferred */,
+                                                    unsigned long long* dclear /* LIT: the count word the NEXT call uses, zeroed here (or NULL) */) {
   static_assert((EPL % 2) == 0, "EPL must be even (16-byte pairs)");
   const int64_t GS = gsize;  // <= LPG * EPL
   constexpr int GPW = 64 / LPG;  // groups per wave
@@ -87,7 +89,8 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
   const int npairs = gsize >> 1;
   // (the list can hold at most every group once: a count outside [0, ngroups] is never followed into memory -- and never
   //  skipped silently either: the context's status word is raised and every later call fails, spx_common.hpp)
-  const int64_t nlist = LIT ? (int64_t)deferred[0] : 0;
+  const int64_t nlist = LIT ? (int64_t)*dcount : 0;
+  if (LIT && dclear != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *dclear = 0ull;  // (nobody else touches that word in this call)
   const bool bad_count = LIT && (nlist < 0 || nlist > ngroups);
   if (bad_count && blockIdx.x == 0 && threadIdx.x == 0) spx_raise_status(status, kSpxStatusCorrupt);
   const int64_t ntodo = LIT ? (bad_count ? 0 : nlist) : ngroups;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
       if (nlist < 0 || nlist > ngroups) g_group_dbg[1] += 1;
       g_group_dbg[2] += 1;
     } else {
-      g_group_dbg[3] = (long long)__hip_atomic_load(deferred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      g_group_dbg[3] = (long long)__hip_atomic_load(dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (g_group_dbg[3] < 0 || g_group_dbg[3] > ngroups) g_group_dbg[5] += 1;
       g_group_dbg[4] += 1;
     }
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
         base = offsets[g];
         const int64_t sz = offsets[g + 1] - base;
         if (sz > LPG * EPL || sz < 0) {  // the hint was wrong for this group: the general kernel takes it
-          if (valid && j == 0) deferred[1 + atomicAdd((unsigned long long*)deferred, 1ull)] = g;
+          if (valid && j == 0) deferred[1 + atomicAdd(dcount, 1ull)] = g;
           valid = false;
           gs = 0;
         } else {
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256, (BINF && EPL >= 16) ? 2 : SPX_GROUP_WAVES) voi
         // (one atomic per group.  A data set whose groups ALL defer is bound by this counter: the hardware already merges
         //  the atomics of a wavefront into one request, ~11 ns each on the one address -- 8e6 groups of 16 = 5e5 requests
         //  = 6 ms; merging them in software changes nothing.  Sharded lists would; not needed for the cases at hand.)
-        if (valid && j == 0) deferred[1 + atomicAdd((unsigned long long*)deferred, 1ull)] = g;
+        if (valid && j == 0) deferred[1 + atomicAdd(dcount, 1ull)] = g;
         valid = false;
       }
       if (status != BINF_ROOT || ru == 0.0) {  // shiftedGroupNormL2Binf.jl:102-103, :107-108
@@ -579,11 +582,28 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
     if (blocks > 0x7fffffff) blocks = 0x7fffffff;
     dim3 grid((unsigned)blocks), block(256);
     long long* deferred = nullptr;
+    unsigned long long *dcount = nullptr, *dclear = nullptr;
     if (BINF || ragged_reg) {  // list of the groups whose bracket needs the reference's literal evaluation / oversize groups
       rc = spx_ws_reserve(ctx, (size_t)(ngroups + 1) * sizeof(long long) + 256);
       if (rc) return rc;
       deferred = reinterpret_cast<long long*>(ctx->ws);
-      { rc = spx_zero_async(ctx, deferred, sizeof(long long)); if (rc) return rc; }
+      dcount = reinterpret_cast<unsigned long long*>(deferred);
+      // Round 4: the zero-fill of the count word was a launch of its own in front of every call (a Binf call at solver sizes:
+      // 17 us against 10.5 for the plain operator, tools/r4/small_latency_all.py).  Uniform Binf layouts now count in one of
+      // two words of the synchronisation state (zero-initialised, never written by another operator): a call uses [set], its
+      // LIT launch -- queued unconditionally behind the main one -- zeroes [set ^ 1] for the next call.  Under a stream capture
+      // (one set would replay for ever) and for ragged layouts the word in front of the list and its zero-fill node stay.
+      const bool graph_safe = spx_capture_check(ctx) || ctx->graph_safe;
+      if (BINF && !ragged_reg && ctx->tune_fewer_launches && !graph_safe) {
+        rc = spx_sync_reserve(ctx, sizeof(SpxSyncHeader));
+        if (rc) return rc;
+        SpxSyncHeader* hdr = reinterpret_cast<SpxSyncHeader*>(ctx->sync);
+        dcount = reinterpret_cast<unsigned long long*>(&hdr->grp_deferred[ctx->grp_def_set]);
+        dclear = reinterpret_cast<unsigned long long*>(&hdr->grp_deferred[ctx->grp_def_set ^ 1]);
+        ctx->grp_def_set ^= 1;
+      } else {
+        rc = spx_zero_async(ctx, deferred, sizeof(long long)); if (rc) return rc;
+      }
     }
     const bool pairs = !ragged_reg && (gsize & 1) == 0 && aligned;  // otherwise 8-byte loads
     if (!BINF && ragged_reg)  // offsets need not span 0:n (src/shiftedGroupNormL2.jl:77 runs over every index)
@@ -592,13 +612,13 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   do {                                                                                                              \
     if (pairs && gsize == (LPG) * (EPL)) {                                                                          \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, true, false, true>), grid, block, 0, ctx->stream, y, q, xk, sj, \
-                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal); \
+                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal, dcount, (unsigned long long*)nullptr); \
     } else if (pairs) {                                                                                             \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, true>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,   \
-                         (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal);    \
+                         (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal, dcount, (unsigned long long*)nullptr);    \
     } else                                                                                                            \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, BINF, false>), grid, block, 0, ctx->stream, y, q, xk, sj, ngroups,  \
-                         (int)gsize, lambda, sigma, delta, deferred, ragged_reg ? offsets : (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal); \
+                         (int)gsize, lambda, sigma, delta, deferred, ragged_reg ? offsets : (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal, dcount, (unsigned long long*)nullptr); \
   } while (0)
     if (lpg == 1 && epl == 2) SPX_LAUNCH_REG(1, 2);
     else if (lpg == 1 && epl == 4) SPX_LAUNCH_REG(1, 4);
@@ -627,10 +647,10 @@ static int run_group(spx_ctx* ctx, double* y, const double* q, const double* xk,
   do {                                                                                                               \
     if (pairs)                                                                                                       \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, true, true, true>), lgrid, block, 0, ctx->stream, y, q, xk, sj,      \
-                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal); \
+                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal, dcount, dclear); \
     else                                                                                                             \
       hipLaunchKernelGGL((k_group_reg<LPG, EPL, true, false, true>), lgrid, block, 0, ctx->stream, y, q, xk, sj,     \
-                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal); \
+                         ngroups, (int)gsize, lambda, sigma, delta, deferred, (const int64_t*)nullptr, ctx->status_dev, ctx->tune_binf_literal, dcount, dclear); \
   } while (0)
         // (its own tiles, by the group size: the list is short, the literal evaluation wants lanes)
         if (gsize <= 16) SPX_LAUNCH_LIT(4, 4);

@@ -292,6 +292,9 @@ struct MemGroup {
 #ifndef SPX_BINF_LAZY
 #define SPX_BINF_LAZY 1  // A/B switch (round 4): lmax (the zlmax pass), froot(lmin) inside the trust region and the start -- see binf_root
 #endif
+#ifndef SPX_BINF_START_MAXTEAM
+#define SPX_BINF_START_MAXTEAM 64  // A/B switch (round 4): largest team (lanes per group) whose iteration starts at ||S|| - sl instead of the bound
+#endif
 #ifndef SPX_BINF_POLY
 #define SPX_BINF_POLY 1  // A/B switch (round 4): approach to a piece's root on the quartic in t instead of Newton in v
 #endif
@@ -757,7 +760,7 @@ __device__ __forceinline__ int binf_root(const G& grp, double lam, double sigma,
     // bracket: ||S|| - sl is the root when nothing is active and close to it when little is -- fewer passes and piece steps
     // for the slowest lane of a wavefront (tools/r4/binf_small_emul.py: 2.68 -> 2.36 passes, 10.9 -> 7.9 steps on groups of 8)
     const double us = nS - sl;
-    if (us > ulo && us < uhi) u = us;
+    if (TEAM <= SPX_BINF_START_MAXTEAM && us > ulo && us < uhi) u = us;
   }
   double sa, sb, psi;
   double tau_full;  // tau of the last full pass (the one sa, sb belong to)

@@ -53,6 +53,70 @@ __device__ __forceinline__ double block_sum(double v, double* lds4) {
   return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
+// How the reduced sum and the infeasibility flags turn into psi(y):
+enum ObjRule {
+  kRuleScaled = 0,   // lambda * sum                                        (generic forms)
+  kRuleBox = 1,      // flag ? +Inf : lambda * sum                           (Box forms: feasibility scan)
+  kRuleCount = 2,    // (flag || sum > limit) ? +Inf : 0                     (IndBallL0, IndBallL0BInf)
+  kRuleGroup = 3,    // bad index ? NaN : flag ? +Inf : sum                  (GroupNormL2(Binf))
+};
+__device__ __forceinline__ double obj_value(int rule, int flag, double acc, double scale, double limit) {
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  if (rule == kRuleScaled) return scale * acc;
+  if (rule == kRuleBox) return flag ? inf : scale * acc;
+  if (rule == kRuleCount) return (flag || acc > limit) ? inf : 0.0;
+  return (flag & 2) ? __longlong_as_double(0x7ff8000000000000ll) : (flag ? inf : acc);
+}
+
+// Round 4: psi(y) in ONE launch.  A call used to be three -- the flag's zero-fill, the reduction, k_obj_final -- and below
+// ~1e6 elements a call costs what its launches cost (tools/r4/small_latency_all.py: 15-16 us against 9 for a prox!).  With
+// `hdr` set, the workgroup that takes the last ticket (spx_fin_ticket) does k_obj_final's work itself: the partials travel as
+// agent-scope atomic stores / loads, are added in the same order (the same bits), the infeasibility bits live in the
+// synchronisation state (zero between launches: the last workgroup resets them) instead of library scratch that other
+// operators write over.  hdr == NULL: the kernel only leaves its partials and bits in `ws` for a later k_obj_final (the
+// forms whose flags have a second source: ragged Binf layouts, the chunked sums of large groups).
+struct ObjFin {
+  SpxSyncHeader* hdr;
+  double* target;  // spx_ctx::value_target (may be NULL)
+  double scale, limit;
+  int rule;
+};
+__device__ __forceinline__ int* obj_flag_word(ObjWs* ws, const ObjFin& fin) { return fin.hdr ? &fin.hdr->fin_flag : &ws->infeasible; }
+// raises `bits` from the first lane of a wavefront that saw them; the atomic has been PERFORMED when the wavefront goes on
+// (its return value is waited for), so the ticket its workgroup takes later is ordered behind it
+__device__ __forceinline__ void obj_raise(int* flagp, bool any, int bits) {
+  if (any && (threadIdx.x & 63) == 0 && (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) {
+    const int old = __hip_atomic_fetch_or(flagp, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(old));
+  }
+}
+// `acc`: this workgroup's sum (block_sum: the same in every lane).  Every wavefront has raised its bits before.
+__device__ __forceinline__ void obj_finish_block(double acc, ObjWs* ws, const ObjFin& fin, double* lds4) {
+  if (fin.hdr == nullptr) {
+    if (threadIdx.x == 0) ws->partial[blockIdx.x] = acc;
+    return;
+  }
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    spx_atomic_store_f64(&ws->partial[blockIdx.x], acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    is_last = spx_fin_ticket(fin.hdr) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  double a = 0.0;
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) a += spx_atomic_load_f64(&ws->partial[b]);  // (k_obj_final's order)
+  a = block_sum(a, lds4);
+  if (threadIdx.x == 0) {
+    const int flag = __hip_atomic_load(&fin.hdr->fin_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double v = obj_value(fin.rule, flag, a, fin.scale, fin.limit);
+    ws->result = v;        // (read back by the host when there is no device target: {result, infeasible})
+    ws->infeasible = flag;
+    if (fin.target) *fin.target = v;
+    __hip_atomic_store(&fin.hdr->fin_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // MODE 0: xsy = (xk + sj) + y over every index                              (generic, :52)
 // MODE 1: Box: the same over the selected indices, plus the feasibility scan of sj + y against
 //         [l - sqrt(eps), u + sqrt(eps)] over EVERY index                  (shiftedNormL1Box.jl:70-82)
@@ -63,7 +127,7 @@ template <class T, class Term, int MODE>
 __global__ __launch_bounds__(256) void k_obj(const T* __restrict__ y, const T* __restrict__ xk,
                                               const T* __restrict__ sj, const T* __restrict__ lv,
                                               const T* __restrict__ uv, const uint8_t* __restrict__ mask,
-                                              T ls, T us, double rad, int64_t n, Term term, ObjWs* ws) {
+                                              T ls, T us, double rad, int64_t n, Term term, ObjWs* ws, ObjFin fin) {
   __shared__ double lds4[4];
   const T slack = sizeof(T) == 8 ? (T)1.4901161193847656e-08 : (T)3.4526698300124393e-04;  // sqrt(eps(T))
   double acc = 0.0;
@@ -134,12 +198,11 @@ __global__ __launch_bounds__(256) void k_obj(const T* __restrict__ y, const T* _
       visit(y[i], xk[i], sj[i], (MODE == 1 && lv) ? lv[i] : ls, (MODE == 1 && uv) ? uv[i] : us,
             (MODE == 1 && mask) ? mask[i] != 0 : true);
   }
-  acc = block_sum(acc, lds4);
-  if (threadIdx.x == 0) ws->partial[blockIdx.x] = acc;
   // an infeasible point sets the flag from EVERY wavefront: once it is up nobody needs to queue on that one address again
   // (psi at an infeasible y of 1e8 elements: 0.45 -> 0.38 ms, the time of a feasible one)
-  if (__any(bad) && (threadIdx.x & 63) == 0 && __hip_atomic_load(&ws->infeasible, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-    atomicOr(&ws->infeasible, 1);
+  obj_raise(obj_flag_word(ws, fin), __any(bad), 1);
+  acc = block_sum(acc, lds4);
+  obj_finish_block(acc, ws, fin, lds4);
 }
 
 // GroupNormL2: sum_g lambda_g ||xsy[idx_g]||_2  (src/groupNormL2.jl:33-39).  TEAM lanes of a wavefront per group, 64 / TEAM
@@ -152,7 +215,7 @@ __global__ __launch_bounds__(256) void k_obj_group(const T* __restrict__ y, cons
                                                     const int64_t* __restrict__ offsets, int64_t gsize, int64_t ngroups,
                                                     const int64_t* __restrict__ index /* NULL: contiguous groups */,
                                                     int64_t nnz, const T* __restrict__ lambda, double rad,
-                                                    ObjWs* ws) {
+                                                    ObjWs* ws, ObjFin fin) {
   __shared__ double lds4[4];
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -210,11 +273,10 @@ __global__ __launch_bounds__(256) void k_obj_group(const T* __restrict__ y, cons
     for (int off = TEAM / 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);  // (inside the team's aligned lane range)
     if (live && j == 0) acc += (double)lambda[g] * sqrt(ss);
   }
+  obj_raise(obj_flag_word(ws, fin), __any(bad), 1);
+  obj_raise(obj_flag_word(ws, fin), __any(bad_index), 2);
   acc = block_sum(acc, lds4);
-  if (threadIdx.x == 0) ws->partial[blockIdx.x] = acc;
-  if (__any(bad) && (threadIdx.x & 63) == 0 && (__hip_atomic_load(&ws->infeasible, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) == 0)
-    atomicOr(&ws->infeasible, 1);
-  if (__any(bad_index) && (threadIdx.x & 63) == 0) atomicOr(&ws->infeasible, 2);
+  obj_finish_block(acc, ws, fin, lds4);
 }
 
 // LARGE contiguous groups -- first of all ONE group over the whole vector, the reference's default GroupNormL2
@@ -380,13 +442,6 @@ __global__ __launch_bounds__(256) void k_obj_linf_uncovered(const double* __rest
     atomicOr(&ws->infeasible, 1);
 }
 
-// How the reduced sum and the infeasibility flags turn into psi(y):
-enum ObjRule {
-  kRuleScaled = 0,   // lambda * sum                                        (generic forms)
-  kRuleBox = 1,      // flag ? +Inf : lambda * sum                           (Box forms: feasibility scan)
-  kRuleCount = 2,    // (flag || sum > limit) ? +Inf : 0                     (IndBallL0, IndBallL0BInf)
-  kRuleGroup = 3,    // bad index ? NaN : flag ? +Inf : sum                  (GroupNormL2(Binf))
-};
 // one workgroup: partials in index order (pairwise inside the wave, fixed shape) -> ws->result = psi(y) by `rule`;
 // target != NULL: the value also goes to the caller's device double (spx_ctx_set_value_target)
 __global__ __launch_bounds__(256) void k_obj_final(ObjWs* ws, int nblocks, int rule, double scale, double limit, double* target) {
@@ -396,12 +451,7 @@ __global__ __launch_bounds__(256) void k_obj_final(ObjWs* ws, int nblocks, int r
   acc = block_sum(acc, lds4);
   if (threadIdx.x == 0) {
     const int flag = ws->infeasible;
-    const double inf = __longlong_as_double(0x7ff0000000000000ll);
-    double v;
-    if (rule == kRuleScaled) v = scale * acc;
-    else if (rule == kRuleBox) v = flag ? inf : scale * acc;
-    else if (rule == kRuleCount) v = (flag || acc > limit) ? inf : 0.0;
-    else v = (flag & 2) ? __longlong_as_double(0x7ff8000000000000ll) : (flag ? inf : acc);
+    const double v = obj_value(rule, flag, acc, scale, limit);
     ws->result = v;
     if (target) *target = v;
   }
@@ -409,9 +459,12 @@ __global__ __launch_bounds__(256) void k_obj_final(ObjWs* ws, int nblocks, int r
 
 // *value = psi(y) (read back, stream synchronised) -- or, with a device value target on the context, NaN on the host and
 // the value in the target, nothing read back.  *flags = the infeasibility bits (0 in the device-target case).
-int obj_finish(spx_ctx* ctx, ObjWs* ws, int blocks, int rule, double scale, double limit, double* value, int* flags) {
-  hipLaunchKernelGGL(k_obj_final, dim3(1), dim3(256), 0, ctx->stream, ws, blocks, rule, scale, limit, ctx->value_target);
-  SPX_LAUNCH_CHECK();
+int obj_finish(spx_ctx* ctx, ObjWs* ws, int blocks, int rule, double scale, double limit, double* value, int* flags,
+               bool fused = false /* the reducing kernel's last workgroup has done k_obj_final's work (ObjFin) */) {
+  if (!fused) {
+    hipLaunchKernelGGL(k_obj_final, dim3(1), dim3(256), 0, ctx->stream, ws, blocks, rule, scale, limit, ctx->value_target);
+    SPX_LAUNCH_CHECK();
+  }
   *flags = 0;
   if (ctx->value_target) {
     *value = std::numeric_limits<double>::quiet_NaN();
@@ -423,6 +476,16 @@ int obj_finish(spx_ctx* ctx, ObjWs* ws, int blocks, int rule, double scale, doub
   SPX_HIP(hipStreamSynchronize(ctx->stream));
   *value = host.r;
   *flags = host.f;
+  return SPX_OK;
+}
+
+// The one-launch form (ObjFin): needs the synchronisation state's header; not while a stream capture has to allocate it.
+int obj_fin_prepare(spx_ctx* ctx, int rule, double scale, double limit, ObjFin* fin) {
+  *fin = ObjFin{nullptr, ctx->value_target, scale, limit, rule};
+  if (!ctx->tune_fewer_launches) return SPX_OK;
+  const int rc = spx_sync_reserve(ctx, sizeof(SpxSyncHeader));
+  if (rc) return rc;
+  fin->hdr = reinterpret_cast<SpxSyncHeader*>(ctx->sync);
   return SPX_OK;
 }
 
@@ -441,15 +504,18 @@ int run_obj(spx_ctx* ctx, const T* y, const T* xk, const T* sj, int64_t n, const
   int rc = spx_ws_reserve(ctx, sizeof(ObjWs) + 256);
   if (rc) return rc;
   SPX_ON_DEVICE(ctx);
+  ObjFin fin;
+  rc = obj_fin_prepare(ctx, rule, scale, limit, &fin);
+  if (rc) return rc;
   ObjWs* ws = reinterpret_cast<ObjWs*>(ctx->ws);
-  { const int rz = spx_zero_async(ctx, &ws->infeasible, sizeof(int)); if (rz) return rz; }
+  if (!fin.hdr) { const int rz = spx_zero_async(ctx, &ws->infeasible, sizeof(int)); if (rz) return rz; }
   int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
   if (blocks > kObjBlocks) blocks = kObjBlocks;
   hipLaunchKernelGGL((k_obj<T, Term, MODE>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, lv, uv, mask, ls,
-                     us, rad, n, Term{}, ws);
+                     us, rad, n, Term{}, ws, fin);
   SPX_LAUNCH_CHECK();
   int flags;
-  return obj_finish(ctx, ws, (int)blocks, rule, scale, limit, value, &flags);
+  return obj_finish(ctx, ws, (int)blocks, rule, scale, limit, value, &flags, fin.hdr != nullptr);
 }
 
 template <class T, int MODE>
@@ -469,7 +535,6 @@ int run_obj_group(spx_ctx* ctx, const T* y, const T* xk, const T* sj, int64_t n,
   if (rc) return rc;
   SPX_ON_DEVICE(ctx);
   ObjWs* ws = reinterpret_cast<ObjWs*>(ctx->ws);
-  { const int rz = spx_zero_async(ctx, &ws->infeasible, sizeof(int)); if (rz) return rz; }
   if constexpr (std::is_same<T, double>::value) {
     // large contiguous groups (uniform size, or CSR offsets with a large average): chunked, the whole chip on every group
     const int64_t avg = ngroups > 0 ? n / ngroups : 0;
@@ -510,6 +575,14 @@ int run_obj_group(spx_ctx* ctx, const T* y, const T* xk, const T* sj, int64_t n,
   int64_t blocks = (ngroups + 4 * gpw - 1) / (4 * gpw);
   if (blocks > kObjBlocks) blocks = kObjBlocks;
   if (blocks < 1) blocks = 1;
+  // one launch unless the trust-region scan of a ragged layout (below) raises bits after this kernel
+  ObjFin fin{nullptr, ctx->value_target, 1.0, 0.0, kRuleGroup};
+  if (!(MODE == 2 && offsets)) {
+    rc = obj_fin_prepare(ctx, kRuleGroup, 1.0, 0.0, &fin);
+    if (rc) return rc;
+    ws = reinterpret_cast<ObjWs*>(ctx->ws);
+  }
+  if (!fin.hdr) { const int rz = spx_zero_async(ctx, &ws->infeasible, sizeof(int)); if (rz) return rz; }
   constexpr bool kF64 = std::is_same<T, double>::value;
   const bool pairs = kF64 && !offsets && !index && gsize > 0 && (gsize & 1) == 0 && spx_aligned16(y) && spx_aligned16(xk) && spx_aligned16(sj);
 #define SPX_OBJ_GROUP(TEAM)                                                                                                  \
@@ -517,12 +590,12 @@ int run_obj_group(spx_ctx* ctx, const T* y, const T* xk, const T* sj, int64_t n,
     if constexpr (kF64) {                                                                                                    \
       if (pairs) {                                                                                                           \
         hipLaunchKernelGGL((k_obj_group<T, MODE, TEAM, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, \
-                           offsets, gsize, ngroups, index, nnz, lambda, rad, ws);                                            \
+                           offsets, gsize, ngroups, index, nnz, lambda, rad, ws, fin);                                       \
         break;                                                                                                               \
       }                                                                                                                      \
     }                                                                                                                        \
     hipLaunchKernelGGL((k_obj_group<T, MODE, TEAM>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, xk, sj, n, offsets, \
-                       gsize, ngroups, index, nnz, lambda, rad, ws);                                                         \
+                       gsize, ngroups, index, nnz, lambda, rad, ws, fin);                                                    \
   } while (0)
   switch (team) {
     case 1: SPX_OBJ_GROUP(1); break;
@@ -541,7 +614,7 @@ int run_obj_group(spx_ctx* ctx, const T* y, const T* xk, const T* sj, int64_t n,
   }
   SPX_LAUNCH_CHECK();
   int bad;
-  rc = obj_finish(ctx, ws, (int)blocks, kRuleGroup, 1.0, 0.0, value, &bad);
+  rc = obj_finish(ctx, ws, (int)blocks, kRuleGroup, 1.0, 0.0, value, &bad, fin.hdr != nullptr);
   if (rc) return rc;
   if (bad & 2) {  // (with a device value target the value is NaN instead: nothing is read back)
     spx_set_error("invalid argument: group index outside [0, n) (BoundsError)");
