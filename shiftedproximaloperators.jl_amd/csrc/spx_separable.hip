@@ -401,6 +401,12 @@ struct WithValue : Base {
   static constexpr bool kObj = true;
   double* partials;  // one slot per wavefront (LDS skeleton) / workgroup (register skeleton, scalar kernel)
   double qscale;     // the prox is taken at qscale * q (R2: q = -nu * grad f, formed on the fly; 1.0 = q itself)
+  // Round 4 (value_publish below): when the call is ONE launch of at most kValueFuseMax workgroups, the workgroup that
+  // finishes last adds the partials itself and the k_value_reduce launch is not queued (fin_hdr != NULL)
+  SpxSyncHeader* fin_hdr = nullptr;
+  double* fin_result = nullptr;  // the library's result slot (read back by the host form)
+  double* fin_target = nullptr;  // spx_ctx::value_target (may be NULL)
+  double fin_scale = 1.0;
   __device__ __forceinline__ double operator()(double q, double x, double s, double l, double u, bool sel) const {
     return Base::operator()(qscale * q, x, s, l, u, sel);
   }
@@ -415,11 +421,66 @@ __device__ __forceinline__ double block_sum4(double v, double* lds4) {  // 256-l
   __syncthreads();
   return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
+// partials[0..count), count <= kValueFuseMax, added by the first 256 lanes of a workgroup in a fixed order (eight loads in
+// flight per lane, a fixed tree, wavefront butterflies, the four wavefronts in order): the order of BOTH the one-launch form
+// (ATOMIC: the slots were written by other workgroups of the same launch) and k_value_reduce on short lists, so that the two
+// forms of a call give the same bits.  Every lane of the workgroup must call it.
+constexpr int kValueFuseMax = 2048;
+template <bool ATOMIC>
+__device__ __forceinline__ double value_reduce_small(const double* partials, int count) {
+  __shared__ double vr_lds4[4];
+  const int t = threadIdx.x;
+  double v8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = t + k * 256;
+    const bool in = t < 256 && i < count;
+    if constexpr (ATOMIC) v8[k] = in ? spx_atomic_load_f64(partials + i) : 0.0;
+    else v8[k] = in ? partials[i] : 0.0;
+  }
+  double acc = ((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7]));
+  acc = wave_sum(acc);
+  __syncthreads();
+  if ((t & 63) == 0 && t < 256) vr_lds4[t >> 6] = acc;
+  __syncthreads();
+  return (vr_lds4[0] + vr_lds4[1]) + (vr_lds4[2] + vr_lds4[3]);
+}
+// The partial sum `t` of this workgroup (valid in thread 0) goes to its slot; in the one-launch form the workgroup that takes
+// the last ticket (spx_fin_ticket) then adds all of them and stores the value.  Every lane of the workgroup must call it.
+template <class Op>
+__device__ __forceinline__ void value_publish(const Op& op, int64_t slot, double t) {
+  if (op.fin_hdr == nullptr) {
+    if (threadIdx.x == 0) op.partials[slot] = t;
+    return;
+  }
+  __shared__ int vp_last;
+  if (threadIdx.x == 0) {
+    spx_atomic_store_f64(op.partials + slot, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    vp_last = spx_fin_ticket(op.fin_hdr) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!vp_last) return;
+  const double sum = value_reduce_small<true>(op.partials, (int)gridDim.x);
+  if (threadIdx.x == 0) {
+    *op.fin_result = sum;
+    if (op.fin_target) *op.fin_target = op.fin_scale * sum;
+  }
+}
+
 // partials[0..count) -> *out, fixed order: reproducible run to run
 // target != NULL: also *target = scale * sum (the caller's device double, spx_ctx_set_value_target)
 __global__ __launch_bounds__(1024) void k_value_reduce(const double* partials, int64_t count, double* out, double scale,
                                                         double* target) {
   __shared__ double lds[16];
+  if (count <= kValueFuseMax) {  // (the order of the one-launch form)
+    const double t = value_reduce_small<false>(partials, (int)count);
+    if (threadIdx.x == 0) {
+      *out = t;
+      if (target) *target = scale * t;
+    }
+    return;
+  }
   // eight independent loads in flight per lane, added in a fixed order (reproducible run to run)
   double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (int64_t i0 = threadIdx.x; i0 < count; i0 += 8 * 1024) {
@@ -540,7 +601,7 @@ __global__ __launch_bounds__(256) void k_sep_vec(double* y_, const double* q_, c
   if constexpr (Op::kObj) {
     __shared__ double lds4[4];
     const double t = block_sum4(hacc, lds4);
-    if (threadIdx.x == 0) op.partials[blockIdx.x] = t;
+    value_publish(op, blockIdx.x, t);
   }
 }
 
@@ -639,11 +700,13 @@ __global__ __launch_bounds__(256) void k_sep_lds(double* y_, const double* q_, c
     const double t = wave_sum(hacc);
     if (lane == 0) *reinterpret_cast<double*>(wl) = t;
     __syncthreads();
+    double tb = 0.0;
     if (threadIdx.x == 0) {
       const double* w0 = reinterpret_cast<const double*>(lds);
       constexpr int stride = NARR * UNROLL * 1024 / 8;
-      op.partials[bid] = (w0[0] + w0[stride]) + (w0[2 * stride] + w0[3 * stride]);
+      tb = (w0[0] + w0[stride]) + (w0[2 * stride] + w0[3 * stride]);
     }
+    value_publish(op, bid, tb);
   }
 }
 
@@ -684,7 +747,18 @@ __global__ __launch_bounds__(256) void k_sep_scalar(double* y, const double* q, 
 template <class Op, bool VECB, bool MASK>
 static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d, const double* xk, const double* sj,
                       const double* l, const double* u, const uint8_t* mask, double ls, double us, int64_t n2, Op op,
-                      int64_t* value_slots /* out: partial slots written (Op::kObj) */) {
+                      int64_t* value_slots /* out: partial slots written (Op::kObj) */,
+                      const SpxSyncHeader* fuse_hdr = nullptr /* Op::kObj: this launch is the whole call -- it may finish the value itself */,
+                      bool* fused = nullptr) {
+  // (Op::kObj) the one-launch form: the grid is the list of slots, short enough for one workgroup to add
+  auto try_fuse = [&](int64_t blocks) {
+    if constexpr (Op::kObj) {
+      if (fuse_hdr != nullptr && blocks <= kValueFuseMax && !ctx->tune_sep_xcd) {
+        op.fin_hdr = const_cast<SpxSyncHeader*>(fuse_hdr);
+        *fused = true;
+      }
+    }
+  };
   if constexpr (Op::kLdsKiB > 0) if (ctx->tune_sep_lds) {
     // 3 input vectors: 6 KiB per wave and vector -> 72 KiB per workgroup; 5 vectors (vector bounds): 3 KiB -> 60 KiB
     constexpr int U = (VECB && Op::kBox) ? (Op::kLdsKiB > SPX_VECB_KIB ? SPX_VECB_KIB : Op::kLdsKiB) : Op::kLdsKiB;  // <= 72 KiB per workgroup
@@ -695,6 +769,7 @@ static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d,
       blocks = xcd_chunk * 8;
     }
     *value_slots = blocks;  // one per workgroup (idle workgroups of the XCD-contiguous experiment write a zero)
+    try_fuse(blocks);
     hipLaunchKernelGGL((k_sep_lds<Op, U, VECB, MASK>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, q, d, xk,
                        sj, l, u, mask, ls, us, n2, op, xcd_chunk);
     SPX_LAUNCH_CHECK();
@@ -706,6 +781,7 @@ static int launch_vec(spx_ctx* ctx, double* y, const double* q, const double* d,
   const int64_t cap = ctx->tune_sep_blocks_per_cu > 0 ? (int64_t)ctx->num_cu * ctx->tune_sep_blocks_per_cu : (int64_t)0x7fffffff;
   if (blocks > cap) blocks = cap;
   *value_slots = blocks;  // one per workgroup
+  try_fuse(blocks);
   if (ctx->tune_sep_nt)
     hipLaunchKernelGGL((k_sep_vec<Op, UNROLL, VECB, MASK, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y,
                        q, d, xk, sj, l, u, mask, ls, us, n2, op);
@@ -731,7 +807,12 @@ static int run_separable(spx_ctx* ctx, double* y, const double* q, const double*
     int rcw = spx_ws_reserve(ctx, 256 + (size_t)maxslots * sizeof(double));
     if (rcw) return rcw;
     partials = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + 256);
+    if (ctx->tune_fewer_launches) {  // (the one-launch form keeps its tickets in the synchronisation state)
+      rcw = spx_sync_reserve(ctx, sizeof(SpxSyncHeader));
+      if (rcw) return rcw;
+    }
   }
+  bool fused = false;
   // The vector skeletons need 16-byte aligned vectors (and a 2-byte aligned mask).  Views that all start 8 bytes off
   // (e.g. view(x, 2:n) of aligned arrays) are peeled: element 0 through the scalar kernel, the rest aligned again.
   auto vec_ok_at = [&](int64_t h) {
@@ -766,16 +847,26 @@ static int run_separable(spx_ctx* ctx, double* y, const double* q, const double*
     const uint8_t* mv = mask ? mask + head : mask;
     int rc;
     int64_t slots = 0;
-    if constexpr (Op::kObj) op.partials = partials + used;
+    const SpxSyncHeader* fh = nullptr;
+    if constexpr (Op::kObj) {
+      op.partials = partials + used;
+      // one launch covers the whole vector (no peeled element in front, no odd element behind): it may finish the value
+      if (ctx->tune_fewer_launches && head == 0 && 2 * n2 == n) {
+        fh = reinterpret_cast<const SpxSyncHeader*>(ctx->sync);
+        op.fin_result = reinterpret_cast<double*>(ctx->ws);
+        op.fin_target = ctx->value_target;
+        op.fin_scale = value_scale;
+      }
+    }
     if constexpr (Op::kBox) {
       const bool vecb = (l || u);
       const bool msk = (mask != nullptr);
-      if (vecb && msk) rc = launch_vec<Op, true, true>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots);
-      else if (vecb) rc = launch_vec<Op, true, false>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots);
-      else if (msk) rc = launch_vec<Op, false, true>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots);
-      else rc = launch_vec<Op, false, false>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots);
+      if (vecb && msk) rc = launch_vec<Op, true, true>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots, fh, &fused);
+      else if (vecb) rc = launch_vec<Op, true, false>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots, fh, &fused);
+      else if (msk) rc = launch_vec<Op, false, true>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots, fh, &fused);
+      else rc = launch_vec<Op, false, false>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots, fh, &fused);
     } else {
-      rc = launch_vec<Op, false, false>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots);
+      rc = launch_vec<Op, false, false>(ctx, yv, qv, dv, xv, sv, lv, uv, mv, ls, us, n2, op, &slots, fh, &fused);
     }
     if (rc) return rc;
     used += slots;
@@ -787,9 +878,11 @@ static int run_separable(spx_ctx* ctx, double* y, const double* q, const double*
   }
   if constexpr (Op::kObj) {
     double* result = reinterpret_cast<double*>(ctx->ws);
-    hipLaunchKernelGGL(k_value_reduce, dim3(1), dim3(1024), 0, ctx->stream, (const double*)partials, used, result,
-                       value_scale, ctx->value_target);
-    SPX_LAUNCH_CHECK();
+    if (!fused) {
+      hipLaunchKernelGGL(k_value_reduce, dim3(1), dim3(1024), 0, ctx->stream, (const double*)partials, used, result,
+                         value_scale, ctx->value_target);
+      SPX_LAUNCH_CHECK();
+    }
     if (ctx->value_target) {  // device-resident value: nothing is read back, the call returns after enqueueing
       *value = std::numeric_limits<double>::quiet_NaN();
       return SPX_OK;

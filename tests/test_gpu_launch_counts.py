@@ -97,6 +97,42 @@ def test_objective_one_launch_into_a_device_double_back_to_back(s):
         assert (np.isinf(got[k]) if k % 3 == 1 else got[k] == want_ok), (k, got[k])
 
 
+@pytest.mark.parametrize("n", [2, 64, 3000, 50_000, 1_000_000, 1_000_001, 6_291_456, 7_000_000])
+def test_prox_value_one_launch(s, orc, n):
+    """prox! fused with the value of h at the result: when one launch covers the vector (aligned, even n) and its grid is at
+    most 2048 workgroups, the last workgroup adds the partial sums (value_publish, csrc/spx_separable.hip) and the
+    k_value_reduce launch is not queued.  y bit for bit and the value: equal to the two-launch form (key 17 = 0) -- both add
+    a short list in the same order --, host and device-target forms, and within 1e-12 of the oracle's psi at the result."""
+    import torch
+    rng = np.random.default_rng(300 + n)
+    x, sj, q = rng.normal(size=n), rng.uniform(-0.5, 0.5, size=n), rng.normal(size=n)
+    xd, sd, qd = _dev(x, sj, q)
+    chi = s.NormLinf(1.0)
+    psis = [("l1", s.shifted(s.shifted(s.NormL1(0.7), xd), sd)), ("l0", s.shifted(s.shifted(s.NormL0(0.7), xd), sd)),
+            ("lhalf", s.shifted(s.shifted(s.RootNormLhalf(0.7), xd), sd)), ("l1", s.shifted(s.shifted(s.NormL1(0.7), xd, 0.9, chi), sd)),
+            ("l0", s.shifted(s.shifted(s.NormL0(0.7), xd, 0.9, chi), sd))]
+    out = torch.full((1,), -1.0, dtype=torch.float64, device="cuda:0")
+    try:
+        for name, psi in psis:
+            _key17(s, 0)
+            y0, v0 = s.prox_value(psi, qd, 1.1)
+            y0 = y0.clone()
+            _key17(s, 1)
+            for rep in range(3):
+                y1, v1 = s.prox_value(psi, qd, 1.1)
+                assert torch.equal(y1.view(torch.int64), y0.view(torch.int64)), (name, n)
+                assert v1 == v0, (name, n, v1, v0)
+            with s.device_values(out):
+                y2, v2 = s.prox_value(psi, qd, 1.1)
+            assert v2 != v2 and float(out.item()) == v0 and torch.equal(y2.view(torch.int64), y0.view(torch.int64))
+            yh = y0.cpu().numpy()
+            term = {"l1": np.abs, "l0": lambda v: (v != 0).astype(float), "lhalf": lambda v: np.sqrt(np.abs(v))}[name]
+            want = 0.7 * float(np.sum(term((x + sj) + yh)))
+            assert abs(v0 - want) <= 1e-12 * max(1.0, abs(want)), (name, n, v0, want)
+    finally:
+        _key17(s, 1)
+
+
 @pytest.mark.parametrize("gs", [2, 8, 16, 50, 128, 300])
 def test_binf_deferred_list_without_the_zero_launch(s, gs):
     """Binf groups with a NON-EMPTY deferred list (degenerate brackets, |X_i| == Delta: the literal evaluation) several calls
