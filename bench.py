@@ -72,7 +72,10 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # SPX_BENCH_FORCE_DIST=1: initialise the process group, barrier and MAX-reduce also with ONE rank (under torch.distributed.run
+    # --nproc-per-node 1) -- the RCCL branch of this file executed on the one-GPU box (profiles/r04_bench_nccl_1rank.txt)
+    dist_on = world > 1 or (os.environ.get("SPX_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -95,7 +98,7 @@ def main():
     psi = s.shifted(s.shifted(s.NormL1(1.0), xk, 1.0, s.NormLinf(1.0)), sj)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     # clock ramp: ~0.1 s of the same call so that the W warm-up steps and the K timed steps see steady-state
@@ -120,7 +123,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([wall, ms.value], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(t[0]), float(t[1])
@@ -170,7 +173,7 @@ def main():
     barrier()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
