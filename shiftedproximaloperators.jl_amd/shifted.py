@@ -59,22 +59,31 @@ def _ctx(device):
     return c
 
 
+_Tensor = torch.Tensor
+
+
 def _is_host(t):
     return isinstance(t, np.ndarray)
 
 
 def _n(t):
-    return t.size if _is_host(t) else t.numel()
+    return t.numel() if type(t) is _Tensor else (t.size if _is_host(t) else t.numel())
 
 
 def _dev(t):
     """torch device of a device vector, None for a host (numpy) vector"""
-    return None if _is_host(t) else t.device
+    return t.device if type(t) is _Tensor else (None if _is_host(t) else t.device)
 
 
 def _vec(t, name, n=None, like=None):
     """Validates a vector argument: a float64 contiguous torch CUDA tensor, or a float64 contiguous numpy array
     (host-pointer forms).  `like`: a vector it must share its kind (and device) with."""
+    # (round 4: a call at solver sizes costs ~9 us in this mirror against 3.9 through the C ABI alone -- tools/r4/py_overhead.py;
+    #  the usual case, a plain device tensor checked against ψ.xk, takes the few tests below and nothing else)
+    if type(t) is _Tensor and type(like) is _Tensor and t.is_cuda and t.dtype is like.dtype and t.dim() == 1:
+        m = t.numel()
+        if (n is None or m == n) and (m <= 1 or t.stride(0) == 1) and t.device == like.device:
+            return t
     if _is_host(t):
         if t.dtype != np.float64:
             raise TypeError("%s must be float64 (got %s)" % (name, t.dtype))
@@ -102,9 +111,16 @@ def _vec(t, name, n=None, like=None):
     return t
 
 
+_NULL = ctypes.c_void_p(0)
+
+
 def _ptr(t):
-    if t is None or _n(t) == 0:
-        return ctypes.c_void_p(0)
+    if t is None:
+        return _NULL
+    if type(t) is _Tensor:
+        return ctypes.c_void_p(t.data_ptr()) if t.numel() else _NULL
+    if _n(t) == 0:
+        return _NULL
     return ctypes.c_void_p(t.ctypes.data if _is_host(t) else t.data_ptr())
 
 
@@ -131,7 +147,7 @@ def _copy_into(dst, src):
 
 
 def _is_real(v):
-    return isinstance(v, numbers.Real)
+    return type(v) is float or type(v) is int or isinstance(v, numbers.Real)
 
 
 # ---------------------------------------------------------------------------------------------
