@@ -272,14 +272,14 @@ def _extra(s, L, ctx, dev, n, torch):
     res["objective_ShiftedNormL1Box"] = {"ms": round(ms, 4), "gelem_s": round(n / ms / 1e6, 2),
                                          "gbs_algorithmic": round(24 * n / ms / 1e6, 1),
                                          "frac_of_peak": round(24 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
-                                         "kernel": "k_obj<double, TermL1, 1> (+ k_obj_final)",
+                                         "kernel": "k_obj<double, TermL1, 1> (one launch: its last workgroup adds the partial sums)",
                                          "note": "host wall time per call incl. the read-back of the value"}
     # the same value left on the device (spx_ctx_set_value_target): no read-back, HIP-event time of back-to-back calls
     vout = torch.zeros(1, dtype=torch.float64, device=dev)
     with s.device_values(vout):
         ms = _time_op(s, L, ctx, lambda: psi_l1b(y))
     res["objective_ShiftedNormL1Box_device_value"] = {"ms": round(ms, 4), "avg_launch_ms": round(ms, 4),
-                                                      "kernel": "k_obj<double, TermL1, 1> (+ k_obj_final)", "gelem_s": round(n / ms / 1e6, 2),
+                                                      "kernel": "k_obj<double, TermL1, 1> (one launch: its last workgroup adds the partial sums)", "gelem_s": round(n / ms / 1e6, 2),
                                                       "gbs_algorithmic": round(24 * n / ms / 1e6, 1),
                                                       "frac_of_peak": round(24 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
                                                       "note": "value stored in a device double, nothing read back"}
@@ -487,7 +487,7 @@ def _graph_iteration(s, dev, torch):
             side.synchronize()
             t_eager = (time.perf_counter() - t0) / reps
         res["n=%d" % nn] = {"us_per_iteration_python_calls": round(t_eager * 1e6, 1), "us_per_iteration_graph_replay": round(t_graph * 1e6, 1),
-                            "kernels": "4 calls: k_sep_lds<OpL1Box>, k_obj<TermL1,1> + k_obj_final, k_sel_coop / k_sel_small, k_b2_coop (+ zero-fill nodes)"}
+                            "kernels": "4 calls, 4 kernels: k_sep_lds<OpL1Box>, k_obj<TermL1,1>, k_sel_coop / k_sel_small, k_b2_coop (+ the zero-fill nodes of the in-launch synchronised kernels in the graph)"}
     return res
 
 
