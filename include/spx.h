@@ -130,7 +130,9 @@ int spx_timer_stop(spx_ctx* ctx, float* elapsed_ms); /* records stop, waits, ret
  * top-r and ShiftedNormL1B2 are sized by it and fall back to their any-grid forms -- this key lets a test force that).
  * Key 10 = samples per lane of the top-r front kernel (0, default: 1 / 2 / 4 by n, 16 for a cut in the bulk of a vector of
  * >= 2^26 elements; 1, 2, 4, 16 force it).  Key 11 = one-launch top-r with v parked in LDS for 2^20 < n <= 16 Ki x resident
- * workgroups (1, default; 0: registers up to 2^21, the sample-predicted path above, as in round 2).  Key 12 = ShiftedNormL1B2
+ * workgroups, and beyond that -- up to 24 Ki x resident workgroups = 6 Mi elements -- with 8 more elements per lane in
+ * registers (1, default; 2: v in LDS up to 2^22, the sample-predicted path above; 0: registers up to 2^21, the sample-predicted
+ * path above, as in round 2).  Key 12 = ShiftedNormL1B2
  * with xk parked in LDS for 2^21 < n <= 2^22 (1, default; 0: the two-pass streaming form from 2^21 on).  (Key 7, round 2's switch
  * to the multi-launch pipelines, is gone with those pipelines.)  Key 13 = large contiguous groups of ShiftedGroupNormL2(Binf)
  * -- first of all ONE group over the whole vector, the reference's `shifted(NormL2(lambda), xk)` -- are owned by a team of

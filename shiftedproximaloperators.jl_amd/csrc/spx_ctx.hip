@@ -146,7 +146,7 @@ SPX_EXPORT int spx_ctx_set_tuning(spx_ctx* ctx, int key, int value) {
     case 8: if (value < 0) break; ctx->tune_coop_cap = value; return SPX_OK;
     case 9: ctx->tune_binf_literal = value ? 1 : 0; return SPX_OK;
     case 10: if (value != 0 && value != 1 && value != 2 && value != 4 && value != 16) break; ctx->tune_front_spl = value; return SPX_OK;
-    case 11: ctx->tune_sel_reg16 = value ? 1 : 0; return SPX_OK;
+    case 11: if (value < 0 || value > 2) break; ctx->tune_sel_reg16 = value; return SPX_OK;  // (2: v in LDS up to 4 Mi, no register slots beyond)
     case 12: ctx->tune_b2_lds = value ? 1 : 0; return SPX_OK;
     case 13: ctx->tune_team = value ? 1 : 0; return SPX_OK;
     case 14: ctx->tune_team_fast = value ? 1 : 0; return SPX_OK;

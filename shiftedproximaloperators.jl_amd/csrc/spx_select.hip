@@ -1444,12 +1444,22 @@ template <> struct SelVec<float> { typedef float type __attribute__((ext_vector_
 // of floats) and moves them with 16-byte accesses; otherwise elements gtid + k NT, one at a time.
 // T = float (round 3): 32 elements per lane, 8 Mi on 256 CUs -- 16 B per element in one launch where the form that parks v in
 // y moves ~44; the first digit is folded as for Float64 (fold_digit_f32).
-template <bool BINF, bool VEC, class T = double>
+// REGX (round 4, third session: the cliff above 2^22 elements -- the sample-predicted pipeline took over there with six launches
+// and ~50 us of fixed cost: n = 6e6 86 us against 44 at 4e6): REGX MORE elements per lane whose v stays in REGISTERS through the
+// digit passes (unrolled visits, as in k_sel_coop<REG>), beside the kSlots elements in LDS: 16 + 8 = 24 Ki elements per
+// workgroup, 6 Mi on 256 CUs.  The registers come from xk + sj, which this form does not keep (32 of them for 16 elements): the
+// storing phase re-reads xk and sj -- 16 B per element more, from the memory-side cache the load phase has just filled -- and
+// forms xk + sj again (the same addition: the same bits).  48 B per element moved instead of 32, in one launch.
+constexpr int kLdsRegX = 8;
+template <bool BINF, bool VEC, class T = double, int REGX = 0>
 __global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk, const T* sj, int64_t n,
                                                    int64_t r, T delta, SelSync* ss, int parity, int use_set, int clear_set) {
   constexpr bool kF64 = std::is_same<T, double>::value;
-  constexpr int kSlots = kF64 ? kLdsEpl : kLdsEpl32;   // elements per lane
+  constexpr int kSlots = kF64 ? kLdsEpl : kLdsEpl32;   // elements per lane in LDS
+  constexpr int kAll = kSlots + REGX;                  // elements per lane
+  constexpr bool kKeepXs = REGX == 0;                  // xk + sj stays in registers (REGX: re-read in the storing phase)
   constexpr int W = 16 / (int)sizeof(T);               // elements per 16-byte vector
+  static_assert(REGX % (2 * W) == 0, "REGX: whole load batches");
   typedef typename SelVec<T>::type VT;
   __shared__ CoopShared sh;
   __shared__ __attribute__((aligned(16))) T lv[kSlots * 1024];
@@ -1473,7 +1483,8 @@ __global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk,
   // first digit of a key: it depends on nothing but the key (the state sel_state_init sets up: the folded digit of a Float64,
   // the plain top digit of a Float32)
   auto digit0 = [&](uint64_t key) -> unsigned int { if constexpr (kF64) return fold_digit(key); else return fold_digit_f32(key); };
-  T xs[kSlots];
+  T xs[kKeepXs ? kSlots : 1];
+  T vr[REGX > 0 ? REGX : 1];  // v of the slots kSlots .. kAll - 1
   SEL_STAMP(31);
   // The first digit is histogrammed while the loads are in flight -- as its own sweep over the 16 Ki elements it was 8 us of
   // VALU work that nothing overlapped.
@@ -1486,12 +1497,16 @@ __global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk,
   const bool fused = kCoopFold && sh.sst.phase == 0;
   constexpr int kBatch = 2 * W;  // elements per batch: two 16-byte vectors of each input (six 16-byte or 3 x 2W narrow loads in flight)
 #pragma unroll
-  for (int s0 = 0; s0 < kSlots; s0 += kBatch) {
+  for (int s0 = 0; s0 < kAll; s0 += kBatch) {
     T vv[kBatch];
+    T xb[kBatch];  // xk + sj of the batch
     // (small n: nothing of this batch belongs to the workgroup -- its first lane's first index is past the end)
     if ((VEC ? W * ((int)(blockIdx.x * blockDim.x) + (s0 / W) * nt) : (int)(blockIdx.x * blockDim.x) + s0 * nt) >= n32) {
 #pragma unroll
-      for (int k = 0; k < kBatch; ++k) xs[s0 + k] = (T)0;
+      for (int k = 0; k < kBatch; ++k) {
+        if constexpr (kKeepXs) xs[s0 + k] = (T)0;
+        if (s0 + k >= kSlots) vr[(s0 + k >= kSlots) ? s0 + k - kSlots : 0] = (T)0;
+      }
       continue;
     }
     if constexpr (VEC) {
@@ -1506,16 +1521,16 @@ __global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk,
         const VT qv = __builtin_nontemporal_load(reinterpret_cast<const VT*>(q) + pc);
 #pragma unroll
         for (int e = 0; e < W; ++e) {
-          xs[s_ + e] = xv[e] + sv[e];
-          vv[W * h + e] = xs[s_ + e] + qv[e];   // shiftedIndBallL0.jl:66
+          xb[W * h + e] = xv[e] + sv[e];
+          vv[W * h + e] = xb[W * h + e] + qv[e];   // shiftedIndBallL0.jl:66
         }
         if (tail && pr == nw) {  // the elements behind the last whole vector: the first `tail` slots of the vector after it
 #pragma unroll
           for (int e = 0; e < W - 1; ++e) {
             if (e < tail) {
               const int i = W * nw + e;
-              xs[s_ + e] = xk[i] + sj[i];
-              vv[W * h + e] = xs[s_ + e] + q[i];
+              xb[W * h + e] = xk[i] + sj[i];
+              vv[W * h + e] = xb[W * h + e] + q[i];
             }
           }
         }
@@ -1526,13 +1541,15 @@ __global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk,
         const int i = index_of(s0 + k);
         const int ic = i < n32 ? i : n32 - 1;  // clamped, unconditional
         const T xv = __builtin_nontemporal_load(xk + ic), sv = __builtin_nontemporal_load(sj + ic), qv = __builtin_nontemporal_load(q + ic);
-        xs[s0 + k] = xv + sv;
-        vv[k] = xs[s0 + k] + qv;               // shiftedIndBallL0.jl:66
+        xb[k] = xv + sv;
+        vv[k] = xb[k] + qv;                    // shiftedIndBallL0.jl:66
       }
     }
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
-      lv[lds_of(s0 + k)] = vv[k];              // (slots beyond n are never read)
+      if constexpr (kKeepXs) xs[s0 + k] = xb[k];
+      if (s0 + k < kSlots) lv[lds_of(s0 + k < kSlots ? s0 + k : 0)] = vv[k];   // (slots beyond n are never read)
+      else vr[(s0 + k >= kSlots) ? s0 + k - kSlots : 0] = vv[k];
       if (fused && index_of(s0 + k) < n32) atomicAdd(&sh.lh[digit0(key_of(vv[k]))], 1u);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1562,11 +1579,9 @@ __global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk,
       //  generic path 2 us per call)
       auto sweep = [&](auto track_tag) {
         constexpr bool kTrack = decltype(track_tag)::value;
-#pragma unroll 2
-      for (int s_ = 0; s_ < kSlots; ++s_) {
-        const int i = index_of(s_);
-        if (i >= n32) continue;
-        const uint64_t key = key_of(lv[lds_of(s_)]);
+      auto visit = [&](int i, T vval) {
+        if (i >= n32) return;
+        const uint64_t key = key_of(vval);
         bool in = true;
         unsigned int dg;
         if (st.phase == 0) {
@@ -1587,6 +1602,16 @@ __global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk,
         // (plain LDS atomics: the wave-aggregated form of coop_select cost this rolled loop 3 us per full sweep on generic data;
         //  on one-key data 64 lanes on one LDS address are ~64 clocks per instruction, 7 us per sweep)
         if (in) atomicAdd(&sh.lh[dg], 1u);
+      };
+#pragma unroll 2
+      for (int s_ = 0; s_ < kSlots; ++s_) visit(index_of(s_), lv[lds_of(s_)]);
+      if constexpr (REGX > 0) {
+#pragma unroll
+        for (int j = 0; j < REGX; ++j) {
+          T vj = vr[j];
+          asm volatile("" : "+v"(vj));  // (opaque per sweep: otherwise the keys and first digits of the eight are hoisted out of the pass loop and spill)
+          visit(index_of(kSlots + j), vj);
+        }
       }
       };
       if (track) sweep(std::true_type{}); else sweep(std::false_type{});
@@ -1621,7 +1646,50 @@ __global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk,
   const SelState fin = sel_uniform(sh.sst);
   const bool poisoned = spx_poisoned(hdr);  // (see coop_select)
   auto P = [&](T val) -> T { return poisoned ? (T)__longlong_as_double(0x7ff8000000000000ll) : val; };
-  if constexpr (VEC) {
+  if constexpr (VEC && !kKeepXs) {
+    // REGX: xk + sj is formed again from re-read vectors, four 16-byte vectors of each at a time (eight loads in flight per lane)
+    const int nw = n32 / W, tail = n32 % W;
+    constexpr int kVB = 4;
+    static_assert((kAll / W) % kVB == 0, "whole batches of vectors");
+#pragma unroll
+    for (int v0 = 0; v0 < kAll / W; v0 += kVB) {
+      VT xv[kVB], sv[kVB];
+#pragma unroll
+      for (int b = 0; b < kVB; ++b) {
+        const int pr = gtid + (v0 + b) * nt;
+        const int pc = pr < nw ? pr : nw - 1;
+        xv[b] = __builtin_nontemporal_load(reinterpret_cast<const VT*>(xk) + pc);
+        sv[b] = __builtin_nontemporal_load(reinterpret_cast<const VT*>(sj) + pc);
+      }
+#pragma unroll
+      for (int b = 0; b < kVB; ++b) {
+        const int s_ = (v0 + b) * W;
+        const int pr = gtid + (v0 + b) * nt;
+        VT vvv;
+        if (s_ < kSlots) {
+          vvv = *reinterpret_cast<const VT*>(&lv[lds_of(s_ < kSlots ? s_ : 0)]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < W; ++e) vvv[e] = vr[(s_ >= kSlots) ? s_ - kSlots + e : 0];
+        }
+        VT o;
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+          T xse = xv[b][e] + sv[b][e];
+          if (tail && pr == nw && e < tail) xse = xk[W * nw + e] + sj[W * nw + e];  // (the elements behind the last whole vector)
+          o[e] = P(sel_out_xs<BINF>((T)vvv[e], (int64_t)(W * pr + e), xse, fin, delta));
+        }
+        if (pr < nw) {
+          __builtin_nontemporal_store(o, reinterpret_cast<VT*>(y) + pr);
+        } else if (tail && pr == nw) {
+#pragma unroll
+          for (int e = 0; e < W - 1; ++e)
+            if (e < tail) y[W * nw + e] = o[e];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (VEC) {
     const int nw = n32 / W, tail = n32 % W;
 #pragma unroll
     for (int s_ = 0; s_ < kSlots; s_ += W) {
@@ -1640,6 +1708,7 @@ __global__ __launch_bounds__(1024) void k_sel_lds(T* y, const T* q, const T* xk,
       __builtin_amdgcn_sched_barrier(0);  // (one vector at a time: hoisted, the LDS reads do not fit beside xs)
     }
   } else {
+    static_assert(VEC || kKeepXs, "the form with register slots exists for 16-byte aligned vectors only");
 #pragma unroll
     for (int s_ = 0; s_ < kSlots; ++s_) {
       const int i = index_of(s_);
@@ -2297,8 +2366,17 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
                              : spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_sel_lds<BINF, false>), 1024, 0);
     lds_cap = (int64_t)kLdsEpl * 1024 * (capl < ctx->num_cu ? capl : ctx->num_cu);
   }
+  // ... and 6 Mi with 8 more elements per lane in registers (k_sel_lds<.., REGX>: 16-byte aligned vectors only; tuning key 11 = 2
+  // keeps the pipeline from 4 Mi on)
+  int64_t hyb_cap = 0;
+  if (ctx->tune_sel_reg16 == 1 && vec && lds_cap > 0) {
+    const int64_t caph = spx_resident_cap(ctx, reinterpret_cast<const void*>(&k_sel_lds<BINF, true, double, kLdsRegX>), 1024, 0);
+    hyb_cap = (int64_t)(kLdsEpl + kLdsRegX) * 1024 * (caph < ctx->num_cu ? caph : ctx->num_cu);
+    if (hyb_cap > 0x7fffffff) hyb_cap = 0;  // (the form indexes with 32-bit integers)
+  }
   int64_t fast_min = ((int64_t)1 << SPX_SEL_REG_MAX_LOG2) + 1;
   if (lds_cap >= fast_min) fast_min = lds_cap + 1;
+  if (hyb_cap >= fast_min) fast_min = hyb_cap + 1;
   const bool try_fast = ctx->tune_sel_fast && (vec || ioff) && (n - ioff) >= fast_min && r > 0 && r < n &&
                         cap_front >= kFrontBlocks;  // (the front kernel's sample layout is tied to its grid)
   rc = spx_sync_reserve(ctx, sizeof(SelSync));
@@ -2318,7 +2396,8 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     // k_sel_lds from 1 Mi elements on (n = 2e6: 34 / 42 us at r = n/100 / n/2 against 39 / 45 with v in registers; n = 1e6:
     // 36 / 30 against 35 / 29 -- tools/r3/topr_small_grid.py), and wherever the register form's grid does not fit
     const bool lds = n <= lds_cap && (n > kLdsMinN || n > reg_cap);
-    const bool reg = !lds && n <= reg_cap;
+    const bool hyb = !lds && n > lds_cap && n <= hyb_cap;  // (vec: hyb_cap is 0 otherwise)
+    const bool reg = !lds && !hyb && n <= reg_cap;
     // Register form: 1 / 2 / 4 / 8 elements per lane by n -- the fewer elements a lane walks per pass the better, until the
     // workgroups are so many that their histogram flushes and arrivals cost more (us per call at r = n/100, 1 / 2 / 4 / 8 per
     // lane: n = 3e4 17.4 / 18.4 / 20.7 / 24.1; n = 1e5 19.8 / 19.3 / 20.8 / 24.4; n = 3e5 26.8 / 22.8 / 22.1 / 24.9; n = 1e6
@@ -2333,8 +2412,9 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
     // (k_sel_lds: every CU the grid may have -- the load phase is most of the kernel and wants all of them pulling; a rendezvous
     //  costs 1.4 us with 256 workgroups since the arrivals are spread over eight counters)
     if (lds) g = lds_cap / ((int64_t)kLdsEpl * 1024);
+    if (hyb) g = hyb_cap / ((int64_t)(kLdsEpl + kLdsRegX) * 1024);
 #ifdef SPX_TEST_HOOKS  // the planted fault of tests/test_gpu_robustness.py: a grid that cannot be resident
-    if (!reg && !lds && ctx->tune_force_grid > 0) g = ctx->tune_force_grid;
+    if (!reg && !lds && !hyb && ctx->tune_force_grid > 0) g = ctx->tune_force_grid;
 #endif
     int use_set = ctx->sel_hist_next, other = use_set ^ 1;
     int clear_set = ctx->sel_hist_dirty[other] ? other : -1;
@@ -2357,6 +2437,9 @@ int run_select(spx_ctx* ctx, double* y, const double* q, const double* xk, const
       else if (lds)
         hipLaunchKernelGGL((k_sel_lds<BINF, false>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r, delta, ss,
                            parity, use_set, clear_set);
+      else if (hyb)
+        hipLaunchKernelGGL((k_sel_lds<BINF, true, double, kLdsRegX>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj,
+                           n, r, delta, ss, parity, use_set, clear_set);
       else
         hipLaunchKernelGGL((k_sel_coop<BINF, false>), dim3((unsigned)g), dim3(1024), 0, ctx->stream, y, q, xk, sj, n, r,
                            delta, ss, parity, use_set, clear_set);

@@ -318,10 +318,13 @@ def test_indball_fast_path_and_fallback(s, orc, case):
         # resident grid of the in-launch synchronised kernels capped (key 8) at 40 workgroups (the front kernel needs 64: the
         # call takes the exact select on a 40-workgroup grid) and at 3 (every kernel on a grid far below the CU count)
         ctx = s.context("cuda:0")
-        for fast, spec, coop in ((1, 1, 0), (1, 0, 0), (0, 1, 0), (1, 1, 40), (0, 1, 3), (1, 1, 100)):
+        # (round 4: at this size the default is the one-launch form with 16 elements per lane in LDS and 8 in registers; the
+        #  pipeline -- the subject here -- runs under tuning key 11 = 2; the last combination is the default form)
+        for fast, spec, coop, form in ((1, 1, 0, 2), (1, 0, 0, 2), (0, 1, 0, 2), (1, 1, 40, 2), (0, 1, 3, 2), (1, 1, 100, 2), (1, 1, 0, 1), (1, 1, 3, 1)):
             s._lib.check(L.spx_ctx_set_tuning(ctx, 2, fast))
             s._lib.check(L.spx_ctx_set_tuning(ctx, 4, spec))
             s._lib.check(L.spx_ctx_set_tuning(ctx, 8, coop))
+            s._lib.check(L.spx_ctx_set_tuning(ctx, 11, form))
             try:
                 psi = s.shifted(s.shifted(s.IndBallL0(r), xd, 1.0, s.NormLinf(1.0)), sd)
                 psi.sol.fill_(float("nan"))  # every entry must be written
@@ -330,11 +333,20 @@ def test_indball_fast_path_and_fallback(s, orc, case):
                 s._lib.check(L.spx_ctx_set_tuning(ctx, 2, 1))
                 s._lib.check(L.spx_ctx_set_tuning(ctx, 4, 1))
                 s._lib.check(L.spx_ctx_set_tuning(ctx, 8, 0))
-            assert _bits_equal(y, ref), (case, r, fast, spec, coop)
-    # plain IndBallL0 (no clamp) through the single-pass form
+                s._lib.check(L.spx_ctx_set_tuning(ctx, 11, 1))
+            assert _bits_equal(y, ref), (case, r, fast, spec, coop, form)
+    # plain IndBallL0 (no clamp) through the single-pass form of the pipeline and through the default form
     ref = top.prox(n // 50)
+    s._lib.check(L.spx_ctx_set_tuning(s.context("cuda:0"), 11, 2))
+    try:
+        assert _bits_equal(s.prox(s.shifted(s.shifted(s.IndBallL0(n // 50), xd), sd), qd, 1.0).cpu().numpy(), ref)
+        # y === q on the fast path (two-pass form: y may not be written before the cut is known)
+        qa = qd.clone()
+        s.prox_bang(qa, s.shifted(s.shifted(s.IndBallL0(n // 50), xd), sd), qa, 1.0)
+        assert _bits_equal(qa.cpu().numpy(), ref)
+    finally:
+        s._lib.check(L.spx_ctx_set_tuning(s.context("cuda:0"), 11, 1))
     assert _bits_equal(s.prox(s.shifted(s.shifted(s.IndBallL0(n // 50), xd), sd), qd, 1.0).cpu().numpy(), ref)
-    # y === q on the fast path (two-pass form: y may not be written before the cut is known)
     s.prox_bang(qd, s.shifted(s.shifted(s.IndBallL0(n // 50), xd), sd), qd, 1.0)
     assert _bits_equal(qd.cpu().numpy(), ref)
 

@@ -23,10 +23,11 @@ def _bits(a, b):
     return np.array_equal(np.asarray(a).view(np.int64), np.asarray(b).view(np.int64))
 
 
-@pytest.mark.parametrize("n", [6_000, 50_000, 1_000_000, 2_600_000, 4_300_000, pytest.param(15_000_000, marks=pytest.mark.soak)])
+@pytest.mark.parametrize("n", [6_000, 50_000, 1_000_000, 2_600_000, 4_300_000, 6_400_000, pytest.param(15_000_000, marks=pytest.mark.soak)])
 def test_iteration_in_a_graph_replays_on_new_data(s, orc, n):
     """n = 6e3: one-workgroup top-r, one-workgroup B2; 5e4 / 1e6: the register-resident one-launch forms; 2.6e6: the forms that
-    park a vector in LDS (256 workgroups); 4.3e6: the sample-predicted top-r pipeline and the streaming B2 form; 1.5e7: the B2
+    park a vector in LDS (256 workgroups); 4.3e6: top-r with 16 elements per lane in LDS and 8 in registers and the streaming B2
+    form; 6.4e6: the sample-predicted top-r pipeline; 1.5e7: the B2
     passes that take their tiles from an atomic counter (zeroed by a node of the graph) -- the iteration then also calls B2 with
     an inactive trust region twice, so that the speculative pass is wrong once and right once per replay."""
     import torch

@@ -319,14 +319,20 @@ def test_indball_l0_nan_inf(s, orc):
         xd, sd, qd = _dev(x, sj, q)
         with np.errstate(all="ignore"):
             top = orc.TopR(q, x, sj)
-        for r in (1, 4, 9, 12, 15, 16, n // 7):
-            with np.errstate(all="ignore"):
-                ref = top.prox(r, 0.6)
-                ref0 = top.prox(r)
-            y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.6, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
-            assert _same_or_both_nan(y, ref), (n, r)
-            y0 = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qd, 1.0).cpu().numpy()
-            assert _same_or_both_nan(y0, ref0), (n, r)
+        L = s._lib.load(); ctx = s.context("cuda:0")
+        try:
+            for form in ((2, 1) if n > 1000 else (1,)):   # the pipeline (key 11 = 2 at this size since round 4) and the default form
+                s._lib.check(L.spx_ctx_set_tuning(ctx, 11, form))
+                for r in (1, 4, 9, 12, 15, 16, n // 7):
+                    with np.errstate(all="ignore"):
+                        ref = top.prox(r, 0.6)
+                        ref0 = top.prox(r)
+                    y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.6, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
+                    assert _same_or_both_nan(y, ref), (n, r, form)
+                    y0 = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qd, 1.0).cpu().numpy()
+                    assert _same_or_both_nan(y0, ref0), (n, r, form)
+        finally:
+            s._lib.check(L.spx_ctx_set_tuning(ctx, 11, 1))
 
 
 @pytest.mark.parametrize("kind", ["scaled", "cauchy", "concentrated"])
@@ -346,21 +352,31 @@ def test_indball_l0_ranks_and_scales(s, orc, kind):
         q = (1.0 + 1e-9 * rng.normal(size=n)) * rng.choice([-1.0, 1.0], size=n)
     xd, sd, qd = _dev(x, sj, q)
     top = orc.TopR(q, x, sj)   # (the reference's sortperm once, every r from it)
-    for r in (1, 50, 5000, n // 100, n // 2, n - 5000):
-        ref = top.prox(r, 0.9)
-        y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.9, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
-        assert _bits_equal(y, ref), (kind, r)
-    r = n // 37  # aliased form (y === q)
-    s.prox_bang(qd, s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qd, 1.0)
-    assert _bits_equal(qd.cpu().numpy(), top.prox(r)), kind
+    L = s._lib.load(); ctx = s.context("cuda:0")
+    try:
+        for form in (2, 1):   # the sample-predicted pipeline (the subject; key 11 = 2 at this size since round 4), the default form
+            s._lib.check(L.spx_ctx_set_tuning(ctx, 11, form))
+            for r in (1, 50, 5000, n // 100, n // 2, n - 5000):
+                ref = top.prox(r, 0.9)
+                y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.9, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
+                assert _bits_equal(y, ref), (kind, r, form)
+            r = n // 37  # aliased form (y === q)
+            qa = qd.clone()
+            s.prox_bang(qa, s.shifted(s.shifted(s.IndBallL0(r), xd), sd), qa, 1.0)
+            assert _bits_equal(qa.cpu().numpy(), top.prox(r)), (kind, form)
+    finally:
+        s._lib.check(L.spx_ctx_set_tuning(ctx, 11, 1))
 
 
 @pytest.mark.parametrize("n,lds", [((1 << 20) - 1, 1), (1 << 20, 1), ((1 << 20) + 1, 1), ((1 << 20) + 3001, 1), ((1 << 21) - 1, 1),
                                    (1 << 21, 0), ((1 << 21) + 1, 0), ((1 << 21) + 3001, 0), ((1 << 21) + 3001, 1),
-                                   ((1 << 22) - 1, 1), (1 << 22, 1), ((1 << 22) + 1, 1), ((1 << 22) + 3001, 1)])
+                                   ((1 << 22) - 1, 1), (1 << 22, 1), ((1 << 22) + 1, 1), ((1 << 22) + 3001, 1),
+                                   ((1 << 22) + 1, 2), ((1 << 22) + 3001, 2), (5_000_003, 1),
+                                   (6 * (1 << 20) - 1, 1), (6 * (1 << 20), 1), (6 * (1 << 20) + 1, 1), (6 * (1 << 20) + 1, 2)])
 def test_indball_l0_at_the_fast_path_threshold(s, orc, n, lds):
-    """Either side of the sizes at which the forms hand over: v in registers -> v in LDS (k_sel_lds, above 2^20) -> the
-    sample-predicted pipeline (above 2^22 = what 256 resident workgroups hold in LDS); with the LDS form switched off (tuning
+    """Either side of the sizes at which the forms hand over: v in registers -> v in LDS (k_sel_lds, above 2^20) -> 16 elements
+    per lane in LDS + 8 in registers (k_sel_lds<.., REGX>, above 2^22 = what 256 resident workgroups hold in LDS; round 4) -> the
+    sample-predicted pipeline (above 6 Mi); key 11 = 2 keeps the pipeline from 2^22 on; with the LDS forms switched off (tuning
     key 11 = 0) the pipeline takes over from the register form at 2^21 (SPX_SEL_REG_MAX_LOG2), as in round 2.  Lattice data
     (ties), all r regimes."""
     L = s._lib.load()
@@ -371,11 +387,16 @@ def test_indball_l0_at_the_fast_path_threshold(s, orc, n, lds):
     xd, sd, qd = _dev(x, sj, q)
     s._lib.check(L.spx_ctx_set_tuning(ctx, 11, lds))
     try:
+        top = orc.TopR(q, x, sj)   # (the reference's sortperm once per input, every r from it)
         for r in (1, 3, 777, n // 100, n // 3, n - 2):
             y = s.prox(s.shifted(s.shifted(s.IndBallL0(r), xd, 0.8, s.NormLinf(1.0)), sd), qd, 1.0).cpu().numpy()
-            assert _bits_equal(y, orc.prox_indball_l0_binf(q, x, sj, r, 0.8)), (n, r)
+            assert _bits_equal(y, top.prox(r, 0.8)), (n, r)
+        if n > (1 << 22):   # y === xk: the form with register slots re-reads xk and sj in its storing phase
+            xa = xd.clone()
+            s.prox_bang(xa, s.shifted(s.shifted(s.IndBallL0(n // 7), xa, 0.8, s.NormLinf(1.0)), sd), qd, 1.0)
+            assert _bits_equal(xa.cpu().numpy(), top.prox(n // 7, 0.8)), n
         s.prox_bang(qd, s.shifted(s.shifted(s.IndBallL0(n // 50), xd), sd), qd, 1.0)      # aliased form
-        assert _bits_equal(qd.cpu().numpy(), orc.prox_indball_l0(q, x, sj, n // 50)), n
+        assert _bits_equal(qd.cpu().numpy(), top.prox(n // 50)), n
     finally:
         s._lib.check(L.spx_ctx_set_tuning(ctx, 11, 1))
 

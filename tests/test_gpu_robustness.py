@@ -89,7 +89,8 @@ sys.path.insert(0, %r)
 import numpy as np, torch
 import __graft_entry__ as ge
 s = ge.build(); L = s._lib.load(); ctx = s.context("cuda:0")
-n = 6_000_000                                  # above what the one-launch forms hold on chip: the sampled pipeline
+n = 6_000_000                                  # above what the LDS form holds on chip; key 11 = 2: no register slots beyond
+assert L.spx_ctx_set_tuning(ctx, 11, 2) == 0   # it (round 4: 6 Mi otherwise) -- the sampled pipeline, whose tail kernel is the subject
 rng = np.random.default_rng(5)
 res = []
 for case in ("ties", "moderate_ties", "ties_aliased"):
@@ -212,7 +213,7 @@ def test_residency_cap_takes_the_smaller_grid_forms(s, orc):
     ctx = s.context("cuda:0")
     rng = np.random.default_rng(11)
     try:
-        for n in (20_000, 300_000, 2_500_000, 4_200_001):
+        for n in (20_000, 300_000, 2_500_000, 4_200_001, 6_400_001):
             x = rng.normal(size=n); sj = rng.uniform(-0.5, 0.5, size=n); q = rng.normal(size=n)
             xd, sd, qd = (torch.from_numpy(t).cuda() for t in (x, sj, q))
             r = n // 20
@@ -258,7 +259,7 @@ def test_replay_after_a_larger_eager_call_outgrew_the_workspace(s, orc):
         it()
     # a much larger eager call on the SAME context (same stream): the workspace grows
     with torch.cuda.stream(side):
-        big = 6_000_000
+        big = 7_000_000   # (beyond what the one-launch top-r forms hold on chip: the pipeline's candidate regions)
         xb = torch.randn(big, dtype=torch.float64, device="cuda"); zb = torch.zeros_like(xb); qb = torch.randn_like(xb)
         yb = torch.empty_like(qb)
         s.prox_bang(yb, s.shifted(s.shifted(s.IndBallL0(big // 7), xb, 1.0, s.NormLinf(1.0)), zb), qb, 1.0)   # candidate regions: ~150 MB

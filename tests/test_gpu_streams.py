@@ -13,7 +13,7 @@ def test_two_streams_interleaved():
     import __graft_entry__ as ge
     s = ge.build()
     dev = torch.device("cuda:0")
-    n = 4_300_000                                # (top-r: the sample-predicted pipeline, which uses the context scratch)
+    n = 6_400_000                                # (top-r: the sample-predicted pipeline, which uses the context scratch)
     g = torch.Generator(device=dev).manual_seed(5)
     mk = lambda: torch.randn(n, dtype=torch.float64, device=dev, generator=g)
     xa, sa, qa, xb, sb, qb = mk(), mk() * 0.3, mk(), mk(), mk() * 0.3, mk()
@@ -58,7 +58,7 @@ def test_two_streams_both_in_launch_synchronised_kernels():
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(11)
     cases = []
-    for n in (300_000, (1 << 21) + 77, (1 << 22) + 77):   # one launch: v in registers / in LDS; the sample-predicted pipeline
+    for n in (300_000, (1 << 21) + 77, (1 << 22) + 77, 6 * (1 << 20) + 77):   # one launch: v in registers / in LDS / in both; the sample-predicted pipeline
         mk = lambda: torch.randn(n, dtype=torch.float64, device=dev, generator=g)
         x, sj, q = mk(), mk() * 0.3, mk()
         psi = s.shifted(s.shifted(s.IndBallL0(n // 37), x, 0.8, s.NormLinf(1.0)), sj)
