@@ -356,17 +356,19 @@ def _extra(s, L, ctx, dev, n, torch):
     # per-call latency at solver-iteration sizes: the two operators with a data-dependent scalar (r-th largest, trust-region
     # root) run as ONE launch with in-launch rendezvous, nothing read back (us per call, HIP events over 50 back-to-back calls)
     # (round 3: up to 2^22 elements the vector stays on chip -- v / xk parked in LDS above 2^20 / 2^21 elements, registers below)
-    for nn in (4_000_000, 1_000_000, 100_000, 10_000):
+    # (round 4: up to 6 Mi elements for top-r -- 16 elements per lane in LDS + 8 in registers, k_sel_lds<.., 8>)
+    for nn in (6_000_000, 4_000_000, 1_000_000, 100_000, 10_000):
         if nn > n:
             continue
         xs, ss_, qs, ys = xk[:nn], sj[:nn], q[:nn], y[:nn]
+        sel_kernel = ("k_sel_lds<true, true, double, 8>" if nn > (1 << 22) else "k_sel_lds<true, true, double, 0>" if nn > (1 << 20)
+                      else "k_sel_coop<true, true, double>" if nn > 8192 else "k_sel_small<true, double>")
         for name, psi_s, kern in (
-                ("ShiftedIndBallL0BInf_r=n/100_n=%d" % nn, s.shifted(s.shifted(s.IndBallL0(max(1, nn // 100)), xs, 1.0, chi), ss_),
-                 "k_sel_lds<true, true, double>" if nn > (1 << 20) else "k_sel_coop<true, true, double>" if nn > 8192 else "k_sel_small<true, double>"),
-                ("ShiftedIndBallL0BInf_r=n/2_n=%d" % nn, s.shifted(s.shifted(s.IndBallL0(max(1, nn // 2)), xs, 1.0, chi), ss_),
-                 "k_sel_lds<true, true, double>" if nn > (1 << 20) else "k_sel_coop<true, true, double>" if nn > 8192 else "k_sel_small<true, double>"),
+                ("ShiftedIndBallL0BInf_r=n/100_n=%d" % nn, s.shifted(s.shifted(s.IndBallL0(max(1, nn // 100)), xs, 1.0, chi), ss_), sel_kernel),
+                ("ShiftedIndBallL0BInf_r=n/2_n=%d" % nn, s.shifted(s.shifted(s.IndBallL0(max(1, nn // 2)), xs, 1.0, chi), ss_), sel_kernel),
                 ("ShiftedNormL1B2_n=%d" % nn, s.shifted(s.shifted(s.NormL1(1.0), xs, 1.0, s.NormL2(1.0)), ss_),
-                 "k_b2_coop<true, 16, 1024, true, true>" if nn > (1 << 21) else "k_b2_coop<true, 16, 512, true, false>")):
+                 "k_b2_coop<false, 1, 1024, true, false>" if nn > (1 << 22) else "k_b2_coop<true, 16, 1024, true, true>" if nn > (1 << 21)
+                 else "k_b2_coop<true, 16, 512, true, false>")):
             s.prox_bang(ys, psi_s, qs, 1.0)
             ms = _time_op(s, L, ctx, lambda: s.prox_bang(ys, psi_s, qs, 1.0), iters=50, rounds=5)
             res[name] = {"us": round(ms * 1e3, 2), "avg_launch_ms": round(ms, 5), "kernel": kern, "n": nn,

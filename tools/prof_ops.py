@@ -34,7 +34,7 @@ if "vecbounds" in which:
     for _ in range(5): s.prox_bang(y, psi, q, 1.0)
     del lv, uv, psi
 if "small" in which:   # solver-iteration sizes: the one-launch forms (v / xk in LDS at 4e6, registers below)
-    for nn in (4_000_000, 1_000_000, 100_000, 10_000):
+    for nn in (6_000_000, 4_000_000, 1_000_000, 100_000, 10_000):
         if nn <= n:
             for psi in (s.shifted(s.shifted(s.IndBallL0(max(1, nn // 100)), xk[:nn], 1.0, chi), sj[:nn]),
                         s.shifted(s.shifted(s.IndBallL0(max(1, nn // 2)), xk[:nn], 1.0, chi), sj[:nn]),
