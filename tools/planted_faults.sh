@@ -31,6 +31,7 @@ FAULTS=(
  "22|spx_objective.hip|s/    __hip_atomic_store(\&fin.hdr->fin_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);/    (void)0;/|tests/test_gpu_launch_counts.py::test_objective_one_launch_same_bits tests/test_gpu_launch_counts.py::test_objective_one_launch_into_a_device_double_back_to_back"
  "23|spx_group.hip|s/if (LIT \&\& dclear != nullptr \&\& blockIdx.x == 0 \&\& threadIdx.x == 0) \*dclear = 0ull;/(void)dclear;/|tests/test_gpu_launch_counts.py::test_binf_deferred_list_without_the_zero_launch"
  "24|spx_separable.hip|s/value_reduce_small<true>(op.partials, (int)gridDim.x);/value_reduce_small<true>(op.partials, (int)gridDim.x - 1);/|tests/test_gpu_launch_counts.py::test_prox_value_one_launch"
+ "25|spx_select.hip|s/          for (int e = 0; e < W; ++e) vvv\[e\] = vr\[(s_ >= kSlots) ? s_ - kSlots + e : 0\];/          for (int e = 0; e < W; ++e) vvv[e] = vr[(s_ >= kSlots) ? s_ - kSlots : 0];/|tests/test_gpu_parity.py::test_indball_l0_at_the_fast_path_threshold"
  "4|spx_group_common.hpp|s/if (sb == 0.0) {/if (false) {/;s/for (int k = 0; k < 64; ++k) {/for (int k = 0; k < 12; ++k) { piece_ok = true;/|tests/test_gpu_parity.py::test_group_binf_many_small_groups tests/test_gpu_parity.py::test_group_binf_zero_groups_strong_lambda"
 )
 case "${1:-}" in
