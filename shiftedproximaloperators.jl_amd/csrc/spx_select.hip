@@ -1079,6 +1079,7 @@ struct SelSync {
   unsigned long long chist[3][kCoopMaxPass][kBins];
   unsigned long long fhist1[kBins];        // k_s2_front: top digit of the sample keys            (cleared by the fallback launch)
   unsigned long long fhist2[5][2][kBins];  // k_s2_front: digits 2..6 of the two rank selections   (cleared by the fallback launch)
+  unsigned long long ftie[8];              // k_s2_front, tie mode: [2 sel + 0 / 1] = largest key / largest ~key among the samples of selection sel's bucket (cleared by the fallback launch)
   SelWs ws;                                // st, fs, hist, shards (cleared by k_s2_front; fs.smax by the fallback launch)
   // k_s2_tail, tie scan: class members per workgroup slice and the cut found by the slice that holds it -- words that are
   // their own ready flag (value + 1, zero = not yet written; cleared by the launch itself after its last reader)
@@ -1773,6 +1774,7 @@ __global__ __launch_bounds__(1024) void k_s2_tail(double* y, const double* q, co
     unsigned long long* z2 = &ss->fhist2[0][0][0];
     for (int64_t k = gt; k < kBins; k += nt) z1[k] = 0ull;
     for (int64_t k = gt; k < 10 * kBins; k += nt) z2[k] = 0ull;
+    if (gt < 8) ss->ftie[gt] = 0ull;
     if (gt == 0) ss->ws.fs.smax = 0ull;
   }
   // written by earlier launches: the same values in every workgroup
@@ -2194,6 +2196,41 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     __syncthreads();
     for (int bb = t; bb < kBins; bb += 1024) { lh[bb] = 0u; lh1[bb] = 0u; }
     __syncthreads();
+    // Round 4: the first tie digit (digit 3) also tracks the smallest and the largest key among the samples of each selected
+    // bucket.  A crowded bucket after 36 key bits is nearly always ONE key (a lattice, a constant, sparse zeros): equal ends
+    // settle the remaining 16 bits without digits 5 and 6 -- two histogram passes, two fenced barriers and two scans, ~17 us of
+    // the ~55 us the front kernel takes in tie mode.  The four words (SelSync::ftie) are zero on entry like the histograms (the
+    // tail launch of the previous call clears them); the minimum is kept as the maximum of ~key.
+    constexpr bool kTieShortcut = kFrontSpl <= 4;  // (k_s2_front<16> sits at its register budget: with the bookkeeping below it spills 46 registers)
+    if (kTieShortcut && digit == 3) {  // (a loop of its own: inside the histogram loop below the accumulators cost registers)
+      __shared__ unsigned long long tstat[16][4];  // per wavefront: {max key, max ~key} of selection 0, of selection 1
+#pragma unroll
+      for (int sel = 0; sel < 2; ++sel) {
+        uint64_t a = 0ull, b = 0ull;  // max key, max ~key of this lane's samples inside the bucket of selection sel
+        if (!(sel == 1 && shared)) {
+#pragma unroll
+          for (int sidx = 0; sidx < kFrontSpl; ++sidx) {
+            const bool in = active[sel] && (keys[sidx] >> hs) == pre[sel];
+            a = (in && keys[sidx] > a) ? keys[sidx] : a;
+            b = (in && ~keys[sidx] > b) ? ~keys[sidx] : b;
+          }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+          const uint64_t oa = __shfl_xor(a, off, 64), ob = __shfl_xor(b, off, 64);
+          a = oa > a ? oa : a;
+          b = ob > b ? ob : b;
+        }
+        if ((t & 63) == 0) { tstat[t >> 6][2 * sel + 0] = a; tstat[t >> 6][2 * sel + 1] = b; }
+      }
+      __syncthreads();
+      // wavefronts -> workgroup -> ONE global atomicMax per word and workgroup (one per wavefront -- 1024 on each of four words of
+      // one cache line -- cost this digit 34 us: atomics on one line retire ~8-12 ns apart)
+      if (t < 4) {
+        unsigned long long m = 0ull;
+        for (int w = 0; w < 16; ++w) m = tstat[w][t] > m ? tstat[w][t] : m;
+        if (m) atomicMax(&ss->ftie[t], m);
+      }
+    }
 #pragma unroll
     for (int sidx = 0; sidx < kFrontSpl; ++sidx) {
       const uint64_t top = keys[sidx] >> hs;
@@ -2212,6 +2249,28 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
     SEL_STAMP(3 + 2 * digit);
     scan_both(ss->fhist2[digit - 1][0], ss->fhist2[digit - 1][shared ? 0 : 1], width);
     bits_done += width;
+    if (kTieShortcut && digit == 3) {
+      // (the same words in every workgroup, read behind the fenced barrier: the same decision everywhere)
+      bool single = true;
+      uint64_t only[2] = {0ull, 0ull};
+#pragma unroll
+      for (int sel = 0; sel < 2; ++sel) {
+        const int src = (sel == 1 && shared) ? 0 : sel;
+        const uint64_t kmax = ss->ftie[2 * src + 0], knmin = ss->ftie[2 * src + 1];
+        only[sel] = kmax;
+        if (active[sel]) single = single && knmin != 0ull && kmax == ~knmin;
+      }
+      if (single) {  // every selected bucket holds one key: it IS the band's end; rank and count inside the bucket are unchanged
+        __syncthreads();
+        if (t == 0) {
+          if (active[0]) pre[0] = only[0];
+          if (active[1]) pre[1] = only[1];
+        }
+        __syncthreads();
+        bits_done = 64;
+        break;
+      }
+    }
   }
   // How much of the SAMPLE lies in the band (tie mode: strictly between its ends)?  Exactly known from the scans: ranks above
   // the upper bucket = rank_hi - quo[0], ranks down to the low end of the lower bucket = rank_lo - quo[1] + bucket[1].  More
