@@ -2110,6 +2110,8 @@ __global__ __launch_bounds__(1024) void k_s2_front(const double* q, const double
   }
 #pragma unroll
   for (int sidx = 0; sidx < kFrontSpl; ++sidx) {
+    // (tried in round 4: hist_add_agg here -- the top digit is sign + exponent, four or five binades hold the sample -- phase A of
+    //  k_s2_front<16> 16.0 -> 19.2 us, of <4> 6.1 -> 6.3: the plain LDS atomics are not what the phase waits for)
     atomicAdd(&lh[keys[sidx] >> (64 - kDigitBits)], 1u);
     const unsigned long long fk = keys[sidx] < kInfKey ? keys[sidx] : 0ull;
     m = fk > m ? fk : m;
