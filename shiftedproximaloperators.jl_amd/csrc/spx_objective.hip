@@ -285,6 +285,8 @@ __global__ __launch_bounds__(256) void k_obj_group(const T* __restrict__ y, cons
 // chunks of kObjChunk elements, one 256-lane workgroup per chunk (16 elements per lane, 24 16-byte loads in flight), the
 // chunk sums land in library scratch and k_obj_chunk_groups adds the chunks of each group in index order: reproducible.
 constexpr int kObjChunk = 4096;
+constexpr int kObjFuseGroups = 256;   // the one-launch form of the chunked psi(y): at most this many (uniform) groups ...
+constexpr int kObjFuseChunks = 4096;  // ... and chunks (16 Mi elements): the last workgroup adds them, 16 loads per lane
 // chunks before group g (CSR layouts; uniform groups need no table)
 __global__ __launch_bounds__(1024) void k_obj_chunk_prefix(const int64_t* __restrict__ offsets, int64_t ngroups, int64_t n,
                                                             int64_t* __restrict__ prefix /* ngroups + 1 */) {
@@ -318,7 +320,10 @@ __global__ __launch_bounds__(256) void k_obj_chunks(const double* __restrict__ y
                                                      const double* __restrict__ sj, int64_t n,
                                                      const int64_t* __restrict__ offsets, int64_t gsize, int64_t ngroups,
                                                      const int64_t* __restrict__ prefix, int64_t nchunks_uniform, int par,
-                                                     double rad, double* __restrict__ chunk_ss, ObjWs* ws) {
+                                                     double rad, double* __restrict__ chunk_ss, ObjWs* ws,
+                                                     ObjFin fin /* hdr != NULL (uniform groups, <= kObjFuseGroups of them, <= kObjFuseChunks
+                                                                   chunks): the last workgroup also does k_obj_chunk_groups' and k_obj_final's work */,
+                                                     const double* __restrict__ lambda) {
   __shared__ double lds4[4];
   const int t = threadIdx.x;
   const int64_t K = prefix ? prefix[ngroups] : nchunks_uniform;
@@ -385,10 +390,45 @@ __global__ __launch_bounds__(256) void k_obj_chunks(const double* __restrict__ y
       for (int64_t i = lo + t; i < hi; i += 256) visit(y[i], xk[i], sj[i]);
     }
     ss = block_sum(ss, lds4);
-    if (t == 0) chunk_ss[k] = ss;
+    if (t == 0) {
+      if (fin.hdr) spx_atomic_store_f64(chunk_ss + k, ss);
+      else chunk_ss[k] = ss;
+    }
   }
-  if (__any(bad) && (threadIdx.x & 63) == 0 && (__hip_atomic_load(&ws->infeasible, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) == 0)
-    atomicOr(&ws->infeasible, 1);
+  obj_raise(obj_flag_word(ws, fin), __any(bad), 1);
+  if (fin.hdr == nullptr) return;
+  // Round 4 (third session): psi(y) of ONE group over the vector -- the reference's default GroupNormL2 -- was four launches at
+  // solver sizes (flag zero-fill, chunk sums, group sums, final).  With few uniform groups the workgroup that takes the last
+  // ticket adds each group's chunk sums in k_obj_chunk_groups' order (lane t: chunks c0 + t, c0 + t + 256, ...; block_sum),
+  // forms lambda_g sqrt(.) and adds the groups as k_obj_final does with one group per slot: the same bits as the three launches.
+  __shared__ int ck_last;
+  __shared__ double ck_part[kObjFuseGroups];
+  __syncthreads();  // (every wavefront has raised its bits)
+  if (t == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ck_last = spx_fin_ticket(fin.hdr) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!ck_last) return;
+  for (int64_t g = 0; g < ngroups; ++g) {
+    const int64_t c0 = g * cpg, c1 = (g + 1) * cpg;
+    double gs = 0.0;
+    for (int64_t c = c0 + t; c < c1; c += 256) gs += spx_atomic_load_f64(chunk_ss + c);
+    gs = block_sum(gs, lds4);
+    if (t == 0) ck_part[g] = 0.0 + lambda[g] * sqrt(gs);  // (k_obj_chunk_groups: acc = 0.0; acc += lambda[g] * sqrt(ss))
+  }
+  __syncthreads();
+  double a = 0.0;
+  if (t < ngroups) a += ck_part[t];                      // (k_obj_final: lane t adds the slots t, t + 256, ...: one slot here)
+  a = block_sum(a, lds4);
+  if (t == 0) {
+    const int flag = __hip_atomic_load(&fin.hdr->fin_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double v = obj_value(fin.rule, flag, a, fin.scale, fin.limit);
+    ws->result = v;
+    ws->infeasible = flag;
+    if (fin.target) *fin.target = v;
+    __hip_atomic_store(&fin.hdr->fin_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 // ws->partial[b] = sum over the groups b, b + grid, ... of lambda_g sqrt(sum of the group's chunk sums, in index order)
 __global__ __launch_bounds__(256) void k_obj_chunk_groups(const double* __restrict__ chunk_ss, const int64_t* __restrict__ prefix,
@@ -546,7 +586,13 @@ int run_obj_group(spx_ctx* ctx, const T* y, const T* xk, const T* sj, int64_t n,
       rc = spx_ws_reserve(ctx, pre_off + (offsets ? (size_t)(ngroups + 1) * sizeof(int64_t) : 0) + 256);
       if (rc) return rc;
       ws = reinterpret_cast<ObjWs*>(ctx->ws);
-      { const int rz = spx_zero_async(ctx, &ws->infeasible, sizeof(int)); if (rz) return rz; }
+      ObjFin cfin{nullptr, ctx->value_target, 1.0, 0.0, kRuleGroup};
+      if (!offsets && ngroups <= kObjFuseGroups && kmax <= kObjFuseChunks) {  // few uniform groups: one launch (k_obj_chunks)
+        rc = obj_fin_prepare(ctx, kRuleGroup, 1.0, 0.0, &cfin);
+        if (rc) return rc;
+        ws = reinterpret_cast<ObjWs*>(ctx->ws);
+      }
+      if (!cfin.hdr) { const int rz = spx_zero_async(ctx, &ws->infeasible, sizeof(int)); if (rz) return rz; }
       double* chunk_ss = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + ss_off);
       int64_t* prefix = offsets ? reinterpret_cast<int64_t*>(static_cast<char*>(ctx->ws) + pre_off) : nullptr;
       if (offsets) hipLaunchKernelGGL(k_obj_chunk_prefix, dim3(1), dim3(1024), 0, ctx->stream, offsets, ngroups, n, prefix);
@@ -555,7 +601,13 @@ int run_obj_group(spx_ctx* ctx, const T* y, const T* xk, const T* sj, int64_t n,
       int64_t cb = kmax < (int64_t)ctx->num_cu * 64 ? kmax : (int64_t)ctx->num_cu * 64;
       if (cb < 1) cb = 1;
       hipLaunchKernelGGL((k_obj_chunks<MODE>), dim3((unsigned)cb), dim3(256), 0, ctx->stream, (const double*)y, (const double*)xk,
-                         (const double*)sj, n, offsets, gsize, ngroups, (const int64_t*)prefix, cpg * ngroups, par, rad, chunk_ss, ws);
+                         (const double*)sj, n, offsets, gsize, ngroups, (const int64_t*)prefix, cpg * ngroups, par, rad, chunk_ss, ws,
+                         cfin, (const double*)lambda);
+      if (cfin.hdr) {
+        SPX_LAUNCH_CHECK();
+        int bad_;
+        return obj_finish(ctx, ws, 0, kRuleGroup, 1.0, 0.0, value, &bad_, true);
+      }
       int64_t gb = ngroups < kObjBlocks ? ngroups : kObjBlocks;
       hipLaunchKernelGGL(k_obj_chunk_groups, dim3((unsigned)gb), dim3(256), 0, ctx->stream, (const double*)chunk_ss,
                          (const int64_t*)prefix, cpg, ngroups, (const double*)lambda, ws);

@@ -74,6 +74,44 @@ def test_objective_one_launch_same_bits(s, n):
         _key17(s, 1)
 
 
+@pytest.mark.parametrize("n,ngroups", [(8192, 1), (10_000, 1), (100_001, 1), (1_000_000, 1), (3_000_000, 3), (16_000_000, 1),
+                                        (16_777_216, 2), (17_000_000, 1), (4_194_304, 256), (4_210_688, 257)])
+def test_objective_of_large_groups_one_launch(s, n, ngroups):
+    """psi(y) of ONE group over the vector (shifted(NormL2(lambda), xk[, Delta, chi]): the reference's default GroupNormL2) and of a
+    few large uniform groups: chunk sums, group sums and the final sum in ONE launch (k_obj_chunks' last workgroup) up to 256
+    groups and 4096 chunks, three launches beyond (the last parameters); the same bits as with tuning key 17 = 0, feasible and
+    infeasible points, and within 1e-12 of the value formed in numpy."""
+    import torch
+    rng = np.random.default_rng(700 + n)
+    n = n // ngroups * ngroups
+    x, sj = rng.normal(size=n), rng.uniform(-0.5, 0.5, size=n)
+    yh = rng.uniform(-0.3, 0.3, size=n)
+    xd, sd, yd = _dev(x, sj, yh)
+    ybad = yd * 10.0
+    lam = rng.uniform(0.5, 1.5, size=ngroups)
+    H = s.GroupNormL2(lam.tolist()) if ngroups == 1 else s.GroupNormL2.uniform(lam.tolist(), n // ngroups)
+    psis = [s.shifted(s.shifted(H, xd), sd), s.shifted(s.shifted(H, xd, 0.9, s.NormLinf(1.0)), sd)]
+    want_np = float(np.sum(lam * np.sqrt(np.sum((((x + sj) + yh) ** 2).reshape(ngroups, -1), axis=1))))
+    qd = _dev(rng.normal(size=n))[0]
+    tmp = torch.empty_like(qd)
+    other = s.shifted(s.shifted(s.IndBallL0(max(1, n // 7)), xd, 0.9, s.NormLinf(1.0)), sd)
+    try:
+        for psi in psis:
+            _key17(s, 0)
+            want = [psi(yd), psi(ybad), psi(yd)]
+            _key17(s, 1)
+            got = [psi(yd), psi(ybad)]
+            s.prox_bang(tmp, other, qd, 1.0)               # writes all over the library's scratch
+            got.append(psi(yd))
+            for a, b in zip(got, want):
+                assert a == b or (np.isinf(a) and np.isinf(b)), (type(psi).__name__, n, ngroups, got, want)
+            assert abs(got[0] - want_np) <= 1e-12 * want_np, (got[0], want_np)
+            for _ in range(3):
+                assert psi(yd) == want[0]
+    finally:
+        _key17(s, 1)
+
+
 def test_objective_one_launch_into_a_device_double_back_to_back(s):
     """200 psi(y) calls queued without a synchronisation, alternating feasible / infeasible points, values into a device
     array slot by slot: the tickets and the flag of one launch must be back at zero before the next one starts."""

@@ -32,6 +32,7 @@ FAULTS=(
  "23|spx_group.hip|s/if (LIT \&\& dclear != nullptr \&\& blockIdx.x == 0 \&\& threadIdx.x == 0) \*dclear = 0ull;/(void)dclear;/|tests/test_gpu_launch_counts.py::test_binf_deferred_list_without_the_zero_launch"
  "24|spx_separable.hip|s/value_reduce_small<true>(op.partials, (int)gridDim.x);/value_reduce_small<true>(op.partials, (int)gridDim.x - 1);/|tests/test_gpu_launch_counts.py::test_prox_value_one_launch"
  "25|spx_select.hip|s/          for (int e = 0; e < W; ++e) vvv\[e\] = vr\[(s_ >= kSlots) ? s_ - kSlots + e : 0\];/          for (int e = 0; e < W; ++e) vvv[e] = vr[(s_ >= kSlots) ? s_ - kSlots : 0];/|tests/test_gpu_parity.py::test_indball_l0_at_the_fast_path_threshold"
+ "26|spx_objective.hip|s/    for (int64_t c = c0 + t; c < c1; c += 256) gs += spx_atomic_load_f64(chunk_ss + c);/    for (int64_t c = c0 + t; c < c1; c += 512) gs += spx_atomic_load_f64(chunk_ss + c);/|tests/test_gpu_launch_counts.py::test_objective_of_large_groups_one_launch"
  "4|spx_group_common.hpp|s/if (sb == 0.0) {/if (false) {/;s/for (int k = 0; k < 64; ++k) {/for (int k = 0; k < 12; ++k) { piece_ok = true;/|tests/test_gpu_parity.py::test_group_binf_many_small_groups tests/test_gpu_parity.py::test_group_binf_zero_groups_strong_lambda"
 )
 case "${1:-}" in
